@@ -1,0 +1,125 @@
+/* rlhip.h -- C ABI of librlhip.so: the MI355X (gfx950) device layer underneath the RandLAPACK
+ * sketch-and-factor path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI on this path: its
+ * drivers are C++ templates that bottom out in blas:: / lapack:: / RandBLAS:: free functions
+ * (RandLAPACK/rl_blaspp.hh:5-9, RandLAPACK/rl_lapackpp.hh:7-9).  Each entry point below names the
+ * reference call site(s) it replaces.  The C++ classes in include/RandLAPACK_amd/ (same names and call
+ * signatures as the reference's driver/comp objects) are written purely against this header.
+ *
+ * Conventions
+ *   - every matrix pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - column-major storage, int64_t dimensions and leading dimensions, 1-based int64_t pivots;
+ *   - op / uplo / diag / side flags are the LAPACK characters ('N','T','U','L','R', ...);
+ *   - return value: 0 success; >0 LAPACK-style info (e.g. potrf failing minor); <0 = -(index of the bad
+ *     argument) or -1000-hipError_t for a runtime failure.  Nothing aborts the process.
+ *   - suffix _f64 / _f32 = the arithmetic type; results of the f64 entry points are what the parity
+ *     tests compare against the CPU oracle.
+ *   - all work is enqueued on the context's HIP stream; entry points that return a value to the host
+ *     (info codes, norms, ranks) synchronise that stream, the others are asynchronous.
+ */
+#ifndef RLHIP_H
+#define RLHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rlhip_ctx rlhip_ctx;
+
+/* ---- context, memory, stream (replaces blas::Queue / lapack::Queue, device_malloc, device_free,
+ *      device_copy_matrix: RandLAPACK/drivers/rl_bqrrp_gpu.hh:232-233, rl_cqrrpt_gpu.hh:267-297) ---- */
+/* own_stream != 0: create a private non-blocking stream (hip_stream ignored);
+ * own_stream == 0: enqueue on hip_stream (a hipStream_t; NULL = the device's default stream, which is what
+ * PyTorch-ROCm uses unless told otherwise). */
+int rlhip_create(rlhip_ctx** ctx, int device, void* hip_stream, int own_stream);
+int rlhip_destroy(rlhip_ctx* ctx);
+int rlhip_sync(rlhip_ctx* ctx);
+void* rlhip_stream(rlhip_ctx* ctx);
+int rlhip_malloc(rlhip_ctx* ctx, void** dev_ptr, size_t bytes);
+int rlhip_free(rlhip_ctx* ctx, void* dev_ptr);
+int rlhip_memcpy_h2d(rlhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int rlhip_memcpy_d2h(rlhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int rlhip_memcpy_d2d(rlhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int rlhip_memset(rlhip_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+/* reserve the scratch arena up front (split-K slabs, trsm panels ...) so no hipMalloc happens later */
+int rlhip_reserve_workspace(rlhip_ctx* ctx, size_t bytes);
+size_t rlhip_workspace_highwater(rlhip_ctx* ctx);
+const char* rlhip_version(void);
+
+/* event timing on the context's stream (bench.py roofline leg) */
+int rlhip_timer_start(rlhip_ctx* ctx);
+int rlhip_timer_stop_ms(rlhip_ctx* ctx, float* ms_host);
+
+/* ---- counter-based RNG: RandBLAS::RNGState + fill_dense (rl_rs.hh:134-139, rl_bqrrp.hh:310-311,
+ *      rl_hqrrp.hh:929-930, rl_abrik.hh:298-299).  dist: 0 = N(0,1), 1 = U(-1,1).
+ *      ctr[4]/key[2] are host arrays; next_ctr_host receives the advanced counter (may be NULL). ---- */
+int rlhip_philox4x32_10(rlhip_ctx* ctx, int64_t nblocks, uint32_t* out_dev, const uint32_t ctr_host[4],
+                        const uint32_t key_host[2]);
+int rlhip_fill_dense_f64(rlhip_ctx* ctx, int dist, int64_t rows, int64_t cols, double* buf,
+                         const uint32_t ctr_host[4], const uint32_t key_host[2], uint32_t next_ctr_host[4]);
+int rlhip_fill_dense_f32(rlhip_ctx* ctx, int dist, int64_t rows, int64_t cols, float* buf,
+                         const uint32_t ctr_host[4], const uint32_t key_host[2], uint32_t next_ctr_host[4]);
+
+/* ---- BLAS-3 on MFMA.  blas::gemm (rl_rs.hh:142,153,165; rl_rf.hh:123; rl_qb.hh:210-218,260;
+ *      rl_rsvd.hh:148), blas::syrk (rl_orth.hh:78; rl_cqrrpt.hh:310; rl_bqrrp.hh:460),
+ *      blas::trsm Side::Right/Uplo::Upper/NoTrans (rl_orth.hh:95; rl_cqrrpt.hh:302,338; rl_bqrrp.hh:457,464),
+ *      blas::trmm Side::Right/Uplo::Upper/NoTrans (rl_cqrrpt.hh:345; rl_bqrrp.hh:497). ---- */
+int rlhip_gemm_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, double alpha,
+                   const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                   int64_t ldc);
+int rlhip_gemm_f32(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
+                   const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                   int64_t ldc);
+/* uplo must be 'U' (the only form the path uses).  Tiles crossing the diagonal are written in full. */
+int rlhip_syrk_f64(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, double alpha, const double* A,
+                   int64_t lda, double beta, double* C, int64_t ldc);
+int rlhip_syrk_f32(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, float alpha, const float* A,
+                   int64_t lda, float beta, float* C, int64_t ldc);
+/* B <- alpha * B * inv(A), A n x n upper triangular, B m x n (side 'R', uplo 'U', trans 'N' only) */
+int rlhip_trsm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                   double alpha, const double* A, int64_t lda, double* B, int64_t ldb);
+int rlhip_trsm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                   float alpha, const float* A, int64_t lda, float* B, int64_t ldb);
+/* B <- alpha * B * A, A n x n upper triangular, B m x n (side 'R', uplo 'U', trans 'N' only) */
+int rlhip_trmm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                   double alpha, const double* A, int64_t lda, double* B, int64_t ldb);
+int rlhip_trmm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
+                   float alpha, const float* A, int64_t lda, float* B, int64_t ldb);
+
+/* ---- LAPACK-level pieces.  lapack::potrf Upper (rl_orth.hh:81; rl_cqrrpt.hh:311; rl_bqrrp.hh:462):
+ *      returns info (0, or the 1-based order of the first non-positive leading minor). ---- */
+int rlhip_potrf_f64(rlhip_ctx* ctx, char uplo, int64_t n, double* A, int64_t lda);
+int rlhip_potrf_f32(rlhip_ctx* ctx, char uplo, int64_t n, float* A, int64_t lda);
+/* lapack::lange(Norm::Fro) (rl_qb.hh:168,221) */
+int rlhip_lange_fro_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, double* result_host);
+int rlhip_lange_fro_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, int64_t lda, float* result_host);
+/* lapack::lacpy / lapack::laset; uplo 'U','L' or 'G' (rl_qb.hh:171; rl_cqrrpt.hh:281; rl_util.hh:102-131) */
+int rlhip_lacpy_f64(rlhip_ctx* ctx, char uplo, int64_t m, int64_t n, const double* A, int64_t lda, double* B,
+                    int64_t ldb);
+int rlhip_lacpy_f32(rlhip_ctx* ctx, char uplo, int64_t m, int64_t n, const float* A, int64_t lda, float* B,
+                    int64_t ldb);
+int rlhip_laset_f64(rlhip_ctx* ctx, char uplo, int64_t m, int64_t n, double offdiag, double diag, double* A,
+                    int64_t lda);
+int rlhip_laset_f32(rlhip_ctx* ctx, char uplo, int64_t m, int64_t n, float offdiag, float diag, float* A,
+                    int64_t lda);
+/* thin SVD of a tall m x n matrix (m >= n), replacing lapack::gesdd(Job::SomeVec) at rl_rsvd.hh:146:
+ * on exit A holds U (m x n), S[n] descending, VT (n x n, ld ldvt).  One-sided Jacobi, entirely on device.
+ * returns the number of sweeps used in *sweeps_host (may be NULL); info > 0 = not converged. */
+int rlhip_gesvdj_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* VT,
+                     int64_t ldvt, int* sweeps_host);
+int rlhip_gesvdj_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* S, float* VT,
+                     int64_t ldvt, int* sweeps_host);
+
+/* ---- diagnostics ---- */
+/* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
+int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);
+/* streaming-read bandwidth microbenchmark over `bytes` of device memory (GB/s) */
+int rlhip_hbm_read_peak(rlhip_ctx* ctx, const void* buf, size_t bytes, double* gbps_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLHIP_H */

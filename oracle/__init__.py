@@ -1,0 +1,261 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy front-end of oracle/liboracle.so (CPU restatement of the reference).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Matrices are
+ordinary (m, n) numpy arrays here; they are converted to Fortran (column-major) order for the calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+i64 = C.c_int64
+dbl = C.c_double
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int64)
+u32p = C.POINTER(C.c_uint32)
+
+
+def build():
+    subprocess.check_call(["make", "-C", str(_HERE), "-s"])
+
+
+def find_host_lapack() -> str:
+    """First hit wins: scipy's bundled OpenBLAS, then system OpenBLAS / LAPACK."""
+    cands = []
+    try:
+        import scipy
+
+        base = Path(scipy.__file__).resolve().parent.parent / "scipy.libs"
+        cands += sorted(glob.glob(str(base / "libscipy_openblas*.so*")))
+    except Exception:
+        pass
+    for pat in ("/usr/lib/x86_64-linux-gnu/libopenblas.so*", "/usr/lib/x86_64-linux-gnu/liblapack.so*",
+                "/usr/lib64/libopenblas.so*", "/usr/lib64/liblapack.so*"):
+        cands += sorted(glob.glob(pat))
+    if not cands:
+        raise RuntimeError("no host LAPACK found for the oracle")
+    return cands[0]
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = _HERE / "liboracle.so"
+    if not so.exists():
+        build()
+    lib = C.CDLL(str(so))
+    lib.oracle_init.restype = C.c_char_p
+    lib.oracle_init.argtypes = [C.c_char_p]
+    err = lib.oracle_init(find_host_lapack().encode())
+    if err:
+        raise RuntimeError(f"oracle_init: {err.decode()}")
+    lib.oracle_get_threads.restype = C.c_int
+    lib.oracle_cond_num_f64.restype = dbl
+    _LIB = lib
+    return lib
+
+
+def set_threads(n: int):
+    load().oracle_set_threads(C.c_int(n))
+
+
+def get_threads() -> int:
+    return int(load().oracle_get_threads())
+
+
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _state(ctr=(0, 0, 0, 0), key=(0, 0)):
+    return np.array(list(ctr) + list(key), dtype=np.uint32)
+
+
+def philox(ctr, key):
+    lib = load()
+    c = np.array(ctr, dtype=np.uint32)
+    k = np.array(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib.oracle_philox4x32_10(_p(c), _p(k), _p(out))
+    return out
+
+
+def fill_dense(rows, cols, ctr=(0, 0, 0, 0), key=(0, 0), dist=0):
+    """returns (rows x cols array, next_ctr)"""
+    lib = load()
+    st = _state(ctr, key)
+    buf = np.zeros((rows, cols), dtype=np.float64, order="F")
+    lib.oracle_fill_dense_f64(C.c_int(dist), i64(rows), i64(cols), _p(buf), _p(st))
+    return buf, tuple(int(x) for x in st[:4])
+
+
+class inject_sketch:
+    """context manager: oracle drivers consume `flat` (column-major concatenation of the fills) instead of
+    generating their own sketch entries"""
+
+    def __init__(self, flat):
+        self.flat = np.ascontiguousarray(np.asarray(flat, dtype=np.float64).ravel())
+
+    def __enter__(self):
+        load().oracle_inject_sketch(_p(self.flat), i64(self.flat.size))
+        return self
+
+    def __exit__(self, *a):
+        load().oracle_inject_sketch(None, i64(0))
+
+
+def col_swap(A, idx, k=None):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    idx = np.array(idx, dtype=np.int64)
+    rc = lib.oracle_col_swap_f64(i64(m), i64(n), i64(n if k is None else k), _p(A), i64(m), _p(idx))
+    return rc, A, idx
+
+
+def col_swap_lda(buf, m, lda, n, idx):
+    """operate on a raw column-major buffer with lda > m"""
+    lib = load()
+    buf = np.array(buf, dtype=np.float64)
+    idx = np.array(idx, dtype=np.int64)
+    rc = lib.oracle_col_swap_f64(i64(m), i64(n), i64(n), _p(buf), i64(lda), _p(idx))
+    return rc, buf, idx
+
+
+def lapmt(A, idx):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    idx = np.array(idx, dtype=np.int64)
+    lib.oracle_lapmt_f64(i64(m), i64(n), _p(A), i64(m), _p(idx))
+    return A, idx
+
+
+def col_swap_int(vec, idx, k=None):
+    lib = load()
+    v = np.array(vec, dtype=np.int64)
+    idx = np.array(idx, dtype=np.int64)
+    rc = lib.oracle_col_swap_i64(i64(v.size), i64(idx.size if k is None else k), _p(v), _p(idx))
+    return rc, v, idx
+
+
+def stab(kind, A, cond_check=False):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, k = A.shape
+    rc = lib.oracle_stab_f64(C.c_int(kind), C.c_int(int(cond_check)), i64(m), i64(k), _p(A))
+    return rc, A
+
+
+def orhr_col(A, output_tau=True):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    T = np.zeros(n if output_tau else (n, n), dtype=np.float64, order="F")
+    D = np.zeros(n)
+    lib.oracle_rl_orhr_col_f64(i64(m), i64(n), _p(A), i64(m), _p(T), _p(D), C.c_int(int(output_tau)))
+    return A, T, D
+
+
+def rs(A, k, p, q, stab_kind=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    lib = load()
+    A = _f(A)
+    m, n = A.shape
+    Om = np.zeros((n, k), order="F")
+    st = _state(ctr, key)
+    rc = lib.oracle_rs_f64(i64(m), i64(n), _p(A), i64(k), i64(p), i64(q), C.c_int(stab_kind), _p(Om), _p(st))
+    return rc, Om, tuple(int(x) for x in st[:4])
+
+
+def rf(A, k, p, q, rs_stab=0, orth_kind=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    lib = load()
+    A = _f(A)
+    m, n = A.shape
+    Q = np.zeros((m, k), order="F")
+    st = _state(ctr, key)
+    rc = lib.oracle_rf_f64(i64(m), i64(n), _p(A), i64(k), i64(p), i64(q), C.c_int(rs_stab), C.c_int(orth_kind), _p(Q),
+                           _p(st))
+    return rc, Q, tuple(int(x) for x in st[:4])
+
+
+def qb(A, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=False, ctr=(0, 0, 0, 0), key=(0, 0)):
+    lib = load()
+    A = _f(A)
+    m, n = A.shape
+    Q = np.zeros((m, k), order="F")
+    BT = np.zeros((n, k), order="F")
+    kk = i64(k)
+    st = _state(ctr, key)
+    rc = lib.oracle_qb_f64(i64(m), i64(n), _p(A), C.byref(kk), i64(b_sz), dbl(tol), i64(p), i64(q), C.c_int(rs_stab),
+                           C.c_int(rf_orth), C.c_int(qb_orth), C.c_int(int(orth_check)), _p(Q), _p(BT), _p(st))
+    kf = int(kk.value)
+    return rc, kf, Q[:, :kf], BT[:, :kf], tuple(int(x) for x in st[:4])
+
+
+def rsvd(A, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=False, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """returns dict(rc, qb_rc, k, U, S, V, next_ctr); A ~= U diag(S) V^T"""
+    lib = load()
+    A = _f(A)
+    m, n = A.shape
+    U = np.zeros((m, k), order="F")
+    S = np.zeros(k)
+    V = np.zeros((n, k), order="F")
+    kk = i64(k)
+    qrc = C.c_int(0)
+    st = _state(ctr, key)
+    rc = lib.oracle_rsvd_f64(i64(m), i64(n), _p(A), C.byref(kk), i64(b_sz), dbl(tol), i64(p), i64(q), C.c_int(rs_stab),
+                             C.c_int(rf_orth), C.c_int(qb_orth), C.c_int(int(orth_check)), _p(U), _p(S), _p(V), _p(st),
+                             C.byref(qrc))
+    kf = int(kk.value)
+    return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:, :kf], S=S[:kf], V=V[:, :kf],
+                next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def cqrrpt(A, A_hat, eps_user):
+    """A (m x n) and the precomputed sketch A_hat (d x n).  returns dict(rc, rank, Q, R, J)"""
+    lib = load()
+    A = _f(A).copy(order="F")
+    A_hat = _f(A_hat).copy(order="F")
+    m, n = A.shape
+    d = A_hat.shape[0]
+    R = np.zeros((n, n), order="F")
+    J = np.zeros(n, dtype=np.int64)
+    rank = i64(0)
+    rc = lib.oracle_cqrrpt_f64(i64(m), i64(n), _p(A), i64(m), _p(R), i64(n), _p(J), i64(d), _p(A_hat), dbl(eps_user),
+                               C.byref(rank))
+    return dict(rc=rc, rank=int(rank.value), Q=A, R=R, J=J)
+
+
+def gesdd(A):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    k = min(m, n)
+    S = np.zeros(k)
+    U = np.zeros((m, k), order="F")
+    VT = np.zeros((k, n), order="F")
+    info = lib.oracle_gesdd_f64(C.c_char(b"S"), i64(m), i64(n), _p(A), i64(m), _p(S), _p(U), i64(m), _p(VT), i64(k))
+    return info, U, S, VT
+
+
+def geqp3(A):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    J = np.zeros(n, dtype=np.int64)
+    tau = np.zeros(min(m, n))
+    info = lib.oracle_geqp3_f64(i64(m), i64(n), _p(A), i64(m), _p(J), _p(tau))
+    return info, A, J, tau

@@ -1,0 +1,97 @@
+"""ctypes binding of librlhip.so (the C ABI declared in include/rlhip.h).
+
+Plumbing only: PyTorch supplies device memory and the HIP stream; every FLOP on the path is executed by
+the hand-written HIP kernels inside librlhip.so.  There is deliberately NO fallback: if the shared
+library is missing or a symbol cannot be resolved this module raises at import/load time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "librlhip.so"
+
+c_i64 = C.c_int64
+c_int = C.c_int
+c_char = C.c_char
+c_dbl = C.c_double
+c_flt = C.c_float
+c_vp = C.c_void_p
+c_sz = C.c_size_t
+u32p = C.POINTER(C.c_uint32)
+
+
+def _blas3(T):
+    return {
+        "gemm": [c_vp, c_char, c_char, c_i64, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64, T, c_vp, c_i64],
+        "syrk": [c_vp, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, T, c_vp, c_i64],
+        "trsm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
+        "trmm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
+        "potrf": [c_vp, c_char, c_i64, c_vp, c_i64],
+        "lange_fro": [c_vp, c_i64, c_i64, c_vp, c_i64, C.POINTER(T)],
+        "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
+        "laset": [c_vp, c_char, c_i64, c_i64, T, T, c_vp, c_i64],
+        "gesvdj": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, C.POINTER(c_int)],
+        "fill_dense": [c_vp, c_int, c_i64, c_i64, c_vp, u32p, u32p, u32p],
+    }
+
+
+# name -> (restype, argtypes); every symbol include/rlhip.h declares must appear here
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "rlhip_version": (C.c_char_p, []),
+    "rlhip_create": (c_int, [C.POINTER(c_vp), c_int, c_vp, c_int]),
+    "rlhip_destroy": (c_int, [c_vp]),
+    "rlhip_sync": (c_int, [c_vp]),
+    "rlhip_stream": (c_vp, [c_vp]),
+    "rlhip_malloc": (c_int, [c_vp, C.POINTER(c_vp), c_sz]),
+    "rlhip_free": (c_int, [c_vp, c_vp]),
+    "rlhip_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "rlhip_memcpy_d2h": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "rlhip_memcpy_d2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
+    "rlhip_memset": (c_int, [c_vp, c_vp, c_int, c_sz]),
+    "rlhip_reserve_workspace": (c_int, [c_vp, c_sz]),
+    "rlhip_workspace_highwater": (c_sz, [c_vp]),
+    "rlhip_timer_start": (c_int, [c_vp]),
+    "rlhip_timer_stop_ms": (c_int, [c_vp, C.POINTER(c_flt)]),
+    "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
+    "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
+    "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
+}
+for _suf, _T in (("f64", c_dbl), ("f32", c_flt)):
+    for _name, _args in _blas3(_T).items():
+        SIGNATURES[f"rlhip_{_name}_{_suf}"] = (c_int, _args)
+
+_lib = None
+
+
+def load():
+    """Load librlhip.so, building nothing.  Raises if it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). randlapack_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH), mode=os.RTLD_GLOBAL if hasattr(os, "RTLD_GLOBAL") else C.DEFAULT_MODE)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the binding drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class RlhipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> int:
+    """Negative return codes are argument / runtime errors -> raise.  Positive codes (LAPACK info) pass through."""
+    if rc < 0:
+        raise RlhipError(f"{what} failed with code {rc}")
+    return rc

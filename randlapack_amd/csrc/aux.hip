@@ -1,0 +1,140 @@
+// HBM-bound helper kernels: norms, copies, fills.  Lanes always run along the contiguous (row)
+// direction of the column-major operands so every wavefront touches whole 512-byte segments.
+#include "rlhip_internal.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-level sum, result valid in thread 0
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* smem /* NT/64 elements */) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) smem[w] = v;
+    __syncthreads();
+    T s = 0;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NT / 64; ++i) s += smem[i];
+    }
+    __syncthreads();
+    return s;
+}
+
+// stage 1: one partial sum of squares per block (fixed grid -> deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void ssq_partial_kernel(int64_t m, int64_t n, const T* __restrict__ A,
+                                                          int64_t lda, double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double acc = 0;
+    // each block walks columns in a strided fashion; threads walk rows
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        const T* col = A + j * lda;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            double v = (double)col[i];
+            acc += v * v;
+        }
+    }
+    double s = block_sum<double, 256>(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void ssq_final_kernel(int np, const double* __restrict__ partial,
+                                                        double* __restrict__ out) {
+    __shared__ double sm[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    double s = block_sum<double, 256>(acc, sm);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lacpy_kernel(int uplo, int64_t m, int64_t n, const T* __restrict__ A,
+                                                    int64_t lda, T* __restrict__ B, int64_t ldb) {
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            bool ok = (uplo == 2) || (uplo == 0 && i <= j) || (uplo == 1 && i >= j);
+            if (ok) B[i + j * ldb] = A[i + j * lda];
+        }
+    }
+}
+
+// LAPACK laset semantics: 'U' sets the strictly upper part to offd, 'L' the strictly lower part, 'G'
+// everything; the first min(m,n) diagonal entries are set to diag in all three cases.
+template <typename T>
+__global__ __launch_bounds__(256) void laset_kernel(int uplo, int64_t m, int64_t n, T offd, T diag,
+                                                    T* __restrict__ A, int64_t lda) {
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            if (i == j) A[i + j * lda] = diag;
+            else if (uplo == 2 || (uplo == 0 && i < j) || (uplo == 1 && i > j)) A[i + j * lda] = offd;
+        }
+    }
+}
+
+inline dim3 grid2d(int64_t m, int64_t n) {
+    int64_t gx = (m + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    int64_t gy = n;
+    if (gy > 1024) gy = 1024;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
+}  // namespace
+
+namespace rlhip {
+
+template <typename T>
+int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* result_host) {
+    if (m < 0) return -2;
+    if (n < 0) return -3;
+    if (m == 0 || n == 0) { *result_host = T(0); return 0; }
+    dim3 grid = grid2d(m, n);
+    int np = (int)(grid.x * grid.y);
+    size_t mark = rlhip_ws_mark(c);
+    double* partial = ws_alloc<double>(c, np);
+    if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    hipLaunchKernelGGL(ssq_partial_kernel<T>, grid, dim3(256), 0, c->stream, m, n, A, lda, partial);
+    RLHIP_LAUNCH_CHECK();
+    double* d_out = (double*)c->d_mail;
+    hipLaunchKernelGGL(ssq_final_kernel, dim3(1), dim3(256), 0, c->stream, np, partial, d_out);
+    RLHIP_LAUNCH_CHECK();
+    RLHIP_CHECK(hipMemcpyAsync(c->h_mail, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    rlhip_ws_release(c, mark);
+    double ssq = *(double*)c->h_mail;
+    *result_host = (T)sqrt(ssq);
+    return 0;
+}
+
+template <typename T>
+int lacpy(rlhip_ctx* c, int uplo, int64_t m, int64_t n, const T* A, int64_t lda, T* B, int64_t ldb) {
+    if (m <= 0 || n <= 0) return 0;
+    hipLaunchKernelGGL(lacpy_kernel<T>, grid2d(m, n), dim3(256), 0, c->stream, uplo, m, n, A, lda, B, ldb);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int laset(rlhip_ctx* c, int uplo, int64_t m, int64_t n, T offd, T diag, T* A, int64_t lda) {
+    if (m <= 0 || n <= 0) return 0;
+    hipLaunchKernelGGL(laset_kernel<T>, grid2d(m, n), dim3(256), 0, c->stream, uplo, m, n, offd, diag, A, lda);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template int lange_fro<double>(rlhip_ctx*, int64_t, int64_t, const double*, int64_t, double*);
+template int lange_fro<float>(rlhip_ctx*, int64_t, int64_t, const float*, int64_t, float*);
+template int lacpy<double>(rlhip_ctx*, int, int64_t, int64_t, const double*, int64_t, double*, int64_t);
+template int lacpy<float>(rlhip_ctx*, int, int64_t, int64_t, const float*, int64_t, float*, int64_t);
+template int laset<double>(rlhip_ctx*, int, int64_t, int64_t, double, double, double*, int64_t);
+template int laset<float>(rlhip_ctx*, int, int64_t, int64_t, float, float, float*, int64_t);
+
+}  // namespace rlhip

@@ -1,0 +1,313 @@
+// extern "C" surface of librlhip.so (declared in include/rlhip.h) + context / scratch-arena management.
+#include "rlhip_internal.h"
+#include "../../include/rlhip.h"
+#include <cstring>
+#include <cstdlib>
+
+namespace rlhip {
+int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]);
+}
+
+// ------------------------------------------------------------------ scratch arena
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    if (c->ws_off + bytes <= c->ws_bytes) {
+        void* p = c->ws + c->ws_off;
+        c->ws_off += bytes;
+        if (c->ws_off > c->ws_highwater) c->ws_highwater = c->ws_off;
+        return p;
+    }
+    // arena exhausted: serve from a dedicated allocation now, grow the arena at release time
+    if (c->n_overflow >= 64) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    c->overflow[c->n_overflow++] = p;
+    c->ws_off += bytes;  // virtual accounting so the high-water mark reflects the true need
+    if (c->ws_off > c->ws_highwater) c->ws_highwater = c->ws_off;
+    return p;
+}
+
+size_t rlhip_ws_mark(rlhip_ctx* c) { return c->ws_off; }
+
+void rlhip_ws_release(rlhip_ctx* c, size_t mark) {
+    c->ws_off = mark;
+    if (mark == 0 && c->n_overflow > 0) {
+        // all scratch users are done: drop the overflow blocks and regrow the arena to the high-water mark
+        hipStreamSynchronize(c->stream);
+        for (int i = 0; i < c->n_overflow; ++i) hipFree(c->overflow[i]);
+        c->n_overflow = 0;
+        if (c->ws) hipFree(c->ws);
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+        size_t want = align_up(c->ws_highwater + (c->ws_highwater >> 3), 1 << 20);
+        if (hipMalloc((void**)&c->ws, want) == hipSuccess) c->ws_bytes = want;
+    }
+}
+
+extern "C" {
+
+const char* rlhip_version(void) { return "rlhip 0.1 (gfx950)"; }
+
+int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) {
+    if (!out) return -1;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[rlhip] no HIP device visible (%s)\n", hipGetErrorString(e));
+        return RLHIP_ERR_HIP(e == hipSuccess ? hipErrorNoDevice : e);
+    }
+    if (device < 0 || device >= ndev) return -2;
+    RLHIP_CHECK(hipSetDevice(device));
+    rlhip_ctx* c = new rlhip_ctx();
+    c->device = device;
+    if (!own_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->owns_stream = false;
+    } else {
+        RLHIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->owns_stream = true;
+    }
+    RLHIP_CHECK(hipHostMalloc((void**)&c->h_mail, 64 * sizeof(int64_t), hipHostMallocDefault));
+    RLHIP_CHECK(hipMalloc((void**)&c->d_mail, 64 * sizeof(int64_t)));
+    RLHIP_CHECK(hipEventCreate(&c->ev0));
+    RLHIP_CHECK(hipEventCreate(&c->ev1));
+    c->ws_bytes = (size_t)64 << 20;
+    RLHIP_CHECK(hipMalloc((void**)&c->ws, c->ws_bytes));
+    *out = c;
+    return 0;
+}
+
+int rlhip_destroy(rlhip_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->n_overflow; ++i) hipFree(c->overflow[i]);
+    if (c->ws) hipFree(c->ws);
+    if (c->d_mail) hipFree(c->d_mail);
+    if (c->h_mail) hipHostFree(c->h_mail);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->owns_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int rlhip_sync(rlhip_ctx* c) { RLHIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
+void* rlhip_stream(rlhip_ctx* c) { return (void*)c->stream; }
+
+int rlhip_malloc(rlhip_ctx* c, void** p, size_t bytes) {
+    RLHIP_CHECK(hipSetDevice(c->device));
+    RLHIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
+    return 0;
+}
+int rlhip_free(rlhip_ctx* c, void* p) {
+    if (!p) return 0;
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(hipFree(p));
+    return 0;
+}
+int rlhip_memcpy_h2d(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    RLHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int rlhip_memcpy_d2h(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    RLHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int rlhip_memcpy_d2d(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
+    RLHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int rlhip_memset(rlhip_ctx* c, void* dst, int byte, size_t bytes) {
+    RLHIP_CHECK(hipMemsetAsync(dst, byte, bytes, c->stream));
+    return 0;
+}
+int rlhip_reserve_workspace(rlhip_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return 0;
+    if (c->ws_off != 0) return -2;  // only legal between top-level calls
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->ws) RLHIP_CHECK(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    bytes = align_up(bytes, 1 << 20);
+    RLHIP_CHECK(hipMalloc((void**)&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return 0;
+}
+size_t rlhip_workspace_highwater(rlhip_ctx* c) { return c->ws_highwater; }
+
+int rlhip_timer_start(rlhip_ctx* c) { RLHIP_CHECK(hipEventRecord(c->ev0, c->stream)); return 0; }
+int rlhip_timer_stop_ms(rlhip_ctx* c, float* ms) {
+    RLHIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    RLHIP_CHECK(hipEventSynchronize(c->ev1));
+    RLHIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+// ------------------------------------------------------------------ RNG
+int rlhip_philox4x32_10(rlhip_ctx* c, int64_t nblocks, uint32_t* out_dev, const uint32_t ctr[4],
+                        const uint32_t key[2]) {
+    return rlhip::philox_raw(c, nblocks, out_dev, ctr, key);
+}
+int rlhip_fill_dense_f64(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, double* buf, const uint32_t ctr[4],
+                         const uint32_t key[2], uint32_t next_ctr[4]) {
+    return rlhip::fill_dense<double>(c, dist, rows, cols, buf, ctr, key, next_ctr);
+}
+int rlhip_fill_dense_f32(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, float* buf, const uint32_t ctr[4],
+                         const uint32_t key[2], uint32_t next_ctr[4]) {
+    return rlhip::fill_dense<float>(c, dist, rows, cols, buf, ctr, key, next_ctr);
+}
+
+// ------------------------------------------------------------------ BLAS-3
+static inline int op_flag(char t, int* out) {
+    if (t == 'N' || t == 'n') { *out = 0; return 0; }
+    if (t == 'T' || t == 't' || t == 'C' || t == 'c') { *out = 1; return 0; }
+    return 1;
+}
+
+#define RLHIP_DEFINE_BLAS3(SUF, T)                                                                              \
+    int rlhip_gemm_##SUF(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, int64_t k, T alpha, const T* A,  \
+                         int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {                     \
+        int fa, fb;                                                                                             \
+        if (op_flag(ta, &fa)) return -2;                                                                        \
+        if (op_flag(tb, &fb)) return -3;                                                                        \
+        return rlhip::gemm<T>(c, fa, fb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);                          \
+    }                                                                                                           \
+    int rlhip_syrk_##SUF(rlhip_ctx* c, char uplo, char trans, int64_t n, int64_t k, T alpha, const T* A,        \
+                         int64_t lda, T beta, T* C, int64_t ldc) {                                              \
+        int ft;                                                                                                 \
+        if (uplo != 'U' && uplo != 'u') return -2;                                                              \
+        if (op_flag(trans, &ft)) return -3;                                                                     \
+        return rlhip::syrk<T>(c, rlhip::Upper, ft, n, k, alpha, A, lda, beta, C, ldc);                           \
+    }                                                                                                           \
+    int rlhip_trsm_##SUF(rlhip_ctx* c, char side, char uplo, char trans, char diag, int64_t m, int64_t n,       \
+                         T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {                                 \
+        if (side != 'R' && side != 'r') return -2;                                                              \
+        if (uplo != 'U' && uplo != 'u') return -3;                                                              \
+        if (trans != 'N' && trans != 'n') return -4;                                                            \
+        int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
+        return rlhip::trsm_right_upper<T>(c, fd, m, n, alpha, A, lda, B, ldb);                                   \
+    }                                                                                                           \
+    int rlhip_trmm_##SUF(rlhip_ctx* c, char side, char uplo, char trans, char diag, int64_t m, int64_t n,       \
+                         T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {                                 \
+        if (side != 'R' && side != 'r') return -2;                                                              \
+        if (uplo != 'U' && uplo != 'u') return -3;                                                              \
+        if (trans != 'N' && trans != 'n') return -4;                                                            \
+        int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
+        return rlhip::trmm_right_upper<T>(c, fd, m, n, alpha, A, lda, B, ldb);                                   \
+    }                                                                                                           \
+    int rlhip_potrf_##SUF(rlhip_ctx* c, char uplo, int64_t n, T* A, int64_t lda) {                              \
+        if (uplo != 'U' && uplo != 'u') return -2;                                                              \
+        int info = 0;                                                                                           \
+        int rc = rlhip::potrf_upper<T>(c, n, A, lda, &info);                                                     \
+        return rc ? rc : info;                                                                                  \
+    }                                                                                                           \
+    int rlhip_lange_fro_##SUF(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* res) {            \
+        return rlhip::lange_fro<T>(c, m, n, A, lda, res);                                                        \
+    }                                                                                                           \
+    int rlhip_lacpy_##SUF(rlhip_ctx* c, char uplo, int64_t m, int64_t n, const T* A, int64_t lda, T* B,         \
+                          int64_t ldb) {                                                                        \
+        int u = (uplo == 'U' || uplo == 'u') ? 0 : (uplo == 'L' || uplo == 'l') ? 1 : 2;                        \
+        return rlhip::lacpy<T>(c, u, m, n, A, lda, B, ldb);                                                      \
+    }                                                                                                           \
+    int rlhip_laset_##SUF(rlhip_ctx* c, char uplo, int64_t m, int64_t n, T offd, T diag, T* A, int64_t lda) {   \
+        int u = (uplo == 'U' || uplo == 'u') ? 0 : (uplo == 'L' || uplo == 'l') ? 1 : 2;                        \
+        return rlhip::laset<T>(c, u, m, n, offd, diag, A, lda);                                                  \
+    }                                                                                                           \
+    int rlhip_gesvdj_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* VT, int64_t ldvt,    \
+                           int* sweeps) {                                                                       \
+        return rlhip::gesvdj<T>(c, m, n, A, lda, S, VT, ldvt, sweeps);                                           \
+    }
+
+RLHIP_DEFINE_BLAS3(f64, double)
+RLHIP_DEFINE_BLAS3(f32, float)
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ microbenchmarks
+namespace {
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma_peak_f64_kernel(int iters, double* out) {
+    d4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+    double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a4, 0, 0, 0);
+        a5 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a5, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a6, 0, 0, 0);
+        a7 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a7, 0, 0, 0);
+    }
+    d4_t s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (s[0] == 12345.678) out[0] = s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(256) void mfma_peak_f32_kernel(int iters, float* out) {
+    f4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+    float x = 1.0f + threadIdx.x * 1e-6f, y = 1.0f - threadIdx.x * 1e-6f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a3, 0, 0, 0);
+        a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a4, 0, 0, 0);
+        a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a5, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a6, 0, 0, 0);
+        a7 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a7, 0, 0, 0);
+    }
+    f4_t s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (s[0] == 12345.678f) out[0] = s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(256) void hbm_read_kernel(const double2* __restrict__ p, size_t n16, double* out) {
+    double acc = 0;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        double2 v = p[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+}  // namespace
+
+extern "C" int rlhip_mfma_peak(rlhip_ctx* c, int is_f64, int iters, double* tflops) {
+    const int blocks = 256 * 8, threads = 256;  // 2 waves per SIMD
+    double* d = (double*)c->d_mail;
+    for (int rep = 0; rep < 2; ++rep) {
+        RLHIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        if (is_f64)
+            hipLaunchKernelGGL(mfma_peak_f64_kernel, dim3(blocks), dim3(threads), 0, c->stream, iters, d);
+        else
+            hipLaunchKernelGGL(mfma_peak_f32_kernel, dim3(blocks), dim3(threads), 0, c->stream, iters, (float*)d);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        RLHIP_CHECK(hipEventSynchronize(c->ev1));
+    }
+    float ms = 0;
+    RLHIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return 0;
+}
+
+extern "C" int rlhip_hbm_read_peak(rlhip_ctx* c, const void* buf, size_t bytes, double* gbps) {
+    size_t n16 = bytes / 16;
+    double* d = (double*)c->d_mail;
+    for (int rep = 0; rep < 2; ++rep) {
+        RLHIP_CHECK(hipEventRecord(c->ev0, c->stream));
+        hipLaunchKernelGGL(hbm_read_kernel, dim3(256 * 16), dim3(256), 0, c->stream, (const double2*)buf, n16, d);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipEventRecord(c->ev1, c->stream));
+        RLHIP_CHECK(hipEventSynchronize(c->ev1));
+    }
+    float ms = 0;
+    RLHIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *gbps = (double)(n16 * 16) / (ms * 1e-3) / 1e9;
+    return 0;
+}

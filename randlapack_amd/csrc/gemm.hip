@@ -1,0 +1,476 @@
+// MFMA GEMM family for gfx950 (MI355X):  C = alpha * op(A) * op(B) + beta * C,  column-major.
+//
+// Replaces, on the sketch-and-factor hot path, every blas::gemm the reference issues
+// (RandLAPACK/comps/rl_rs.hh:142,153,165; rl_rf.hh:123; rl_qb.hh:210-218,260; drivers/rl_rsvd.hh:148)
+// and serves as the engine underneath syrk / trsm / trmm / larfb in this library.
+//
+// Design (CDNA4-first, not a cuBLAS call pattern):
+//  * v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, one 64x64 (or 64x32 / 64x16) output tile per
+//    64-lane wavefront, accumulators resident in the unified VGPR/AGPR file.
+//  * The MFMA "A" operand is fed with op(B) and the MFMA "B" operand with op(A), so each lane's D
+//    elements lie along the contiguous (row) direction of column-major C -> 128-byte store segments.
+//  * op(A) / op(B) tiles are staged through LDS with paddings chosen for conflict-free ds_read_b64
+//    fragment reads (see lds strides below); global loads are 16-byte, coalesced along whichever index
+//    is contiguous in memory for that operand ("MC" = tile-row index contiguous, "KC" = reduction
+//    index contiguous).
+//  * register prefetch of tile t+1 while tile t is multiplied, double-buffered LDS, ONE barrier per
+//    K-tile.
+//  * tall reductions (A^T*Q, Gram matrices) use a deterministic split-K: each K-slice writes a slab
+//    to scratch and a second kernel sums the slabs in fixed order (bitwise reproducible run to run,
+//    unlike atomics).
+#include "rlhip_internal.h"
+
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<double> {
+    using acc_t = d4_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // f64 D layout: col = lane & 15, row = (lane >> 4) + 4 * r
+    static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mma<float> {
+    using acc_t = f4_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // f32 D layout: col = lane & 15, row = 4 * (lane >> 4) + r
+    static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename T>
+struct GemmArgs {
+    int64_t M, N, K;
+    const T* A;
+    int64_t lda;
+    const T* B;
+    int64_t ldb;
+    T* C;
+    int64_t ldc;
+    T alpha, beta;
+    int64_t kchunk;  // K extent handled by one z-slice (multiple of BK)
+    T* slab;         // split-K scratch (M*N per z-slice) or nullptr
+    int tri;         // 0: all tiles; 1: skip tiles strictly below the diagonal (syrk upper, M==N, BM==BN)
+};
+
+constexpr int PADM = 16;  // MC tile: row stride (R + 16) elements -> (R+16) % 32 == 16 for R % 32 == 0
+template <typename T>
+struct PadK {
+    static constexpr int v = 2;  // KC tile, f64: stride BK+2 == 18 -> i*18 + kq distinct mod 32
+};
+template <>
+struct PadK<float> {
+    static constexpr int v = 4;  // keep 16-byte alignment of 4-float chunks
+};
+
+template <typename T, int ROWS, int BK, bool KC>
+struct TileGeom {
+    static constexpr int V = 16 / (int)sizeof(T);
+    static constexpr int stride = KC ? (BK + PadK<T>::v) : (ROWS + PADM);
+    static constexpr int elems = KC ? ROWS * stride : BK * stride;
+};
+
+// Loads one operand tile (ROWS x BK logical, element (r, kk)) into registers.
+// KC: element (r,kk) at g[kk + r*ld]   MC: element (r,kk) at g[r + kk*ld]
+template <typename T, int ROWS, int BK, int NT>
+struct RegCnt {
+    static constexpr int V = 16 / (int)sizeof(T);
+    static constexpr int TCH = ROWS * BK / V;            // 16-byte chunks in the tile
+    static constexpr int NCH = (TCH + NT - 1) / NT;      // chunks per thread (last may be idle)
+    static constexpr int n = NCH * V;
+};
+
+template <typename T, int ROWS, int BK, bool KC, int NT, bool VEC, bool CHECK>
+__device__ __forceinline__ void tile_gload(T* reg, const T* __restrict__ g,
+                                           int64_t ld, int64_t r0, int64_t k0, int64_t rmax, int64_t kmax,
+                                           int tid) {
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int NCH = RegCnt<T, ROWS, BK, NT>::NCH;
+    constexpr int TCH = RegCnt<T, ROWS, BK, NT>::TCH;
+    constexpr int CPL = KC ? (BK / V) : (ROWS / V);  // chunks per contiguous line
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        int c = tid + u * NT;
+        if (TCH % NT != 0 && c >= TCH) break;
+        int line = c / CPL;
+        int off = (c % CPL) * V;
+        int64_t r = KC ? (int64_t)line : (int64_t)off;
+        int64_t kk = KC ? (int64_t)off : (int64_t)line;
+        const T* p = KC ? (g + (k0 + kk) + (r0 + r) * ld) : (g + (r0 + r) + (k0 + kk) * ld);
+        if (VEC && !CHECK) {
+            typedef T vec_t __attribute__((ext_vector_type(V)));
+            vec_t v = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+            for (int e = 0; e < V; ++e) reg[u * V + e] = v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                int64_t rr = KC ? (r0 + r) : (r0 + r + e);
+                int64_t kq = KC ? (k0 + kk + e) : (k0 + kk);
+                bool ok = !CHECK || (rr < rmax && kq < kmax);
+                reg[u * V + e] = ok ? p[e] : T(0);
+            }
+        }
+    }
+}
+
+template <typename T, int ROWS, int BK, bool KC, int NT>
+__device__ __forceinline__ void tile_sstore(const T* reg, T* __restrict__ s,
+                                            int tid) {
+    constexpr int V = 16 / (int)sizeof(T);
+    constexpr int NCH = RegCnt<T, ROWS, BK, NT>::NCH;
+    constexpr int TCH = RegCnt<T, ROWS, BK, NT>::TCH;
+    constexpr int CPL = KC ? (BK / V) : (ROWS / V);
+    constexpr int stride = TileGeom<T, ROWS, BK, KC>::stride;
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+        int c = tid + u * NT;
+        if (TCH % NT != 0 && c >= TCH) break;
+        int line = c / CPL;
+        int off = (c % CPL) * V;
+        vec_t v;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = reg[u * V + e];
+        *reinterpret_cast<vec_t*>(s + line * stride + off) = v;
+    }
+}
+
+// fragment read: element (r, kk) of the staged tile
+template <typename T, int ROWS, int BK, bool KC>
+__device__ __forceinline__ T tile_frag(const T* __restrict__ s, int r, int kk) {
+    constexpr int stride = TileGeom<T, ROWS, BK, KC>::stride;
+    return KC ? s[r * stride + kk] : s[kk * stride + r];
+}
+
+template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, bool VEC>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs<T> g) {
+    constexpr int NWM = BM / WM, NWN = BN / WN;
+    constexpr int NT = NWM * NWN * 64;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    using GA = TileGeom<T, BM, BK, A_KC>;
+    using GB = TileGeom<T, BN, BK, B_KC>;
+    using acc_t = typename Mma<T>::acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sA0 = reinterpret_cast<T*>(smem_raw);
+    T* sB0 = sA0 + 2 * GA::elems;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm0 = (wid % NWM) * WM;
+    const int wn0 = (wid / NWM) * WN;
+
+    const int64_t tile_m = blockIdx.x, tile_n = blockIdx.y;
+    if (g.tri && tile_m > tile_n) return;
+    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
+    const int64_t kend = (kbeg + g.kchunk < g.K) ? (kbeg + g.kchunk) : g.K;
+    const int64_t nk = (kend - kbeg + BK - 1) / BK;
+
+    const bool full_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = acc_t{0, 0, 0, 0};
+
+    T ra[RegCnt<T, BM, BK, NT>::n];
+    T rb[RegCnt<T, BN, BK, NT>::n];
+
+    auto gload = [&](int64_t kt) {
+        const int64_t k0 = kbeg + kt * BK;
+        const bool full = full_mn && (k0 + BK <= kend);
+        if (full) {
+            tile_gload<T, BM, BK, A_KC, NT, VEC, false>(ra, g.A, g.lda, m0, k0, g.M, kend, tid);
+            tile_gload<T, BN, BK, B_KC, NT, VEC, false>(rb, g.B, g.ldb, n0, k0, g.N, kend, tid);
+        } else {
+            tile_gload<T, BM, BK, A_KC, NT, VEC, true>(ra, g.A, g.lda, m0, k0, g.M, kend, tid);
+            tile_gload<T, BN, BK, B_KC, NT, VEC, true>(rb, g.B, g.ldb, n0, k0, g.N, kend, tid);
+        }
+    };
+
+    if (nk > 0) {
+        gload(0);
+        tile_sstore<T, BM, BK, A_KC, NT>(ra, sA0, tid);
+        tile_sstore<T, BN, BK, B_KC, NT>(rb, sB0, tid);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15;  // index inside a 16-tile
+    const int fk = lane >> 4;  // k offset inside a 4-step
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        const T* sA = sA0 + cur * GA::elems;
+        const T* sB = sB0 + cur * GB::elems;
+        const bool more = (kt + 1 < nk);
+        if (more) gload(kt + 1);
+
+#pragma unroll
+        for (int s = 0; s < BK / 4; ++s) {
+            T af[TM], bf[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) af[t] = tile_frag<T, BM, BK, A_KC>(sA, wm0 + 16 * t + fr, 4 * s + fk);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) bf[u] = tile_frag<T, BN, BK, B_KC>(sB, wn0 + 16 * u + fr, 4 * s + fk);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) acc[t][u] = Mma<T>::mma(bf[u], af[t], acc[t][u]);
+        }
+
+        if (more) {
+            T* nA = sA0 + (cur ^ 1) * GA::elems;
+            T* nB = sB0 + (cur ^ 1) * GB::elems;
+            tile_sstore<T, BM, BK, A_KC, NT>(ra, nA, tid);
+            tile_sstore<T, BN, BK, B_KC, NT>(rb, nB, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue. lane owns C[i = fr][j = drow(lane, r)] of each 16x16 tile.
+    if (g.slab) {
+        T* out = g.slab + (int64_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int64_t i = m0 + wm0 + 16 * t + fr;
+                    int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
+                    if (i < g.M && j < g.N) out[i + j * g.M] = acc[t][u][r];
+                }
+    } else {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int64_t i = m0 + wm0 + 16 * t + fr;
+                    int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
+                    if (i < g.M && j < g.N) {
+                        T v = g.alpha * acc[t][u][r];
+                        if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
+                        g.C[i + j * g.ldc] = v;
+                    }
+                }
+    }
+}
+
+// sums split-K slabs in fixed z order: C = alpha * sum_z slab[z] + beta * C
+template <typename T>
+__global__ void splitk_reduce_kernel(int64_t M, int64_t N, int nz, const T* __restrict__ slab, T alpha, T beta,
+                                     T* __restrict__ C, int64_t ldc, int tri, int tile) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = M * N;
+    for (; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = idx % M, j = idx / M;
+        if (tri && (i / tile) > (j / tile)) continue;
+        T s = 0;
+        for (int z = 0; z < nz; ++z) s += slab[(int64_t)z * total + idx];
+        T v = alpha * s;
+        if (beta != T(0)) v += beta * C[i + j * ldc];
+        C[i + j * ldc] = v;
+    }
+}
+
+template <typename T>
+__global__ void scale_kernel(int64_t M, int64_t N, T beta, T* __restrict__ C, int64_t ldc) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = M * N;
+    for (; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = idx % M, j = idx / M;
+        C[i + j * ldc] = (beta == T(0)) ? T(0) : beta * C[i + j * ldc];
+    }
+}
+
+template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN>
+int launch_cfg(rlhip_ctx* c, GemmArgs<T>& g, bool vec, int64_t splitk) {
+    using GA = TileGeom<T, BM, BK, A_KC>;
+    using GB = TileGeom<T, BN, BK, B_KC>;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr size_t smem = 2 * (size_t)(GA::elems + GB::elems) * sizeof(T);
+    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN), (unsigned)splitk);
+    auto kv = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, true>;
+    auto ks = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, false>;
+    static bool attr_set_v = false, attr_set_s = false;
+    if (vec) {
+        if (!attr_set_v) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set_v = true;
+        }
+        hipLaunchKernelGGL(kv, grid, dim3(NT), smem, c->stream, g);
+    } else {
+        if (!attr_set_s) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set_s = true;
+        }
+        hipLaunchKernelGGL(ks, grid, dim3(NT), smem, c->stream, g);
+    }
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+constexpr int NUM_CU = 256;
+
+template <typename T, bool A_KC, bool B_KC>
+int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
+    constexpr int BK = 16;
+    const int64_t M = g.M, N = g.N, K = g.K;
+    constexpr int V = 16 / (int)sizeof(T);
+    // 16-byte vector loads need aligned bases, leading dimensions multiple of V and (for MC tiles) no
+    // ragged start; tile origins are multiples of 16 already.
+    bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % V == 0) && (g.ldb % V == 0);
+
+    // tile shape by N (the narrow dimension on this path), then split-K to fill 256 CUs
+    int cfg;
+    int64_t bm, bn;
+    if (N > 128 && !tri) { cfg = 0; bm = 128; bn = 256; }
+    else if (N > 64 || tri) { cfg = 1; bm = 128; bn = 128; }
+    else if (N > 32) { cfg = 2; bm = 256; bn = 64; }
+    else if (N > 16) { cfg = 3; bm = 256; bn = 32; }
+    else { cfg = 4; bm = 256; bn = 16; }
+
+    int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tri) { int64_t tn = (N + bn - 1) / bn; tiles = tn * (tn + 1) / 2; }
+    int64_t ktiles = (K + BK - 1) / BK;
+    // Split-K choice by a tiny time model: workgroup rounds over 256 CUs (one resident workgroup per
+    // CU at these LDS sizes) x per-slice reduction length, plus the slab write+read traffic.
+    int64_t splitk = 1;
+    {
+        const double flops_cu = 78.6e12 / NUM_CU * (sizeof(T) == 4 ? 2.0 : 1.0);
+        const double t_tile_k = 2.0 * bm * bn * BK / flops_cu;  // seconds per K-tile per workgroup
+        const double slab_bw = 4.0e12;
+        int64_t maxs = ktiles / 32;
+        if (maxs > 256) maxs = 256;
+        double best = 1e300;
+        for (int64_t s = 1; s <= (maxs < 1 ? 1 : maxs); ++s) {
+            int64_t kc = (ktiles + s - 1) / s;
+            int64_t se = (ktiles + kc - 1) / kc;  // effective slices
+            int64_t rounds = (tiles * se + NUM_CU - 1) / NUM_CU;
+            double t = rounds * (kc * t_tile_k + 2e-6);
+            if (se > 1) t += 2.0 * se * (double)M * N * sizeof(T) / slab_bw + 3e-6;
+            if ((double)se * M * N * sizeof(T) > 8e9) continue;
+            if (t < best * 0.97) { best = t; splitk = se; }
+        }
+    }
+    int64_t kchunk = ((ktiles + splitk - 1) / splitk) * BK;
+    splitk = (K + kchunk - 1) / kchunk;
+    if (splitk < 1) splitk = 1;
+    g.kchunk = kchunk;
+    g.tri = tri;
+
+    size_t mark = rlhip_ws_mark(c);
+    T alpha = g.alpha, beta = g.beta;
+    if (splitk > 1) {
+        g.slab = ws_alloc<T>(c, (size_t)splitk * M * N);
+        if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    } else {
+        g.slab = nullptr;
+    }
+
+    int rc = 0;
+    switch (cfg) {
+        case 0: rc = launch_cfg<T, A_KC, B_KC, 128, 256, BK, 64, 64>(c, g, vec, splitk); break;
+        case 1: rc = launch_cfg<T, A_KC, B_KC, 128, 128, BK, 64, 64>(c, g, vec, splitk); break;
+        case 2: rc = launch_cfg<T, A_KC, B_KC, 256, 64, BK, 64, 64>(c, g, vec, splitk); break;
+        case 3: rc = launch_cfg<T, A_KC, B_KC, 256, 32, BK, 64, 32>(c, g, vec, splitk); break;
+        default: rc = launch_cfg<T, A_KC, B_KC, 256, 16, BK, 64, 16>(c, g, vec, splitk); break;
+    }
+    if (rc) { rlhip_ws_release(c, mark); return rc; }
+
+    if (splitk > 1) {
+        int64_t total = M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, M, N, (int)splitk,
+                           g.slab, alpha, beta, g.C, g.ldc, tri, (int)bm);
+        RLHIP_LAUNCH_CHECK();
+    }
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+}  // namespace
+
+namespace rlhip {
+
+template <typename T>
+int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri) {
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0) return -5;
+    if (m == 0 || n == 0) return 0;
+    if (k == 0 || alpha == T(0)) {
+        if (beta == T(1)) return 0;
+        int64_t total = m * n;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(scale_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, m, n, beta, C, ldc);
+        RLHIP_LAUNCH_CHECK();
+        return 0;
+    }
+    int64_t arows = transA ? k : m, brows = transB ? n : k;
+    if (lda < (arows > 1 ? arows : 1)) return -8;
+    if (ldb < (brows > 1 ? brows : 1)) return -10;
+    if (ldc < (m > 1 ? m : 1)) return -13;
+    GemmArgs<T> g;
+    g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.beta = beta; g.kchunk = 0; g.slab = nullptr; g.tri = 0;
+    // op(A) element (i,kk):  NoTrans -> A[i + kk*lda] (MC);  Trans -> A[kk + i*lda] (KC)
+    // op(B) element (kk,j):  NoTrans -> B[kk + j*ldb] (KC);  Trans -> B[j + kk*ldb] (MC)
+    if (!transA && !transB) return gemm_dispatch<T, false, true>(c, g, tri);
+    if (transA && !transB) return gemm_dispatch<T, true, true>(c, g, tri);
+    if (!transA && transB) return gemm_dispatch<T, false, false>(c, g, tri);
+    return gemm_dispatch<T, true, false>(c, g, tri);
+}
+
+template <typename T>
+int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+         int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
+    return gemm_impl<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
+}
+
+// syrk: only Trans (C = alpha*A^T*A + beta*C, A is k x n) and NoTrans (C = alpha*A*A^T + beta*C, A is n x k).
+// Only tiles touching the `uplo` triangle are computed; inside diagonal tiles both halves are written
+// (the strictly-other triangle of diagonal tiles is therefore overwritten with the symmetric values --
+// callers on this path treat that part as scratch, exactly like LAPACK callers must).
+template <typename T>
+int syrk(rlhip_ctx* c, int uplo, int trans, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, T beta,
+         T* C, int64_t ldc) {
+    if (uplo != Upper) return -2;  // the path only ever asks for Upper (rl_orth.hh:78, rl_cqrrpt.hh:310)
+    if (trans) return gemm_impl<T>(c, 1, 0, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1);
+    return gemm_impl<T>(c, 0, 1, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1);
+}
+
+template int gemm<double>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
+                          const double*, int64_t, double, double*, int64_t);
+template int gemm<float>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
+                         const float*, int64_t, float, float*, int64_t);
+template int syrk<double>(rlhip_ctx*, int, int, int64_t, int64_t, double, const double*, int64_t, double,
+                          double*, int64_t);
+template int syrk<float>(rlhip_ctx*, int, int, int64_t, int64_t, float, const float*, int64_t, float, float*,
+                         int64_t);
+
+}  // namespace rlhip
+
+namespace rlhip {
+template int gemm_impl<double>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
+                               const double*, int64_t, double, double*, int64_t, int);
+template int gemm_impl<float>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
+                              const float*, int64_t, float, float*, int64_t, int);
+}  // namespace rlhip

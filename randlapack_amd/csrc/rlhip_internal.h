@@ -1,0 +1,103 @@
+// Internal (non-ABI) declarations shared by the HIP translation units of librlhip.so.
+// Everything here is MI355X / gfx950 only: 64-lane wavefronts, MFMA, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <cstdio>
+
+#define RLHIP_ERR_HIP(e) (-1000 - (int)(e))
+
+#define RLHIP_CHECK(expr)                                                     \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) {                                               \
+            fprintf(stderr, "[rlhip] %s:%d: %s -> %s\n", __FILE__, __LINE__,  \
+                    #expr, hipGetErrorString(_e));                            \
+            return RLHIP_ERR_HIP(_e);                                         \
+        }                                                                     \
+    } while (0)
+
+#define RLHIP_LAUNCH_CHECK() RLHIP_CHECK(hipGetLastError())
+
+// Execution context: one HIP stream + a growable device scratch arena + a small
+// pinned host mailbox for info codes / scalars coming back from the device.
+struct rlhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // scratch arena (bump allocator, reset per top-level call via ws_mark/ws_release)
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_off = 0;
+    // overflow blocks allocated when the arena is too small (freed + arena regrown at release)
+    void* overflow[64];
+    int n_overflow = 0;
+    size_t ws_highwater = 0;
+    // pinned mailbox
+    int64_t* h_mail = nullptr;   // 64 x int64 host-pinned
+    int64_t* d_mail = nullptr;   // 64 x int64 device
+    // timing of the most recent GEMM-family launch set (bench.py roofline leg)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+// scratch arena helpers (capi.hip)
+void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes);           // 256-B aligned, never fails softly (nullptr on OOM)
+size_t rlhip_ws_mark(rlhip_ctx* c);
+void rlhip_ws_release(rlhip_ctx* c, size_t mark);
+
+template <typename T>
+static inline T* ws_alloc(rlhip_ctx* c, size_t n) { return (T*)rlhip_ws_alloc(c, n * sizeof(T)); }
+
+// ---- typed internal entry points (implemented in the .hip files; the extern "C" ABI wraps them) ----
+namespace rlhip {
+
+enum Op : int { NoTrans = 0, Trans = 1 };
+enum Uplo : int { Upper = 0, Lower = 1 };
+enum Diag : int { NonUnit = 0, Unit = 1 };
+enum Dist : int { Gaussian = 0, UniformPM1 = 1 };
+
+template <typename T>
+int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+         int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc);
+
+// C(upper or lower) = alpha * op(A)^T-style Gram + beta*C, LAPACK syrk semantics (only `uplo` part referenced/written)
+template <typename T>
+int syrk(rlhip_ctx* c, int uplo, int trans, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+         T beta, T* C, int64_t ldc);
+
+template <typename T>
+int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host);
+
+// B <- alpha * B * inv(op(A)),  A upper triangular n x n (Side::Right, Uplo::Upper, NoTrans)
+template <typename T>
+int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda,
+                     T* B, int64_t ldb);
+
+// B <- alpha * B * A,  A upper triangular n x n (Side::Right, Uplo::Upper, NoTrans); B is m x n
+template <typename T>
+int trmm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda,
+                     T* B, int64_t ldb);
+
+template <typename T>
+int fill_dense(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, T* buf, const uint32_t ctr[4],
+               const uint32_t key[2], uint32_t next_ctr[4]);
+
+template <typename T>
+int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* result_host);
+
+template <typename T>
+int lacpy(rlhip_ctx* c, int uplo /*0 upper,1 lower,2 general*/, int64_t m, int64_t n, const T* A,
+          int64_t lda, T* B, int64_t ldb);
+
+template <typename T>
+int laset(rlhip_ctx* c, int uplo /*0 upper,1 lower,2 general*/, int64_t m, int64_t n, T offdiag, T diag,
+          T* A, int64_t lda);
+
+// one-sided Jacobi SVD of a tall m x n (m >= n) matrix: A = U diag(S) VT.
+// On exit A holds U (m x n), S descending, VT n x n (ld ldvt).
+template <typename T>
+int gesvdj(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* VT, int64_t ldvt,
+           int* sweeps_host);
+
+}  // namespace rlhip

@@ -1,0 +1,163 @@
+// Triangular solve / multiply from the right with an upper-triangular factor:
+//   trsm:  B <- alpha * B * inv(U)     (blas::trsm Side::Right, Uplo::Upper, NoTrans:
+//          RandLAPACK/comps/rl_orth.hh:95, drivers/rl_cqrrpt.hh:302,338, drivers/rl_bqrrp.hh:457,464)
+//   trmm:  B <- alpha * B * U          (blas::trmm, drivers/rl_cqrrpt.hh:345, drivers/rl_bqrrp.hh:497)
+//
+// trsm design.  Rows of B are independent in a right-side solve, so the matrix is cut into 256-row
+// slabs, one row per lane, and solved by TRUE substitution (no explicit inverse of U: on CQRRPT's
+// preconditioning step cond(U) can exceed 1e10 and an inverse-based solve would lose the
+// eps*||A|| residual the reference's tests demand).  Column blocks of width DB=256 are chained
+// left-to-right; the off-diagonal contribution of earlier blocks is one MFMA GEMM per block
+// (B_J = alpha*B_J - X_{<J} U_{<J,J}), the diagonal block is a fused kernel:
+//   * U_JJ is first packed row-major into scratch so that the values a lane needs next are wave-uniform
+//     and contiguous -> the compiler turns them into s_load_dwordx16 + SGPR operands of v_fma_f64,
+//   * 32-column sub-blocks live in registers (64 VGPRs); earlier x values of the same row are re-read
+//     from L1/L2 (coalesced: lanes = consecutive rows).
+// fp64 vector FMA and fp64 MFMA have the same peak on MI355X (78.6 TF), so the VALU diagonal kernel is
+// not a bottleneck: at k=256 it is 2*m*k^2/2 flops against 2*m*n*k for the sketch GEMM.
+#include "rlhip_internal.h"
+
+namespace rlhip {
+template <typename T>
+int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
+              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri);
+}
+
+namespace {
+
+constexpr int SB = 32;    // register sub-block
+constexpr int DB = 256;   // diagonal block handled by one fused kernel
+
+// Ut[l * ldp + c] = U[l, c] for l <= c < nb (row-major, zero below the diagonal), padded with the identity
+// up to ldp (a multiple of SB).  Diagonal entries hold the RECIPROCAL (LAPACK's dtrsm multiplies by
+// 1/A(j,j) as well), or 1 for Diag::Unit.
+template <typename T>
+__global__ void pack_upper_rows_kernel(int nb, int ldp, int unit, const T* __restrict__ U, int64_t ldu,
+                                       T* __restrict__ Ut) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ldp * ldp) return;
+    int c = idx % ldp, l = idx / ldp;
+    T v = 0;
+    if (l < nb && c < nb) {
+        if (l < c) v = U[l + (int64_t)c * ldu];
+        else if (l == c) v = unit ? T(1) : T(1) / U[l + (int64_t)c * ldu];
+    } else if (l == c) {
+        v = 1;
+    }
+    Ut[(int64_t)l * ldp + c] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_diag_kernel(int64_t m, int nb, int ldp, T alpha,
+                                                        const T* __restrict__ Ut, T* __restrict__ B,
+                                                        int64_t ldb) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = r < m;
+    const int64_t rr = live ? r : 0;  // dead lanes shadow row 0 without storing (keeps control flow uniform)
+    T* __restrict__ row = B + rr;
+    const int nsb = ldp / SB;
+    for (int sb = 0; sb < nsb; ++sb) {
+        const int c0 = sb * SB;
+        T acc[SB];
+#pragma unroll
+        for (int c = 0; c < SB; ++c) acc[c] = (c0 + c < nb) ? alpha * row[(int64_t)(c0 + c) * ldb] : T(0);
+        // contribution of the already solved columns of this diagonal block
+        for (int l = 0; l < c0; ++l) {
+            const T xl = row[(int64_t)l * ldb];
+            const T* __restrict__ u = Ut + (int64_t)l * ldp + c0;
+#pragma unroll
+            for (int c = 0; c < SB; ++c) acc[c] -= xl * u[c];
+        }
+        // triangular solve inside the sub-block
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+            const T* __restrict__ u = Ut + (int64_t)(c0 + c) * ldp + c0;
+            acc[c] *= u[c];  // reciprocal diagonal
+#pragma unroll
+            for (int c2 = c + 1; c2 < SB; ++c2) acc[c2] -= acc[c] * u[c2];
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < SB; ++c)
+                if (c0 + c < nb) row[(int64_t)(c0 + c) * ldb] = acc[c];
+        }
+    }
+}
+
+template <typename T>
+__global__ void copy_triu_kernel(int64_t n, int unit, const T* __restrict__ U, int64_t ldu, T* __restrict__ W) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t i = idx % n, j = idx / n;
+    T v = 0;
+    if (i < j) v = U[i + j * ldu];
+    else if (i == j) v = unit ? T(1) : U[i + j * ldu];
+    W[idx] = v;
+}
+
+}  // namespace
+
+namespace rlhip {
+
+template <typename T>
+int lacpy(rlhip_ctx* c, int uplo, int64_t m, int64_t n, const T* A, int64_t lda, T* B, int64_t ldb);
+
+template <typename T>
+int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B,
+                     int64_t ldb) {
+    if (m < 0) return -6;
+    if (n < 0) return -7;
+    if (lda < (n > 1 ? n : 1)) return -10;
+    if (ldb < (m > 1 ? m : 1)) return -12;
+    if (m == 0 || n == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* Ut = ws_alloc<T>(c, (size_t)DB * DB);
+    if (!Ut) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    for (int64_t j0 = 0; j0 < n; j0 += DB) {
+        int nb = (int)((n - j0 < DB) ? (n - j0) : DB);
+        int ldp = (nb + SB - 1) / SB * SB;
+        T a = alpha;
+        if (j0 > 0) {
+            // B_J = alpha * B_J - X_{<J} * U_{<J,J}
+            int rc = gemm_impl<T>(c, 0, 0, m, nb, j0, T(-1), B, ldb, A + j0 * lda, lda, alpha, B + j0 * ldb, ldb, 0);
+            if (rc) { rlhip_ws_release(c, mark); return rc; }
+            a = T(1);
+        }
+        hipLaunchKernelGGL(pack_upper_rows_kernel<T>, dim3((ldp * ldp + 255) / 256), dim3(256), 0, c->stream, nb,
+                           ldp, diag, A + j0 + j0 * lda, lda, Ut);
+        RLHIP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, nb,
+                           ldp, a, Ut, B + j0 * ldb, ldb);
+        RLHIP_LAUNCH_CHECK();
+    }
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+template <typename T>
+int trmm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B,
+                     int64_t ldb) {
+    if (m < 0) return -6;
+    if (n < 0) return -7;
+    if (lda < (n > 1 ? n : 1)) return -10;
+    if (ldb < (m > 1 ? m : 1)) return -12;
+    if (m == 0 || n == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* W = ws_alloc<T>(c, (size_t)n * n);
+    T* Bc = ws_alloc<T>(c, (size_t)m * n);
+    if (!W || !Bc) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipLaunchKernelGGL(copy_triu_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, diag, A,
+                       lda, W);
+    RLHIP_LAUNCH_CHECK();
+    int rc = lacpy<T>(c, 2, m, n, B, ldb, Bc, m);
+    if (!rc) rc = gemm_impl<T>(c, 0, 0, m, n, n, alpha, Bc, m, W, n, T(0), B, ldb, 0);
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+template int trsm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
+template int trsm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
+template int trmm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
+template int trmm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
+
+}  // namespace rlhip

@@ -1,0 +1,191 @@
+"""Thin Python handles over the rlhip C ABI for tests / bench / smoke.
+
+A column-major m x n matrix is held as a torch tensor `t` of shape (n, m), contiguous, so that
+element (i, j) is `t[j, i]` and the leading dimension is m.  `cm_from_numpy` / `cm_to_numpy` convert
+from/to ordinary (m, n) numpy arrays.  Nothing in here computes: it forwards pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_TORCH_DT = None
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _suffix(t):
+    torch = _torch()
+    if t.dtype == torch.float64:
+        return "f64", C.c_double
+    if t.dtype == torch.float32:
+        return "f32", C.c_float
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def cm_from_numpy(a: np.ndarray, device="cuda:0"):
+    """(m, n) numpy -> column-major device tensor of shape (n, m)."""
+    torch = _torch()
+    a = np.asarray(a)
+    return torch.from_numpy(np.ascontiguousarray(a.T)).to(device)
+
+
+def cm_to_numpy(t) -> np.ndarray:
+    """column-major device tensor (n, m) -> (m, n) numpy."""
+    return t.detach().cpu().numpy().T.copy()
+
+
+def cm_empty(m: int, n: int, dtype=None, device="cuda:0"):
+    torch = _torch()
+    return torch.empty((n, m), dtype=dtype or torch.float64, device=device)
+
+
+def cm_zeros(m: int, n: int, dtype=None, device="cuda:0"):
+    torch = _torch()
+    return torch.zeros((n, m), dtype=dtype or torch.float64, device=device)
+
+
+class Context:
+    """One rlhip context bound to torch's CURRENT HIP stream on `device` (so torch.cuda.Event timing and
+    torch allocations are ordered with the kernels)."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("randlapack_amd needs a HIP device (torch.cuda.is_available() is False)")
+        self.lib = _lib.load()
+        self.device = device
+        torch.cuda.set_device(device)
+        stream = torch.cuda.current_stream(device).cuda_stream if use_torch_stream else 0
+        h = C.c_void_p()
+        _lib.check(self.lib.rlhip_create(C.byref(h), device, C.c_void_p(stream), 0 if use_torch_stream else 1),
+                   "rlhip_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rlhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self.lib.rlhip_sync(self.h), "rlhip_sync")
+
+    # ---- timing on the context stream
+    def timer_start(self):
+        _lib.check(self.lib.rlhip_timer_start(self.h), "timer_start")
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.rlhip_timer_stop_ms(self.h, C.byref(ms)), "timer_stop")
+        return float(ms.value)
+
+    def reserve_workspace(self, nbytes: int):
+        _lib.check(self.lib.rlhip_reserve_workspace(self.h, nbytes), "reserve_workspace")
+
+    # ---- RNG
+    @staticmethod
+    def _u32(vals):
+        arr = (C.c_uint32 * len(vals))(*[int(v) & 0xFFFFFFFF for v in vals])
+        return arr
+
+    def philox(self, nblocks: int, ctr, key):
+        torch = _torch()
+        out = torch.empty(4 * nblocks, dtype=torch.int32, device=f"cuda:{self.device}")
+        _lib.check(
+            self.lib.rlhip_philox4x32_10(self.h, nblocks, out.data_ptr(), self._u32(ctr), self._u32(key)), "philox"
+        )
+        return out.cpu().numpy().view(np.uint32)
+
+    def fill_dense(self, buf, rows: int, cols: int, ctr=(0, 0, 0, 0), key=(0, 0), dist: int = 0):
+        suf, _ = _suffix(buf)
+        nxt = (C.c_uint32 * 4)()
+        fn = getattr(self.lib, f"rlhip_fill_dense_{suf}")
+        _lib.check(fn(self.h, dist, rows, cols, buf.data_ptr(), self._u32(ctr), self._u32(key), nxt), "fill_dense")
+        return tuple(int(x) for x in nxt)
+
+    # ---- BLAS-3 (column-major tensors, see module docstring)
+    def gemm(self, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, Cm, ldc):
+        suf, T = _suffix(Cm)
+        fn = getattr(self.lib, f"rlhip_gemm_{suf}")
+        return _lib.check(
+            fn(self.h, ta.encode(), tb.encode(), m, n, k, T(alpha), A.data_ptr(), lda, B.data_ptr(), ldb, T(beta),
+               Cm.data_ptr(), ldc),
+            "gemm",
+        )
+
+    def syrk(self, uplo, trans, n, k, alpha, A, lda, beta, Cm, ldc):
+        suf, T = _suffix(Cm)
+        fn = getattr(self.lib, f"rlhip_syrk_{suf}")
+        return _lib.check(
+            fn(self.h, uplo.encode(), trans.encode(), n, k, T(alpha), A.data_ptr(), lda, T(beta), Cm.data_ptr(), ldc),
+            "syrk",
+        )
+
+    def trsm(self, m, n, alpha, A, lda, B, ldb, diag="N"):
+        suf, T = _suffix(B)
+        fn = getattr(self.lib, f"rlhip_trsm_{suf}")
+        return _lib.check(
+            fn(self.h, b"R", b"U", b"N", diag.encode(), m, n, T(alpha), A.data_ptr(), lda, B.data_ptr(), ldb), "trsm"
+        )
+
+    def trmm(self, m, n, alpha, A, lda, B, ldb, diag="N"):
+        suf, T = _suffix(B)
+        fn = getattr(self.lib, f"rlhip_trmm_{suf}")
+        return _lib.check(
+            fn(self.h, b"R", b"U", b"N", diag.encode(), m, n, T(alpha), A.data_ptr(), lda, B.data_ptr(), ldb), "trmm"
+        )
+
+    def potrf(self, n, A, lda) -> int:
+        suf, _ = _suffix(A)
+        fn = getattr(self.lib, f"rlhip_potrf_{suf}")
+        return _lib.check(fn(self.h, b"U", n, A.data_ptr(), lda), "potrf")
+
+    def lange_fro(self, m, n, A, lda) -> float:
+        suf, T = _suffix(A)
+        res = T()
+        fn = getattr(self.lib, f"rlhip_lange_fro_{suf}")
+        _lib.check(fn(self.h, m, n, A.data_ptr(), lda, C.byref(res)), "lange")
+        return float(res.value)
+
+    def lacpy(self, uplo, m, n, A, lda, B, ldb):
+        suf, _ = _suffix(A)
+        fn = getattr(self.lib, f"rlhip_lacpy_{suf}")
+        return _lib.check(fn(self.h, uplo.encode(), m, n, A.data_ptr(), lda, B.data_ptr(), ldb), "lacpy")
+
+    def laset(self, uplo, m, n, offd, diag, A, lda):
+        suf, T = _suffix(A)
+        fn = getattr(self.lib, f"rlhip_laset_{suf}")
+        return _lib.check(fn(self.h, uplo.encode(), m, n, T(offd), T(diag), A.data_ptr(), lda), "laset")
+
+    def gesvdj(self, m, n, A, lda, S, VT, ldvt):
+        suf, _ = _suffix(A)
+        sweeps = C.c_int()
+        fn = getattr(self.lib, f"rlhip_gesvdj_{suf}")
+        info = _lib.check(fn(self.h, m, n, A.data_ptr(), lda, S.data_ptr(), VT.data_ptr(), ldvt, C.byref(sweeps)),
+                          "gesvdj")
+        return info, int(sweeps.value)
+
+    # ---- diagnostics
+    def mfma_peak(self, is_f64=True, iters=20000) -> float:
+        tf = C.c_double()
+        _lib.check(self.lib.rlhip_mfma_peak(self.h, 1 if is_f64 else 0, iters, C.byref(tf)), "mfma_peak")
+        return float(tf.value)
+
+    def hbm_read_peak(self, buf) -> float:
+        g = C.c_double()
+        nbytes = buf.numel() * buf.element_size()
+        _lib.check(self.lib.rlhip_hbm_read_peak(self.h, buf.data_ptr(), nbytes, C.byref(g)), "hbm_read_peak")
+        return float(g.value)
