@@ -1,0 +1,128 @@
+// blas:: call surface of the hot path, device flavour (cf. the reference's RandLAPACK/rl_blaspp.hh:3-9, which
+// pulls these names from BLAS++).  Every function takes a blas::Queue& last, exactly like BLAS++'s device
+// API that the reference's GPU drivers use (drivers/rl_cqrrpt_gpu.hh:303-353, rl_bqrrp_gpu.hh:615-667), and
+// forwards to the C ABI in rlhip.h.  All pointers are device pointers.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include "../rlhip.h"
+
+namespace blas {
+
+enum class Layout : char { ColMajor = 'C', RowMajor = 'R' };
+enum class Op : char { NoTrans = 'N', Trans = 'T', ConjTrans = 'C' };
+enum class Side : char { Left = 'L', Right = 'R' };
+enum class Diag : char { NonUnit = 'N', Unit = 'U' };
+enum class Uplo : char { Upper = 'U', Lower = 'L', General = 'G' };
+
+inline char to_char(Op v) { return (char)v; }
+inline char to_char(Side v) { return (char)v; }
+inline char to_char(Diag v) { return (char)v; }
+inline char to_char(Uplo v) { return (char)v; }
+inline char to_char(Layout v) { return (char)v; }
+
+class Error : public std::runtime_error {
+public:
+    explicit Error(std::string const& m) : std::runtime_error(m) {}
+};
+
+inline void check(int rc, const char* what) {
+    if (rc < 0) throw Error(std::string(what) + " failed with code " + std::to_string(rc));
+}
+
+// One HIP device + stream + scratch arena.  Mirrors blas::Queue(device) / .sync() / .stream().
+class Queue {
+    rlhip_ctx* ctx_ = nullptr;
+    bool owned_ = false;
+public:
+    explicit Queue(int device = 0) {
+        check(rlhip_create(&ctx_, device, nullptr, 1), "rlhip_create");
+        owned_ = true;
+    }
+    // adopt an existing context (e.g. one bound to PyTorch's stream)
+    explicit Queue(rlhip_ctx* ctx) : ctx_(ctx), owned_(false) {}
+    Queue(Queue const&) = delete;
+    Queue& operator=(Queue const&) = delete;
+    ~Queue() { if (owned_ && ctx_) rlhip_destroy(ctx_); }
+    void sync() { check(rlhip_sync(ctx_), "rlhip_sync"); }
+    void* stream() const { return rlhip_stream(ctx_); }
+    rlhip_ctx* ctx() const { return ctx_; }
+};
+
+template <typename T>
+T* device_malloc(int64_t n, Queue& q) {
+    void* p = nullptr;
+    check(rlhip_malloc(q.ctx(), &p, (size_t)(n > 0 ? n : 1) * sizeof(T)), "device_malloc");
+    return (T*)p;
+}
+inline void device_free(void* p, Queue& q) { check(rlhip_free(q.ctx(), p), "device_free"); }
+template <typename T>
+void device_memset(T* p, int byte, int64_t n, Queue& q) { check(rlhip_memset(q.ctx(), p, byte, (size_t)n * sizeof(T)), "memset"); }
+template <typename T>
+void device_copy_vector(int64_t n, T const* src, T* dst, Queue& q) {
+    check(rlhip_memcpy_d2d(q.ctx(), dst, src, (size_t)n * sizeof(T)), "device_copy_vector");
+}
+template <typename T>
+void copy_to_host(int64_t n, T const* dev, T* host, Queue& q) { check(rlhip_memcpy_d2h(q.ctx(), host, dev, (size_t)n * sizeof(T)), "d2h"); }
+template <typename T>
+void copy_to_device(int64_t n, T const* host, T* dev, Queue& q) { check(rlhip_memcpy_h2d(q.ctx(), dev, host, (size_t)n * sizeof(T)), "h2d"); }
+
+// RAII scope over the queue's stream-ordered scratch arena
+class Scratch {
+    Queue& q_;
+    size_t mark_;
+public:
+    explicit Scratch(Queue& q) : q_(q), mark_(rlhip_scratch_mark(q.ctx())) {}
+    ~Scratch() { rlhip_scratch_release(q_.ctx(), mark_); }
+    template <typename T>
+    T* alloc(int64_t n) {
+        void* p = nullptr;
+        check(rlhip_scratch_alloc(q_.ctx(), &p, (size_t)(n > 0 ? n : 1) * sizeof(T)), "scratch_alloc");
+        return (T*)p;
+    }
+};
+
+// ---- level 3 (ColMajor only, as on the whole reference path)
+inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, double alpha, double const* A, int64_t lda,
+                 double const* B, int64_t ldb, double beta, double* C, int64_t ldc, Queue& q) {
+    check(rlhip_gemm_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc), "gemm");
+}
+inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, float alpha, float const* A, int64_t lda,
+                 float const* B, int64_t ldb, float beta, float* C, int64_t ldc, Queue& q) {
+    check(rlhip_gemm_f32(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc), "gemm");
+}
+inline void syrk(Layout, Uplo u, Op t, int64_t n, int64_t k, double alpha, double const* A, int64_t lda, double beta,
+                 double* C, int64_t ldc, Queue& q) {
+    check(rlhip_syrk_f64(q.ctx(), (char)u, (char)t, n, k, alpha, A, lda, beta, C, ldc), "syrk");
+}
+inline void syrk(Layout, Uplo u, Op t, int64_t n, int64_t k, float alpha, float const* A, int64_t lda, float beta,
+                 float* C, int64_t ldc, Queue& q) {
+    check(rlhip_syrk_f32(q.ctx(), (char)u, (char)t, n, k, alpha, A, lda, beta, C, ldc), "syrk");
+}
+inline void trsm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
+                 double* B, int64_t ldb, Queue& q) {
+    check(rlhip_trsm_f64(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trsm");
+}
+inline void trsm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda,
+                 float* B, int64_t ldb, Queue& q) {
+    check(rlhip_trsm_f32(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trsm");
+}
+inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
+                 double* B, int64_t ldb, Queue& q) {
+    check(rlhip_trmm_f64(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trmm");
+}
+inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda,
+                 float* B, int64_t ldb, Queue& q) {
+    check(rlhip_trmm_f32(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trmm");
+}
+
+}  // namespace blas
+
+namespace RandLAPACK {
+using blas::Layout;
+using blas::Op;
+using blas::Side;
+using blas::Diag;
+using blas::Uplo;
+}  // namespace RandLAPACK

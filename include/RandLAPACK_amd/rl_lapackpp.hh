@@ -1,0 +1,73 @@
+// lapack:: call surface of the hot path, device flavour (cf. RandLAPACK/rl_lapackpp.hh:5-9).
+#pragma once
+#include "rl_blaspp.hh"
+
+namespace lapack {
+
+using blas::Queue;
+enum class Job : char { NoVec = 'N', Vec = 'V', SomeVec = 'S', AllVec = 'A' };
+enum class Norm : char { One = '1', Inf = 'I', Fro = 'F', Max = 'M' };
+enum class MatrixType : char { General = 'G', Lower = 'L', Upper = 'U' };
+inline char to_char(Job v) { return (char)v; }
+inline char to_char(Norm v) { return (char)v; }
+inline char to_char(MatrixType v) { return (char)v; }
+
+// returns LAPACK info (0 or the order of the failing minor), like lapack::potrf
+inline int64_t potrf(blas::Uplo u, int64_t n, double* A, int64_t lda, Queue& q) {
+    int rc = rlhip_potrf_f64(q.ctx(), (char)u, n, A, lda); blas::check(rc, "potrf"); return rc;
+}
+inline int64_t potrf(blas::Uplo u, int64_t n, float* A, int64_t lda, Queue& q) {
+    int rc = rlhip_potrf_f32(q.ctx(), (char)u, n, A, lda); blas::check(rc, "potrf"); return rc;
+}
+inline double lange(Norm nt, int64_t m, int64_t n, double const* A, int64_t lda, Queue& q) {
+    if (nt != Norm::Fro) throw blas::Error("lange: only Norm::Fro is on the path");
+    double r = 0; blas::check(rlhip_lange_fro_f64(q.ctx(), m, n, A, lda, &r), "lange"); return r;
+}
+inline float lange(Norm nt, int64_t m, int64_t n, float const* A, int64_t lda, Queue& q) {
+    if (nt != Norm::Fro) throw blas::Error("lange: only Norm::Fro is on the path");
+    float r = 0; blas::check(rlhip_lange_fro_f32(q.ctx(), m, n, A, lda, &r), "lange"); return r;
+}
+inline void lacpy(MatrixType t, int64_t m, int64_t n, double const* A, int64_t lda, double* B, int64_t ldb, Queue& q) {
+    blas::check(rlhip_lacpy_f64(q.ctx(), (char)t, m, n, A, lda, B, ldb), "lacpy");
+}
+inline void lacpy(MatrixType t, int64_t m, int64_t n, float const* A, int64_t lda, float* B, int64_t ldb, Queue& q) {
+    blas::check(rlhip_lacpy_f32(q.ctx(), (char)t, m, n, A, lda, B, ldb), "lacpy");
+}
+inline void laset(MatrixType t, int64_t m, int64_t n, double offd, double diag, double* A, int64_t lda, Queue& q) {
+    blas::check(rlhip_laset_f64(q.ctx(), (char)t, m, n, offd, diag, A, lda), "laset");
+}
+inline void laset(MatrixType t, int64_t m, int64_t n, float offd, float diag, float* A, int64_t lda, Queue& q) {
+    blas::check(rlhip_laset_f32(q.ctx(), (char)t, m, n, offd, diag, A, lda), "laset");
+}
+inline void add_diag(int64_t n, double alpha, double* A, int64_t lda, Queue& q) {
+    blas::check(rlhip_add_diag_f64(q.ctx(), n, alpha, A, lda), "add_diag");
+}
+inline void add_diag(int64_t n, float alpha, float* A, int64_t lda, Queue& q) {
+    blas::check(rlhip_add_diag_f32(q.ctx(), n, alpha, A, lda), "add_diag");
+}
+// Job::SomeVec, tall (m >= n).  Returns info (>0: Jacobi did not converge).
+inline int64_t gesdd(Job job, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,
+                     double* VT, int64_t ldvt, Queue& q) {
+    if (job != Job::SomeVec) throw blas::Error("gesdd: only Job::SomeVec is on the path");
+    int rc = rlhip_gesdd_f64(q.ctx(), m, n, A, lda, S, U, ldu, VT, ldvt, nullptr); blas::check(rc, "gesdd"); return rc;
+}
+inline int64_t gesdd(Job job, int64_t m, int64_t n, float* A, int64_t lda, float* S, float* U, int64_t ldu,
+                     float* VT, int64_t ldvt, Queue& q) {
+    if (job != Job::SomeVec) throw blas::Error("gesdd: only Job::SomeVec is on the path");
+    int rc = rlhip_gesdd_f32(q.ctx(), m, n, A, lda, S, U, ldu, VT, ldvt, nullptr); blas::check(rc, "gesdd"); return rc;
+}
+// singular values only of a (small) matrix copy -- used by util::cond_num_check
+inline int64_t gesvdj(int64_t m, int64_t n, double* A, int64_t lda, double* S, double* VT, int64_t ldvt, Queue& q) {
+    int rc = rlhip_gesvdj_f64(q.ctx(), m, n, A, lda, S, VT, ldvt, nullptr); blas::check(rc, "gesvdj"); return rc;
+}
+inline int64_t gesvdj(int64_t m, int64_t n, float* A, int64_t lda, float* S, float* VT, int64_t ldvt, Queue& q) {
+    int rc = rlhip_gesvdj_f32(q.ctx(), m, n, A, lda, S, VT, ldvt, nullptr); blas::check(rc, "gesvdj"); return rc;
+}
+
+}  // namespace lapack
+
+namespace RandLAPACK {
+using lapack::Job;
+using lapack::MatrixType;
+using lapack::Norm;
+}  // namespace RandLAPACK

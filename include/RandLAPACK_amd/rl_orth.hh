@@ -1,0 +1,54 @@
+// Stabilization objects (reference: RandLAPACK/comps/rl_orth.hh).  Same class names, constructor arguments and
+// call() contract; the extra leading constructor argument is the device queue.
+#pragma once
+#include <cmath>
+#include <limits>
+#include "rl_blaspp.hh"
+#include "rl_lapackpp.hh"
+#include "rl_util.hh"
+
+namespace RandLAPACK {
+
+template <typename T>
+class Stabilization {                                             // rl_orth.hh:13-23
+public:
+    virtual ~Stabilization() {}
+    virtual int call(int64_t m, int64_t k, T* A) = 0;
+};
+
+/// Cholesky-QR, Q factor only, in place: G = A^T A (upper) -> G = R^T R -> A <- A R^{-1}.   (rl_orth.hh:26-98)
+/// return 1 + chol_fail = true when the Cholesky breaks down; return 1 when cond_check is on and
+/// cond(R) > 1/sqrt(eps).
+template <typename T>
+class CholQRQ : public Stabilization<T> {
+public:
+    CholQRQ(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
+        cond_check = c_check;
+        verbose = verb;
+        chol_fail = false;
+    }
+    int call(int64_t m, int64_t k, T* A) override {
+        blas::Scratch ws(q);
+        T* gram = ws.alloc<T>(k * k);
+        lapack::laset(MatrixType::General, k, k, T(0), T(0), gram, k, q);
+        blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, T(1), A, m, T(0), gram, k, q);      // :78
+        if (lapack::potrf(Uplo::Upper, k, gram, k, q)) {                                                 // :81
+            chol_fail = true;
+            return 1;
+        }
+        if (cond_check) {                                                                                // :88-93
+            // the reference takes the SVD of the k x k buffer whose strictly lower part is zero
+            if (k > 1) lapack::laset(MatrixType::Lower, k - 1, k, T(0), T(0), gram + 1, k, q);
+            if (util::cond_num_check(k, k, gram, verbose, q) > (1 / std::sqrt(std::numeric_limits<T>::epsilon())))
+                return 1;
+        }
+        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, k, T(1), gram, k, A, m, q);  // :95
+        return 0;
+    }
+    blas::Queue& q;
+    bool chol_fail;
+    bool cond_check;
+    bool verbose;
+};
+
+}  // namespace RandLAPACK

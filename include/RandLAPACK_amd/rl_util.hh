@@ -1,0 +1,45 @@
+// RandLAPACK::util helpers that steer control flow on the path (reference: RandLAPACK/misc/rl_util.hh),
+// operating on device buffers.
+#pragma once
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "rl_blaspp.hh"
+#include "rl_lapackpp.hh"
+
+namespace RandLAPACK::util {
+
+/// s_max / s_min of an m x n (m >= n) device matrix, inf if s_min == 0.      (rl_util.hh:403-424)
+/// The reference takes an SVD of a copy with gesdd(NoVec); here the copy goes through the device Jacobi SVD.
+template <typename T>
+T cond_num_check(int64_t m, int64_t n, T const* A, bool verbose, blas::Queue& q) {
+    (void)verbose;
+    blas::Scratch ws(q);
+    T* cpy = ws.alloc<T>(m * n);
+    T* s = ws.alloc<T>(n);
+    T* vt = ws.alloc<T>(n * n);
+    lapack::lacpy(MatrixType::General, m, n, A, m, cpy, m, q);
+    lapack::gesvdj(m, n, cpy, m, s, vt, n, q);
+    std::vector<T> sh(n);
+    blas::copy_to_host(n, s, sh.data(), q);
+    return (sh[n - 1] == 0) ? std::numeric_limits<T>::infinity() : sh[0] / sh[n - 1];
+}
+
+/// true when the columns of A have LOST orthonormality: ||A^T A - I||_F / sqrt(k) > 1e-10 (double) or 1e-2
+/// (float).                                                                    (rl_util.hh:468-496)
+/// As in the reference the Gram buffer's strictly lower triangle is left at zero.
+template <typename T>
+bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Queue& q) {
+    (void)verbose;
+    blas::Scratch ws(q);
+    T* G = ws.alloc<T>(k * k);
+    lapack::laset(MatrixType::General, k, k, T(0), T(0), G, k, q);
+    blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, T(1), A, m, T(0), G, k, q);
+    if (k > 1) lapack::laset(MatrixType::Lower, k - 1, k, T(0), T(0), G + 1, k, q);   // keep the upper triangle only
+    lapack::add_diag(k, T(-1), G, k, q);                                              // G - I
+    T orth_err = lapack::lange(Norm::Fro, k, k, G, k, q);
+    constexpr T tol = (sizeof(T) == sizeof(double)) ? (T)1.0e-10 : (T)1.0e-2;
+    return orth_err / std::sqrt((T)k) > tol;
+}
+
+}  // namespace RandLAPACK::util

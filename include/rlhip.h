@@ -49,6 +49,14 @@ int rlhip_reserve_workspace(rlhip_ctx* ctx, size_t bytes);
 size_t rlhip_workspace_highwater(rlhip_ctx* ctx);
 const char* rlhip_version(void);
 
+/* stream-ordered scratch arena for driver temporaries (Omega, Gram matrices, split-K slabs ...): a bump
+ * allocator that replaces the reference's new[]/delete[] of work buffers inside call() (e.g. rl_rs.hh:130,
+ * rl_rf.hh:116, rl_orth.hh:76).  Take a mark, allocate, release back to the mark; memory handed out is
+ * only valid for work enqueued on the context's stream before the release. */
+size_t rlhip_scratch_mark(rlhip_ctx* ctx);
+int rlhip_scratch_alloc(rlhip_ctx* ctx, void** dev_ptr, size_t bytes);
+int rlhip_scratch_release(rlhip_ctx* ctx, size_t mark);
+
 /* event timing on the context's stream (bench.py roofline leg) */
 int rlhip_timer_start(rlhip_ctx* ctx);
 int rlhip_timer_stop_ms(rlhip_ctx* ctx, float* ms_host);
@@ -112,6 +120,22 @@ int rlhip_gesvdj_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t ld
                      int64_t ldvt, int* sweeps_host);
 int rlhip_gesvdj_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* S, float* VT,
                      int64_t ldvt, int* sweeps_host);
+
+/* A[i,i] += alpha for i < n (the "A_gram[i*k+i] -= 1" loop of util::orthogonality_check, rl_util.hh:480-482) */
+int rlhip_add_diag_f64(rlhip_ctx* ctx, int64_t n, double alpha, double* A, int64_t lda);
+int rlhip_add_diag_f32(rlhip_ctx* ctx, int64_t n, float alpha, float* A, int64_t lda);
+/* lapack::gesdd(Job::SomeVec) contract for a tall matrix (m >= n): A (destroyed) = U diag(S) VT with
+ * U m x n (ldu), VT n x n (ldvt), S descending.  Cholesky-QR2 preconditioning + Jacobi on R^T; falls back
+ * to rlhip_gesvdj on A when the Cholesky steps cannot be trusted.  (rl_rsvd.hh:146) */
+int rlhip_gesdd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,
+                    double* VT, int64_t ldvt, int* sweeps_host);
+int rlhip_gesdd_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* S, float* U, int64_t ldu,
+                    float* VT, int64_t ldvt, int* sweeps_host);
+/* util::transposition (misc/rl_util.hh:315-334): AT (n x m, ld ldat) = A^T; upper_only != 0 moves only i <= j */
+int rlhip_transpose_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, double* AT,
+                        int64_t ldat, int upper_only);
+int rlhip_transpose_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat,
+                        int upper_only);
 
 /* ---- diagnostics ---- */
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */

@@ -1,0 +1,44 @@
+/* rlhip_drivers.h -- C entry points of the driver/comp objects (include/RandLAPACK_amd/), for bindings that
+ * cannot instantiate C++ templates (ctypes in tests/bench, or a C caller).  Each function builds the same
+ * object graph a RandLAPACK user builds (Stabilization -> RS -> RF -> QB -> RSVD) and invokes
+ * call().  All matrices are DEVICE pointers, column-major.
+ *
+ * state[6] = RNGState: counter[0..3], key[0..1]; advanced in place exactly as the reference threads it
+ * (`state = fill_dense(D, buf, state)`, comps/rl_rs.hh:135).
+ * stab kinds: 0 = CholQRQ, 1 = HQRQ, 2 = PLUL (comps/rl_orth.hh:26-65,101-141,167-207).
+ * Return codes are the reference's (RS 0/1, RF 0/1/2, QB 0/2/3/4/5/6, RSVD 0); -100 = RandLAPACK::Error
+ * (bad argument), -101 = device/runtime failure; rlhip_last_error() gives the message.
+ */
+#ifndef RLHIP_DRIVERS_H
+#define RLHIP_DRIVERS_H
+#include "rlhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* rlhip_last_error(void);
+
+/* Stabilization<double>::call(m, k, A)                                   comps/rl_orth.hh:69-98 */
+int rlhip_drv_stab_f64(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, double* A, int* chol_fail);
+/* RS<double>::call -> Omega (n x k, caller allocated)                    comps/rl_rs.hh:117-178 */
+int rlhip_drv_rs_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t k, int64_t p, int64_t q,
+                     int stab_kind, double* Omega, uint32_t state[6]);
+/* RF<double>::call -> Q (m x k, caller allocated)                        comps/rl_rf.hh:107-137 */
+int rlhip_drv_rf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t k, int64_t p, int64_t q,
+                     int rs_stab, int orth_kind, double* Q, uint32_t state[6]);
+/* QB<double>::call; *Q (m x k) and *BT (n x k) are allocated by the callee, free with rlhip_free.
+ *                                                                         comps/rl_qb.hh:134-268 */
+int rlhip_drv_qb_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t* k, int64_t b_sz, double tol,
+                     int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** Q,
+                     double** BT, uint32_t state[6]);
+/* RSVD<double>::call; *U (m x k), *S (k), *V (n x k) allocated by the callee, free with rlhip_free.
+ * *qb_ret receives QB's return code.                                      drivers/rl_rsvd.hh:114-154 */
+int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t* k, int64_t b_sz, double tol,
+                       int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** U,
+                       double** S, double** V, uint32_t state[6], int* qb_ret);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -33,6 +33,9 @@ def _blas3(T):
         "lange_fro": [c_vp, c_i64, c_i64, c_vp, c_i64, C.POINTER(T)],
         "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "laset": [c_vp, c_char, c_i64, c_i64, T, T, c_vp, c_i64],
+        "add_diag": [c_vp, c_i64, T, c_vp, c_i64],
+        "gesdd": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_int)],
+        "transpose": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
         "gesvdj": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, C.POINTER(c_int)],
         "fill_dense": [c_vp, c_int, c_i64, c_i64, c_vp, u32p, u32p, u32p],
     }
@@ -54,12 +57,26 @@ SIGNATURES = {
     "rlhip_memset": (c_int, [c_vp, c_vp, c_int, c_sz]),
     "rlhip_reserve_workspace": (c_int, [c_vp, c_sz]),
     "rlhip_workspace_highwater": (c_sz, [c_vp]),
+    "rlhip_scratch_mark": (c_sz, [c_vp]),
+    "rlhip_scratch_alloc": (c_int, [c_vp, C.POINTER(c_vp), c_sz]),
+    "rlhip_scratch_release": (c_int, [c_vp, c_sz]),
     "rlhip_timer_start": (c_int, [c_vp]),
     "rlhip_timer_stop_ms": (c_int, [c_vp, C.POINTER(c_flt)]),
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }
+dpp = C.POINTER(c_vp)
+SIGNATURES.update({
+    "rlhip_last_error": (C.c_char_p, []),
+    "rlhip_drv_stab_f64": (c_int, [c_vp, c_int, c_int, c_i64, c_i64, c_vp, C.POINTER(c_int)]),
+    "rlhip_drv_rs_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, u32p]),
+    "rlhip_drv_rf_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, u32p]),
+    "rlhip_drv_qb_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int, c_int,
+                                 c_int, c_int, dpp, dpp, u32p]),
+    "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
+                                   c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
+})
 for _suf, _T in (("f64", c_dbl), ("f32", c_flt)):
     for _name, _args in _blas3(_T).items():
         SIGNATURES[f"rlhip_{_name}_{_suf}"] = (c_int, _args)

@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void laset_kernel(int uplo, int64_t m, int64_t
     }
 }
 
+template <typename T>
+__global__ void add_diag_kernel(int64_t n, T alpha, T* __restrict__ A, int64_t lda) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[i + i * lda] += alpha;
+}
+
 inline dim3 grid2d(int64_t m, int64_t n) {
     int64_t gx = (m + 255) / 256;
     if (gx > 64) gx = 64;
@@ -129,6 +135,16 @@ int laset(rlhip_ctx* c, int uplo, int64_t m, int64_t n, T offd, T diag, T* A, in
     RLHIP_LAUNCH_CHECK();
     return 0;
 }
+
+template <typename T>
+int add_diag(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_diag_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, alpha, A, lda);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int add_diag<double>(rlhip_ctx*, int64_t, double, double*, int64_t);
+template int add_diag<float>(rlhip_ctx*, int64_t, float, float*, int64_t);
 
 template int lange_fro<double>(rlhip_ctx*, int64_t, int64_t, const double*, int64_t, double*);
 template int lange_fro<float>(rlhip_ctx*, int64_t, int64_t, const float*, int64_t, float*);

@@ -140,6 +140,14 @@ int rlhip_reserve_workspace(rlhip_ctx* c, size_t bytes) {
 }
 size_t rlhip_workspace_highwater(rlhip_ctx* c) { return c->ws_highwater; }
 
+/* scratch arena (stream-ordered bump allocator) for driver temporaries */
+size_t rlhip_scratch_mark(rlhip_ctx* c) { return rlhip_ws_mark(c); }
+int rlhip_scratch_alloc(rlhip_ctx* c, void** p, size_t bytes) {
+    *p = rlhip_ws_alloc(c, bytes);
+    return *p ? 0 : RLHIP_ERR_HIP(hipErrorOutOfMemory);
+}
+int rlhip_scratch_release(rlhip_ctx* c, size_t mark) { rlhip_ws_release(c, mark); return 0; }
+
 int rlhip_timer_start(rlhip_ctx* c) { RLHIP_CHECK(hipEventRecord(c->ev0, c->stream)); return 0; }
 int rlhip_timer_stop_ms(rlhip_ctx* c, float* ms) {
     RLHIP_CHECK(hipEventRecord(c->ev1, c->stream));
@@ -217,6 +225,17 @@ static inline int op_flag(char t, int* out) {
     int rlhip_laset_##SUF(rlhip_ctx* c, char uplo, int64_t m, int64_t n, T offd, T diag, T* A, int64_t lda) {   \
         int u = (uplo == 'U' || uplo == 'u') ? 0 : (uplo == 'L' || uplo == 'l') ? 1 : 2;                        \
         return rlhip::laset<T>(c, u, m, n, offd, diag, A, lda);                                                  \
+    }                                                                                                           \
+    int rlhip_add_diag_##SUF(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda) {                             \
+        return rlhip::add_diag<T>(c, n, alpha, A, lda);                                                          \
+    }                                                                                                           \
+    int rlhip_gesdd_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U, int64_t ldu, T* VT,  \
+                          int64_t ldvt, int* sweeps) {                                                          \
+        return rlhip::gesdd_tall<T>(c, m, n, A, lda, S, U, ldu, VT, ldvt, sweeps);                               \
+    }                                                                                                           \
+    int rlhip_transpose_##SUF(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat,  \
+                              int upper_only) {                                                                 \
+        return rlhip::transpose<T>(c, m, n, A, lda, AT, ldat, upper_only);                                       \
     }                                                                                                           \
     int rlhip_gesvdj_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* VT, int64_t ldvt,    \
                            int* sweeps) {                                                                       \

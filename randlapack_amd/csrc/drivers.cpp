@@ -1,0 +1,137 @@
+// C entry points over the C++ driver/comp objects (include/rlhip_drivers.h).  Host-only C++: everything that
+// touches the GPU goes through the C ABI in rlhip.h.
+#include <cstring>
+#include <memory>
+#include <string>
+#include "../../include/RandLAPACK_amd.hh"
+#include "../../include/rlhip_drivers.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+using RNG = r123::Philox4x32;
+using State = RandBLAS::RNGState<RNG>;
+
+State load_state(const uint32_t s[6]) {
+    State st;
+    for (int i = 0; i < 4; ++i) st.counter[i] = s[i];
+    st.key[0] = s[4];
+    st.key[1] = s[5];
+    return st;
+}
+void store_state(State const& st, uint32_t s[6]) {
+    for (int i = 0; i < 4; ++i) s[i] = st.counter[i];
+    s[4] = st.key[0];
+    s[5] = st.key[1];
+}
+
+template <typename T>
+std::unique_ptr<RandLAPACK::Stabilization<T>> make_stab(blas::Queue& q, int kind, bool cond_check) {
+    switch (kind) {
+        case 0: return std::make_unique<RandLAPACK::CholQRQ<T>>(q, cond_check, false);
+        default: throw RandLAPACK::Error("stabilization kind " + std::to_string(kind) + " is not available on the device yet");
+    }
+}
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (RandLAPACK::Error const& e) {
+        g_last_error = e.what();
+        return -100;
+    } catch (std::exception const& e) {
+        g_last_error = e.what();
+        return -101;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rlhip_last_error(void) { return g_last_error.c_str(); }
+
+int rlhip_drv_stab_f64(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, double* A, int* chol_fail) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto st = make_stab<double>(q, kind, cond_check != 0);
+        int rc = st->call(m, k, A);
+        if (chol_fail) {
+            auto* c = dynamic_cast<RandLAPACK::CholQRQ<double>*>(st.get());
+            *chol_fail = (c && c->chol_fail) ? 1 : 0;
+        }
+        return rc;
+    });
+}
+
+int rlhip_drv_rs_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t k, int64_t p, int64_t q_,
+                     int stab_kind, double* Omega, uint32_t state[6]) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto stab = make_stab<double>(q, stab_kind, false);
+        RandLAPACK::RS<double, RNG> rs(q, *stab, p, q_, false, false);
+        State st = load_state(state);
+        int rc = rs.call(m, n, A, k, Omega, st);
+        store_state(st, state);
+        return rc;
+    });
+}
+
+int rlhip_drv_rf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t k, int64_t p, int64_t q_,
+                     int rs_stab, int orth_kind, double* Q, uint32_t state[6]) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto s1 = make_stab<double>(q, rs_stab, false);
+        auto s2 = make_stab<double>(q, orth_kind, false);
+        RandLAPACK::RS<double, RNG> rs(q, *s1, p, q_, false, false);
+        RandLAPACK::RF<double, RNG> rf(q, rs, *s2, false, false);
+        State st = load_state(state);
+        int rc = rf.call(m, n, A, k, Q, st);
+        store_state(st, state);
+        return rc;
+    });
+}
+
+int rlhip_drv_qb_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t* k, int64_t b_sz, double tol, int64_t p,
+                     int64_t q_, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** Q, double** BT,
+                     uint32_t state[6]) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto s1 = make_stab<double>(q, rs_stab, false);
+        auto s2 = make_stab<double>(q, rf_orth, false);
+        auto s3 = make_stab<double>(q, qb_orth, false);
+        RandLAPACK::RS<double, RNG> rs(q, *s1, p, q_, false, false);
+        RandLAPACK::RF<double, RNG> rf(q, rs, *s2, false, false);
+        RandLAPACK::QB<double, RNG> qb(q, rf, *s3, false, orth_check != 0);
+        State st = load_state(state);
+        *Q = nullptr;
+        *BT = nullptr;
+        int rc = qb.call(m, n, A, *k, b_sz, tol, *Q, *BT, st);
+        store_state(st, state);
+        return rc;
+    });
+}
+
+int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t* k, int64_t b_sz, double tol, int64_t p,
+                       int64_t q_, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** U, double** S,
+                       double** V, uint32_t state[6], int* qb_ret) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto s1 = make_stab<double>(q, rs_stab, false);
+        auto s2 = make_stab<double>(q, rf_orth, false);
+        auto s3 = make_stab<double>(q, qb_orth, false);
+        RandLAPACK::RS<double, RNG> rs(q, *s1, p, q_, false, false);
+        RandLAPACK::RF<double, RNG> rf(q, rs, *s2, false, false);
+        RandLAPACK::QB<double, RNG> qb(q, rf, *s3, false, orth_check != 0);
+        RandLAPACK::RSVD<double, RNG> rsvd(q, qb, b_sz);
+        State st = load_state(state);
+        *U = *S = *V = nullptr;
+        int rc = rsvd.call(m, n, A, *k, tol, *U, *S, *V, st);
+        store_state(st, state);
+        if (qb_ret) *qb_ret = rsvd.qb_return;
+        return rc;
+    });
+}
+
+}  // extern "C"

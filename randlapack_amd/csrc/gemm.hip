@@ -19,6 +19,7 @@
 //    to scratch and a second kernel sums the slabs in fixed order (bitwise reproducible run to run,
 //    unlike atomics).
 #include "rlhip_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -151,8 +152,19 @@ __device__ __forceinline__ T tile_frag(const T* __restrict__ s, int r, int kk) {
     return KC ? s[r * stride + kk] : s[kk * stride + r];
 }
 
-template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, bool VEC>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmArgs<T> g) {
+// blockIdx.x enumerates output tiles.  The hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs (id % 8); the remap below hands every XCD a CONTIGUOUS run of logical tile ids, and logical ids run
+// N-fastest, so the N-tiles that share one A row-panel (and neighbouring M-tiles that share B) sit on
+// the same XCD's L2 at the same time.  Bijective for any tile count (guide section 5, T1).
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nwg) {
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = bid % 8, slot = bid / 8;
+    const int64_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, bool VEC, int MINW, bool EARLY, int DBG = 0>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(GemmArgs<T> g) {
     constexpr int NWM = BM / WM, NWN = BN / WN;
     constexpr int NT = NWM * NWN * 64;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -170,7 +182,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     const int wm0 = (wid % NWM) * WM;
     const int wn0 = (wid / NWM) * WN;
 
-    const int64_t tile_m = blockIdx.x, tile_n = blockIdx.y;
+    const int64_t tiles_n = (g.N + BN - 1) / BN;
+    const int64_t lid = xcd_remap((int64_t)blockIdx.x, (int64_t)gridDim.x);
+    const int64_t tile_m = lid / tiles_n, tile_n = lid % tiles_n;
     if (g.tri && tile_m > tile_n) return;
     const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.kchunk;
@@ -189,6 +203,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
     T rb[RegCnt<T, BN, BK, NT>::n];
 
     auto gload = [&](int64_t kt) {
+        if (DBG == 1 && kt > 0) return;  // diagnostic: LDS+MFMA loop without global traffic
         const int64_t k0 = kbeg + kt * BK;
         const bool full = full_mn && (k0 + BK <= kend);
         if (full) {
@@ -219,6 +234,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
 
 #pragma unroll
         for (int s = 0; s < BK / 4; ++s) {
+            if (EARLY && s == BK / 8 && more) {
+                // stage tile t+1 into the idle LDS buffer while half of this tile's MFMAs are still queued:
+                // only the barrier itself (not the LDS write latency) then separates two tiles' MFMA streams
+                T* nA = sA0 + (cur ^ 1) * GA::elems;
+                T* nB = sB0 + (cur ^ 1) * GB::elems;
+                tile_sstore<T, BM, BK, A_KC, NT>(ra, nA, tid);
+                tile_sstore<T, BN, BK, B_KC, NT>(rb, nB, tid);
+            }
             T af[TM], bf[TN];
 #pragma unroll
             for (int t = 0; t < TM; ++t) af[t] = tile_frag<T, BM, BK, A_KC>(sA, wm0 + 16 * t + fr, 4 * s + fk);
@@ -230,7 +253,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(GemmAr
                 for (int u = 0; u < TN; ++u) acc[t][u] = Mma<T>::mma(bf[u], af[t], acc[t][u]);
         }
 
-        if (more) {
+        if (!EARLY && more) {
             T* nA = sA0 + (cur ^ 1) * GA::elems;
             T* nB = sB0 + (cur ^ 1) * GB::elems;
             tile_sstore<T, BM, BK, A_KC, NT>(ra, nA, tid);
@@ -297,31 +320,29 @@ __global__ void scale_kernel(int64_t M, int64_t N, T beta, T* __restrict__ C, in
     }
 }
 
-template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN>
-int launch_cfg(rlhip_ctx* c, GemmArgs<T>& g, bool vec, int64_t splitk) {
+template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, int MINW, bool EARLY, bool VEC, int DBG = 0>
+int launch_one(rlhip_ctx* c, GemmArgs<T>& g, int64_t splitk) {
     using GA = TileGeom<T, BM, BK, A_KC>;
     using GB = TileGeom<T, BN, BK, B_KC>;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr size_t smem = 2 * (size_t)(GA::elems + GB::elems) * sizeof(T);
-    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN), (unsigned)splitk);
-    auto kv = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, true>;
-    auto ks = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, false>;
-    static bool attr_set_v = false, attr_set_s = false;
-    if (vec) {
-        if (!attr_set_v) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set_v = true;
-        }
-        hipLaunchKernelGGL(kv, grid, dim3(NT), smem, c->stream, g);
-    } else {
-        if (!attr_set_s) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set_s = true;
-        }
-        hipLaunchKernelGGL(ks, grid, dim3(NT), smem, c->stream, g);
+    const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
+    auto kern = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, VEC, MINW, EARLY, DBG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
     }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, c->stream, g);
     RLHIP_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, int MINW, bool EARLY>
+int launch_cfg(rlhip_ctx* c, GemmArgs<T>& g, bool vec, int64_t splitk) {
+    if (vec) return launch_one<T, A_KC, B_KC, BM, BN, BK, WM, WN, MINW, EARLY, true>(c, g, splitk);
+    return launch_one<T, A_KC, B_KC, BM, BN, BK, WM, WN, MINW, EARLY, false>(c, g, splitk);
 }
 
 constexpr int NUM_CU = 256;
@@ -336,9 +357,12 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
     bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % V == 0) && (g.ldb % V == 0);
 
     // tile shape by N (the narrow dimension on this path), then split-K to fill 256 CUs
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("RLHIP_GEMM_VARIANT"); variant = e ? atoi(e) : 0; }
     int cfg;
     int64_t bm, bn;
-    if (N > 128 && !tri) { cfg = 0; bm = 128; bn = 256; }
+    if (N > 128 && !tri && (variant & 2)) { cfg = 5; bm = 128; bn = 128; }
+    else if (N > 128 && !tri) { cfg = 0; bm = 128; bn = 256; }
     else if (N > 64 || tri) { cfg = 1; bm = 128; bn = 128; }
     else if (N > 32) { cfg = 2; bm = 256; bn = 64; }
     else if (N > 16) { cfg = 3; bm = 256; bn = 32; }
@@ -351,7 +375,8 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
     // CU at these LDS sizes) x per-slice reduction length, plus the slab write+read traffic.
     int64_t splitk = 1;
     {
-        const double flops_cu = 78.6e12 / NUM_CU * (sizeof(T) == 4 ? 2.0 : 1.0);
+        const int64_t slots = NUM_CU * ((cfg == 0) ? 1 : 2);  // co-resident workgroups on the chip
+        const double flops_cu = 78.6e12 / slots * (sizeof(T) == 4 ? 2.0 : 1.0);
         const double t_tile_k = 2.0 * bm * bn * BK / flops_cu;  // seconds per K-tile per workgroup
         const double slab_bw = 4.0e12;
         int64_t maxs = ktiles / 32;
@@ -360,7 +385,7 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
         for (int64_t s = 1; s <= (maxs < 1 ? 1 : maxs); ++s) {
             int64_t kc = (ktiles + s - 1) / s;
             int64_t se = (ktiles + kc - 1) / kc;  // effective slices
-            int64_t rounds = (tiles * se + NUM_CU - 1) / NUM_CU;
+            int64_t rounds = (tiles * se + slots - 1) / slots;
             double t = rounds * (kc * t_tile_k + 2e-6);
             if (se > 1) t += 2.0 * se * (double)M * N * sizeof(T) / slab_bw + 3e-6;
             if ((double)se * M * N * sizeof(T) > 8e9) continue;
@@ -384,11 +409,19 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
 
     int rc = 0;
     switch (cfg) {
-        case 0: rc = launch_cfg<T, A_KC, B_KC, 128, 256, BK, 64, 64>(c, g, vec, splitk); break;
-        case 1: rc = launch_cfg<T, A_KC, B_KC, 128, 128, BK, 64, 64>(c, g, vec, splitk); break;
-        case 2: rc = launch_cfg<T, A_KC, B_KC, 256, 64, BK, 64, 64>(c, g, vec, splitk); break;
-        case 3: rc = launch_cfg<T, A_KC, B_KC, 256, 32, BK, 64, 32>(c, g, vec, splitk); break;
-        default: rc = launch_cfg<T, A_KC, B_KC, 256, 16, BK, 64, 16>(c, g, vec, splitk); break;
+        case 0:
+            if (variant & 4) rc = launch_one<T, A_KC, B_KC, 128, 256, BK, 64, 64, 1, false, true, 1>(c, g, splitk);
+            else if (variant & 1) rc = launch_cfg<T, A_KC, B_KC, 128, 256, BK, 64, 64, 1, true>(c, g, vec, splitk);
+            else rc = launch_cfg<T, A_KC, B_KC, 128, 256, BK, 64, 64, 1, false>(c, g, vec, splitk);
+            break;
+        case 5:
+            if (variant & 1) rc = launch_cfg<T, A_KC, B_KC, 128, 128, BK, 64, 64, 2, true>(c, g, vec, splitk);
+            else rc = launch_cfg<T, A_KC, B_KC, 128, 128, BK, 64, 64, 2, false>(c, g, vec, splitk);
+            break;
+        case 1: rc = launch_cfg<T, A_KC, B_KC, 128, 128, BK, 64, 64, 2, false>(c, g, vec, splitk); break;
+        case 2: rc = launch_cfg<T, A_KC, B_KC, 256, 64, BK, 64, 64, 2, false>(c, g, vec, splitk); break;
+        case 3: rc = launch_cfg<T, A_KC, B_KC, 256, 32, BK, 64, 32, 2, false>(c, g, vec, splitk); break;
+        default: rc = launch_cfg<T, A_KC, B_KC, 256, 16, BK, 64, 16, 2, false>(c, g, vec, splitk); break;
     }
     if (rc) { rlhip_ws_release(c, mark); return rc; }
 

@@ -168,7 +168,7 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     int rc = laset<T>(c, 2, n, n, T(0), T(1), V, n);
     if (rc) { rlhip_ws_release(c, mark); return rc; }
     const T tol = std::sqrt((T)m) * std::numeric_limits<T>::epsilon();
-    const int max_sweeps = 30;
+    const int max_sweeps = 60;
     int sweep = 0;
     int info = 0;
     if (n > 1) {

@@ -100,4 +100,18 @@ template <typename T>
 int gesvdj(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* VT, int64_t ldvt,
            int* sweeps_host);
 
+
+// A[i,i] += alpha
+template <typename T>
+int add_diag(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda);
+
+// AT (n x m, ld ldat) = A^T (A m x n); upper_only: only entries i <= j of A are moved
+template <typename T>
+int transpose(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat, int upper_only);
+
+// thin SVD of a tall matrix with separate outputs (LAPACK gesdd 'S' contract); A is destroyed
+template <typename T>
+int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U, int64_t ldu, T* VT,
+               int64_t ldvt, int* sweeps_host);
+
 }  // namespace rlhip

@@ -189,3 +189,78 @@ class Context:
         nbytes = buf.numel() * buf.element_size()
         _lib.check(self.lib.rlhip_hbm_read_peak(self.h, buf.data_ptr(), nbytes, C.byref(g)), "hbm_read_peak")
         return float(g.value)
+
+
+# ------------------------------------------------------------------------------------------------------
+# driver-level entry points (include/rlhip_drivers.h): the C++ RS/RF/QB/RSVD objects behind a C ABI
+# ------------------------------------------------------------------------------------------------------
+def _state_arr(ctr, key):
+    return (C.c_uint32 * 6)(*[int(v) & 0xFFFFFFFF for v in list(ctr) + list(key)])
+
+
+def _adopt(ctx: "Context", ptr: C.c_void_p, rows: int, cols: int):
+    """copy a callee-allocated column-major device block into a torch tensor (cols, rows) and free it"""
+    torch = _torch()
+    t = torch.empty((cols, rows), dtype=torch.float64, device=f"cuda:{ctx.device}")
+    if rows * cols > 0:
+        _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, t.data_ptr(), ptr, rows * cols * 8), "memcpy_d2d")
+    _lib.check(ctx.lib.rlhip_free(ctx.h, ptr), "rlhip_free")
+    return t
+
+
+def _drv_check(ctx, rc, what):
+    if rc <= -100:
+        raise _lib.RlhipError(f"{what}: {ctx.lib.rlhip_last_error().decode()} (code {rc})")
+    return rc
+
+
+def drv_stab(ctx: Context, kind: int, A, m: int, k: int, cond_check: bool = False):
+    cf = C.c_int(0)
+    rc = ctx.lib.rlhip_drv_stab_f64(ctx.h, kind, int(cond_check), m, k, A.data_ptr(), C.byref(cf))
+    return _drv_check(ctx, rc, "stab"), bool(cf.value)
+
+
+def drv_rs(ctx: Context, A, m, n, k, p, q, stab_kind=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    Om = cm_empty(n, k, device=f"cuda:{ctx.device}")
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_rs_f64(ctx.h, m, n, A.data_ptr(), k, p, q, stab_kind, Om.data_ptr(), st)
+    return _drv_check(ctx, rc, "rs"), Om, tuple(int(x) for x in st[:4])
+
+
+def drv_rf(ctx: Context, A, m, n, k, p, q, rs_stab=0, orth_kind=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    Q = cm_empty(m, k, device=f"cuda:{ctx.device}")
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_rf_f64(ctx.h, m, n, A.data_ptr(), k, p, q, rs_stab, orth_kind, Q.data_ptr(), st)
+    return _drv_check(ctx, rc, "rf"), Q, tuple(int(x) for x in st[:4])
+
+
+def drv_qb(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=False,
+           ctr=(0, 0, 0, 0), key=(0, 0)):
+    kk = C.c_int64(k)
+    Qp, Bp = C.c_void_p(), C.c_void_p()
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_qb_f64(ctx.h, m, n, A.data_ptr(), C.byref(kk), b_sz, tol, p, q, rs_stab, rf_orth, qb_orth,
+                                  int(orth_check), C.byref(Qp), C.byref(Bp), st)
+    _drv_check(ctx, rc, "qb")
+    Q = _adopt(ctx, Qp, m, k)
+    BT = _adopt(ctx, Bp, n, k)
+    kf = int(kk.value)
+    return rc, kf, Q[:kf], BT[:kf], tuple(int(x) for x in st[:4])
+
+
+def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=False,
+             ctr=(0, 0, 0, 0), key=(0, 0), keep_on_device=True):
+    """RSVD::call.  Returns dict(rc, qb_rc, k, U, S, V, next_ctr); U/V are column-major tensors (k, m)/(k, n)."""
+    kk = C.c_int64(k)
+    Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    qrc = C.c_int(0)
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_rsvd_f64(ctx.h, m, n, A.data_ptr(), C.byref(kk), b_sz, tol, p, q, rs_stab, rf_orth, qb_orth,
+                                    int(orth_check), C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(qrc))
+    _drv_check(ctx, rc, "rsvd")
+    kf = int(kk.value)
+    kal = max(kf, 1)
+    U = _adopt(ctx, Up, m, kal)
+    S = _adopt(ctx, Sp, kal, 1).reshape(-1)
+    V = _adopt(ctx, Vp, n, kal)
+    return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))

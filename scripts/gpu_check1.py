@@ -1,5 +1,5 @@
 import sys, time, json
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from randlapack_amd.device import Context, cm_from_numpy, cm_to_numpy, cm_empty, cm_zeros
 ctx = Context(0)

@@ -1,0 +1,134 @@
+"""The reference's own property tests, run against the CPU oracle at the reference's
+sizes and tolerances.  This is what 'pins' the factorization part of the oracle: the reference holds no
+golden factors, only these norm bounds."""
+import numpy as np
+import pytest
+
+from _gen import poly_mat, poly_singvals, with_singvals
+
+EPS = np.finfo(np.float64).eps
+
+
+def _qb_checks(A, Q, B, k, tol_test, A_k=None):
+    # test/comps/test_qb.cc:162-174
+    assert np.linalg.norm(Q.T @ Q - np.eye(Q.shape[1])) <= tol_test
+    if A_k is not None:
+        assert np.linalg.norm(A_k - Q @ B) <= tol_test * 10
+
+
+@pytest.mark.parametrize("b_sz,p", [(2, 5), (10, 2), (10, 5), (2, 2)])
+def test_qb_polynomial_decay(orc, b_sz, p):
+    # test_qb.cc:236-363: 100x100, k=50, polynomial decay cond 2025, tol = eps^0.75
+    rng = np.random.default_rng(0)
+    m = n = 100
+    k = 50
+    A = with_singvals(m, n, np.concatenate([poly_singvals(k, 0.1, 2025.0, 2.0)]), rng)  # exact rank k
+    tol = EPS**0.75
+    rc, kf, Q, BT, _ = orc.qb(A, k, b_sz, tol, p, 1, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=False)
+    assert rc in (0, 3) and kf == k
+    assert np.linalg.norm(Q.T @ Q - np.eye(kf)) <= EPS**0.625
+    assert np.linalg.norm(A - Q @ BT.T) <= EPS**0.625 * np.linalg.norm(A)
+
+
+def test_qb_zero_tol_exact_rank(orc):
+    # test_qb.cc:219-229: ||A - QB|| <= tol ||A|| once the whole rank is captured
+    rng = np.random.default_rng(1)
+    A = with_singvals(100, 100, poly_singvals(20, 0.1, 100.0, 2.0), rng)
+    rc, kf, Q, BT, _ = orc.qb(A, 30, 10, 0.0, 2, 1)
+    assert np.linalg.norm(A - Q @ BT.T) <= 1e-9 * np.linalg.norm(A)
+
+
+def test_rf_hqrq(orc):
+    # test/comps/test_rf.cc:143-201: 100x100, k in {100, 50}, p=5, HQRQ; ||Q^T Q - I|| <= eps^0.625
+    rng = np.random.default_rng(2)
+    for k in (100, 50):
+        A = poly_mat(100, 100, 100, rng, cond=2025.0)
+        rc, Q, _ = orc.rf(A, k, 5, 1, rs_stab=1, orth_kind=1)
+        assert rc == 0
+        assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS**0.625
+
+
+def test_cholqrq_twice(orc):
+    # test/comps/test_orth.cc:135-153: CholQRQ twice on a 1000x200 Gaussian-sketched matrix
+    rng = np.random.default_rng(3)
+    Y = poly_mat(1000, 300, 300, rng, cond=100.0) @ rng.standard_normal((300, 200))
+    rc, Q1 = orc.stab(0, Y)
+    assert rc == 0
+    rc, Q2 = orc.stab(0, Q1)
+    assert rc == 0
+    assert np.linalg.norm(Q2.T @ Q2 - np.eye(200)) <= EPS**0.625
+
+
+def test_cholqrq_reports_failure(orc):
+    A = np.ones((50, 4))  # rank 1 -> Cholesky breaks down -> return 1 (rl_orth.hh:81-85)
+    rc, _ = orc.stab(0, A)
+    assert rc == 1
+
+
+def test_plul_singular_input(orc):
+    # test_orth.cc:109-133: PLUL on a singular input returns 0, entries finite and <= 1 in magnitude
+    A = np.zeros((20, 5))
+    A[:, 0] = 1.0
+    rc, L = orc.stab(2, A)
+    assert rc == 0 and np.all(np.isfinite(L)) and np.abs(L).max() <= 1.0
+
+
+def test_rsvd_config1(orc):
+    # BASELINE.json configs[0]: RSVD 4096x512 fp64, rank 64, p=2, q=1, tol=eps^0.5625 (test_rsvd.cc:176)
+    rng = np.random.default_rng(4)
+    m, n, k = 4096, 512, 64
+    A = poly_mat(m, n, n, rng)
+    r = orc.rsvd(A, k, k, EPS**0.5625, 2, 1)
+    assert r["rc"] == 0 and r["qb_rc"] == 3 and r["k"] == k  # fixed-rank run ends with QB code 3
+    s_true = np.linalg.svd(A, compute_uv=False)
+    A_k_err = np.sqrt(np.sum(s_true[k:] ** 2))
+    err = np.linalg.norm(A - (r["U"] * r["S"]) @ r["V"].T)
+    assert err <= 1.25 * A_k_err + 1e-12      # two power passes get close to the optimal rank-k error
+    np.testing.assert_allclose(r["S"][:10], s_true[:10], rtol=1e-6)
+    assert np.linalg.norm(r["U"].T @ r["U"] - np.eye(k)) <= EPS**0.625
+    assert np.linalg.norm(r["V"].T @ r["V"] - np.eye(k)) <= EPS**0.625
+    assert r["next_ctr"] == (n * k // 4, 0, 0, 0)
+
+
+def test_rsvd_argument_checks(orc):
+    A = np.zeros((4, 4))
+    assert orc.rsvd(A, 2, 2, -1.0, 0, 1)["rc"] == -1   # tol < 0  (rl_rsvd.hh:131)
+
+
+def test_cqrrpt_rank_deficient(orc):
+    # test/drivers/test_cqrrpt.cc:184-304 scaled down: m x 200, rank 100; eps = eps^0.85
+    rng = np.random.default_rng(5)
+    m, n, rank = 4000, 200, 100
+    A = poly_mat(m, n, rank, rng, cond=1e6)
+    d = int(1.25 * n)
+    S = rng.standard_normal((d, m))
+    r = orc.cqrrpt(A, S @ A, EPS**0.85)
+    assert r["rc"] == 0
+    assert abs(r["rank"] - rank) <= 5                      # test_cqrrpt.cc:178-179
+    k = r["rank"]
+    Q, R, J = r["Q"][:, :k], r["R"][:k, :], r["J"]
+    atol = EPS**0.75
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= 100 * atol * np.linalg.norm(A)   # :102-104
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= atol * np.sqrt(n) * 100
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+
+
+def test_cqrrpt_zero_matrix(orc):
+    r = orc.cqrrpt(np.zeros((50, 5)), np.zeros((7, 5)), EPS**0.85)
+    assert r["rc"] == 0 and r["rank"] == 0                 # rl_cqrrpt.hh:256-261
+
+
+def test_orhr_col_matches_lapack_semantics(orc):
+    # Householder reconstruction: Q - S = L U, V = unit-lower L, tau_i = -u_ii * d_i  (rl_util.hh:339-379)
+    rng = np.random.default_rng(6)
+    m, n = 60, 12
+    Q = np.linalg.qr(rng.standard_normal((m, n)))[0]
+    A, tau, D = orc.orhr_col(Q, output_tau=True)
+    V = np.tril(A, -1) + np.eye(m, n)
+    H = np.eye(m)
+    for i in range(n):
+        v = V[:, i:i + 1]
+        H = H @ (np.eye(m) - tau[i] * (v @ v.T))
+    # H[:, :n] = Q * diag(D): reconstructed reflectors reproduce Q up to the sign vector
+    np.testing.assert_allclose(H[:, :n], Q * D, atol=1e-12)
+    assert set(np.unique(D)).issubset({-1.0, 1.0})
