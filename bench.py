@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: RSVD rank-256 of a 200000 x 20000 fp64 dense matrix (BASELINE.json configs[1]).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full RandLAPACK::RSVD::call (sketch GEMM -> CholQR -> B = Q^T A -> SVD of B^T -> U) on the
+synthetic matrix, which is generated ON the GPU before the timed region (inputs resident in HBM).  Rank 0
+prints ONE JSON line.  Extra objects on the line:
+  roofline     -- the dominant kernel (fused-sketch MFMA GEMM  Y = A * Omega): algorithmic 2*m*n*k flops per
+                  launch / average launch duration measured live with HIP events on the kernel's stream,
+                  against the 78.6 TFLOP/s dense fp64 MFMA peak of MI355X.
+  cpu_baseline -- the CPU oracle (restatement of the reference path over host LAPACK) timed on the host cores
+                  on a bounded row-sample of the same workload (N=1, rank 0 only).
+
+Multi-GPU: tall matrices shard by row blocks: every rank owns m/N rows, regenerates the same
+Omega from the counter-based RNG, and the only exchanges are all-reduces of the k x k Gram matrix and the
+n x k factor B^T over RCCL.  Total work is fixed as N grows -> "scaling": "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+M, N, K = 200_000, 20_000, 256
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (measured 77.7 by rlhip_mfma_peak)
+
+
+def rsvd_flops(m, n, k, p=0):
+    # 2mnk(2+p) + 2mk^2 (CholQR syrk+trsm) + 2mk^2 (U = Q*Uhat) + gesdd(n,k) ~ 6nk^2 + 8k^3
+    return 2.0 * m * n * k * (2 + p) + 2.0 * m * k * k + 2.0 * m * k * k + 6.0 * n * k * k + 8.0 * k**3
+
+
+def cpu_baseline(n, k, budget_rows=49152):
+    """Oracle RSVD on a bounded sample (same n and k, fewer rows) on the host cores."""
+    import numpy as np
+    import oracle
+
+    oracle.load()
+    cores = os.cpu_count() or 1
+    oracle.set_threads(cores)
+    rng = np.random.default_rng(0)
+    A = np.asfortranarray(rng.standard_normal((budget_rows, n)))
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = oracle.rsvd(A, k, k, 1e-12, 0, 1)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert r["k"] == k
+    # the reference also pays the m x n copy and the wasted final update (rl_qb.hh:171,260): count useful flops only
+    gf = rsvd_flops(budget_rows, n, k) / best / 1e9
+    return dict(value=round(gf, 2), unit="GFLOP/s", cores=oracle.get_threads(), kind="port",
+                sample=f"oracle RSVD (CholQRQ, p=0, one block) on {budget_rows}x{n} fp64 Gaussian, rank {k}, "
+                       f"best of 2, {best:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--m", type=int, default=M)
+    ap.add_argument("--n", type=int, default=N)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from randlapack_amd import device as dev
+    from randlapack_amd import sharded
+
+    ctx = dev.Context(local_rank)
+    m, n, k = args.m, args.n, args.k
+    # row-block sharding: rank r owns rows [r*mloc, (r+1)*mloc) (last rank takes the remainder)
+    mloc = m // world + (m % world if rank == world - 1 else 0)
+    row0 = rank * (m // world)
+    A = dev.cm_empty(mloc, n, device=f"cuda:{local_rank}")
+    # synthetic iid N(0,1) data, generated in HBM; each rank uses its own key so the global matrix is iid
+    ctx.fill_dense(A, mloc, n, key=(7 + rank, 0))
+    ctx.sync()
+
+    def step():
+        if world == 1:
+            return dev.drv_rsvd(ctx, A, mloc, n, k, k, 1e-12, 0, 1, key=(0, 0))
+        return sharded.rsvd_rowsharded(ctx, dist, A, mloc, n, k, key=(0, 0))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    flops = rsvd_flops(m, n, k)
+    value = flops / (dt / args.steps) / 1e9
+
+    # ---- roofline leg: the dominant kernel, timed live with HIP events on the kernel's own stream
+    Om = dev.cm_empty(n, k, device=f"cuda:{local_rank}")
+    ctx.fill_dense(Om, n, k, key=(0, 0))
+    Y = dev.cm_empty(mloc, k, device=f"cuda:{local_rank}")
+    reps = 5
+    ctx.gemm("N", "N", mloc, k, n, 1.0, A, mloc, Om, n, 0.0, Y, mloc)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.gemm("N", "N", mloc, k, n, 1.0, A, mloc, Om, n, 0.0, Y, mloc)
+    kernel_ms = ctx.timer_stop_ms() / reps
+    achieved = 2.0 * mloc * n * k / (kernel_ms * 1e-3) / 1e12
+    roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=None,
+                    kernel="gemm_kernel<double,NN,128x256x16> (Y = A*Omega, incl. split-K reduce)",
+                    launch_ms=round(kernel_ms, 3), flops_per_launch=2.0 * mloc * n * k)
+
+    if rank == 0:
+        out = {
+            "metric": "GFLOP/s (sketch+factor) for RSVD rank-256 on m x n dense fp64",
+            "value": round(value, 1),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic iid N(0,1), generated on-device from Philox4x32-10",
+            "config": {"workload": f"RSVD {m}x{n} fp64 rank {k}, one QB block, p=0, CholQRQ (BASELINE configs[1])",
+                       "m": m, "n": n, "k": k, "parallelism": f"row-block x{world}",
+                       "algorithmic_flops": flops, "qb_return": r["qb_rc"], "k_out": r["k"]},
+            "roofline": roofline,
+            "frac_of_peak_whole_job": round(value / 1e3 / (PEAK_F64_MFMA_TFLOPS * world), 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, k)
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,17 @@ public:
     Queue& operator=(Queue const&) = delete;
     ~Queue() { if (owned_ && ctx_) rlhip_destroy(ctx_); }
     void sync() { check(rlhip_sync(ctx_), "rlhip_sync"); }
+
+    // ---- row-block sharding (one process per GPU).  world() == 1 -> everything below is a no-op.
+    int world() const { return rlhip_comm_size(ctx_); }
+    int rank() const { return rlhip_comm_rank(ctx_); }
+    // Drivers mark, around each call that reduces over the row index, whether the operand's rows are the
+    // sharded dimension (m-long objects: A, Y, Q, Omega_1) or replicated (n- or k-long objects: Omega, B^T, R).
+    bool rows_sharded = false;
+    bool reduce_over_rows() const { return rows_sharded && world() > 1; }
+    void allreduce_sum(double* buf, int64_t count) { check(rlhip_allreduce_sum_f64(ctx_, buf, count), "allreduce"); }
+    void allreduce_sum(float* buf, int64_t count) { check(rlhip_allreduce_sum_f32(ctx_, buf, count), "allreduce"); }
+    void allreduce_sum_host(double* x, int64_t n) { check(rlhip_allreduce_sum_host_f64(ctx_, x, n), "allreduce_host"); }
     void* stream() const { return rlhip_stream(ctx_); }
     rlhip_ctx* ctx() const { return ctx_; }
 };
@@ -67,6 +78,15 @@ template <typename T>
 void copy_to_host(int64_t n, T const* dev, T* host, Queue& q) { check(rlhip_memcpy_d2h(q.ctx(), host, dev, (size_t)n * sizeof(T)), "d2h"); }
 template <typename T>
 void copy_to_device(int64_t n, T const* host, T* dev, Queue& q) { check(rlhip_memcpy_h2d(q.ctx(), dev, host, (size_t)n * sizeof(T)), "h2d"); }
+
+// RAII: declare whether row-reductions issued inside the scope run over the sharded dimension
+class RowsSharded {
+    Queue& q_;
+    bool prev_;
+public:
+    RowsSharded(Queue& q, bool on) : q_(q), prev_(q.rows_sharded) { q.rows_sharded = on; }
+    ~RowsSharded() { q_.rows_sharded = prev_; }
+};
 
 // RAII scope over the queue's stream-ordered scratch arena
 class Scratch {

@@ -32,6 +32,7 @@ public:
         T* gram = ws.alloc<T>(k * k);
         lapack::laset(MatrixType::General, k, k, T(0), T(0), gram, k, q);
         blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, T(1), A, m, T(0), gram, k, q);      // :78
+        if (q.reduce_over_rows()) q.allreduce_sum(gram, k * k);   // row-sharded: Gram = sum of the ranks' Grams
         if (lapack::potrf(Uplo::Upper, k, gram, k, q)) {                                                 // :81
             chol_fail = true;
             return 1;

@@ -49,6 +49,12 @@ public:
         T* A_cpy = A;
         T* A_own = nullptr;
         T norm_A = lapack::lange(Norm::Fro, m, n, A, m, q);                                               // :168
+        if (q.world() > 1) {                                       // ||A||_F^2 = sum over the row blocks
+            double ssq = (double)norm_A * (double)norm_A;
+            q.allreduce_sum_host(&ssq, 1);
+            norm_A = (T)std::sqrt(ssq);
+        }
+        blas::RowsSharded sh(q, true);                             // Q_i, Q: rows sharded
         if (!single_block) {
             A_own = blas::device_malloc<T>(m * n, q);
             lapack::lacpy(MatrixType::General, m, n, A, m, A_own, m, q);                                  // :171
@@ -65,10 +71,12 @@ public:
             if (orth_check && util::orthogonality_check(m, b_sz, Q_i, verbose, q)) { k = curr_sz; return done(4); }   // :198-206
             if (curr_sz != 0) {                                                                           // :209-215
                 blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, curr_sz, b_sz, m, T(1), Q, m, Q_i, m, T(0), QtQi, next_sz, q);
+                if (q.world() > 1) q.allreduce_sum(QtQi, next_sz * b_sz);
                 blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, b_sz, curr_sz, T(-1), Q, m, QtQi, next_sz, T(1), Q_i, m, q);
                 orth.call(m, b_sz, Q_i);
             }
             blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, n, b_sz, m, T(1), A_cpy, m, Q_i, m, T(0), BT_i, n, q);   // :218
+            if (q.world() > 1) q.allreduce_sum(BT_i, n * b_sz);     // B_i^T = sum_g A_g^T Q_g : the n x b exchange
             T norm_B_i = lapack::lange(Norm::Fro, n, b_sz, BT_i, n, q);                                   // :221
             norm_B = std::hypot(norm_B, norm_B_i);
             prev_err = approx_err;

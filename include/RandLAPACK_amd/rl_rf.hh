@@ -28,6 +28,7 @@ public:
         T* Omega = ws.alloc<T>(n * k);
         if (rs.call(m, n, A, k, Omega, state)) return 1;                                                  // :118-120
         blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, T(1), A, m, Omega, n, T(0), Q, m, q);   // :123
+        blas::RowsSharded sh(q, true);                             // Q's rows are the sharded dimension
         if (cond_check) cond_nums.push_back(util::cond_num_check(m, k, Q, verbose, q));                  // :125-127
         if (orth.call(m, k, Q)) return 2;                                                                 // :129-132
         return 0;

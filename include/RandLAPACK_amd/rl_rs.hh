@@ -39,18 +39,23 @@ public:
             RandBLAS::DenseDist D(m, k);
             state = RandBLAS::fill_dense(D, Omega_1, state, q);                                          // :137-139
             blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, n, k, m, T(1), A, m, Omega_1, m, T(0), Omega, n, q);  // :142
+            if (q.world() > 1) q.allreduce_sum(Omega, n * k);      // A^T Omega_1 sums over the sharded rows
             ++p_done;
-            if ((p_done % qq == 0) && Stab_Obj.call(n, k, Omega)) return 1;                              // :145-148
+            { blas::RowsSharded rep(q, false);
+              if ((p_done % qq == 0) && Stab_Obj.call(n, k, Omega)) return 1; }                           // :145-148
         }
         while (p - p_done > 0) {
             blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, T(1), A, m, Omega, n, T(0), Omega_1, m, q);  // :153
             ++p_done;
-            if (cond_check) cond_nums.push_back(util::cond_num_check(m, k, Omega_1, verbose, q));
-            if ((p_done % qq == 0) && Stab_Obj.call(m, k, Omega_1)) return 1;                             // :159-162
+            { blas::RowsSharded sh(q, true);
+              if (cond_check) cond_nums.push_back(util::cond_num_check(m, k, Omega_1, verbose, q));
+              if ((p_done % qq == 0) && Stab_Obj.call(m, k, Omega_1)) return 1; }                         // :159-162
             blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, n, k, m, T(1), A, m, Omega_1, m, T(0), Omega, n, q);   // :165
+            if (q.world() > 1) q.allreduce_sum(Omega, n * k);
             ++p_done;
-            if (cond_check) cond_nums.push_back(util::cond_num_check(n, k, Omega, verbose, q));
-            if ((p_done % qq == 0) && Stab_Obj.call(n, k, Omega)) return 1;                               // :171-172
+            { blas::RowsSharded rep(q, false);
+              if (cond_check) cond_nums.push_back(util::cond_num_check(n, k, Omega, verbose, q));
+              if ((p_done % qq == 0) && Stab_Obj.call(n, k, Omega)) return 1; }                           // :171-172
         }
         return 0;
     }

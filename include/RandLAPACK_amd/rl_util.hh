@@ -14,6 +14,8 @@ namespace RandLAPACK::util {
 template <typename T>
 T cond_num_check(int64_t m, int64_t n, T const* A, bool verbose, blas::Queue& q) {
     (void)verbose;
+    if (q.reduce_over_rows())
+        throw blas::Error("cond_num_check of a row-sharded matrix is not available (needs a distributed SVD)");
     blas::Scratch ws(q);
     T* cpy = ws.alloc<T>(m * n);
     T* s = ws.alloc<T>(n);
@@ -35,6 +37,7 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
     T* G = ws.alloc<T>(k * k);
     lapack::laset(MatrixType::General, k, k, T(0), T(0), G, k, q);
     blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, T(1), A, m, T(0), G, k, q);
+    if (q.reduce_over_rows()) q.allreduce_sum(G, k * k);
     if (k > 1) lapack::laset(MatrixType::Lower, k - 1, k, T(0), T(0), G + 1, k, q);   // keep the upper triangle only
     lapack::add_diag(k, T(-1), G, k, q);                                              // G - I
     T orth_err = lapack::lange(Norm::Fro, k, k, G, k, q);

@@ -137,6 +137,21 @@ int rlhip_transpose_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, i
 int rlhip_transpose_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat,
                         int upper_only);
 
+/* ---- row-block sharding across the GPUs of a node (new design; the reference has no
+ *      distributed code).  One process per GPU.  Sum all-reduces run on the context's stream through RCCL
+ *      (bound at run time), or through a host-installed hook.  With no communicator every call is a no-op,
+ *      so single-GPU callers never notice. ---- */
+typedef int (*rlhip_allreduce_hook)(void* user, void* dev_buf, int64_t count, int is_f64);
+int rlhip_comm_unique_id(unsigned char id_out[128]);                 /* rank 0: ncclGetUniqueId */
+int rlhip_comm_init(rlhip_ctx* ctx, int nranks, int rank, const unsigned char id[128]);
+int rlhip_comm_set_hook(rlhip_ctx* ctx, rlhip_allreduce_hook hook, void* user, int nranks, int rank);
+int rlhip_comm_destroy(rlhip_ctx* ctx);
+int rlhip_comm_size(rlhip_ctx* ctx);
+int rlhip_comm_rank(rlhip_ctx* ctx);
+int rlhip_allreduce_sum_f64(rlhip_ctx* ctx, double* buf, int64_t count);
+int rlhip_allreduce_sum_f32(rlhip_ctx* ctx, float* buf, int64_t count);
+int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /* n <= 16 scalars */
+
 /* ---- diagnostics ---- */
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);

@@ -66,6 +66,18 @@ SIGNATURES = {
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }
+HOOK = C.CFUNCTYPE(c_int, c_vp, c_vp, c_i64, c_int)
+SIGNATURES.update({
+    "rlhip_comm_unique_id": (c_int, [c_vp]),
+    "rlhip_comm_init": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "rlhip_comm_set_hook": (c_int, [c_vp, HOOK, c_vp, c_int, c_int]),
+    "rlhip_comm_destroy": (c_int, [c_vp]),
+    "rlhip_comm_size": (c_int, [c_vp]),
+    "rlhip_comm_rank": (c_int, [c_vp]),
+    "rlhip_allreduce_sum_f64": (c_int, [c_vp, c_vp, c_i64]),
+    "rlhip_allreduce_sum_f32": (c_int, [c_vp, c_vp, c_i64]),
+    "rlhip_allreduce_sum_host_f64": (c_int, [c_vp, C.POINTER(c_dbl), c_i64]),
+})
 dpp = C.POINTER(c_vp)
 SIGNATURES.update({
     "rlhip_last_error": (C.c_char_p, []),

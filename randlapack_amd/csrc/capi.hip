@@ -81,6 +81,7 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
 
 int rlhip_destroy(rlhip_ctx* c) {
     if (!c) return 0;
+    rlhip_comm_destroy(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->n_overflow; ++i) hipFree(c->overflow[i]);

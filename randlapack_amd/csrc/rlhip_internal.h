@@ -39,6 +39,8 @@ struct rlhip_ctx {
     int64_t* d_mail = nullptr;   // 64 x int64 device
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // row-sharding communicator (comm.hip), nullptr = single GPU
+    void* comm = nullptr;
 };
 
 // scratch arena helpers (capi.hip)

@@ -1,0 +1,259 @@
+"""-m gpu: each HIP kernel family through the C ABI against the CPU oracle / numpy on the same inputs.
+Tolerances are stated per test; integer work (Philox, pivots) is bit-exact."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+EPS = np.finfo(np.float64).eps
+
+
+def _dev():
+    from randlapack_amd import device
+
+    return device
+
+
+def relerr(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def test_library_is_the_hip_one(ctx):
+    assert ctx.lib.rlhip_version().decode().startswith("rlhip")
+    assert ctx.mfma_peak(True, 2000) > 10.0  # TFLOP/s: the MFMA pipe is really being driven
+
+
+def test_philox_kat_device(ctx):
+    for v in json.loads((G / "philox_kat.json").read_text()):
+        out = ctx.philox(1, v["ctr"], v["key"])
+        assert [int(x) for x in out] == v["out"]          # bit-exact
+
+
+def test_philox_counter_blocks_match_oracle(ctx, orc):
+    out = ctx.philox(5, (0xFFFFFFFD, 7, 0, 0), (11, 13)).reshape(5, 4)
+    for b in range(5):
+        lo = 0xFFFFFFFD + b
+        ref = orc.philox((lo & 0xFFFFFFFF, 7 + (lo >> 32), 0, 0), (11, 13))
+        assert list(out[b]) == list(ref)
+
+
+@pytest.mark.parametrize("rows,cols,dist", [(1000, 300, 0), (17, 5, 0), (3, 1, 1), (257, 33, 1)])
+def test_fill_dense_matches_oracle(ctx, orc, rows, cols, dist):
+    d = _dev()
+    buf = d.cm_empty(rows, cols)
+    nxt = ctx.fill_dense(buf, rows, cols, ctr=(5, 0, 0, 0), key=(9, 1), dist=dist)
+    ref, nxt_ref = orc.fill_dense(rows, cols, ctr=(5, 0, 0, 0), key=(9, 1), dist=dist)
+    assert nxt == nxt_ref                                  # state threading is integer-exact
+    # the float stage uses device libm vs glibc: a few ulp at most
+    np.testing.assert_allclose(d.cm_to_numpy(buf), ref, rtol=0, atol=4e-15)
+
+
+def test_fill_dense_f32_is_rounded_f64(ctx, orc):
+    import torch
+
+    d = _dev()
+    buf = d.cm_empty(64, 8, dtype=torch.float32)
+    ctx.fill_dense(buf, 64, 8)
+    ref, _ = orc.fill_dense(64, 8)
+    np.testing.assert_allclose(d.cm_to_numpy(buf), ref.astype(np.float32), rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 70, 45), (257, 256, 130), (128, 256, 64), (1000, 17, 33), (64, 300, 1000),
+                                   (5, 3, 2), (513, 129, 4000), (1, 1, 1), (130, 20, 7)])
+@pytest.mark.parametrize("ta", "NT")
+@pytest.mark.parametrize("tb", "NT")
+def test_gemm_f64(ctx, m, n, k, ta, tb):
+    d = _dev()
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((k, n)), rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A if ta == "N" else A.T.copy())
+    Bd = d.cm_from_numpy(B if tb == "N" else B.T.copy())
+    Cd = d.cm_from_numpy(C0)
+    ctx.gemm(ta, tb, m, n, k, 1.5, Ad, m if ta == "N" else k, Bd, k if tb == "N" else n, -0.5, Cd, m)
+    ref = 1.5 * A @ B - 0.5 * C0
+    assert relerr(d.cm_to_numpy(Cd), ref) < 50 * EPS * np.sqrt(k)
+
+
+def test_gemm_f32(ctx):
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(0)
+    m, n, k = 300, 200, 500
+    A, B = rng.standard_normal((m, k)).astype(np.float32), rng.standard_normal((k, n)).astype(np.float32)
+    Cd = d.cm_zeros(m, n, dtype=torch.float32)
+    ctx.gemm("N", "N", m, n, k, 1.0, d.cm_from_numpy(A), m, d.cm_from_numpy(B), k, 0.0, Cd, m)
+    assert relerr(d.cm_to_numpy(Cd), A.astype(np.float64) @ B.astype(np.float64)) < 1e-5
+
+
+def test_gemm_submatrix_ld_and_beta_zero_ignores_nan(ctx):
+    d = _dev()
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((50, 40))
+    B = rng.standard_normal((40, 30))
+    Cfull = np.full((60, 30), np.nan)
+    Ad, Bd, Cd = d.cm_from_numpy(A), d.cm_from_numpy(B), d.cm_from_numpy(Cfull)
+    # use the top-left 33 x 21 x 17 sub-problem with the parents' leading dimensions
+    ctx.gemm("N", "N", 33, 21, 17, 1.0, Ad, 50, Bd, 40, 0.0, Cd, 60)
+    out = d.cm_to_numpy(Cd)
+    np.testing.assert_allclose(out[:33, :21], A[:33, :17] @ B[:17, :21], atol=1e-12)
+    assert np.isnan(out[33:, :]).all() and np.isnan(out[:33, 21:]).all()      # nothing else touched
+
+
+def test_gemm_is_deterministic_run_to_run(ctx):
+    d = _dev()
+    rng = np.random.default_rng(2)
+    m, n, k = 100, 256, 60000                         # forces the split-K path
+    A, B = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    Ad, Bd = d.cm_from_numpy(A), d.cm_from_numpy(B)
+    outs = []
+    for _ in range(3):
+        Cd = d.cm_zeros(m, n)
+        ctx.gemm("T", "N", m, n, k, 1.0, Ad, k, Bd, k, 0.0, Cd, m)
+        outs.append(d.cm_to_numpy(Cd))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])   # bitwise
+    assert relerr(outs[0], A.T @ B) < 1e-12
+
+
+@pytest.mark.parametrize("n,k", [(256, 5000), (100, 300), (300, 2000), (1, 10), (130, 17)])
+def test_syrk_upper(ctx, n, k):
+    d = _dev()
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((k, n))
+    Cd = d.cm_zeros(n, n)
+    ctx.syrk("U", "T", n, k, 1.0, d.cm_from_numpy(A), k, 0.0, Cd, n)
+    assert relerr(np.triu(d.cm_to_numpy(Cd)), np.triu(A.T @ A)) < 1e-13
+
+
+@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 256, 700])
+def test_potrf_upper(ctx, n):
+    d = _dev()
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((2 * n + 3, n))
+    Gm = X.T @ X
+    Gd = d.cm_from_numpy(Gm)
+    assert ctx.potrf(n, Gd, n) == 0
+    R = np.triu(d.cm_to_numpy(Gd))
+    assert relerr(R.T @ R, Gm) < 1e-13
+    assert (np.diag(R) > 0).all()
+
+
+def test_potrf_reports_first_bad_minor(ctx, orc):
+    d = _dev()
+    Gm = np.eye(40)
+    Gm[17, 17] = -1.0
+    assert ctx.potrf(40, d.cm_from_numpy(Gm), 40) == 18                    # LAPACK info semantics
+    Gm = np.ones((6, 6))                                                     # rank 1 -> fails at minor 2
+    assert ctx.potrf(6, d.cm_from_numpy(Gm), 6) == 2
+
+
+@pytest.mark.parametrize("m,n", [(1000, 256), (333, 100), (2000, 600), (70, 5), (1, 1), (513, 257)])
+def test_trsm_right_upper_matches_lapack(ctx, orc, m, n):
+    import ctypes as C
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2 * np.eye(n)
+    B = rng.standard_normal((m, n))
+    Bd = d.cm_from_numpy(B)
+    ctx.trsm(m, n, 2.0, d.cm_from_numpy(U), n, Bd, m)
+    X = d.cm_to_numpy(Bd)
+    # LAPACK's own trsm on the host as the reference
+    Bh = np.asfortranarray(B.copy())
+    Uh = np.asfortranarray(U)
+    orc.load().oracle_trsm_right_upper_f64(C.c_int64(m), C.c_int64(n), C.c_double(2.0), Uh.ctypes.data_as(C.c_void_p),
+                                           C.c_int64(n), Bh.ctypes.data_as(C.c_void_p), C.c_int64(m))
+    assert relerr(X, Bh) < 1e-11
+    assert relerr(X @ U, 2.0 * B) < 1e-12                                  # backward-stable residual
+
+
+def test_trsm_is_substitution_not_inverse(ctx):
+    # graded R with cond ~1e12 (CQRRPT's preconditioning regime): residual must stay at eps*||B||
+    d = _dev()
+    rng = np.random.default_rng(3)
+    m, n = 400, 64
+    U = np.triu(rng.standard_normal((n, n))) * np.logspace(0, -12, n)[:, None] + np.diag(np.logspace(0, -12, n))
+    B = rng.standard_normal((m, n)) @ U
+    Bd = d.cm_from_numpy(B)
+    ctx.trsm(m, n, 1.0, d.cm_from_numpy(U), n, Bd, m)
+    X = d.cm_to_numpy(Bd)
+    assert np.linalg.norm(X @ U - B) <= 1e-13 * np.linalg.norm(B) * n
+
+
+@pytest.mark.parametrize("m,n", [(1000, 256), (40, 300), (7, 7)])
+def test_trmm_right_upper(ctx, m, n):
+    d = _dev()
+    rng = np.random.default_rng(m * n)
+    U = rng.standard_normal((n, n))       # strictly-lower garbage must be ignored
+    B = rng.standard_normal((m, n))
+    Bd = d.cm_from_numpy(B)
+    ctx.trmm(m, n, 0.5, d.cm_from_numpy(U), n, Bd, m)
+    assert relerr(d.cm_to_numpy(Bd), 0.5 * B @ np.triu(U)) < 1e-13
+
+
+def test_lange_lacpy_laset_transpose(ctx):
+    d = _dev()
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((1234, 77))
+    Ad = d.cm_from_numpy(A)
+    assert abs(ctx.lange_fro(1234, 77, Ad, 1234) - np.linalg.norm(A)) < 1e-10
+    assert ctx.lange_fro(0, 5, Ad, 1) == 0.0
+    Bd = d.cm_zeros(1234, 77)
+    ctx.lacpy("U", 1234, 77, Ad, 1234, Bd, 1234)
+    np.testing.assert_array_equal(d.cm_to_numpy(Bd), np.triu(A))
+    ctx.laset("L", 1234, 77, 0.0, 1.0, Ad, 1234)      # LAPACK: strictly lower <- 0, diagonal <- 1
+    ref = np.triu(A, 1) + np.eye(1234, 77)
+    np.testing.assert_array_equal(d.cm_to_numpy(Ad), ref)
+    import ctypes as C
+    T = d.cm_zeros(77, 1234)
+    ctx.lib.rlhip_transpose_f64(ctx.h, 1234, 77, Ad.data_ptr(), 1234, T.data_ptr(), 77, 0)
+    np.testing.assert_array_equal(d.cm_to_numpy(T), ref.T)
+
+
+@pytest.mark.parametrize("m,n,cond", [(300, 64, 1e8), (256, 256, 1e3), (50, 7, 10.0), (65, 33, 1e6)])
+def test_gesvdj(ctx, m, n, cond):
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)) @ np.diag(np.logspace(0, -np.log10(cond), n)) @ np.linalg.qr(rng.standard_normal((n, n)))[0]
+    Ad = d.cm_from_numpy(A)
+    S = torch.empty(n, dtype=torch.float64, device="cuda")
+    VT = d.cm_empty(n, n)
+    info, sweeps = ctx.gesvdj(m, n, Ad, m, S, VT, n)
+    assert info == 0 and sweeps > 0
+    U, s, vt = d.cm_to_numpy(Ad), S.cpu().numpy(), d.cm_to_numpy(VT)
+    sref = np.linalg.svd(A, compute_uv=False)
+    assert np.all(np.diff(s) <= 0)
+    # LAPACK's own values are only accurate to eps*sigma_max in absolute terms, so that is the yardstick
+    np.testing.assert_allclose(s, sref, rtol=1e-12, atol=1e-14 * sref[0])
+    assert np.abs(U * s @ vt - A).max() <= 1e-13 * np.abs(A).max() * n
+    assert np.linalg.norm(U.T @ U - np.eye(n)) <= 1e-12 * n
+    assert np.linalg.norm(vt @ vt.T - np.eye(n)) <= 1e-12 * n
+
+
+@pytest.mark.parametrize("m,n,cond", [(2000, 64, 10.0), (5000, 256, 1e5), (300, 40, 1e12), (40, 40, 1e3)])
+def test_gesdd_tall_vs_lapack(ctx, orc, m, n, cond):
+    import ctypes as C
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    A = np.linalg.qr(rng.standard_normal((m, n)))[0] * np.logspace(0, -np.log10(cond), n) @ np.linalg.qr(
+        rng.standard_normal((n, n)))[0]
+    Ad = d.cm_from_numpy(A)
+    S = torch.empty(n, dtype=torch.float64, device="cuda")
+    U, VT = d.cm_empty(m, n), d.cm_empty(n, n)
+    sw = C.c_int()
+    info = ctx.lib.rlhip_gesdd_f64(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n,
+                                   C.byref(sw))
+    assert info == 0
+    u, s, vt = d.cm_to_numpy(U), S.cpu().numpy(), d.cm_to_numpy(VT)
+    _, _, s_ref, _ = orc.gesdd(A)
+    # same backward-error class as LAPACK's gesdd: absolute error eps * sigma_max
+    assert np.max(np.abs(s - s_ref)) <= 1e-13 * s_ref[0] * np.sqrt(n)
+    assert np.linalg.norm(u * s @ vt - A) <= 1e-13 * np.linalg.norm(A) * n
+    assert np.linalg.norm(u.T @ u - np.eye(n)) <= 1e-11 * n
