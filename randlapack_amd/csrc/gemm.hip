@@ -441,6 +441,19 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
 
 namespace rlhip {
 
+int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
+                     const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                     int64_t ldc);
+
+template <typename T>
+static int try_streamk(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T,
+                       T*, int64_t) { return 0; }
+template <>
+int try_streamk<double>(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
 template <typename T>
 int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
               int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri) {
@@ -461,6 +474,17 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (lda < (arows > 1 ? arows : 1)) return -8;
     if (ldb < (brows > 1 ? brows : 1)) return -10;
     if (ldc < (m > 1 ? m : 1)) return -13;
+    if (!tri && !transB && m >= 128 && n % 256 == 0 && k % 16 == 0) {
+        // big data passes: persistent stream-K kernel on the multiple-of-128 row block, generic kernel on the rest
+        const int64_t m_main = (m / 128) * 128;
+        int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            if (m_main == m) return 0;
+            const T* A2 = transA ? (A + m_main * lda) : (A + m_main);
+            return gemm_impl<T>(c, transA, transB, m - m_main, n, k, alpha, A2, lda, B, ldb, beta, C + m_main, ldc, 0);
+        }
+    }
     GemmArgs<T> g;
     g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.kchunk = 0; g.slab = nullptr; g.tri = 0;

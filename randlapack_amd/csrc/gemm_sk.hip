@@ -1,0 +1,299 @@
+// Persistent "stream-K" fp64 MFMA GEMM for the two data passes of the sketch-and-factor path:
+//     Y   = A  * Omega   (m x k  <-  m x n . n x k,  NN)       RandLAPACK/comps/rl_rf.hh:123, rl_rs.hh:153
+//     B^T = A^T * Q      (n x k  <-  n x m . m x k,  TN)       RandLAPACK/comps/rl_qb.hh:218, rl_rs.hh:142,165
+// i.e. C(M x N) = alpha * op(A) * B + beta * C with N a multiple of 256, K a multiple of 16, op(B) = B.
+//
+// Why a second GEMM kernel (measured on MI355X):
+//   * the register-staged kernel in gemm.hip loses ~7 % to wave quantisation at 1563 tiles / 256 CUs and ~5 %
+//     to exposed HBM latency, and its split-K needs a shape-dependent heuristic;
+//   * here ONE workgroup per CU owns an equal, contiguous share of the (tile, k-tile) iteration space
+//     ("stream-K"), so every CU finishes at the same time for ANY shape; tiles cut by a share boundary are
+//     written as partial slabs and summed by a fix-up kernel in fixed k order (bitwise reproducible);
+//   * operands go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass) into a
+//     3-deep ring of 48 KiB stages (144 of the CU's 160 KiB): two K-tiles (~7 us) of loads are always in
+//     flight behind a counted s_waitcnt vmcnt(6) and a single raw s_barrier per K-tile;
+//   * fragments are fetched with ds_read_b128 (two MFMA operands per read, 4 LDS cycles per 16 bytes instead of
+//     the 8-16 of the ds_read2_b64 pairs hipcc builds from scalar reads -- PMC showed 1e9 bank-conflict cycles
+//     and a 14 % matrix-pipe bubble with those).  To make 16 contiguous bytes useful to ONE lane the
+//     reduction index and the row index are re-enumerated (any bijection is legal as long as both operands
+//     agree):  MFMA step (sigma, h), lane group fk  <->  kk = 8*sigma + 2*fk + h   (KC images: one 16-byte
+//     piece = kk, kk+1);  MC image: fragment x, lane fr  <->  row 32*(x>>1) + 2*fr + (x&1)  (rows i, i+1).
+//   * LDS images: the DMA destination is lane-linear by construction, so bank-conflict freedom is obtained
+//     by permuting the SOURCE addresses:  KC operand (Omega, Q, A of A^T*Q): row r keeps 16-byte piece c at
+//     slot c ^ ((r >> 1) & 7);  MC operand (A of A*Omega): plain (the b128 lane groups already spread).
+//   * v_mfma_f64_16x16x4_f64, 64 x 64 accumulator tile per wave (2 x 4 waves -> 128 x 256 block tile).
+#include "rlhip_internal.h"
+#include <cstdlib>
+
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int BM = 128, BN = 256, BK = 16;
+constexpr int STAGE_A = BM * BK * 8;          // 16 KiB
+constexpr int STAGE_B = BN * BK * 8;          // 32 KiB
+constexpr int STAGE = STAGE_A + STAGE_B;      // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int SLAB_ELEMS = BM * BN;
+
+struct SkArgs {
+    int64_t M, N, K;          // M multiple of 128, N multiple of 256, K multiple of 16 (caller peels the rest)
+    const double* A; int64_t lda;
+    const double* B; int64_t ldb;
+    double* C; int64_t ldc;
+    double alpha, beta;
+    int64_t tiles_m, tiles_n, ktiles;
+    double* slab;             // 2 * gridDim.x slots of 128 x 256
+};
+
+__device__ __forceinline__ void glds16(const double* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool A_KC>
+__global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    const int64_t KT = g.ktiles;
+    const int64_t W = g.tiles_m * g.tiles_n * KT;
+    const int64_t P = gridDim.x, w = blockIdx.x;
+    const int64_t ws = (w * W) / P, we = ((w + 1) * W) / P;
+    const int64_t first_tile = ws / KT;
+
+    // ---- per-lane constants of the fragment reads (see header for the index re-enumeration)
+    // KC image: 16-byte piece c of row r lives at byte r*128 + ((c ^ ((r>>1)&7)) << 4); with r = 16*x + fr the
+    // key is fr>>1; step pair sigma uses piece c = 4*sigma + fk
+    const int kc_key = (fr >> 1) & 7;
+    const int kc_off0 = ((0 + fk) ^ kc_key) << 4, kc_off1 = ((4 + fk) ^ kc_key) << 4;
+    // MC image: byte(i, kk) = kk*1024 + i*8 ; lane reads rows (32*xi + 2*fr, +1) of k-row kk = 8*sigma + 2*fk + h
+    const int mc_row = (wm0 + 2 * fr) * 8, mc_k = 2 * fk * 1024;
+
+    // ---- per-lane source offsets of this wave's 6 DMA pieces per K-tile (elements, relative to tile origin)
+    // A: chunks {wid, wid+8}; B: chunks {wid, wid+8, wid+16, wid+24}
+    int64_t a_src[2], b_src[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = wid + 8 * h;
+        if (A_KC) {
+            const int r = 8 * c + (lane >> 3), q = lane & 7;
+            a_src[h] = (int64_t)r * g.lda + 2 * (q ^ ((r >> 1) & 7));
+        } else {
+            a_src[h] = (int64_t)c * g.lda + 2 * lane;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int c = wid + 8 * h;
+        const int r = 8 * c + (lane >> 3), q = lane & 7;
+        b_src[h] = (int64_t)r * g.ldb + 2 * (q ^ ((r >> 1) & 7));
+    }
+    const int64_t a_step = A_KC ? (int64_t)BK : (int64_t)BK * g.lda;
+
+    for (int64_t pos = ws; pos < we;) {
+        const int64_t tile = pos / KT;
+        const int64_t kt0 = pos - tile * KT;
+        int64_t nk = KT - kt0;
+        if (nk > we - pos) nk = we - pos;
+        const int64_t tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+        const int64_t m0 = tile_m * BM, n0 = tile_n * BN, k0 = kt0 * BK;
+
+        const double* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
+        const double* Bg = g.B + k0 + n0 * g.ldb;
+
+        auto issue = [&](int64_t t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
+            unsigned char* st = smem + stage * STAGE;
+            const double* Ap = Ag + t * a_step;
+            const double* Bp = Bg + t * BK;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) glds16(Ap + a_src[h], st + (wid + 8 * h) * 1024);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) glds16(Bp + b_src[h], st + STAGE_A + (wid + 8 * h) * 1024);
+        };
+
+        d4_t acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = d4_t{0, 0, 0, 0};
+
+        // ---- software pipeline (one rendezvous per K-tile, placed in the MIDDLE of the tile):
+        //   F0 = fragments of step pair 0, F1 = step pair 1.  While the 32 MFMAs of F0 run, F1 is fetched; at
+        //   the mid-point the wave retires its own DMA pieces of tile t+1 (the only group outstanding) and
+        //   meets the other waves: after that barrier tile t+1 is visible to everybody AND everybody has left
+        //   tile t-1, so tile t+2 may be DMA'd into t-1's stage and F0 of tile t+1 may be fetched while the 32
+        //   MFMAs of F1 run.  The matrix pipe therefore never waits for a tile boundary.
+        d2_t fa0[4], fb0[4], fa1[4], fb1[4];
+        auto fetch = [&](const unsigned char* sA, int sg, d2_t (&a)[4], d2_t (&b)[4]) {
+            const unsigned char* sB = sA + STAGE_A;
+            const int kc = sg ? kc_off1 : kc_off0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) b[x] = *reinterpret_cast<const d2_t*>(sB + (wn0 + 16 * x + fr) * 128 + kc);
+            if (A_KC) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) a[x] = *reinterpret_cast<const d2_t*>(sA + (wm0 + 16 * x + fr) * 128 + kc);
+            } else {
+                // MC image: a[2*h + xi] = rows (32*xi + 2*fr, +1) of k-row 8*sg + 2*fk + h
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int xi = 0; xi < 2; ++xi)
+                        a[2 * h + xi] = *reinterpret_cast<const d2_t*>(sA + (8 * sg + h) * 1024 + mc_k + mc_row + xi * 256);
+            }
+        };
+        auto mma16 = [&](d2_t (&a)[4], d2_t (&b)[4], int h) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double av = A_KC ? a[x][h] : a[2 * h + (x >> 1)][x & 1];
+                    acc[x][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][h], av, acc[x][u], 0, 0, 0);
+                }
+        };
+
+        __builtin_amdgcn_s_barrier();   // nobody still reads the ring (previous segment)
+        issue(0, 0);
+        if (nk > 1) {
+            issue(1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();   // tile 0 visible
+        fetch(smem, 0, fa0, fb0);
+        int st_cur = 0;   // ring stage holding tile t
+        for (int64_t t = 0; t < nk; ++t) {
+            const int st_next = (st_cur == 2) ? 0 : st_cur + 1;
+            const int st_prev = (st_cur == 0) ? 2 : st_cur - 1;
+            fetch(smem + st_cur * STAGE, 1, fa1, fb1);
+            mma16(fa0, fb0, 0);
+            mma16(fa0, fb0, 1);
+            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // unconditional (straight-line code lets hipcc use a counted lgkmcnt for F1 instead of lgkmcnt(0));
+            // on the last tile this reads a stale stage and the values are never used
+            fetch(smem + st_next * STAGE, 0, fa0, fb0);
+            mma16(fa1, fb1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) issue(t + 2, st_prev);   // DMA issue slots hidden behind the 16 MFMAs just queued
+            __builtin_amdgcn_sched_barrier(0);
+            mma16(fa1, fb1, 1);
+            st_cur = st_next;
+        }
+
+        // ---- epilogue: lane owns C[i = 16x + fr][j = 16u + fk + 4r] of its 64 x 64 wave tile
+        // C row of fragment x, lane fr (MC images interleave fragment pairs, see header)
+        auto crow = [&](int x) { return A_KC ? (wm0 + 16 * x + fr) : (wm0 + 32 * (x >> 1) + 2 * fr + (x & 1)); };
+        const bool whole = (kt0 == 0) && (nk == KT);
+        if (whole) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t i = m0 + crow(x);
+                        const int64_t j = n0 + wn0 + 16 * u + fk + 4 * r;
+                        double v = g.alpha * acc[x][u][r];
+                        if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
+                        g.C[i + j * g.ldc] = v;
+                    }
+        } else {
+            double* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        out[crow(x) + (wn0 + 16 * u + fk + 4 * r) * BM] = acc[x][u][r];
+        }
+        pos += nk;
+    }
+}
+
+// Sums the partial slabs of every tile that was cut by a share boundary, in increasing k order.
+__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P) {
+    const int64_t KT = g.ktiles, tile = blockIdx.x;
+    const int64_t W = g.tiles_m * g.tiles_n * KT;
+    const int64_t lo = tile * KT, hi = lo + KT;
+    // first / last share intersecting [lo, hi)
+    int64_t w0 = (lo * P) / W;
+    while (w0 > 0 && (w0 * W) / P > lo) --w0;
+    while (((w0 + 1) * W) / P <= lo) ++w0;
+    int64_t w1 = w0;
+    while (((w1 + 1) * W) / P < hi) ++w1;
+    if (w0 == w1) return;   // one workgroup covered the whole tile and wrote C itself
+    const int64_t tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    for (int e = threadIdx.x; e < SLAB_ELEMS; e += 256) {
+        double s = 0;
+        for (int64_t w = w0; w <= w1; ++w) {
+            const int64_t first_tile_w = ((w * W) / P) / KT;
+            const double* slab = g.slab + (2 * w + (tile != first_tile_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+            s += slab[e];
+        }
+        const int64_t i = m0 + (e % BM), j = n0 + (e / BM);
+        double v = g.alpha * s;
+        if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
+        g.C[i + j * g.ldc] = v;
+    }
+}
+
+}  // namespace
+
+namespace rlhip {
+
+// returns 1 if the problem was handled here, 0 if the caller should use the generic kernel, <0 on error
+int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
+                     const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                     int64_t ldc) {
+    static int enabled = -1, num_cu = 0;
+    if (enabled < 0) {
+        const char* e = getenv("RLHIP_STREAMK");
+        enabled = e ? atoi(e) : 1;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) num_cu = prop.multiProcessorCount;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    if (!enabled || transB) return 0;
+    if (m % BM || n % BN || k % BK || m <= 0 || n <= 0 || k <= 0) return 0;
+    if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % 2 || ldb % 2) return 0;
+    const int64_t tiles_m = m / BM, tiles_n = n / BN, ktiles = k / BK;
+    const int64_t W = tiles_m * tiles_n * ktiles;
+    if (W < (int64_t)num_cu * 64) return 0;   // too little work to amortise the persistent launch
+    SkArgs g;
+    g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;
+    const int64_t P = num_cu;
+    size_t mark = rlhip_ws_mark(c);
+    g.slab = ws_alloc<double>(c, (size_t)2 * P * SLAB_ELEMS);
+    if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    constexpr int smem = NSTAGE * STAGE;
+    static bool attr[2] = {false, false};
+    if (transA) {
+        if (!attr[1]) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL(gemm_sk_kernel<true>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
+    } else {
+        if (!attr[0]) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr[0] = true;
+        }
+        hipLaunchKernelGGL(gemm_sk_kernel<false>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
+    }
+    RLHIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_sk_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, c->stream, g, P);
+    RLHIP_LAUNCH_CHECK();
+    rlhip_ws_release(c, mark);
+    return 1;
+}
+
+}  // namespace rlhip
