@@ -87,6 +87,184 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(int64_t m, int n, int
     }
 }
 
+
+// 64-lane sum without LDS traffic: four DPP row_shr steps leave each 16-lane row's total in its last lane, four
+// v_readlane pick those up as scalars.  (__shfl_xor lowers to ds_bpermute_b32 pairs: 36 LDS round trips per
+// column pair, which made the reductions -- not the rotations -- the cost of a round.)
+__device__ __forceinline__ double dpp_shr_add(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2, hi2;
+    switch (ctrl_sel) {   // row_shr:1,2,4,8 with bound_ctrl (zero fill)
+        case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true); break;
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true); break;
+        case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true); break;
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xF, 0xF, true); break;
+    }
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_shr_add(v, 1);
+    v = dpp_shr_add(v, 2);
+    v = dpp_shr_add(v, 4);
+    v = dpp_shr_add(v, 8);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// fp64 reciprocal / reciprocal square root from the hardware seeds (v_rcp_f64 / v_rsq_f64) + two Newton steps:
+// ~10 instructions instead of the ~40 of an IEEE division or sqrt.  The rotation parameters are wave-uniform
+// scalars evaluated on the vector ALU, so this is the critical path of the LDS-resident sweep.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-resident block Jacobi for short matrices (m <= 256 rows, e.g. the k x k factor R^T of the RSVD tail).
+// The per-round launches of the kernel above cost ~9 us each (4.5 us of work + the launch gap) x 255 rounds
+// x 11 sweeps = 25 ms at k = 256 -- a quarter of the whole RSVD.  Here the n columns are cut into blocks of
+// 32; one workgroup owns a PAIR of blocks (64 columns = a 256 x 64 fp64 panel = 128 KiB of LDS), runs a
+// complete round-robin sweep over the 2016 column pairs inside the panel out of LDS (one wavefront per
+// pair, shuffle reductions, no global traffic), accumulates the rotations in a 64 x 64 matrix J (32 KiB,
+// LDS: 160 KiB in total, the whole CU), writes the panel back and applies J to the matching 64 columns of
+// V.  An outer tournament over the block pairs (NB-1 launches of NB/2 workgroups) visits every column
+// pair once per outer sweep.
+constexpr int JB = 32;            // block width
+constexpr int JP = 2 * JB;        // panel width
+constexpr int JM = 256;           // panel rows (LDS)
+
+template <typename T>
+__global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
+                                                            int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
+                                                            unsigned* __restrict__ nrot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JM] column-major
+    T* Js = Xs + JP * JM;                              // [JP][JP] column-major
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // block pair of this workgroup (circle method over NB blocks)
+    int P, Q;
+    {
+        const int sl = blockIdx.x;
+        if (intra) { P = 2 * sl; Q = 2 * sl + 1; }
+        else if (sl == 0) { P = NB - 1; Q = oround % (NB - 1); }
+        else { P = (oround + sl) % (NB - 1); Q = (oround - sl + (NB - 1)) % (NB - 1); }
+        if (P > Q) { int t = P; P = Q; Q = t; }
+    }
+    auto gcol = [&](int c) { return (c < JB) ? (P * JB + c) : (Q * JB + (c - JB)); };   // panel col -> global col
+    // ---- load panel (zero padded), J = I
+    for (int e = tid; e < JP * JM; e += 1024) {
+        const int r = e % JM, c = e / JM;
+        const int gc = gcol(c);
+        Xs[e] = (r < m && gc < n) ? A[r + (int64_t)gc * lda] : T(0);
+    }
+    for (int e = tid; e < JP * JP; e += 1024) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
+    __syncthreads();
+    unsigned my_rot = 0;
+    const T tol2 = tol * tol;
+    // intra = 1: the 2 x 496 pairs INSIDE the two blocks (31 rounds, 16 pairs per block per round)
+    // intra = 0: the 32 x 32 CROSS pairs between the blocks (32 rounds of 32 pairs): every column pair of the
+    //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
+    const int nrounds = intra ? (JB - 1) : JB;
+    for (int round = 0; round < nrounds; ++round) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int sl = wid + 16 * half;            // 32 pairs per round, 16 waves
+            int p, q;
+            if (intra) {
+                const int blk = sl >> 4, s16 = sl & 15;
+                if (s16 == 0) { p = JB - 1; q = round; }
+                else { p = (round + s16) % (JB - 1); q = (round - s16 + (JB - 1)) % (JB - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                p += JB * blk; q += JB * blk;
+            } else {
+                p = sl; q = JB + ((sl + round) & (JB - 1));
+            }
+            T* xp = Xs + p * JM;
+            T* xq = Xs + q * JM;
+            T x[4], y[4];
+            T aa = 0, bb = 0, ab = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = xp[lane + 64 * j];
+                y[j] = xq[lane + 64 * j];
+                aa += x[j] * x[j]; bb += y[j] * y[j]; ab += x[j] * y[j];
+            }
+            aa = (T)wave_sum_dpp((double)aa);
+            bb = (T)wave_sum_dpp((double)bb);
+            ab = (T)wave_sum_dpp((double)ab);
+            if (ab * ab > tol2 * aa * bb && aa > T(0) && bb > T(0)) {      // wave-uniform; |ab| > tol*||x||*||y||
+                const double zeta = (double)(bb - aa) * fast_rcp(2.0 * (double)ab);
+                const double w = fma(zeta, zeta, 1.0);
+                const double den = fabs(zeta) + w * fast_rsqrt(w);
+                const double tt = copysign(fast_rcp(den), zeta);
+                const T cs = (T)fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * (T)tt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xp[lane + 64 * j] = cs * x[j] - sn * y[j];
+                    xq[lane + 64 * j] = sn * x[j] + cs * y[j];
+                }
+                const T jp = Js[lane + p * JP], jq = Js[lane + q * JP];
+                Js[lane + p * JP] = cs * jp - sn * jq;
+                Js[lane + q * JP] = sn * jp + cs * jq;
+                ++my_rot;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && my_rot) atomicAdd(nrot, my_rot);
+    // ---- write the rotated panel back
+    for (int e = tid; e < JP * JM; e += 1024) {
+        const int r = e % JM, c = e / JM;
+        const int gc = gcol(c);
+        if (r < m && gc < n) A[r + (int64_t)gc * lda] = Xs[e];
+    }
+    // ---- V[:, panel] <- V[:, panel] * J on the matrix cores: the panel's LDS is free now, so a 256-row slab of
+    //      V's 64 panel columns is staged there; wave w owns rows 16w..16w+15 of the slab (16 waves = 256
+    //      rows) x all 64 columns = 4 MFMA tiles x 16 k-steps.  Operands are swapped (J as the MFMA A operand)
+    //      so that each lane's results run along rows -> 128-byte store segments.
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int r0 = 0; r0 < n; r0 += JM) {
+        __syncthreads();
+        for (int e = tid; e < JP * JM; e += 1024) {
+            const int r = e % JM, c = e / JM;
+            const int gc = gcol(c);
+            Xs[e] = (r0 + r < n && gc < n) ? V[(r0 + r) + (int64_t)gc * ldv] : T(0);
+        }
+        __syncthreads();
+        d4_t acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = d4_t{0, 0, 0, 0};
+#pragma unroll 4
+        for (int st = 0; st < JP / 4; ++st) {
+            const double vf = (double)Xs[(16 * wid + fr) + (4 * st + fk) * JM];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double jf = (double)Js[(4 * st + fk) + (16 * u + fr) * JP];
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, vf, acc[u], 0, 0, 0);
+            }
+        }
+        const int row = r0 + 16 * wid + fr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gc = gcol(16 * u + fk + 4 * r);
+                if (row < n && gc < n) V[row + (int64_t)gc * ldv] = (T)acc[u][r];
+            }
+    }
+}
+
 // column norms -> S (unsorted), one workgroup per column
 template <typename T>
 __global__ __launch_bounds__(256) void colnorm_kernel(int64_t m, const T* __restrict__ A, int64_t lda,
@@ -171,7 +349,33 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     const int max_sweeps = 60;
     int sweep = 0;
     int info = 0;
-    if (n > 1) {
+    if (n > 1 && m <= JM && sizeof(T) == 8) {
+        // LDS-resident block Jacobi (see jacobi_block_kernel)
+        int NBk = (n + JB - 1) / JB;
+        if (NBk < 2) NBk = 2;
+        if (NBk % 2) ++NBk;
+        constexpr int smem = (JP * JM + JP * JP) * (int)sizeof(T);
+        static bool attr_set = false;
+        if (!attr_set) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        for (; sweep < max_sweeps; ++sweep) {
+            hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
+            hipLaunchKernelGGL(jacobi_block_kernel<T>, dim3(NBk / 2), dim3(1024), smem, c->stream, (int)m, n, NBk, 0, 1,
+                               A, lda, V, (int64_t)n, tol, d_nrot);
+            for (int oround = 0; oround < NBk - 1; ++oround) {
+                hipLaunchKernelGGL(jacobi_block_kernel<T>, dim3(NBk / 2), dim3(1024), smem, c->stream, (int)m, n, NBk,
+                                   oround, 0, A, lda, V, (int64_t)n, tol, d_nrot);
+            }
+            RLHIP_LAUNCH_CHECK();
+            RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            unsigned nrot = *(unsigned*)(c->h_mail + 16);
+            if (nrot == 0) { ++sweep; break; }
+        }
+        if (sweep >= max_sweeps) info = 1;
+    } else if (n > 1) {
         for (; sweep < max_sweeps; ++sweep) {
             hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
             for (int round = 0; round < N - 1; ++round) {
