@@ -142,7 +142,7 @@ def main():
     achieved = 2.0 * mloc * n * k / (kernel_ms * 1e-3) / 1e12
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=None,
-                    kernel="gemm_kernel<double,NN,128x256x16> (Y = A*Omega, incl. split-K reduce)",
+                    kernel="gemm_sk_kernel<NN> stream-K 128x256x16 (Y = A*Omega) + fix-up",
                     launch_ms=round(kernel_ms, 3), flops_per_launch=2.0 * mloc * n * k)
 
     if rank == 0:
