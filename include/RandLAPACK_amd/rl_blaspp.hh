@@ -52,6 +52,10 @@ public:
     int rank() const { return rlhip_comm_rank(ctx_); }
     // Drivers mark, around each call that reduces over the row index, whether the operand's rows are the
     // sharded dimension (m-long objects: A, Y, Q, Omega_1) or replicated (n- or k-long objects: Omega, B^T, R).
+    // Fused-norm request (QB): the next blas::gemm whose A operand is exactly this matrix also returns ||A||_F
+    // (one pass over A instead of two).  Consumed at most once.
+    struct NormRequest { const void* ptr = nullptr; int64_t rows = 0, cols = 0, ld = 0; bool done = false; double value = 0; };
+    NormRequest norm_req;
     bool rows_sharded = false;
     bool reduce_over_rows() const { return rows_sharded && world() > 1; }
     void allreduce_sum(double* buf, int64_t count) { check(rlhip_allreduce_sum_f64(ctx_, buf, count), "allreduce"); }
@@ -106,6 +110,16 @@ public:
 // ---- level 3 (ColMajor only, as on the whole reference path)
 inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, double alpha, double const* A, int64_t lda,
                  double const* B, int64_t ldb, double beta, double* C, int64_t ldc, Queue& q) {
+    auto& nr = q.norm_req;
+    if (nr.ptr == (const void*)A && !nr.done && nr.ld == lda &&
+        ((ta == Op::NoTrans && nr.rows == m && nr.cols == k) || (ta != Op::NoTrans && nr.rows == k && nr.cols == m))) {
+        double nrm = 0;
+        check(rlhip_gemm_norma_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &nrm,
+                                   nullptr), "gemm_norma");
+        nr.done = true;
+        nr.value = nrm;
+        return;
+    }
     check(rlhip_gemm_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc), "gemm");
 }
 inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, float alpha, float const* A, int64_t lda,

@@ -48,18 +48,20 @@ public:
         const bool single_block = (b_sz >= k_in);
         T* A_cpy = A;
         T* A_own = nullptr;
-        T norm_A = lapack::lange(Norm::Fro, m, n, A, m, q);                                               // :168
-        if (q.world() > 1) {                                       // ||A||_F^2 = sum over the row blocks
-            double ssq = (double)norm_A * (double)norm_A;
-            q.allreduce_sum_host(&ssq, 1);
-            norm_A = (T)std::sqrt(ssq);
-        }
-        blas::RowsSharded sh(q, true);                             // Q_i, Q: rows sharded
+        // ||A||_F (:168) is only consumed after the first block's B_i (:225); it is obtained from the first GEMM
+        // that streams A (inside rf.call) instead of a separate 8*m*n-byte pass -- identical value, one pass less.
+        T norm_A = 0;
+        bool have_norm = false;
         if (!single_block) {
             A_own = blas::device_malloc<T>(m * n, q);
             lapack::lacpy(MatrixType::General, m, n, A, m, A_own, m, q);                                  // :171
             A_cpy = A_own;
         }
+        if constexpr (sizeof(T) == 8) {
+            q.norm_req = blas::Queue::NormRequest();
+            q.norm_req.ptr = A_cpy; q.norm_req.rows = m; q.norm_req.cols = n; q.norm_req.ld = m;
+        }
+        blas::RowsSharded sh(q, true);                             // Q_i, Q: rows sharded
         auto done = [&](int code) { if (A_own) blas::device_free(A_own, q); return code; };
 
         while (curr_sz < k) {
@@ -67,7 +69,18 @@ public:
             next_sz = curr_sz + b_sz;
             T* Q_i = Q + m * curr_sz;
             T* BT_i = BT + n * curr_sz;
-            if (rf.call(m, n, A_cpy, b_sz, Q_i, state)) { k = curr_sz; return done(6); }                  // :190-196
+            if (rf.call(m, n, A_cpy, b_sz, Q_i, state)) { k = curr_sz; q.norm_req = blas::Queue::NormRequest(); return done(6); }   // :190-196
+            if (!have_norm) {
+                if (q.norm_req.done) norm_A = (T)q.norm_req.value;
+                else norm_A = lapack::lange(Norm::Fro, m, n, A_cpy, m, q);   // A_cpy still equals A here
+                q.norm_req = blas::Queue::NormRequest();
+                if (q.world() > 1) {                                   // ||A||_F^2 = sum over the row blocks
+                    double ssq = (double)norm_A * (double)norm_A;
+                    q.allreduce_sum_host(&ssq, 1);
+                    norm_A = (T)std::sqrt(ssq);
+                }
+                have_norm = true;
+            }
             if (orth_check && util::orthogonality_check(m, b_sz, Q_i, verbose, q)) { k = curr_sz; return done(4); }   // :198-206
             if (curr_sz != 0) {                                                                           // :209-215
                 blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, curr_sz, b_sz, m, T(1), Q, m, Q_i, m, T(0), QtQi, next_sz, q);

@@ -81,6 +81,12 @@ int rlhip_gemm_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t 
 int rlhip_gemm_f32(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, float alpha,
                    const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                    int64_t ldc);
+/* gemm + ||A||_F in ONE pass over A (QB needs both: rl_qb.hh:168 then rl_rf.hh:123 read A twice in the
+ * reference).  A is (m x k) for transa 'N', (k x m) for 'T'.  *fused_host = 1 when the norm came out of the GEMM
+ * kernel itself (stream-K path), 0 when a separate lange pass was needed.  Synchronises the stream. */
+int rlhip_gemm_norma_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, double alpha,
+                         const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
+                         int64_t ldc, double* norm_a_host, int* fused_host);
 /* uplo must be 'U' (the only form the path uses).  Tiles crossing the diagonal are written in full. */
 int rlhip_syrk_f64(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, double alpha, const double* A,
                    int64_t lda, double beta, double* C, int64_t ldc);

@@ -63,6 +63,8 @@ SIGNATURES = {
     "rlhip_timer_start": (c_int, [c_vp]),
     "rlhip_timer_stop_ms": (c_int, [c_vp, C.POINTER(c_flt)]),
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
+    "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
+                                     c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }

@@ -46,6 +46,13 @@ void rlhip_ws_release(rlhip_ctx* c, size_t mark) {
     }
 }
 
+namespace rlhip {
+template <typename T>
+int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+              const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev, int* ssq_done);
+}
+__global__ void rlhip_zero_f64_kernel(double* p) { *p = 0.0; }
+
 extern "C" {
 
 const char* rlhip_version(void) { return "rlhip 0.1 (gfx950)"; }
@@ -242,6 +249,38 @@ static inline int op_flag(char t, int* out) {
                            int* sweeps) {                                                                       \
         return rlhip::gesvdj<T>(c, m, n, A, lda, S, VT, ldvt, sweeps);                                           \
     }
+
+
+
+/* C = alpha*op(A)*op(B) + beta*C  AND  ||A||_F in one pass over A when the stream-K kernel takes the problem
+ * (the A tiles are in LDS anyway); otherwise gemm followed by lange.  A is (m x k) for 'N', (k x m) for 'T'. */
+int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+                         int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                         double* norm_a_host, int* fused_host) {
+    int fa, fb;
+    if (op_flag(ta, &fa)) return -2;
+    if (op_flag(tb, &fb)) return -3;
+    double* d_ssq = (double*)(c->d_mail + 40);
+    hipLaunchKernelGGL(rlhip_zero_f64_kernel, dim3(1), dim3(1), 0, c->stream, d_ssq);
+    int done = 0;
+    int rc = rlhip::gemm_impl<double>(c, fa, fb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, d_ssq, &done);
+    if (rc) return rc;
+    if (fused_host) *fused_host = done;
+    const int64_t arows = fa ? k : m, acols = fa ? m : k;
+    if (!done) return rlhip::lange_fro<double>(c, arows, acols, A, lda, norm_a_host);
+    double ssq_main = 0, rest = 0;
+    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 40, d_ssq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    ssq_main = *(double*)(c->h_mail + 40);
+    const int64_t m_main = (m / 128) * 128;
+    if (m_main < m) {   // rows (or, for op = T, columns) peeled off to the generic kernel
+        const double* A2 = fa ? (A + m_main * lda) : (A + m_main);
+        rc = rlhip::lange_fro<double>(c, fa ? k : (m - m_main), fa ? (m - m_main) : k, A2, lda, &rest);
+        if (rc) return rc;
+    }
+    *norm_a_host = sqrt(ssq_main + rest * rest);
+    return 0;
+}
 
 RLHIP_DEFINE_BLAS3(f64, double)
 RLHIP_DEFINE_BLAS3(f32, float)

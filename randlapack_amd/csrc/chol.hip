@@ -94,7 +94,8 @@ namespace rlhip {
 
 template <typename T>
 int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
-              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri);
+              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev = nullptr,
+              int* ssq_done = nullptr);
 
 template <typename T>
 int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {

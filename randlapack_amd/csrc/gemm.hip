@@ -443,20 +443,21 @@ namespace rlhip {
 
 int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
                      const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc);
+                     int64_t ldc, double* ssqA_dev);
 
 template <typename T>
 static int try_streamk(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T,
-                       T*, int64_t) { return 0; }
+                       T*, int64_t, double*) { return 0; }
 template <>
 int try_streamk<double>(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
-                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
-    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ssq) {
+    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq);
 }
 
 template <typename T>
 int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
-              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri) {
+              int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev, int* ssq_done) {
+    if (ssq_done) *ssq_done = 0;
     if (m < 0) return -3;
     if (n < 0) return -4;
     if (k < 0) return -5;
@@ -477,12 +478,14 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (!tri && !transB && m >= 128 && n % 256 == 0 && k % 16 == 0) {
         // big data passes: persistent stream-K kernel on the multiple-of-128 row block, generic kernel on the rest
         const int64_t m_main = (m / 128) * 128;
-        int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+        int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssqA_dev);
         if (rc < 0) return rc;
         if (rc == 1) {
+            if (ssqA_dev && ssq_done) *ssq_done = 1;   // covers op(A)'s first m_main rows; caller adds the peeled block
             if (m_main == m) return 0;
             const T* A2 = transA ? (A + m_main * lda) : (A + m_main);
-            return gemm_impl<T>(c, transA, transB, m - m_main, n, k, alpha, A2, lda, B, ldb, beta, C + m_main, ldc, 0);
+            return gemm_impl<T>(c, transA, transB, m - m_main, n, k, alpha, A2, lda, B, ldb, beta, C + m_main, ldc, 0,
+                                nullptr, nullptr);
         }
     }
     GemmArgs<T> g;
@@ -499,7 +502,7 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
 template <typename T>
 int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
          int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
-    return gemm_impl<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0);
+    return gemm_impl<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, nullptr, nullptr);
 }
 
 // syrk: only Trans (C = alpha*A^T*A + beta*C, A is k x n) and NoTrans (C = alpha*A*A^T + beta*C, A is n x k).
@@ -510,8 +513,8 @@ template <typename T>
 int syrk(rlhip_ctx* c, int uplo, int trans, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, T beta,
          T* C, int64_t ldc) {
     if (uplo != Upper) return -2;  // the path only ever asks for Upper (rl_orth.hh:78, rl_cqrrpt.hh:310)
-    if (trans) return gemm_impl<T>(c, 1, 0, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1);
-    return gemm_impl<T>(c, 0, 1, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1);
+    if (trans) return gemm_impl<T>(c, 1, 0, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1, nullptr, nullptr);
+    return gemm_impl<T>(c, 0, 1, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, 1, nullptr, nullptr);
 }
 
 template int gemm<double>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
@@ -527,7 +530,7 @@ template int syrk<float>(rlhip_ctx*, int, int, int64_t, int64_t, float, const fl
 
 namespace rlhip {
 template int gemm_impl<double>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, double, const double*, int64_t,
-                               const double*, int64_t, double, double*, int64_t, int);
+                               const double*, int64_t, double, double*, int64_t, int, double*, int*);
 template int gemm_impl<float>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, float, const float*, int64_t,
-                              const float*, int64_t, float, float*, int64_t, int);
+                              const float*, int64_t, float, float*, int64_t, int, double*, int*);
 }  // namespace rlhip

@@ -47,6 +47,7 @@ struct SkArgs {
     double alpha, beta;
     int64_t tiles_m, tiles_n, ktiles;
     double* slab;             // 2 * gridDim.x slots of 128 x 256
+    double* ssq_part;         // nullptr, or gridDim.x partial sums of squares of op(A) (fused ||A||_F^2)
 };
 
 __device__ __forceinline__ void glds16(const double* g, unsigned char* lds_wave_base) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
     }
     const int64_t a_step = A_KC ? (int64_t)BK : (int64_t)BK * g.lda;
 
+    double ssq_acc = 0.0;
     for (int64_t pos = ws; pos < we;) {
         const int64_t tile = pos / KT;
         const int64_t kt0 = pos - tile * KT;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
         //   tile t-1, so tile t+2 may be DMA'd into t-1's stage and F0 of tile t+1 may be fetched while the 32
         //   MFMAs of F1 run.  The matrix pipe therefore never waits for a tile boundary.
         d2_t fa0[4], fb0[4], fa1[4], fb1[4];
+        const bool do_ssq = (g.ssq_part != nullptr) && (tile_n == 0);   // every A element is staged once by tile_n == 0
         auto fetch = [&](const unsigned char* sA, int sg, d2_t (&a)[4], d2_t (&b)[4]) {
             const unsigned char* sB = sA + STAGE_A;
             const int kc = sg ? kc_off1 : kc_off0;
@@ -171,6 +174,11 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
             const int st_next = (st_cur == 2) ? 0 : st_cur + 1;
             const int st_prev = (st_cur == 0) ? 2 : st_cur - 1;
             fetch(smem + st_cur * STAGE, 1, fa1, fb1);
+            if (do_ssq) {   // 128 x 16 doubles of the A stage / 512 threads = two b128 reads per thread (layout-agnostic)
+                const d2_t* sa = reinterpret_cast<const d2_t*>(smem + st_cur * STAGE);
+                const d2_t v0 = sa[tid], v1 = sa[tid + 512];
+                ssq_acc = fma(v0[0], v0[0], fma(v0[1], v0[1], fma(v1[0], v1[0], fma(v1[1], v1[1], ssq_acc))));
+            }
             mma16(fa0, fb0, 0);
             mma16(fa0, fb0, 1);
             if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,6 +223,20 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
         }
         pos += nk;
     }
+    if (g.ssq_part) {   // deterministic: fixed lane->element map, fixed reduction tree, one partial per workgroup
+        double v = ssq_acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) red[wid] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double sacc = 0;
+            for (int i = 0; i < 8; ++i) sacc += red[i];
+            g.ssq_part[w] = sacc;
+        }
+    }
 }
 
 // Sums the partial slabs of every tile that was cut by a share boundary, in increasing k order.
@@ -245,6 +267,19 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P)
     }
 }
 
+__global__ __launch_bounds__(256) void ssq_sum_kernel(int np, const double* __restrict__ part, double* __restrict__ out) {
+    __shared__ double sm[256];
+    double a = 0;
+    for (int i = threadIdx.x; i < np; i += 256) a += part[i];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) sm[threadIdx.x] += sm[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += sm[0];   // accumulates: the caller zero-initialises / adds the peeled rows
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -252,7 +287,7 @@ namespace rlhip {
 // returns 1 if the problem was handled here, 0 if the caller should use the generic kernel, <0 on error
 int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
                      const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc) {
+                     int64_t ldc, double* ssqA_dev) {
     static int enabled = -1, num_cu = 0;
     if (enabled < 0) {
         const char* e = getenv("RLHIP_STREAMK");
@@ -274,6 +309,7 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
     size_t mark = rlhip_ws_mark(c);
     g.slab = ws_alloc<double>(c, (size_t)2 * P * SLAB_ELEMS);
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    g.ssq_part = ssqA_dev ? ws_alloc<double>(c, (size_t)P) : nullptr;
     constexpr int smem = NSTAGE * STAGE;
     static bool attr[2] = {false, false};
     if (transA) {
@@ -292,6 +328,10 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
     RLHIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_sk_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, c->stream, g, P);
     RLHIP_LAUNCH_CHECK();
+    if (ssqA_dev) {
+        hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);
+        RLHIP_LAUNCH_CHECK();
+    }
     rlhip_ws_release(c, mark);
     return 1;
 }
