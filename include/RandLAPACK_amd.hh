@@ -11,3 +11,4 @@
 #include "RandLAPACK_amd/rl_rf.hh"
 #include "RandLAPACK_amd/rl_qb.hh"
 #include "RandLAPACK_amd/rl_rsvd.hh"
+#include "RandLAPACK_amd/rl_cqrrpt.hh"

@@ -1,0 +1,154 @@
+// CQRRPTalg / CQRRPT (reference: RandLAPACK/drivers/rl_cqrrpt.hh:20-391): Cholesky QR with randomized
+// pivoting for tall matrices.  A (m x n, device) -> Q in place, R (n x n), J (1-based pivots), rank.
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "rl_exceptions.hh"
+#include "rl_blaspp.hh"
+#include "rl_lapackpp.hh"
+#include "rl_randblas.hh"
+#include "rl_util.hh"
+
+namespace RandLAPACK {
+
+template <typename T, typename RNG>
+class CQRRPTalg {
+public:
+    virtual ~CQRRPTalg() {}
+    virtual int call(int64_t m, int64_t n, T* A, int64_t lda, T* R, int64_t ldr, int64_t* J, T d_factor,
+                     RandBLAS::RNGState<RNG>& state) = 0;
+};
+
+struct CQRRPTSubroutines {
+    enum QRCP { hqrrp, bqrrp, geqp3 };
+};
+
+template <typename T, typename RNG = RandBLAS::DefaultRNG>
+class CQRRPT : public CQRRPTalg<T, RNG> {
+public:
+    using Subroutines = CQRRPTSubroutines;
+
+    CQRRPT(blas::Queue& queue, bool time_subroutines, T ep) : q(queue) {
+        timing = time_subroutines;
+        eps = ep;
+        nnz = 2;                       // reference default (rl_cqrrpt.hh constructor)
+        qrcp = Subroutines::QRCP::geqp3;
+        orthogonalization = false;
+        rank = 0;
+    }
+
+    /// A (m x n, lda, DEVICE) is overwritten by Q (first `rank` columns orthonormal), R (n x n, ldr, DEVICE) receives
+    /// the rank x n upper-trapezoidal factor, J (n, DEVICE int64, 1-based) the pivots.  Return codes as the
+    /// reference: 0 ok (also for an all-zero sketch, :256-261), 1 when R_sk has a zero on its diagonal (:296-301).
+    /// SURVEY.md A.6 is the behavioural spec.  Only qrcp == geqp3 (the default) is on the device so far.
+    int call(int64_t m, int64_t n, T* A, int64_t lda, T* R, int64_t ldr, int64_t* J, T d_factor,
+             RandBLAS::RNGState<RNG>& state) override {
+        randlapack_require(m >= 0) << "m=" << m << " must be >= 0";                                      // :161-168
+        randlapack_require(n >= 0) << "n=" << n << " must be >= 0";
+        randlapack_require(lda >= m) << "lda=" << lda << " < m=" << m << " (lda must be >= m for ColMajor)";
+        randlapack_require(ldr >= n) << "ldr=" << ldr << " < n=" << n << " (ldr must be >= n)";
+        randlapack_require(d_factor >= (T)1.0) << "d_factor=" << d_factor << " must be >= 1.0";
+        randlapack_require(!(A == nullptr && m > 0 && n > 0)) << "A buffer is null but m=" << m << " and n=" << n << " imply a nonempty matrix";
+        randlapack_require(!(R == nullptr && n > 0)) << "R buffer is null but n=" << n << " > 0";
+        randlapack_require(!(J == nullptr && n > 0)) << "J buffer is null but n=" << n << " > 0";
+        randlapack_require(qrcp == Subroutines::QRCP::geqp3) << "only QRCP::geqp3 is available on the device";
+        using clk = std::chrono::steady_clock;
+        auto stamp = [&]() { if (timing) q.sync(); return clk::now(); };
+        auto t_total0 = stamp();
+
+        int64_t k = n;
+        const int64_t d = (int64_t)(d_factor * n);                                                          // :198 (truncation)
+        const T eps_initial_rank_estimation = 2 * std::pow(std::numeric_limits<T>::epsilon(), (T)0.95);   // :200
+        int64_t new_rank;
+        if (n == 0 || m == 0) { rank = 0; return 0; }
+
+        blas::Scratch ws(q);
+        T* A_hat = ws.alloc<T>(d * n);
+        T* tau = ws.alloc<T>(n);
+
+        // ---- sketch: S = SparseSkOp(SparseDist(d, m, nnz), state); state = S.next_state; A_hat = S * A  (:214-222)
+        auto t0 = stamp();
+        {
+            RandBLAS::SparseDist DS(d, m, nnz);
+            RandBLAS::SparseSkOp<T, RNG> S(DS, state, q);
+            state = S.next_state;
+            if (sketch_override)   // parity-test hook: both sides factor the SAME precomputed sketch
+                lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_hat, d, q);
+            else
+                RandBLAS::sketch_general(Layout::ColMajor, Op::NoTrans, Op::NoTrans, d, n, m, (T)1.0, S, 0, 0, A, lda,
+                                         (T)0.0, A_hat, d, q);
+            if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_hat, d, sketch_export, d, q);
+        }
+        auto t1 = stamp();
+        // ---- QRCP of the sketch (:247)
+        lapack::geqp3(d, n, A_hat, d, J, tau, q);
+        auto t2 = stamp();
+
+        std::vector<T> diag(n);
+        lapack::get_diag(n < d ? n : d, A_hat, d, diag.data(), q);
+        if (!diag[0]) { rank = 0; return 0; }                                                               // :256-261
+        for (int64_t i = 0; i < n; ++i) {                                                                   // :267-272
+            if (std::abs(diag[i]) / std::abs(diag[0]) < eps_initial_rank_estimation) { k = i; break; }
+        }
+        rank = k;
+        new_rank = k;
+        auto t3 = stamp();
+
+        lapack::lacpy(MatrixType::Upper, k, k, A_hat, d, R, ldr, q);                                        // :281
+        // :287-288 (the reference permutes with a scratch copy of J because lapmt uses it as workspace; the device
+        // kernel leaves its index vector untouched, so J itself is passed)
+        util::col_swap(m, n, k, A, lda, J, q);
+        auto t4 = stamp();
+
+        for (int64_t i = 0; i < k; ++i)                                                                     // :296-301 diag_is_nonzero
+            if (diag[i] == (T)0) return 1;
+        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, q);   // :302
+        auto t5 = stamp();
+
+        blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, A, lda, (T)0.0, R, ldr, q);     // :310
+        if (q.world() > 1) throw blas::Error("CQRRPT: row-sharded execution is not wired yet");
+        if (lapack::potrf(Uplo::Upper, k, R, ldr, q)) {                                                     // :311
+            // a-posteriori rank estimate from the (partially factored) diagonal                               :319-331
+            std::vector<T> rd(k);
+            lapack::get_diag(k, R, ldr, rd.data(), q);
+            T running_max = rd[0], running_min = rd[0];
+            const T cond_threshold = std::sqrt(eps / std::numeric_limits<T>::epsilon());
+            for (int64_t i = 0; i < k; ++i) {
+                T curr = std::abs(rd[i]);
+                running_max = std::max(running_max, curr);
+                running_min = std::min(running_min, curr);
+                if ((running_min * cond_threshold < running_max) && i > 1) { new_rank = i - 1; break; }
+            }
+        }
+        rank = new_rank;                                                                                     // :335
+        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, new_rank, (T)1.0, R, ldr, A, lda, q);   // :338
+        auto t6 = stamp();
+        randlapack_require(!orthogonalization) << "orthogonalization mode needs the device geqrf/orgqr (not built yet)";
+        // R <- R_chol * R_sk (rows 0..new_rank-1, all n columns)                                               :345
+        blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, new_rank, n, (T)1.0, A_hat, d, R, ldr, q);
+        if (timing) {                                                                                        // :370-384
+            auto t7 = stamp();
+            auto us = [](clk::time_point a, clk::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            long saso = us(t0, t1), qrcp_t = us(t1, t2), rr = us(t2, t3), piv = us(t3, t4), trsm_t = us(t4, t5), chol = us(t5, t6);
+            long total = us(t_total0, t7);
+            times = {saso, qrcp_t, rr, chol, piv, trsm_t, total - (saso + qrcp_t + rr + chol + piv + trsm_t), total};
+        }
+        return 0;
+    }
+
+    blas::Queue& q;
+    bool timing;
+    T eps;
+    int64_t rank;
+    std::vector<long> times;   // {saso, qrcp, rank_reveal, cholqr, a_mod_piv, a_mod_trsm, rest, total} in microseconds
+    int64_t nnz;
+    Subroutines::QRCP qrcp;
+    bool orthogonalization;
+    // testing hooks (not in the reference): a d x n sketch to use instead of S*A / a buffer receiving the sketch
+    const T* sketch_override = nullptr;
+    T* sketch_export = nullptr;
+};
+
+}  // namespace RandLAPACK

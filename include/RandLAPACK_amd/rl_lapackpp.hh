@@ -45,6 +45,19 @@ inline void add_diag(int64_t n, double alpha, double* A, int64_t lda, Queue& q) 
 inline void add_diag(int64_t n, float alpha, float* A, int64_t lda, Queue& q) {
     blas::check(rlhip_add_diag_f32(q.ctx(), n, alpha, A, lda), "add_diag");
 }
+// column-pivoted QR of a device matrix; jpvt (device int64, 1-based on exit), tau (device)
+inline int64_t geqp3(int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, Queue& q) {
+    int rc = rlhip_geqp3_f64(q.ctx(), m, n, A, lda, jpvt, tau); blas::check(rc, "geqp3"); return rc;
+}
+inline int64_t geqp3(int64_t m, int64_t n, float* A, int64_t lda, int64_t* jpvt, float* tau, Queue& q) {
+    int rc = rlhip_geqp3_f32(q.ctx(), m, n, A, lda, jpvt, tau); blas::check(rc, "geqp3"); return rc;
+}
+inline void get_diag(int64_t n, double const* A, int64_t lda, double* diag_host, Queue& q) {
+    blas::check(rlhip_get_diag_f64(q.ctx(), n, A, lda, diag_host), "get_diag");
+}
+inline void get_diag(int64_t n, float const* A, int64_t lda, float* diag_host, Queue& q) {
+    blas::check(rlhip_get_diag_f32(q.ctx(), n, A, lda, diag_host), "get_diag");
+}
 // Job::SomeVec, tall (m >= n).  Returns info (>0: Jacobi did not converge).
 inline int64_t gesdd(Job job, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,
                      double* VT, int64_t ldvt, Queue& q) {

@@ -51,4 +51,45 @@ RNGState<RNG> fill_dense(DenseDist const& D, float* buf, RNGState<RNG> const& st
     return next;
 }
 
+
+// ---- sparse sketching operator (short-axis-sparse), cf. RandBLAS::SparseDist / SparseSkOp / sketch_general as used at
+//      drivers/rl_cqrrpt.hh:214-222.  n_rows = d (sketch dimension), n_cols = m, vec_nnz nonzeros per column.
+struct SparseDist {
+    int64_t n_rows, n_cols, vec_nnz;
+    SparseDist(int64_t r, int64_t c, int64_t nnz) : n_rows(r), n_cols(c), vec_nnz(nnz) {}
+};
+
+template <typename T, typename RNG = DefaultRNG>
+struct SparseSkOp {
+    SparseDist dist;
+    RNGState<RNG> seed_state, next_state;
+    rlhip_saso* handle = nullptr;
+    blas::Queue& q;
+    SparseSkOp(SparseDist const& D, RNGState<RNG> const& st, blas::Queue& queue) : dist(D), seed_state(st), next_state(st), q(queue) {
+        blas::check(rlhip_saso_create(q.ctx(), D.n_rows, D.n_cols, (int)D.vec_nnz, st.counter.data(), st.key.data(),
+                                      next_state.counter.data(), &handle), "saso_create");
+    }
+    SparseSkOp(SparseSkOp const&) = delete;
+    SparseSkOp& operator=(SparseSkOp const&) = delete;
+    ~SparseSkOp() { if (handle) rlhip_saso_destroy(q.ctx(), handle); }
+};
+
+// B (d x n) = alpha * S * A (m x n) + beta * B  -- the only sketch_general shape on the path (left sketch, no offsets)
+template <typename RNG>
+void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t n, int64_t m, double alpha,
+                    SparseSkOp<double, RNG>& S, int64_t ro, int64_t co, double const* A, int64_t lda, double beta, double* B,
+                    int64_t ldb, blas::Queue& q) {
+    if (opS != blas::Op::NoTrans || opA != blas::Op::NoTrans || ro != 0 || co != 0 || d != S.dist.n_rows || m != S.dist.n_cols)
+        throw blas::Error("sketch_general: only the plain left sketch S*A is on the path");
+    blas::check(rlhip_saso_apply_f64(q.ctx(), S.handle, n, alpha, A, lda, beta, B, ldb), "saso_apply");
+}
+template <typename RNG>
+void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t n, int64_t m, float alpha,
+                    SparseSkOp<float, RNG>& S, int64_t ro, int64_t co, float const* A, int64_t lda, float beta, float* B,
+                    int64_t ldb, blas::Queue& q) {
+    if (opS != blas::Op::NoTrans || opA != blas::Op::NoTrans || ro != 0 || co != 0 || d != S.dist.n_rows || m != S.dist.n_cols)
+        throw blas::Error("sketch_general: only the plain left sketch S*A is on the path");
+    blas::check(rlhip_saso_apply_f32(q.ctx(), S.handle, n, alpha, A, lda, beta, B, ldb), "saso_apply");
+}
+
 }  // namespace RandBLAS

@@ -45,4 +45,20 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
     return orth_err / std::sqrt((T)k) > tol;
 }
 
+
+/// Forward column permutation (== lapack::lapmt(true, ...)): on exit column i of A holds former column idx[i]-1.
+/// idx is a DEVICE vector of n 1-based indices and is left untouched (the reference's lapmt restores it).
+/// k > n throws std::runtime_error like the reference.                               (rl_util.hh:151-164)
+template <typename T>
+void col_swap(int64_t m, int64_t n, int64_t k, T* A, int64_t lda, int64_t const* idx, blas::Queue& q) {
+    if (k > n) throw std::runtime_error("Invalid rank parameter.");
+    if constexpr (sizeof(T) == 8) blas::check(rlhip_col_swap_f64(q.ctx(), m, n, k, (double*)A, lda, idx), "col_swap");
+    else blas::check(rlhip_col_swap_f32(q.ctx(), m, n, k, (float*)A, lda, idx), "col_swap");
+}
+/// Integer-vector overload: the first k entries of A are permuted by the permutation idx of 1..k (rl_util.hh:174-198)
+inline void col_swap(int64_t n, int64_t k, int64_t* A, int64_t const* idx, blas::Queue& q) {
+    if (k > n) throw std::runtime_error("Incorrect rank parameter.");
+    blas::check(rlhip_col_swap_i64(q.ctx(), n, k, A, idx), "col_swap_i64");
+}
+
 }  // namespace RandLAPACK::util

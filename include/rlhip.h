@@ -87,7 +87,7 @@ int rlhip_gemm_f32(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t 
 int rlhip_gemm_norma_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                          int64_t ldc, double* norm_a_host, int* fused_host);
-/* uplo must be 'U' (the only form the path uses).  Tiles crossing the diagonal are written in full. */
+/* uplo must be 'U' (the only form the path uses); the strictly lower triangle of C is not touched. */
 int rlhip_syrk_f64(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, double alpha, const double* A,
                    int64_t lda, double beta, double* C, int64_t ldc);
 int rlhip_syrk_f32(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, float alpha, const float* A,
@@ -142,6 +142,35 @@ int rlhip_transpose_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, i
                         int64_t ldat, int upper_only);
 int rlhip_transpose_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat,
                         int upper_only);
+
+/* ---- sparse sketching operator (SASO): RandBLAS::SparseDist(d, m, nnz) + SparseSkOp(DS, state) +
+ *      sketch_general(ColMajor, NoTrans, NoTrans, d, n, m, alpha, S, 0, 0, A, lda, beta, B, ldb)
+ *      (rl_cqrrpt.hh:214-222, rl_cqrrt.hh:174-182).  S is d x m with nnz nonzeros (+-1) per column.
+ *      next_ctr_host receives `S.next_state`.  Structure of this library's operator: sketch.hip header. ---- */
+typedef struct rlhip_saso rlhip_saso;
+int rlhip_saso_create(rlhip_ctx* ctx, int64_t d, int64_t m, int nnz, const uint32_t ctr_host[4],
+                      const uint32_t key_host[2], uint32_t next_ctr_host[4], rlhip_saso** S);
+int rlhip_saso_destroy(rlhip_ctx* ctx, rlhip_saso* S);
+int rlhip_saso_apply_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, double alpha, const double* A, int64_t lda,
+                         double beta, double* B, int64_t ldb);
+int rlhip_saso_apply_f32(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, float alpha, const float* A, int64_t lda,
+                         float beta, float* B, int64_t ldb);
+int rlhip_saso_dense_f64(rlhip_ctx* ctx, const rlhip_saso* S, double* dense_d_by_m);   /* tests / debugging */
+int rlhip_saso_dense_f32(rlhip_ctx* ctx, const rlhip_saso* S, float* dense_d_by_m);
+/* util::col_swap (misc/rl_util.hh:151-164 == lapmt forward): on exit column i holds former column idx[i]-1.
+ * idx: DEVICE array of n 1-based indices, left untouched.  k > n is an error (reference throws).  In place,
+ * one read + one write of the matrix, lanes along rows. */
+int rlhip_col_swap_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const int64_t* idx);
+int rlhip_col_swap_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, float* A, int64_t lda, const int64_t* idx);
+/* integer-vector overload (rl_util.hh:174-198): first k entries of A permuted by a permutation idx of 1..k */
+int rlhip_col_swap_i64(rlhip_ctx* ctx, int64_t n, int64_t k, int64_t* A, const int64_t* idx);
+/* lapack::geqp3 (rl_cqrrpt.hh:247): column-pivoted Householder QR, LAPACK output format (R above, reflectors
+ * below the diagonal, tau, 1-based jpvt); all arrays on the device.  jpvt entries on entry are ignored. */
+int rlhip_geqp3_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau);
+int rlhip_geqp3_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* jpvt, float* tau);
+/* diag(A)[0..n) to the host (rank tests read R's diagonal: rl_cqrrpt.hh:267-272,319-331, rl_bqrrp.hh:421-427) */
+int rlhip_get_diag_f64(rlhip_ctx* ctx, int64_t n, const double* A, int64_t lda, double* diag_host);
+int rlhip_get_diag_f32(rlhip_ctx* ctx, int64_t n, const float* A, int64_t lda, float* diag_host);
 
 /* ---- row-block sharding across the GPUs of a node (new design; the reference has no
  *      distributed code).  One process per GPU.  Sum all-reduces run on the context's stream through RCCL

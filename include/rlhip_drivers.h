@@ -38,6 +38,15 @@ int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t*
                        int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** U,
                        double** S, double** V, uint32_t state[6], int* qb_ret);
 
+/* CQRRPT<double>::call with qrcp = geqp3.  A (m x n, lda) -> Q; R (n x n, ldr); J (n, device int64).  If A_hat_in
+ * is non-NULL it is used as the d x n sketch (ld d) instead of generating a SASO (parity tests share one sketch
+ * between this path and the oracle, like test/drivers/test_bqrrp_gpu.cu:91-110); if A_hat_out is non-NULL the
+ * sketch that was factored is copied there BEFORE geqp3.  *rank_out = CQRRPT::rank; times_us[8] may be NULL.
+ *                                                                         drivers/rl_cqrrpt.hh:147-391 */
+int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr,
+                         int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
+                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,11 @@ def _blas3(T):
         "lange_fro": [c_vp, c_i64, c_i64, c_vp, c_i64, C.POINTER(T)],
         "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "laset": [c_vp, c_char, c_i64, c_i64, T, T, c_vp, c_i64],
+        "saso_apply": [c_vp, c_vp, c_i64, T, c_vp, c_i64, T, c_vp, c_i64],
+        "saso_dense": [c_vp, c_vp, c_vp],
+        "col_swap": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "geqp3": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
+        "get_diag": [c_vp, c_i64, c_vp, c_i64, C.POINTER(T)],
         "add_diag": [c_vp, c_i64, T, c_vp, c_i64],
         "gesdd": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_int)],
         "transpose": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
@@ -65,6 +70,9 @@ SIGNATURES = {
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
     "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
+    "rlhip_saso_create": (c_int, [c_vp, c_i64, c_i64, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
+    "rlhip_saso_destroy": (c_int, [c_vp, c_vp]),
+    "rlhip_col_swap_i64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }
@@ -88,6 +96,8 @@ SIGNATURES.update({
     "rlhip_drv_rf_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, u32p]),
     "rlhip_drv_qb_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int, c_int,
                                  c_int, c_int, dpp, dpp, u32p]),
+    "rlhip_drv_cqrrpt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_i64, c_dbl, u32p, c_vp,
+                                     c_vp, C.POINTER(c_i64), C.POINTER(C.c_long)]),
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })

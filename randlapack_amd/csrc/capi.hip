@@ -5,6 +5,16 @@
 #include <cstdlib>
 
 namespace rlhip {
+struct SasoOp;
+int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
+               uint32_t next_ctr[4], SasoOp** out);
+int saso_destroy(rlhip_ctx* c, SasoOp* op);
+template <typename T> int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S);
+template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta,
+                                     T* B, int64_t ldb);
+template <typename T> int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx);
+int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev);
+template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
 int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]);
 }
 
@@ -178,6 +188,15 @@ int rlhip_fill_dense_f32(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, flo
     return rlhip::fill_dense<float>(c, dist, rows, cols, buf, ctr, key, next_ctr);
 }
 
+int rlhip_saso_create(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
+                      uint32_t next_ctr[4], rlhip_saso** out) {
+    return rlhip::saso_build(c, d, m, nnz, ctr, key, next_ctr, (rlhip::SasoOp**)out);
+}
+int rlhip_saso_destroy(rlhip_ctx* c, rlhip_saso* S) { return rlhip::saso_destroy(c, (rlhip::SasoOp*)S); }
+int rlhip_col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx) {
+    return rlhip::col_swap_i64(c, n, k, A, idx);
+}
+
 // ------------------------------------------------------------------ BLAS-3
 static inline int op_flag(char t, int* out) {
     if (t == 'N' || t == 'n') { *out = 0; return 0; }
@@ -233,6 +252,26 @@ static inline int op_flag(char t, int* out) {
     int rlhip_laset_##SUF(rlhip_ctx* c, char uplo, int64_t m, int64_t n, T offd, T diag, T* A, int64_t lda) {   \
         int u = (uplo == 'U' || uplo == 'u') ? 0 : (uplo == 'L' || uplo == 'l') ? 1 : 2;                        \
         return rlhip::laset<T>(c, u, m, n, offd, diag, A, lda);                                                  \
+    }                                                                                                           \
+    int rlhip_saso_apply_##SUF(rlhip_ctx* c, const rlhip_saso* S, int64_t n, T alpha, const T* A, int64_t lda, T beta, \
+                               T* B, int64_t ldb) {                                                             \
+        return rlhip::saso_apply<T>(c, (const rlhip::SasoOp*)S, n, alpha, A, lda, beta, B, ldb);                 \
+    }                                                                                                           \
+    int rlhip_saso_dense_##SUF(rlhip_ctx* c, const rlhip_saso* S, T* dense) {                                   \
+        return rlhip::saso_dense<T>(c, (const rlhip::SasoOp*)S, dense);                                          \
+    }                                                                                                           \
+    int rlhip_col_swap_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx) { \
+        return rlhip::col_swap<T>(c, m, n, k, A, lda, idx);                                                      \
+    }                                                                                                           \
+    int rlhip_geqp3_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt, T* tau) {       \
+        return rlhip::geqp3<T>(c, m, n, A, lda, jpvt, tau);                                                      \
+    }                                                                                                           \
+    int rlhip_get_diag_##SUF(rlhip_ctx* c, int64_t n, const T* A, int64_t lda, T* diag_host) {                  \
+        if (n <= 0) return 0;                                                                                   \
+        RLHIP_CHECK(hipMemcpy2DAsync(diag_host, sizeof(T), A, (size_t)(lda + 1) * sizeof(T), sizeof(T), (size_t)n, \
+                                     hipMemcpyDeviceToHost, c->stream));                                        \
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));                                                           \
+        return 0;                                                                                               \
     }                                                                                                           \
     int rlhip_add_diag_##SUF(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda) {                             \
         return rlhip::add_diag<T>(c, n, alpha, A, lda);                                                          \

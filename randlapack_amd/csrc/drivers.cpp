@@ -134,4 +134,23 @@ int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t*
     });
 }
 
+int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr,
+                         int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
+                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::CQRRPT<double, RNG> alg(q, times_us != nullptr, eps);
+        alg.nnz = nnz;
+        alg.sketch_override = A_hat_in;
+        alg.sketch_export = A_hat_out;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A, lda, R, ldr, J, d_factor, st);
+        store_state(st, state);
+        if (rank_out) *rank_out = alg.rank;
+        if (times_us && alg.times.size() == 8)
+            for (int i = 0; i < 8; ++i) times_us[i] = alg.times[i];
+        return rc;
+    });
+}
+
 }  // extern "C"

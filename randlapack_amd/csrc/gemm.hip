@@ -284,7 +284,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(
                 for (int r = 0; r < 4; ++r) {
                     int64_t i = m0 + wm0 + 16 * t + fr;
                     int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
-                    if (i < g.M && j < g.N) {
+                    if (i < g.M && j < g.N && !(g.tri && i > j)) {   // tri: LAPACK uplo contract, strictly lower part untouched
                         T v = g.alpha * acc[t][u][r];
                         if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
                         g.C[i + j * g.ldc] = v;
@@ -301,7 +301,7 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t N, int nz, const T* __re
     int64_t total = M * N;
     for (; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = idx % M, j = idx / M;
-        if (tri && (i / tile) > (j / tile)) continue;
+        if (tri && i > j) continue;   // LAPACK uplo contract: the strictly lower triangle is never written
         T s = 0;
         for (int z = 0; z < nz; ++z) s += slab[(int64_t)z * total + idx];
         T v = alpha * s;
@@ -506,9 +506,9 @@ int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, 
 }
 
 // syrk: only Trans (C = alpha*A^T*A + beta*C, A is k x n) and NoTrans (C = alpha*A*A^T + beta*C, A is n x k).
-// Only tiles touching the `uplo` triangle are computed; inside diagonal tiles both halves are written
-// (the strictly-other triangle of diagonal tiles is therefore overwritten with the symmetric values --
-// callers on this path treat that part as scratch, exactly like LAPACK callers must).
+// Only tiles touching the upper triangle are computed and only elements i <= j are written: the strictly lower
+// triangle of C is left untouched, as LAPACK promises (CQRRPT relies on it: R's lower part must stay zero for
+// the trmm at rl_cqrrpt.hh:345).
 template <typename T>
 int syrk(rlhip_ctx* c, int uplo, int trans, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, T beta,
          T* C, int64_t ldc) {

@@ -1,0 +1,377 @@
+// Sparse sketching operator (SASO) for CQRRPT / CQRRT and the column-permutation kernels.
+//
+// Replaces RandBLAS::SparseDist / SparseSkOp / sketch_general at RandLAPACK/drivers/rl_cqrrpt.hh:214-222
+// (A_hat = S * A, S is d x m with `nnz` nonzeros of value +-1 in every column) and util::col_swap
+// (misc/rl_util.hh:151-198 == LAPACK lapmt forward) at rl_cqrrpt.hh:288, rl_bqrrp.hh:369.
+//
+// RandBLAS is absent from the reference tree, so the operator's random structure is this library's own
+// ("parity unpinned").  It is chosen so that the INVERSE map (which input rows feed sketch
+// row r) is closed-form: the sketch can then be applied as a deterministic GATHER -- every output element is
+// summed by one thread in a fixed order, bitwise reproducible -- instead of a scatter with floating-point
+// atomics.  Input rows are cut into blocks of d; inside block t, input row u (0 <= u < d) feeds the nnz sketch
+// rows   r_i(u) = (a_t * u + b_{t,i}) mod d,   gcd(a_t, d) = 1, b_{t,0..nnz-1} pairwise distinct
+// (=> nnz DISTINCT rows per column, each row index uniform), with iid signs.  (a_t, b_t) come from
+// Philox(ctr + t), the signs of input row j from Philox(ctr + T + j); next state = ctr + T + m, T = ceil(m/d).
+//
+// apply: grid = (column tiles of 8) x (groups of row blocks); a workgroup stages the d x 8 block of A in LDS
+// (coalesced reads, A is streamed exactly once), each thread owns up to 8 sketch rows x 8 columns of
+// accumulators in registers and gathers its nnz source rows per block from LDS with ds_read_b128; partial
+// sketches of the row-block groups are summed in fixed order.  HBM-bound: 8*m*n bytes.
+#include "rlhip_internal.h"
+
+namespace {
+
+__device__ inline void philox4x32_10_dev(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ inline void ctr_add_dev(const uint32_t base[4], uint64_t inc, uint32_t out[4]) {
+    uint64_t lo = ((uint64_t)base[1] << 32) | base[0], hi = ((uint64_t)base[3] << 32) | base[2];
+    uint64_t nlo = lo + inc;
+    if (nlo < lo) hi += 1;
+    out[0] = (uint32_t)nlo; out[1] = (uint32_t)(nlo >> 32); out[2] = (uint32_t)hi; out[3] = (uint32_t)(hi >> 32);
+}
+__device__ inline int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; }
+// modular inverse of a mod d (gcd = 1), extended Euclid
+__device__ inline int64_t modinv(int64_t a, int64_t d) {
+    int64_t t = 0, nt = 1, r = d, nr = a % d;
+    while (nr) { int64_t q = r / nr; int64_t tmp = t - q * nt; t = nt; nt = tmp; tmp = r - q * nr; r = nr; nr = tmp; }
+    return t < 0 ? t + d : t;
+}
+
+struct SasoState { uint32_t ctr[4]; uint32_t key[2]; };
+
+// one thread per row block t: parameters a_t^{-1} and b_{t,i}
+__global__ void saso_params_kernel(int64_t d, int64_t T, int nnz, SasoState st, int64_t* __restrict__ ainv,
+                                   int64_t* __restrict__ b) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    uint32_t c[4], r[4];
+    ctr_add_dev(st.ctr, (uint64_t)t, c);
+    philox4x32_10_dev(c, st.key, r);
+    // a: first candidate >= 1 (from r[0]) coprime with d
+    int64_t a = 1 + (int64_t)(r[0] % (uint32_t)(d > 1 ? d - 1 : 1));
+    while (gcd64(a, d) != 1) { a += 1; if (a >= d) a = 1; }
+    ainv[t] = (d > 1) ? modinv(a, d) : 0;
+    // b_i: LCG walk seeded by r[1..3], rejection for distinctness
+    uint64_t s = ((uint64_t)r[1] << 32) | r[2];
+    for (int i = 0; i < nnz; ++i) {
+        for (;;) {
+            s = s * 6364136223846793005ull + ((uint64_t)r[3] | 1ull);
+            int64_t cand = (int64_t)((s >> 33) % (uint64_t)d);
+            bool dup = false;
+            for (int l = 0; l < i; ++l) dup |= (b[t * nnz + l] == cand);
+            if (!dup) { b[t * nnz + i] = cand; break; }
+        }
+    }
+}
+
+// src[(t*nnz + i)*d + r] = u | (sign << 31); u == 0x7fffffff marks "no source row" (beyond m, last partial block)
+__global__ void saso_lists_kernel(int64_t d, int64_t m, int64_t T, int nnz, SasoState st,
+                                  const int64_t* __restrict__ ainv, const int64_t* __restrict__ b,
+                                  int32_t* __restrict__ src) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = T * nnz * d;
+    if (idx >= total) return;
+    int64_t r = idx % d, ti = idx / d, i = ti % nnz, t = ti / nnz;
+    int64_t u = ((r - b[t * nnz + i] + d) % d) * ainv[t] % d;     // inverse of r = a u + b
+    int64_t j = t * d + u;
+    if (j >= m) { src[idx] = 0x7fffffff; return; }
+    uint32_t c[4], w[4];
+    ctr_add_dev(st.ctr, (uint64_t)(T + j), c);
+    philox4x32_10_dev(c, st.key, w);
+    uint32_t bit = (w[(i >> 5) & 3] >> (i & 31)) & 1u;
+    src[idx] = (int32_t)((uint32_t)u | (bit << 31));
+}
+
+// dense copy of S (d x m, column-major) for tests: S[r, j] = +-1
+template <typename T>
+__global__ void saso_dense_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, const int32_t* __restrict__ src,
+                                  T* __restrict__ S) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Tb * nnz * d) return;
+    int32_t e = src[idx];
+    if ((e & 0x7fffffff) == 0x7fffffff) return;
+    int64_t r = idx % d, t = (idx / d) / nnz;
+    int64_t j = t * d + (int64_t)(e & 0x7fffffff);
+    S[r + j * d] += (e & 0x80000000) ? T(-1) : T(1);    // distinct (r, j) per entry: no race
+}
+
+constexpr int CT = 8;     // columns per workgroup
+constexpr int RPT = 8;    // sketch rows per thread (256 threads -> d <= 2048 per pass)
+
+// partial[g][r + c*d] = sum over row blocks t in group g of sum_i sign * A[t*d + u_i(r), c]
+template <typename T>
+__global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, int64_t m, int64_t Tb, int nnz,
+                                                         const int32_t* __restrict__ src, const T* __restrict__ A,
+                                                         int64_t lda, int64_t t_per_group, int64_t r_base,
+                                                         T* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sA = reinterpret_cast<T*>(smem_raw);                     // [d][CT] row-major
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * CT;
+    const int64_t g = blockIdx.y;
+    const int64_t t0 = g * t_per_group, t1 = (t0 + t_per_group < Tb) ? (t0 + t_per_group) : Tb;
+    T acc[RPT][CT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = T(0);
+    for (int64_t t = t0; t < t1; ++t) {
+        __syncthreads();
+        // stage A[t*d : t*d+d, c0:c0+CT] (zero padded) -- threads run along rows: coalesced
+        for (int64_t e = tid; e < d * CT; e += 256) {
+            const int64_t u = e % d, c = e / d;
+            const int64_t j = t * d + u;
+            sA[u * CT + c] = (j < m && c0 + c < n) ? A[j + (c0 + c) * lda] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int64_t r = r_base + tid + 256 * q;
+            if (r < d) {
+                for (int i = 0; i < nnz; ++i) {
+                    const int32_t e = src[(t * nnz + i) * d + r];
+                    if ((e & 0x7fffffff) != 0x7fffffff) {
+                        const T sg = (e & 0x80000000) ? T(-1) : T(1);
+                        const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                    }
+                }
+            }
+        }
+    }
+    T* out = partial + g * d * n;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int64_t r = r_base + tid + 256 * q;
+        if (r < d)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                if (c0 + c < n) out[r + (c0 + c) * d] = acc[q][c];
+    }
+}
+
+template <typename T>
+__global__ void saso_reduce_kernel(int64_t total, int G, const T* __restrict__ partial, T alpha, T beta,
+                                   T* __restrict__ out, int64_t d, int64_t ldo) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    T s = 0;
+    for (int g = 0; g < G; ++g) s += partial[(int64_t)g * total + idx];
+    int64_t r = idx % d, c = idx / d;
+    T v = alpha * s;
+    if (beta != T(0)) v += beta * out[r + c * ldo];
+    out[r + c * ldo] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column permutation (forward lapmt): on exit column i holds former column idx[i]-1.
+// moves[] = cycle-ordered list built by one thread; each thread of the apply kernel owns one row and walks
+// the list, so the whole matrix is read once and written once, in place, with lanes along rows.
+__global__ void perm_moves_kernel(int64_t n, const int64_t* __restrict__ idx, int64_t* __restrict__ moves,
+                                  int64_t* __restrict__ nmoves, unsigned char* __restrict__ seen) {
+    if (threadIdx.x || blockIdx.x) return;
+    for (int64_t i = 0; i < n; ++i) seen[i] = 0;
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (seen[i]) continue;
+        seen[i] = 1;
+        int64_t s = idx[i] - 1;
+        if (s == i) continue;                 // fixed point
+        // cycle: i <- s <- idx[s]-1 <- ... ; encode as (start marker, dst, src ...): -(i+1) opens a cycle
+        moves[w++] = -(i + 1);
+        int64_t j = i;
+        while (s != i) {
+            moves[w++] = s;                   // column j receives column s
+            seen[s] = 1;
+            j = s;
+            s = idx[j] - 1;
+        }
+    }
+    *nmoves = w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void perm_apply_kernel(int64_t m, T* __restrict__ A, int64_t lda,
+                                                         const int64_t* __restrict__ moves,
+                                                         const int64_t* __restrict__ nmoves) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const int64_t nm = *nmoves;
+    T* row = A + r;
+    T saved = 0;
+    int64_t start = 0, cur = 0;
+    for (int64_t q = 0; q < nm; ++q) {
+        const int64_t v = moves[q];
+        if (v < 0) {                           // new cycle: close the previous one first
+            if (q > 0) row[cur * lda] = saved;
+            start = -v - 1;
+            saved = row[start * lda];
+            cur = start;
+        } else {
+            row[cur * lda] = row[v * lda];
+            cur = v;
+        }
+    }
+    if (nm > 0) row[cur * lda] = saved;
+}
+
+// integer vector overload (rl_util.hh:174-198): permutes the first k entries by a permutation of 1..k
+__global__ void vec_gather_i64_kernel(int64_t k, const int64_t* __restrict__ in, const int64_t* __restrict__ idx,
+                                      int64_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) out[i] = in[idx[i] - 1];
+}
+
+}  // namespace
+
+namespace rlhip {
+
+// opaque device-side operator
+struct SasoOp {
+    int64_t d, m, T;
+    int nnz;
+    int32_t* src;       // T * nnz * d
+    int64_t* ainv;      // T
+    int64_t* b;         // T * nnz
+};
+
+int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
+               uint32_t next_ctr[4], SasoOp** out) {
+    if (d <= 0 || m < 0 || nnz <= 0 || nnz > d || nnz > 128) return -2;
+    SasoOp* op = new SasoOp();
+    op->d = d; op->m = m; op->nnz = nnz; op->T = (m + d - 1) / d;
+    const int64_t T = op->T > 0 ? op->T : 1;
+    RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (size_t)(T * nnz * d)));
+    RLHIP_CHECK(hipMalloc((void**)&op->ainv, sizeof(int64_t) * (size_t)T));
+    RLHIP_CHECK(hipMalloc((void**)&op->b, sizeof(int64_t) * (size_t)(T * nnz)));
+    SasoState st;
+    for (int i = 0; i < 4; ++i) st.ctr[i] = ctr[i];
+    st.key[0] = key[0]; st.key[1] = key[1];
+    if (op->T > 0) {
+        hipLaunchKernelGGL(saso_params_kernel, dim3((unsigned)((op->T + 63) / 64)), dim3(64), 0, c->stream, d, op->T, nnz,
+                           st, op->ainv, op->b);
+        int64_t total = op->T * nnz * d;
+        hipLaunchKernelGGL(saso_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d, m, op->T,
+                           nnz, st, op->ainv, op->b, op->src);
+        RLHIP_LAUNCH_CHECK();
+    }
+    if (next_ctr) {
+        uint64_t inc = (uint64_t)op->T + (uint64_t)m;
+        uint64_t lo = ((uint64_t)ctr[1] << 32) | ctr[0], hi = ((uint64_t)ctr[3] << 32) | ctr[2];
+        uint64_t nlo = lo + inc;
+        if (nlo < lo) hi += 1;
+        next_ctr[0] = (uint32_t)nlo; next_ctr[1] = (uint32_t)(nlo >> 32);
+        next_ctr[2] = (uint32_t)hi; next_ctr[3] = (uint32_t)(hi >> 32);
+    }
+    *out = op;
+    return 0;
+}
+
+int saso_destroy(rlhip_ctx* c, SasoOp* op) {
+    if (!op) return 0;
+    hipStreamSynchronize(c->stream);
+    hipFree(op->src); hipFree(op->ainv); hipFree(op->b);
+    delete op;
+    return 0;
+}
+
+template <typename T>
+int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S /* d x m, zeroed here */) {
+    RLHIP_CHECK(hipMemsetAsync(S, 0, sizeof(T) * (size_t)(op->d * op->m), c->stream));
+    int64_t total = op->T * op->nnz * op->d;
+    if (total > 0) {
+        hipLaunchKernelGGL(saso_dense_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, op->d,
+                           op->m, op->T, op->nnz, op->src, S);
+        RLHIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// B (d x n, ldb) = alpha * S * A (m x n, lda) + beta * B
+template <typename T>
+int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb) {
+    const int64_t d = op->d, m = op->m;
+    if (n <= 0) return 0;
+    if (lda < (m > 1 ? m : 1)) return -6;
+    if (ldb < d) return -9;
+    const size_t smem = sizeof(T) * (size_t)d * CT;
+    if (smem > 160 * 1024) return -2;   // d up to 2560 (fp64)
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)saso_apply_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t ctiles = (n + CT - 1) / CT;
+    int64_t G = (1024 + ctiles - 1) / ctiles;                       // ~4 workgroups per CU in flight
+    if (G > op->T) G = op->T;
+    if (G < 1) G = 1;
+    const int64_t tpg = (op->T + G - 1) / G;
+    G = (op->T + tpg - 1) / tpg;
+    if (G < 1) G = 1;
+    size_t mark = rlhip_ws_mark(c);
+    T* partial = ws_alloc<T>(c, (size_t)G * d * n);
+    if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    if (op->T == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
+    for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT) {
+        if (op->T > 0)
+            hipLaunchKernelGGL(saso_apply_kernel<T>, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m,
+                               op->T, op->nnz, op->src, A, lda, tpg, r_base, partial);
+    }
+    RLHIP_LAUNCH_CHECK();
+    const int64_t total = d * n;
+    hipLaunchKernelGGL(saso_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, total, (int)G,
+                       partial, alpha, beta, B, d, ldb);
+    RLHIP_LAUNCH_CHECK();
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+// in-place forward column permutation; idx is a DEVICE array of n 1-based indices (left untouched)
+template <typename T>
+int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx_dev) {
+    if (k > n) return -3;                       // reference throws (rl_util.hh:159-160)
+    if (m <= 0 || n <= 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    int64_t* moves = ws_alloc<int64_t>(c, (size_t)(2 * n + 2));
+    int64_t* nmoves = ws_alloc<int64_t>(c, 1);
+    unsigned char* seen = ws_alloc<unsigned char>(c, (size_t)n);
+    if (!moves || !nmoves || !seen) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipLaunchKernelGGL(perm_moves_kernel, dim3(1), dim3(1), 0, c->stream, n, idx_dev, moves, nmoves, seen);
+    hipLaunchKernelGGL(perm_apply_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, A, lda, moves,
+                       nmoves);
+    RLHIP_LAUNCH_CHECK();
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev) {
+    if (k > n) return -3;
+    if (k <= 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    int64_t* tmp = ws_alloc<int64_t>(c, (size_t)k);
+    if (!tmp) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    hipLaunchKernelGGL(vec_gather_i64_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, k, A, idx_dev, tmp);
+    RLHIP_CHECK(hipMemcpyAsync(A, tmp, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToDevice, c->stream));
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+template int saso_dense<double>(rlhip_ctx*, const SasoOp*, double*);
+template int saso_dense<float>(rlhip_ctx*, const SasoOp*, float*);
+template int saso_apply<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const double*, int64_t, double, double*, int64_t);
+template int saso_apply<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const float*, int64_t, float, float*, int64_t);
+template int col_swap<double>(rlhip_ctx*, int64_t, int64_t, int64_t, double*, int64_t, const int64_t*);
+template int col_swap<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, int64_t, const int64_t*);
+
+}  // namespace rlhip

@@ -264,3 +264,30 @@ def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb
     S = _adopt(ctx, Sp, kal, 1).reshape(-1)
     V = _adopt(ctx, Vp, n, kal)
     return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
+               want_sketch=False, timing=False):
+    """CQRRPT::call (qrcp = geqp3).  A (column-major tensor (n, m)) is overwritten by Q.  Returns dict(rc, rank, R, J,
+    next_ctr[, sketch][, times_us])."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    if eps is None:
+        eps = float(np.finfo(np.float64).eps ** 0.85)
+    d = int(d_factor * n)
+    R = cm_zeros(n, n, device=dev)
+    J = torch.zeros(n, dtype=torch.int64, device=dev)
+    sk_out = cm_empty(d, n, device=dev) if want_sketch else None
+    rank = C.c_int64(0)
+    st = _state_arr(ctr, key)
+    times = (C.c_long * 8)() if timing else None
+    rc = ctx.lib.rlhip_drv_cqrrpt_f64(ctx.h, m, n, A.data_ptr(), m, R.data_ptr(), n, J.data_ptr(), d_factor, nnz, eps, st,
+                                      sketch_in.data_ptr() if sketch_in is not None else None,
+                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times)
+    _drv_check(ctx, rc, "cqrrpt")
+    out = dict(rc=rc, rank=int(rank.value), R=R, J=J, next_ctr=tuple(int(x) for x in st[:4]))
+    if want_sketch:
+        out["sketch"] = sk_out
+    if timing:
+        out["times_us"] = [int(t) for t in times]
+    return out
