@@ -5,14 +5,15 @@
 // given the same sketch the pivot vector equals LAPACK's except on exact near-ties of partial norms.
 //
 // Execution model: ONE persistent launch.  Column position j lives with workgroup j % G (cyclic, so the load
-// stays balanced as the factorization advances).  Per step there are two grid-wide rendezvous:
-//   R1  every workgroup has published its best local candidate (norm, position)        -> pivot p is known
-//   R2  the owner of p has turned that column into the Householder vector (dlarfg) and published it,
-//       the owner of k has published the column that moves to position p              -> everybody updates
-// after R2 each wave applies H to whole columns it owns (wavefront DPP reductions, no block barrier),
-// down-dates their norms and the workgroup publishes its candidate for the next step.
-// The grid barrier is a monotonic counter with agent-scope release/acquire (guide section 6, G16); the
-// grid is sized to the CU count so all workgroups are co-resident.
+// stays balanced as the factorization advances) and is kept in that workgroup's LDS when it fits.  Per step there
+// is ONE grid-wide rendezvous: before it every workgroup publishes its best local candidate (norm, position)
+// TOGETHER WITH the finished Householder column it would produce (dlarfg applied speculatively to its own
+// candidate -- an m-length pass, cheaper than a second rendezvous), and the owner of position k publishes the
+// column that will move away; after it everybody knows the winner, reads the winner's finished column, installs
+// the two moved columns, applies H to the columns it owns (one wavefront per column, shuffle reductions, no block
+// barrier) and down-dates their norms.  Published buffers are double-buffered by step parity (a workgroup can be
+// at most one rendezvous ahead).  Measured 1280 x 1024: two-rendezvous/global-memory version 61 ms -> LDS
+// columns 36 ms -> single rendezvous + fence-free publication: see DESIGN.md.
 #include "rlhip_internal.h"
 #include <cmath>
 #include <limits>
@@ -23,23 +24,33 @@ template <typename T>
 struct QrcpArgs {
     int64_t m, n;
     T* A; int64_t lda;
-    int64_t* jpvt;            // device, 1-based on exit; entries != 0 on entry are NOT treated as fixed (caller passes zeros)
+    int64_t* jpvt;            // device, 1-based on exit; entry values are ignored (no "fixed" columns)
     T* tau;
     T* vn1; T* vn2;           // n each
-    T* cand_val; int64_t* cand_pos;   // G each
-    T* pcol; T* kcol;         // m each
-    T* scal;                  // [0] = tau_k
+    T* cand_val; int64_t* cand_pos; T* cand_tau;   // 2 x G each (step parity)
+    T* slot;                  // 2 x G x m : each workgroup's speculative "finished pivot column"
+    T* kcol;                  // 2 x m     : column currently at position k (moves to position p)
     unsigned* bar;            // barrier counter (zeroed by the host)
     T tol3z;
+    int use_lds;              // owned columns live in LDS for the whole factorization
 };
 
+// ---- cross-workgroup traffic uses agent-scope relaxed atomics on 8-byte granules (sc1 write-through stores /
+//      L1-bypassing loads): no cache-maintenance fences are needed around the rendezvous (guide section 6, G16:
+//      "8-B agent atomics both sides"), which keeps a step's single grid barrier at a few microseconds.
+template <typename T>
+__device__ __forceinline__ void pub_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T pub_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's published stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        // one L1 invalidate per step: everything published before the rendezvous was stored write-through (sc1),
+        // so after this acquire it can be read with ordinary wide loads
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -59,118 +70,175 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     const int64_t m = g.m, n = g.n;
     const int64_t kmax = m < n ? m : n;
     __shared__ T s_val[4];
-    __shared__ int64_t s_pos[4];
     unsigned epoch = 0;
-
-    // ---- initial column norms + jpvt + first candidates (columns me, me+G, ...; one wave per column)
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_smem[];
+    const int64_t cpw = (n + G - 1) / G;                 // owned positions: j = me + G*s, s < cpw
+    T* l_vn1 = reinterpret_cast<T*>(qr_smem);            // partial norms of the owned positions (local to the owner)
+    T* l_vn2 = l_vn1 + cpw;
+    T* l_v = l_vn2 + cpw;                                // the step's finished pivot column (m)
+    T* lds_cols = l_v + m;
+    __shared__ T s_cval[256];
+    __shared__ int64_t s_cpos[256];
+    __shared__ int s_cw[256];
+    // column position j -> storage (generic pointer: LDS slot j/G of the owner, or the matrix itself)
+    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + (j / G) * m) : (g.A + j * g.lda); };
+    if (g.use_lds) {
+        for (int64_t j = me; j < n; j += G) {
+            T* dst = lds_cols + (j / G) * m;
+            const T* src = g.A + j * g.lda;
+            for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    // ---- initial column norms + jpvt (columns me, me+G, ...; one wave per column).  vn1/vn2/jpvt entries of a
+    //      position are only ever written by that position's owner, except the swap at the pivot step.
     for (int64_t j = me + G * wid; j < n; j += 4 * G) {
-        const T* col = g.A + j * g.lda;
+        const T* col = colptr(j);
         T ss = 0;
         for (int64_t i = lane; i < m; i += 64) ss += col[i] * col[i];
         ss = wave_sum(ss);
-        if (lane == 0) { T nr = sqrt(ss); g.vn1[j] = nr; g.vn2[j] = nr; g.jpvt[j] = j + 1; }
+        if (lane == 0) {
+            T nr = sqrt(ss);
+            l_vn1[j / G] = nr; l_vn2[j / G] = nr;
+            __hip_atomic_store(g.jpvt + j, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
 
     for (int64_t k = 0; k < kmax; ++k) {
-        // ---- publish local candidate over owned positions >= k (first maximum: smallest position wins ties)
-        {
-            T best = T(-1); int64_t bpos = n;
-            for (int64_t j = me; j < n; j += G) {
-                if (j < k) continue;
-                T v = g.vn1[j];
-                if (v > best) { best = v; bpos = j; }   // increasing j: strict > keeps the first maximum
-            }
-            // the scan above is done redundantly by every thread (few columns per workgroup)
-            if (tid == 0) { g.cand_val[me] = best; g.cand_pos[me] = bpos; }
+        const int par = (int)(k & 1);
+        T* my_slot = g.slot + ((int64_t)par * G + me) * m;
+        T* kcol = g.kcol + (int64_t)par * (m + 2);
+        // ---- A. local candidate over owned positions >= k (first maximum) and its SPECULATIVE reflector
+        T best = T(-1); int64_t bpos = n;
+        for (int64_t j = me; j < n; j += G) {
+            if (j < k) continue;
+            T v = l_vn1[j / G];
+            if (v > best) { best = v; bpos = j; }   // increasing j: strict > keeps the first maximum
         }
-        grid_barrier(g.bar, (unsigned)(G * (++epoch)));                                           // R1
-        // ---- global pivot (every workgroup, redundantly)
-        T pbest = T(-1); int64_t p = n;
-        for (int64_t w = 0; w < G; ++w) {
-            T v = g.cand_val[w]; int64_t q = g.cand_pos[w];
-            if (v > pbest || (v == pbest && q < p)) { pbest = v; p = q; }
-        }
-        if (p >= n) p = k;   // all remaining norms are NaN/negative: keep the natural order
-        const int64_t own_p = p % G, own_k = k % G;
-        // ---- owner of p: build the reflector from column p (it becomes column k) and publish it
-        if (me == own_p) {
-            T* col = g.A + p * g.lda;
-            // xnorm over rows k+1..m-1
+        T my_tau = 0;
+        if (bpos < n) {
+            const T* col = colptr(bpos);
             T ss = 0;
             for (int64_t i = k + 1 + tid; i < m; i += 256) ss += col[i] * col[i];
             ss = wave_sum(ss);
+            __syncthreads();
             if (lane == 0) s_val[wid] = ss;
             __syncthreads();
             const T xnorm = sqrt(s_val[0] + s_val[1] + s_val[2] + s_val[3]);
             const T alpha = col[k];
-            T tauk = 0, beta = alpha, scale = 0;
+            T beta = alpha, scale = 0;
             if (xnorm != T(0)) {                                    // dlarfg (without the safmin rescaling loop)
                 beta = -copysign(hypot(alpha, xnorm), alpha);
-                tauk = (beta - alpha) / beta;
+                my_tau = (beta - alpha) / beta;
                 scale = T(1) / (alpha - beta);
             }
-            __syncthreads();
             for (int64_t i = tid; i < m; i += 256) {
                 T v = col[i];
                 if (i == k) v = beta; else if (i > k) v *= scale;
-                g.pcol[i] = v;
+                pub_store(my_slot + i, v);
             }
-            if (tid == 0) { g.scal[0] = tauk; g.tau[k] = tauk; }
         }
-        if (me == own_k && p != k) {
-            const T* col = g.A + k * g.lda;
-            for (int64_t i = tid; i < m; i += 256) g.kcol[i] = col[i];
+        if (tid == 0) {
+            pub_store(g.cand_val + par * G + me, best);
+            __hip_atomic_store(g.cand_pos + par * G + me, bpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pub_store(g.cand_tau + par * G + me, my_tau);
         }
-        grid_barrier(g.bar, (unsigned)(G * (++epoch)));                                           // R2
-        // ---- install the moved columns, swap bookkeeping
+        const int64_t own_k = k % G;
         if (me == own_k) {
-            T* col = g.A + k * g.lda;
-            for (int64_t i = tid; i < m; i += 256) col[i] = g.pcol[i];
+            const T* col = colptr(k);
+            for (int64_t i = tid; i < m; i += 256) pub_store(kcol + i, col[i]);
+            if (tid == 0) { pub_store(kcol + m, l_vn1[k / G]); pub_store(kcol + m + 1, l_vn2[k / G]); }
+        }
+        grid_barrier(g.bar, (unsigned)(G * (++epoch)));                                           // the step's rendezvous
+        // ---- B. global pivot (every workgroup, redundantly): max norm, ties -> smallest position
+        //      (thread w inspects workgroup w's candidate; tree reduction in LDS -- a serial scan of G atomic loads
+        //      by every thread cost ~35 us per step)
+        {
+            T v = T(-1); int64_t q = n; int w = (int)own_k;
+            for (int64_t ww = tid; ww < G; ww += 256) {
+                T v2 = g.cand_val[par * G + ww];
+                int64_t q2 = g.cand_pos[par * G + ww];
+                if (q2 < n && (v2 > v || (v2 == v && q2 < q))) { v = v2; q = q2; w = (int)ww; }
+            }
+            s_cval[tid] = v; s_cpos[tid] = q; s_cw[tid] = w;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (tid < st) {
+                    T v2 = s_cval[tid + st]; int64_t q2 = s_cpos[tid + st];
+                    if (q2 < n && (v2 > s_cval[tid] || (v2 == s_cval[tid] && q2 < s_cpos[tid]))) {
+                        s_cval[tid] = v2; s_cpos[tid] = q2; s_cw[tid] = s_cw[tid + st];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        int64_t p = s_cpos[0]; int64_t wstar = s_cw[0];
+        if (p >= n) { p = k; wstar = own_k; }   // nothing comparable left (NaNs): natural order
+        const int64_t own_p = p % G;
+        const T tauk = g.cand_tau[par * G + wstar];
+        const T* vcol = g.slot + ((int64_t)par * G + wstar) * m;    // finished column: R above k, beta at k, v below
+        // ---- C. install the moved columns, swap bookkeeping
+        for (int64_t i = tid; i < m; i += 256) l_v[i] = vcol[i];
+        __syncthreads();
+        if (me == own_k) {
+            T* col = colptr(k);
+            for (int64_t i = tid; i < m; i += 256) col[i] = l_v[i];
+            if (tid == 0) g.tau[k] = tauk;
         }
         if (p != k && me == own_p) {
-            T* col = g.A + p * g.lda;
-            for (int64_t i = tid; i < m; i += 256) col[i] = g.kcol[i];
+            T* col = colptr(p);
+            for (int64_t i = tid; i < m; i += 256) col[i] = kcol[i];
             if (tid == 0) {
-                g.vn1[p] = g.vn1[k]; g.vn2[p] = g.vn2[k];
-                int64_t t = g.jpvt[p]; g.jpvt[p] = g.jpvt[k]; g.jpvt[k] = t;
+                l_vn1[p / G] = kcol[m];
+                l_vn2[p / G] = kcol[m + 1];
+                int64_t jp = __hip_atomic_load(g.jpvt + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int64_t jk = __hip_atomic_load(g.jpvt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.jpvt + p, jk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.jpvt + k, jp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
-        // ---- apply H = I - tau v v^T (v_k = 1, v below from pcol) to owned columns j > k, one wave per column
-        const T tauk = g.scal[0];
+        // ---- D. apply H = I - tau v v^T (v_k = 1) to owned columns j > k, one wave per column; down-date norms
         for (int64_t j = me + G * wid; j < n; j += 4 * G) {
             if (j <= k) continue;
-            T* col = g.A + j * g.lda;
+            T* col = colptr(j);
             if (tauk != T(0)) {
                 T w = 0;
-                for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : g.pcol[i]) * col[i];
+                for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : l_v[i]) * col[i];
                 w = wave_sum(w) * tauk;
-                for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : g.pcol[i]);
+                for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : l_v[i]);
             }
-            // norm down-date (dlaqp2): vn1(j) *= sqrt(max(0, 1 - (|A(k,j)|/vn1(j))^2)) with recomputation safeguard
-            T v1 = g.vn1[j];
+            // dlaqp2: vn1(j) *= sqrt(max(0, 1 - (|A(k,j)|/vn1(j))^2)), recomputed when cancellation is detected
+            T v1 = l_vn1[j / G];
             if (v1 != T(0)) {
                 T akj = fabs(col[k]);
                 T r = akj / v1;
                 T temp = T(1) - r * r;
                 temp = temp > T(0) ? temp : T(0);
-                T q = v1 / g.vn2[j];
+                T q = v1 / l_vn2[j / G];
                 T temp2 = temp * q * q;
                 if (temp2 <= g.tol3z) {
                     T ss = 0;
                     for (int64_t i = k + 1 + lane; i < m; i += 64) ss += col[i] * col[i];
                     ss = wave_sum(ss);
                     v1 = sqrt(ss);
-                    if (lane == 0) { g.vn1[j] = v1; g.vn2[j] = v1; }
+                    if (lane == 0) { l_vn1[j / G] = v1; l_vn2[j / G] = v1; }
                 } else {
-                    if (lane == 0) g.vn1[j] = v1 * sqrt(temp);
+                    if (lane == 0) l_vn1[j / G] = v1 * sqrt(temp);
                 }
             }
         }
         __syncthreads();
     }
-    // tau for any remaining min(m,n) entries is already written; nothing else to do
+    if (g.use_lds) {
+        __syncthreads();
+        for (int64_t j = me; j < n; j += G) {
+            const T* src = lds_cols + (j / G) * m;
+            T* dst = g.A + j * g.lda;
+            for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
+        }
+    }
 }
 
 __global__ void zero_u32(unsigned* p) { *p = 0; }
@@ -191,24 +259,43 @@ int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_d
         num_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
         if (num_cu <= 0) num_cu = 256;
     }
-    int64_t G = (n + 3) / 4;           // ~4 columns (one per wave) per workgroup
-    if (G > num_cu) G = num_cu;        // co-residency: one workgroup per CU at most
+    // Fewer, fatter workgroups make the two rendezvous per step cheaper; the owned columns are kept in LDS when
+    // they fit (<= 150 KiB per workgroup), which also keeps the release fences of the grid barrier clean.
+    int64_t G = (n + 7) / 8;           // ~8 columns (two per wave) per workgroup
+    if (G > num_cu / 2) G = num_cu / 2;
     if (G < 1) G = 1;
+    const int64_t cols_per_wg = (n + G - 1) / G;
+    size_t lds_bytes = (size_t)cols_per_wg * (size_t)m * sizeof(T);
+    int use_lds = lds_bytes + (size_t)m * sizeof(T) <= 140 * 1024;
+    if (!use_lds) {
+        // try more workgroups before giving up on LDS residency
+        int64_t G2 = num_cu;
+        int64_t cpw2 = (n + G2 - 1) / G2;
+        if ((size_t)(cpw2 + 1) * m * sizeof(T) <= 140 * 1024) { G = G2; lds_bytes = (size_t)cpw2 * m * sizeof(T); use_lds = 1; }
+        else lds_bytes = 0;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)qrcp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
     size_t mark = rlhip_ws_mark(c);
     QrcpArgs<T> g;
     g.m = m; g.n = n; g.A = A; g.lda = lda; g.jpvt = jpvt_dev; g.tau = tau_dev;
-    g.vn1 = ws_alloc<T>(c, n); g.vn2 = ws_alloc<T>(c, n);
-    g.cand_val = ws_alloc<T>(c, G); g.cand_pos = ws_alloc<int64_t>(c, G);
-    g.pcol = ws_alloc<T>(c, m); g.kcol = ws_alloc<T>(c, m);
-    g.scal = ws_alloc<T>(c, 4);
+    g.vn1 = ws_alloc<T>(c, n); g.vn2 = ws_alloc<T>(c, n);   // (kept for ABI of the args struct; norms live in LDS)
+    g.cand_val = ws_alloc<T>(c, 2 * G); g.cand_pos = ws_alloc<int64_t>(c, 2 * G); g.cand_tau = ws_alloc<T>(c, 2 * G);
+    g.slot = ws_alloc<T>(c, (size_t)2 * G * m); g.kcol = ws_alloc<T>(c, (size_t)2 * (m + 2));
     g.bar = ws_alloc<unsigned>(c, 4);
     g.tol3z = std::sqrt(std::numeric_limits<T>::epsilon());
-    if (!g.vn1 || !g.vn2 || !g.cand_val || !g.cand_pos || !g.pcol || !g.kcol || !g.scal || !g.bar) {
+    g.use_lds = use_lds;
+    if (!g.vn1 || !g.vn2 || !g.cand_val || !g.cand_pos || !g.cand_tau || !g.slot || !g.kcol || !g.bar) {
         rlhip_ws_release(c, mark);
         return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     }
     hipLaunchKernelGGL(zero_u32, dim3(1), dim3(1), 0, c->stream, g.bar);
-    hipLaunchKernelGGL(qrcp_kernel<T>, dim3((unsigned)G), dim3(256), 0, c->stream, g);
+    const size_t cpw_final = (size_t)((n + G - 1) / G);
+    const size_t dyn = (2 * cpw_final + (size_t)m) * sizeof(T) + (use_lds ? cpw_final * (size_t)m * sizeof(T) : 0);
+    hipLaunchKernelGGL(qrcp_kernel<T>, dim3((unsigned)G), dim3(256), dyn, c->stream, g);
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);
     return 0;
