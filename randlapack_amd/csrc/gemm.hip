@@ -443,15 +443,15 @@ namespace rlhip {
 
 int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
                      const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc, double* ssqA_dev);
+                     int64_t ldc, double* ssqA_dev, int tri);
 
 template <typename T>
 static int try_streamk(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T,
-                       T*, int64_t, double*) { return 0; }
+                       T*, int64_t, double*, int) { return 0; }
 template <>
 int try_streamk<double>(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
-                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ssq) {
-    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq);
+                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ssq, int tri) {
+    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq, tri);
 }
 
 template <typename T>
@@ -475,10 +475,15 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (lda < (arows > 1 ? arows : 1)) return -8;
     if (ldb < (brows > 1 ? brows : 1)) return -10;
     if (ldc < (m > 1 ? m : 1)) return -13;
+    if (tri && !transB && m == n && n % 256 == 0 && k % 16 == 0) {
+        int rc = try_streamk<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 1);
+        if (rc < 0) return rc;
+        if (rc == 1) return 0;
+    }
     if (!tri && !transB && m >= 128 && n % 256 == 0 && k % 16 == 0) {
         // big data passes: persistent stream-K kernel on the multiple-of-128 row block, generic kernel on the rest
         const int64_t m_main = (m / 128) * 128;
-        int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssqA_dev);
+        int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssqA_dev, 0);
         if (rc < 0) return rc;
         if (rc == 1) {
             if (ssqA_dev && ssq_done) *ssq_done = 1;   // covers op(A)'s first m_main rows; caller adds the peeled block

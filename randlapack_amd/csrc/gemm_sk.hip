@@ -48,7 +48,23 @@ struct SkArgs {
     int64_t tiles_m, tiles_n, ktiles;
     double* slab;             // 2 * gridDim.x slots of 128 x 256
     double* ssq_part;         // nullptr, or gridDim.x partial sums of squares of op(A) (fused ||A||_F^2)
+    int tri;                  // 1: syrk-upper -- only tiles touching i <= j are computed, only i <= j is written
+    int64_t ntiles;           // number of active tiles
 };
+
+// active tile index -> (tile_m, tile_n).  Full: row-major over N.  Tri (128 x 256 tiles, upper): column tn holds the
+// tiles tm < min(tiles_m, 2*tn + 2).
+__device__ __forceinline__ void sk_tile(const SkArgs& g, int64_t a, int64_t& tm, int64_t& tn) {
+    if (!g.tri) { tm = a / g.tiles_n; tn = a - tm * g.tiles_n; return; }
+    tn = 0;
+    for (;;) {
+        int64_t cnt = 2 * tn + 2;
+        if (cnt > g.tiles_m) cnt = g.tiles_m;
+        if (a < cnt) break;
+        a -= cnt; ++tn;
+    }
+    tm = a;
+}
 
 __device__ __forceinline__ void glds16(const double* g, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
@@ -62,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
     const int fr = lane & 15, fk = lane >> 4;
 
     const int64_t KT = g.ktiles;
-    const int64_t W = g.tiles_m * g.tiles_n * KT;
+    const int64_t W = g.ntiles * KT;
     const int64_t P = gridDim.x, w = blockIdx.x;
     const int64_t ws = (w * W) / P, we = ((w + 1) * W) / P;
     const int64_t first_tile = ws / KT;
@@ -102,7 +118,8 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
         const int64_t kt0 = pos - tile * KT;
         int64_t nk = KT - kt0;
         if (nk > we - pos) nk = we - pos;
-        const int64_t tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+        int64_t tile_m, tile_n;
+        sk_tile(g, tile, tile_m, tile_n);
         const int64_t m0 = tile_m * BM, n0 = tile_n * BN, k0 = kt0 * BK;
 
         const double* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
                     for (int r = 0; r < 4; ++r) {
                         const int64_t i = m0 + crow(x);
                         const int64_t j = n0 + wn0 + 16 * u + fk + 4 * r;
+                        if (g.tri && i > j) continue;
                         double v = g.alpha * acc[x][u][r];
                         if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
                         g.C[i + j * g.ldc] = v;
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
 // Sums the partial slabs of every tile that was cut by a share boundary, in increasing k order.
 __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P) {
     const int64_t KT = g.ktiles, tile = blockIdx.x;
-    const int64_t W = g.tiles_m * g.tiles_n * KT;
+    const int64_t W = g.ntiles * KT;
     const int64_t lo = tile * KT, hi = lo + KT;
     // first / last share intersecting [lo, hi)
     int64_t w0 = (lo * P) / W;
@@ -251,9 +269,12 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P)
     int64_t w1 = w0;
     while (((w1 + 1) * W) / P < hi) ++w1;
     if (w0 == w1) return;   // one workgroup covered the whole tile and wrote C itself
-    const int64_t tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+    int64_t tile_m, tile_n;
+    sk_tile(g, tile, tile_m, tile_n);
     const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
-    for (int e = threadIdx.x; e < SLAB_ELEMS; e += 256) {
+    // blockIdx.y slices the tile so that a tile shared by many workgroups (tall Gram matrices) is not summed by one CU
+    const int per = SLAB_ELEMS / (int)gridDim.y;
+    for (int e = blockIdx.y * per + threadIdx.x; e < (int)(blockIdx.y + 1) * per; e += 256) {
         double s = 0;
         for (int64_t w = w0; w <= w1; ++w) {
             const int64_t first_tile_w = ((w * W) / P) / KT;
@@ -261,6 +282,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P)
             s += slab[e];
         }
         const int64_t i = m0 + (e % BM), j = n0 + (e / BM);
+        if (g.tri && i > j) continue;
         double v = g.alpha * s;
         if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
         g.C[i + j * g.ldc] = v;
@@ -287,7 +309,7 @@ namespace rlhip {
 // returns 1 if the problem was handled here, 0 if the caller should use the generic kernel, <0 on error
 int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
                      const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc, double* ssqA_dev) {
+                     int64_t ldc, double* ssqA_dev, int tri) {
     static int enabled = -1, num_cu = 0;
     if (enabled < 0) {
         const char* e = getenv("RLHIP_STREAMK");
@@ -300,11 +322,18 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
     if (m % BM || n % BN || k % BK || m <= 0 || n <= 0 || k <= 0) return 0;
     if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % 2 || ldb % 2) return 0;
     const int64_t tiles_m = m / BM, tiles_n = n / BN, ktiles = k / BK;
-    const int64_t W = tiles_m * tiles_n * ktiles;
+    int64_t ntiles = tiles_m * tiles_n;
+    if (tri) {
+        if (m != n) return 0;
+        ntiles = 0;
+        for (int64_t tn = 0; tn < tiles_n; ++tn) ntiles += (2 * tn + 2 < tiles_m) ? (2 * tn + 2) : tiles_m;
+    }
+    const int64_t W = ntiles * ktiles;
     if (W < (int64_t)num_cu * 64) return 0;   // too little work to amortise the persistent launch
     SkArgs g;
     g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;
+    g.tri = tri; g.ntiles = ntiles;
     const int64_t P = num_cu;
     size_t mark = rlhip_ws_mark(c);
     g.slab = ws_alloc<double>(c, (size_t)2 * P * SLAB_ELEMS);
@@ -326,7 +355,7 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
         hipLaunchKernelGGL(gemm_sk_kernel<false>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
     }
     RLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_sk_fixup_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, c->stream, g, P);
+    hipLaunchKernelGGL(gemm_sk_fixup_kernel, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P);
     RLHIP_LAUNCH_CHECK();
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);

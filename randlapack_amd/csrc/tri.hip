@@ -112,24 +112,39 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     if (ldb < (m > 1 ? m : 1)) return -12;
     if (m == 0 || n == 0) return 0;
     size_t mark = rlhip_ws_mark(c);
-    T* Ut = ws_alloc<T>(c, (size_t)DB * DB);
+    T* Ut = ws_alloc<T>(c, (size_t)SB * SB);
     if (!Ut) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    // Two-level blocking.  Outer 256-column blocks: the contribution of everything to the left is ONE wide MFMA
+    // GEMM (N = 256 -> stream-K path at scale).  Inside a block, 32-column sub-blocks: a narrow MFMA GEMM (N = 32,
+    // K <= 224) brings in the already solved columns of the block, then the row-per-lane substitution kernel
+    // finishes the 32 x 32 triangle entirely in registers.  (A single VALU kernel for the whole 256-block ran at
+    // ~8 % of the fp64 vector peak -- its inner loop re-reads x from L2 and U through the scalar cache.  Two fused
+    // MFMA kernels were also tried and REJECTED at m = 1e6, k = 1024: 64-row slab in LDS + U from L2: 60 ms;
+    // wave-owned rows with X fragments from L2 + staged U chunks: 38 ms; this two-level scheme: 36 ms.)
     for (int64_t j0 = 0; j0 < n; j0 += DB) {
-        int nb = (int)((n - j0 < DB) ? (n - j0) : DB);
-        int ldp = (nb + SB - 1) / SB * SB;
+        const int nb = (int)((n - j0 < DB) ? (n - j0) : DB);
         T a = alpha;
         if (j0 > 0) {
-            // B_J = alpha * B_J - X_{<J} * U_{<J,J}
             int rc = gemm_impl<T>(c, 0, 0, m, nb, j0, T(-1), B, ldb, A + j0 * lda, lda, alpha, B + j0 * ldb, ldb, 0);
             if (rc) { rlhip_ws_release(c, mark); return rc; }
             a = T(1);
         }
-        hipLaunchKernelGGL(pack_upper_rows_kernel<T>, dim3((ldp * ldp + 255) / 256), dim3(256), 0, c->stream, nb,
-                           ldp, diag, A + j0 + j0 * lda, lda, Ut);
-        RLHIP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, nb,
-                           ldp, a, Ut, B + j0 * ldb, ldb);
-        RLHIP_LAUNCH_CHECK();
+        for (int s0 = 0; s0 < nb; s0 += SB) {
+            const int sbw = (nb - s0 < SB) ? (nb - s0) : SB;
+            const int64_t jc = j0 + s0;
+            T a2 = a;
+            if (s0 > 0) {
+                int rc = gemm_impl<T>(c, 0, 0, m, sbw, s0, T(-1), B + j0 * ldb, ldb, A + j0 + jc * lda, lda, a, B + jc * ldb,
+                                      ldb, 0);
+                if (rc) { rlhip_ws_release(c, mark); return rc; }
+                a2 = T(1);
+            }
+            hipLaunchKernelGGL(pack_upper_rows_kernel<T>, dim3((SB * SB + 255) / 256), dim3(256), 0, c->stream, sbw, SB, diag,
+                               A + jc + jc * lda, lda, Ut);
+            hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, sbw, SB, a2,
+                               Ut, B + jc * ldb, ldb);
+            RLHIP_LAUNCH_CHECK();
+        }
     }
     rlhip_ws_release(c, mark);
     return 0;
