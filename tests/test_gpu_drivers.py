@@ -172,3 +172,88 @@ def test_rsvd_full_size_properties(ctx):
     lhs = A[cols] @ U.T                                  # (len(cols), m) @ (m, k)
     rhs = V[:, cols].T * S
     assert float(torch.linalg.norm(lhs - rhs)) <= 1e-9 * float(torch.linalg.norm(rhs))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CQRRPT (drivers/rl_cqrrpt.hh) vs the oracle, sharing ONE sketch (test_bqrrp_gpu.cu:91-110 precedent)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,rank,cond", [(10000, 200, 200, 1.0), (4000, 200, 100, 1e6), (2000, 50, 50, 1e10),
+                                           (10, 5, 5, 1.0), (5000, 300, 300, 1e8)])
+def test_cqrrpt_vs_oracle_shared_sketch(ctx, orc, m, n, rank, cond):
+    d = _d()
+    rng = np.random.default_rng(m + n + rank)
+    A = rng.standard_normal((m, n)) if cond == 1.0 else poly_mat(m, n, rank, rng, cond=cond)
+    eps_user = EPS**0.85
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, eps=eps_user, want_sketch=True, key=(11, 0))
+    o = orc.cqrrpt(A, d.cm_to_numpy(r["sketch"]), eps_user)
+    assert r["rc"] == o["rc"] == 0
+    assert r["rank"] == o["rank"]                                            # rank: exact (same thresholds, a19)
+    k = r["rank"]
+    J, Jo = r["J"].cpu().numpy(), o["J"]
+    np.testing.assert_array_equal(J[:k], Jo[:k])                             # pivot order: bit-exact
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    Q, R = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k]
+    if np.array_equal(J, Jo):
+        assert np.linalg.norm(R - o["R"][:k]) <= EPS**0.6 * np.linalg.norm(o["R"])       # ||dR||_F <= eps^0.6
+    atol = EPS**0.75
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= atol * np.linalg.norm(A)                # test_cqrrpt.cc:102-104
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= atol * np.sqrt(n)
+    assert abs(k - rank) <= 5                                                              # :178-179
+
+
+def test_cqrrpt_own_sketch_properties_and_state(ctx):
+    d = _d()
+    rng = np.random.default_rng(5)
+    m, n = 20000, 256
+    A = poly_mat(m, n, n, rng, cond=1e8)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, key=(3, 0))
+    dsk = int(1.25 * n)
+    assert r["rc"] == 0 and r["next_ctr"] == ((m + dsk - 1) // dsk + m, 0, 0, 0)
+    k = r["rank"]
+    J = r["J"].cpu().numpy()
+    Q, R = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k]
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= EPS**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS**0.75 * np.sqrt(n)
+    # rank-revealing quality: |R_ii| tracks the singular values within a modest factor
+    s = np.linalg.svd(A, compute_uv=False)[:k]
+    ratio = np.abs(np.diag(R)) / s
+    assert ratio.max() < 50 and ratio.min() > 1 / 50
+
+
+def test_cqrrpt_zero_matrix_and_bad_args(ctx):
+    from randlapack_amd._lib import RlhipError
+
+    d = _d()
+    A = d.cm_zeros(50, 5)
+    r = d.drv_cqrrpt(ctx, A, 50, 5)
+    assert r["rc"] == 0 and r["rank"] == 0 and float(A.abs().max()) == 0.0        # rl_cqrrpt.hh:256-261
+    with pytest.raises(RlhipError):
+        d.drv_cqrrpt(ctx, A, 50, 5, d_factor=0.5)                                  # d_factor < 1 (:165)
+
+
+def test_cqrrpt_full_size_properties(ctx):
+    """BASELINE.json configs[2]: 1048576 x 1024 fp64, d = 1280, nnz = 4."""
+    import torch
+
+    d = _d()
+    m, n = 1048576, 1024
+    A = d.cm_empty(m, n)
+    ctx.fill_dense(A, m, n, key=(3, 0))
+    colsum_before = A.sum(dim=1)                       # per-column sums survive a pure column permutation
+    A0_sample = A[:, :4096].clone()
+    r = d.drv_cqrrpt(ctx, A, m, n, 1.25, 4)
+    assert r["rc"] == 0 and r["rank"] == n
+    J = r["J"].cpu().numpy()
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    Q, R = A, r["R"]                                   # Q stored (n, m); R stored (n, n) column-major -> R[j, i] = R_ij
+    I = torch.eye(n, device="cuda", dtype=torch.float64)
+    assert float(torch.linalg.norm(Q @ Q.T - I)) <= EPS**0.75 * np.sqrt(n)
+    Rm = R.T                                           # (n, n) with Rm[i, j] = R_ij
+    assert float(torch.linalg.norm(torch.tril(Rm, -1))) == 0.0
+    # A P = Q R on a 4096-row sample
+    AP = A0_sample[torch.from_numpy(J - 1).cuda()]     # (n, 4096): rows = permuted columns of A
+    QR = (Q[:, :4096].T @ Rm).T
+    assert float(torch.linalg.norm(AP - QR)) <= EPS**0.75 * float(torch.linalg.norm(AP))
+    del colsum_before

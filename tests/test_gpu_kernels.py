@@ -257,3 +257,122 @@ def test_gesdd_tall_vs_lapack(ctx, orc, m, n, cond):
     assert np.max(np.abs(s - s_ref)) <= 1e-13 * s_ref[0] * np.sqrt(n)
     assert np.linalg.norm(u * s @ vt - A) <= 1e-13 * np.linalg.norm(A) * n
     assert np.linalg.norm(u.T @ u - np.eye(n)) <= 1e-11 * n
+
+
+# ---------------------------------------------------------------------------------------------------
+# CQRRPT building blocks: col_swap (exact KATs), geqp3 (pivots bit-exact vs LAPACK), SASO
+# ---------------------------------------------------------------------------------------------------
+def _col_swap_dev(ctx, A, J, k=None):
+    import torch
+
+    d = _dev()
+    m, n = A.shape
+    Ad = d.cm_from_numpy(A)
+    Jd = torch.from_numpy(np.asarray(J, dtype=np.int64)).cuda()
+    rc = ctx.lib.rlhip_col_swap_f64(ctx.h, m, n, n if k is None else k, Ad.data_ptr(), m, Jd.data_ptr())
+    return rc, d.cm_to_numpy(Ad), Jd.cpu().numpy()
+
+
+def test_col_swap_golden_kats_device(ctx):
+    import torch
+
+    d = _dev()
+    cs = json.loads((G / "col_swap_kats.json").read_text())
+    for c in cs["structured"]:                                   # test_util.cc:215-243
+        A = np.array(c["A"]).reshape(c["n"], c["m"]).T
+        rc, B, J = _col_swap_dev(ctx, A, c["J"])
+        assert rc == 0 and list(J) == c["J"]
+        np.testing.assert_array_equal(B.T.ravel(), np.array(c["expect"]))
+    c = cs["lda"]                                                # test_util.cc:245-266 (lda > m, padding rows untouched)
+    buf = torch.tensor(c["A"], dtype=torch.float64, device="cuda")
+    Jd = torch.tensor(c["J"], dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_col_swap_f64(ctx.h, c["m"], c["n"], c["n"], buf.data_ptr(), c["lda"], Jd.data_ptr()) == 0
+    np.testing.assert_array_equal(buf.cpu().numpy(), np.array(c["expect"]))
+    for c in cs["int_vector"]:                                   # test_util.cc:268-293 (prefix-only contract)
+        v = torch.tensor(c["A"], dtype=torch.int64, device="cuda")
+        Jd = torch.tensor(c["J"], dtype=torch.int64, device="cuda")
+        assert ctx.lib.rlhip_col_swap_i64(ctx.h, c["n"], c["k"], v.data_ptr(), Jd.data_ptr()) == 0
+        assert v.cpu().tolist() == c["expect"] and Jd.cpu().tolist() == c["J"]
+
+
+@pytest.mark.parametrize("m,n,k,seed", [(10, 7, 7, 0), (10, 7, 4, 1), (1000, 200, 200, 2), (8, 12, 5, 3), (5, 1, 1, 5),
+                                        (6, 9, 1, 6), (513, 64, 64, 7)])
+def test_col_swap_gather_contract_device(ctx, orc, m, n, k, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n))
+    J = rng.permutation(n) + 1
+    rc, B, Jout = _col_swap_dev(ctx, A, J, k)
+    assert rc == 0
+    np.testing.assert_array_equal(Jout, J)
+    np.testing.assert_array_equal(B, A[:, J - 1])               # bit-exact data movement
+    np.testing.assert_array_equal(B, orc.col_swap(A, J, k)[1])  # == oracle == LAPACK lapmt
+    assert _col_swap_dev(ctx, A, J, n + 1)[0] != 0              # k > n is an error (rl_util.hh:159-160)
+
+
+@pytest.mark.parametrize("m,n,kind", [(50, 20, "scaled"), (300, 200, "scaled"), (1280, 1024, "gauss"), (200, 300, "scaled"),
+                                      (640, 512, "lowrank"), (33, 33, "gauss")])
+def test_geqp3_pivots_match_lapack(ctx, orc, m, n, kind):
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    if kind == "scaled":       # well separated column norms (the bit-exact pivot variant)
+        A = rng.standard_normal((m, n)) * np.logspace(0, -3, n)[rng.permutation(n)]
+    elif kind == "lowrank":
+        A = rng.standard_normal((m, 40)) @ rng.standard_normal((40, n))
+    else:
+        A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    Jd = torch.zeros(n, dtype=torch.int64, device="cuda")
+    tau = torch.zeros(min(m, n), dtype=torch.float64, device="cuda")
+    assert ctx.lib.rlhip_geqp3_f64(ctx.h, m, n, Ad.data_ptr(), m, Jd.data_ptr(), tau.data_ptr()) == 0
+    info, Ao, Jo, tauo = orc.geqp3(A)
+    J = Jd.cpu().numpy()
+    r = min(m, n)
+    Rg, Ro = np.triu(d.cm_to_numpy(Ad))[:r], np.triu(Ao)[:r]
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    if kind == "lowrank":
+        # pivots are pinned only while the remaining column norms are above rounding noise
+        np.testing.assert_array_equal(J[:40], Jo[:40])
+        assert np.abs(np.abs(np.diag(Rg)[:40]) - np.abs(np.diag(Ro)[:40])).max() <= 1e-12 * np.abs(Ro[0, 0])
+    else:
+        np.testing.assert_array_equal(J, Jo)                                     # pivot order: bit-exact
+        assert np.abs(Rg - Ro).max() <= EPS**0.75 * np.abs(Ro).max()             # tau / R tolerances of
+        assert np.abs(tau.cpu().numpy() - tauo).max() <= EPS**0.75              # test_bqrrp_gpu.cu:231-249
+    # it is a valid QRCP regardless: A[:, J] = Q R with |R_ii| non-increasing up to noise
+    dg = np.abs(np.diag(Rg))
+    assert np.all(dg[1:] <= dg[:-1] * (1 + 1e-8) + 1e-12 * dg[0])
+
+
+def test_saso_structure_apply_and_state(ctx):
+    import ctypes as C
+
+    d = _dev()
+    rng = np.random.default_rng(0)
+    for (dd, m, n, nnz) in [(40, 1000, 16, 4), (25, 333, 9, 2), (64, 64, 5, 8), (1280, 5000, 24, 4)]:
+        S = C.c_void_p()
+        nxt = (C.c_uint32 * 4)()
+        u32 = lambda v: (C.c_uint32 * len(v))(*v)
+        assert ctx.lib.rlhip_saso_create(ctx.h, dd, m, nnz, u32((7, 0, 0, 0)), u32((5, 0)), nxt, C.byref(S)) == 0
+        T = (m + dd - 1) // dd
+        assert list(nxt) == [7 + T + m, 0, 0, 0]                                   # S.next_state rule
+        Sd = d.cm_empty(dd, m)
+        ctx.lib.rlhip_saso_dense_f64(ctx.h, S, Sd.data_ptr())
+        Sh = d.cm_to_numpy(Sd)
+        assert set(np.unique(Sh)) <= {-1.0, 0.0, 1.0}
+        assert set((Sh != 0).sum(0)) == {nnz}                                       # exactly nnz DISTINCT rows per column
+        assert abs(Sh.sum()) < 6 * np.sqrt(m * nnz)                                 # signs are balanced
+        A = rng.standard_normal((m, n))
+        Bd = d.cm_from_numpy(rng.standard_normal((dd, n)))
+        B0 = d.cm_to_numpy(Bd)
+        ctx.lib.rlhip_saso_apply_f64(ctx.h, S, n, 2.0, d.cm_from_numpy(A).data_ptr(), m, -1.0, Bd.data_ptr(), dd)
+        ref = 2.0 * Sh @ A - B0
+        assert np.abs(d.cm_to_numpy(Bd) - ref).max() <= 1e-13 * np.abs(ref).max() * nnz
+        # deterministic (gather, fixed summation order): bitwise identical on a second application
+        B2 = d.cm_from_numpy(B0)
+        ctx.lib.rlhip_saso_apply_f64(ctx.h, S, n, 2.0, d.cm_from_numpy(A).data_ptr(), m, -1.0, B2.data_ptr(), dd)
+        assert np.array_equal(d.cm_to_numpy(B2), d.cm_to_numpy(Bd))
+        # it is an (approximate) isometry in expectation: E ||S x||^2 = nnz ||x||^2
+        x = rng.standard_normal(m)
+        assert 0.3 * nnz <= np.linalg.norm(Sh @ x) ** 2 / np.linalg.norm(x) ** 2 <= 3 * nnz
+        ctx.lib.rlhip_saso_destroy(ctx.h, S)
