@@ -12,3 +12,4 @@
 #include "RandLAPACK_amd/rl_qb.hh"
 #include "RandLAPACK_amd/rl_rsvd.hh"
 #include "RandLAPACK_amd/rl_cqrrpt.hh"
+#include "RandLAPACK_amd/rl_bqrrp.hh"

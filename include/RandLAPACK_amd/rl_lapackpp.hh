@@ -58,6 +58,18 @@ inline void get_diag(int64_t n, double const* A, int64_t lda, double* diag_host,
 inline void get_diag(int64_t n, float const* A, int64_t lda, float* diag_host, Queue& q) {
     blas::check(rlhip_get_diag_f32(q.ctx(), n, A, lda, diag_host), "get_diag");
 }
+inline bool any_abs_gt(int64_t n, double const* x, double thr, Queue& q) { int a = 0; blas::check(rlhip_any_abs_gt_f64(q.ctx(), n, x, thr, &a), "any_abs_gt"); return a != 0; }
+inline bool any_abs_gt(int64_t n, float const* x, float thr, Queue& q) { int a = 0; blas::check(rlhip_any_abs_gt_f32(q.ctx(), n, x, thr, &a), "any_abs_gt"); return a != 0; }
+inline void orhr_col(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt, double* D, Queue& q) { blas::check(rlhip_orhr_col_f64(q.ctx(), m, n, nb, A, lda, T, ldt, D), "orhr_col"); }
+inline void orhr_col(int64_t m, int64_t n, int64_t nb, float* A, int64_t lda, float* T, int64_t ldt, float* D, Queue& q) { blas::check(rlhip_orhr_col_f32(q.ctx(), m, n, nb, A, lda, T, ldt, D), "orhr_col"); }
+inline void gemqrt(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, int64_t nb, double const* V, int64_t ldv, double const* T, int64_t ldt, double* C, int64_t ldc, Queue& q) { blas::check(rlhip_gemqrt_f64(q.ctx(), (char)s, (char)t, m, n, k, nb, V, ldv, T, ldt, C, ldc), "gemqrt"); }
+inline void gemqrt(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, int64_t nb, float const* V, int64_t ldv, float const* T, int64_t ldt, float* C, int64_t ldc, Queue& q) { blas::check(rlhip_gemqrt_f32(q.ctx(), (char)s, (char)t, m, n, k, nb, V, ldv, T, ldt, C, ldc), "gemqrt"); }
+inline void larft(int64_t m, int64_t k, double const* V, int64_t ldv, double const* tau, double* T, int64_t ldt, Queue& q) { blas::check(rlhip_larft_f64(q.ctx(), m, k, V, ldv, tau, T, ldt), "larft"); }
+inline void larft(int64_t m, int64_t k, float const* V, int64_t ldv, float const* tau, float* T, int64_t ldt, Queue& q) { blas::check(rlhip_larft_f32(q.ctx(), m, k, V, ldv, tau, T, ldt), "larft"); }
+inline void row_sign(int64_t n, double* R, int64_t ldr, double const* D, Queue& q) { blas::check(rlhip_row_sign_f64(q.ctx(), n, R, ldr, D), "row_sign"); }
+inline void row_sign(int64_t n, float* R, int64_t ldr, float const* D, Queue& q) { blas::check(rlhip_row_sign_f32(q.ctx(), n, R, ldr, D), "row_sign"); }
+inline void tau_from_t(int64_t k, int64_t nb, double const* T, int64_t ldt, double* tau, Queue& q) { blas::check(rlhip_tau_from_t_f64(q.ctx(), k, nb, T, ldt, tau), "tau_from_t"); }
+inline void tau_from_t(int64_t k, int64_t nb, float const* T, int64_t ldt, float* tau, Queue& q) { blas::check(rlhip_tau_from_t_f32(q.ctx(), k, nb, T, ldt, tau), "tau_from_t"); }
 // Job::SomeVec, tall (m >= n).  Returns info (>0: Jacobi did not converge).
 inline int64_t gesdd(Job job, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,
                      double* VT, int64_t ldvt, Queue& q) {

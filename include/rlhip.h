@@ -172,6 +172,42 @@ int rlhip_geqp3_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda,
 int rlhip_get_diag_f64(rlhip_ctx* ctx, int64_t n, const double* A, int64_t lda, double* diag_host);
 int rlhip_get_diag_f32(rlhip_ctx* ctx, int64_t n, const float* A, int64_t lda, float* diag_host);
 
+/* lapack::getrf (rl_bqrrp.hh:343, rl_orth.hh:219): row-pivoted LU of an m x n (m up to ~1e5, tall) device matrix;
+ * ipiv: DEVICE int64, 1-based, min(m,n) entries.  Returns LAPACK info (first exactly-zero pivot) or 0. */
+int rlhip_getrf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv);
+int rlhip_getrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv);
+/* J <- iota(1..cols); for i < min(sd, cols): swap(J[ipiv[i]-1], J[i])   (rl_bqrrp.hh:345-350; CUDA twin
+ * LUQRCP_piv_process_gpu_global, rl_cuda_kernels.cuh:203-220).  Integer-exact. */
+int rlhip_luqrcp_piv(rlhip_ctx* ctx, int64_t sd, int64_t cols, const int64_t* ipiv, int64_t* J);
+
+/* ---- Householder reconstruction / block reflectors (BQRRP, HQRRP) ----
+ * lapack::orhr_col(m, n, nb, A, lda, T, ldt, D) (rl_bqrrp.hh:480; util::rl_orhr_col rl_util.hh:339-379; CUDA twin
+ * rl_cuda_kernels.cuh:772-803): A holds orthonormal columns on entry, the unit-lower-trapezoidal V on exit; T (nb x n)
+ * the compact-WY factors; D (n) the sign vector. */
+int rlhip_orhr_col_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt,
+                       double* D);
+int rlhip_orhr_col_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t nb, float* A, int64_t lda, float* T, int64_t ldt,
+                       float* D);
+/* lapack::gemqrt(Side::Left, Op::Trans, m, n, k, nb, V, ldv, T, ldt, C, ldc) (rl_bqrrp.hh:543) = the block-Householder
+ * apply; with rlhip_larft_* it also serves lapack::ormqr (rl_bqrrp.hh:545, cusolver_ormqr rl_bqrrp_gpu.hh:734). */
+int rlhip_gemqrt_f64(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const double* V,
+                     int64_t ldv, const double* T, int64_t ldt, double* C, int64_t ldc);
+int rlhip_gemqrt_f32(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const float* V,
+                     int64_t ldv, const float* T, int64_t ldt, float* C, int64_t ldc);
+/* lapack::larft(Forward, Columnwise): T (k x k) from V (m x k) and tau (k) */
+int rlhip_larft_f64(rlhip_ctx* ctx, int64_t m, int64_t k, const double* V, int64_t ldv, const double* tau, double* T, int64_t ldt);
+int rlhip_larft_f32(rlhip_ctx* ctx, int64_t m, int64_t k, const float* V, int64_t ldv, const float* tau, float* T, int64_t ldt);
+/* R(j,i) *= D(j), j <= i  (rl_bqrrp.hh:485-487; R_cholqr_signs_gpu rl_cuda_kernels.cuh:222-235) */
+int rlhip_row_sign_f64(rlhip_ctx* ctx, int64_t n, double* R, int64_t ldr, const double* D);
+int rlhip_row_sign_f32(rlhip_ctx* ctx, int64_t n, float* R, int64_t ldr, const float* D);
+/* tau(i) = T(i % nb, i)  (rl_bqrrp.hh:490-491) */
+int rlhip_tau_from_t_f64(rlhip_ctx* ctx, int64_t k, int64_t nb, const double* T, int64_t ldt, double* tau);
+int rlhip_tau_from_t_f32(rlhip_ctx* ctx, int64_t k, int64_t nb, const float* T, int64_t ldt, float* tau);
+/* *any_host = 1 iff some |x[i]| > thr, i < n: the zero-block test of rl_bqrrp.hh:373-379 with the CPU semantics (the
+ * reference's CUDA all_of only honours its first block) */
+int rlhip_any_abs_gt_f64(rlhip_ctx* ctx, int64_t n, const double* x, double thr, int* any_host);
+int rlhip_any_abs_gt_f32(rlhip_ctx* ctx, int64_t n, const float* x, float thr, int* any_host);
+
 /* ---- row-block sharding across the GPUs of a node (new design; the reference has no
  *      distributed code).  One process per GPU.  Sum all-reduces run on the context's stream through RCCL
  *      (bound at run time), or through a host-installed hook.  With no communicator every call is a no-op,

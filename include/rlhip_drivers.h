@@ -47,6 +47,13 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
                          int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
                          const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us);
 
+/* BQRRP<double>::call with {qrcp_wide = geqp3, qr_tall = cholqr, apply_trans_q = gemqrt}.  A (m x n, lda) -> GEQP3
+ * format, tau (min(m,n)), J (n) all on the device.  A_sk_in / A_sk_out: shared-sketch hooks as for CQRRPT (d x n,
+ * ld d, d = (int64)(d_factor * b_sz)).  times_us[9] may be NULL.              drivers/rl_bqrrp.hh:155-665 */
+int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,
+                        int64_t internal_nb, double tol, double* tau, int64_t* J, uint32_t state[6],
+                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,3 +259,43 @@ def geqp3(A):
     tau = np.zeros(min(m, n))
     info = lib.oracle_geqp3_f64(i64(m), i64(n), _p(A), i64(m), _p(J), _p(tau))
     return info, A, J, tau
+
+
+def bqrrp(A, b_sz, d_factor=1.0, qrcp_wide=0, qr_tall=2, apply_trans_q=0, internal_nb=None, tol=None, sketch=None,
+          ctr=(0, 0, 0, 0), key=(0, 0)):
+    """BQRRP::call.  qrcp_wide 0 luqr / 1 geqp3; qr_tall 0 geqrt / 1 cholqr / 2 geqrf; apply_trans_q 0 ormqr / 1 gemqrt.
+    returns dict(rc, rank, A (GEQP3 format), tau, J, next_ctr)"""
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    tau = np.zeros(min(m, n))
+    J = np.zeros(n, dtype=np.int64)
+    rank = i64(0)
+    st = _state(ctr, key)
+    if tol is None:
+        tol = float(np.finfo(np.float64).eps)
+    sk = None if sketch is None else _f(sketch).copy(order="F")
+    rc = lib.oracle_bqrrp_f64(i64(m), i64(n), _p(A), i64(m), dbl(d_factor), i64(b_sz), i64(internal_nb or b_sz), dbl(tol),
+                              C.c_int(qrcp_wide), C.c_int(qr_tall), C.c_int(apply_trans_q), _p(tau), _p(J), _p(st),
+                              _p(sk) if sk is not None else None, C.byref(rank))
+    return dict(rc=rc, rank=int(rank.value), A=A, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def ungqr(A, tau, k=None):
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    kk = min(m, n) if k is None else k
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    lib.oracle_ungqr_f64(i64(m), i64(min(m, n)), i64(kk), _p(A), i64(m), _p(tau))
+    return A[:, :min(m, n)]
+
+
+def lapack_orhr_col(Q, nb):
+    lib = load()
+    A = _f(Q).copy(order="F")
+    m, n = A.shape
+    T = np.zeros((nb, n), order="F")
+    D = np.zeros(n)
+    info = lib.oracle_orhr_col_f64(i64(m), i64(n), i64(nb), _p(A), i64(m), _p(T), i64(nb), _p(D))
+    return info, A, T, D

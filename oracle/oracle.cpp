@@ -203,6 +203,36 @@ void laswp(int64_t n, double* A, int64_t lda, int64_t k1, int64_t k2, const int6
     lapack().dlaswp(&n_, A, &lda_, &k1_, &k2_, ip.data(), &inc_);
 }
 
+int ormqr_lt(int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* tau, double* C, int64_t ldc) {
+    char s = 'L', t = 'T';
+    lint m_ = L(m), n_ = L(n), k_ = L(k), lda_ = L(lda), ldc_ = L(ldc), info = 0, lwork = -1;
+    double wq = 0;
+    lapack().dormqr(&s, &t, &m_, &n_, &k_, A, &lda_, tau, C, &ldc_, &wq, &lwork, &info, 1, 1);
+    lwork = (lint)wq;
+    std::vector<double> work(std::max<lint>(1, lwork));
+    lapack().dormqr(&s, &t, &m_, &n_, &k_, A, &lda_, tau, C, &ldc_, work.data(), &lwork, &info, 1, 1);
+    return (int)info;
+}
+int gemqrt_lt(int64_t m, int64_t n, int64_t k, int64_t nb, const double* V, int64_t ldv, const double* T, int64_t ldt,
+              double* C, int64_t ldc) {
+    char s = 'L', t = 'T';
+    lint m_ = L(m), n_ = L(n), k_ = L(k), nb_ = L(nb), ldv_ = L(ldv), ldt_ = L(ldt), ldc_ = L(ldc), info = 0;
+    std::vector<double> work((size_t)std::max<int64_t>(1, n * nb));
+    lapack().dgemqrt(&s, &t, &m_, &n_, &k_, &nb_, V, &ldv_, T, &ldt_, C, &ldc_, work.data(), &info, 1, 1);
+    return (int)info;
+}
+int geqrt(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt) {
+    lint m_ = L(m), n_ = L(n), nb_ = L(nb), lda_ = L(lda), ldt_ = L(ldt), info = 0;
+    std::vector<double> work((size_t)std::max<int64_t>(1, n * nb));
+    lapack().dgeqrt(&m_, &n_, &nb_, A, &lda_, T, &ldt_, work.data(), &info);
+    return (int)info;
+}
+int orhr_col(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt, double* D) {
+    lint m_ = L(m), n_ = L(n), nb_ = L(nb), lda_ = L(lda), ldt_ = L(ldt), info = 0;
+    lapack().dorhr_col(&m_, &n_, &nb_, A, &lda_, T, &ldt_, D, &info);
+    return (int)info;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // util:: helpers (misc/rl_util.hh)
 // ---------------------------------------------------------------------------------------------------
@@ -432,6 +462,109 @@ struct QB {
     }
 };
 
+
+// drivers/rl_bqrrp.hh:155-665  BQRRP::call.  qrcp_wide: 0 luqr (default), 1 geqp3.  qr_tall: 0 geqrt, 1 cholqr,
+// 2 geqrf (default).  apply_trans_q: 0 ormqr (default), 1 gemqrt.  The d x n sketch A_sk = S*A is SUPPLIED when
+// A_sk_in != nullptr (shared-sketch parity, test/drivers/test_bqrrp_gpu.cu:91-110), else generated from the
+// oracle's own Gaussian stream (:309-313; the reference passes m where lda is meant, SURVEY.md B -- lda is used).
+int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz_in, int64_t internal_nb_in,
+               double tol, int qrcp_wide, int qr_tall, int apply_trans_q, double* tau, int64_t* J, RNGState& st,
+               const double* A_sk_in, int64_t* rank_out) {
+    int64_t rows = m, cols = n, curr_sz = 0, b_sz = b_sz_in;
+    const int64_t mn = std::min(m, n);
+    const int64_t maxiter = (int64_t)std::ceil(mn / (double)b_sz);                            // :220
+    const int64_t b_sz_const = b_sz;
+    const int64_t d = (int64_t)(d_factor * b_sz);                                             // :224
+    int64_t sampling_dimension = d, block_rank = b_sz, internal_nb = internal_nb_in;
+    double* A_work = A;
+    std::vector<int64_t> J_buffer(n, 0), J_buffer_lu(std::max<int64_t>(1, std::min(d, n)), 0);
+    std::vector<double> A_sk_store((size_t)d * n, 0.0), A_sk_trans((size_t)n * d, 0.0);
+    std::vector<double> R_tall_qr((size_t)b_sz_const * b_sz_const, 0.0), T_dat((size_t)b_sz_const * b_sz_const, 0.0), Work2(n, 0.0);
+    double* A_sk = A_sk_store.data();
+    if (A_sk_in) {
+        std::memcpy(A_sk, A_sk_in, sizeof(double) * (size_t)d * n);
+    } else {
+        std::vector<double> S((size_t)d * m);
+        fill_dense(0, d, m, S.data(), st);                                                     // :310-311
+        gemm('N', 'N', d, n, m, 1.0, S.data(), d, A, lda, 0.0, A_sk, d);                       // :312
+    }
+    *rank_out = 0;
+    for (int64_t iter = 0; iter < maxiter; ++iter) {
+        b_sz = std::min(b_sz, mn - curr_sz);                                                   // :322-324
+        internal_nb = std::min(internal_nb, b_sz);
+        block_rank = b_sz;
+        std::fill(J_buffer.begin(), J_buffer.end(), 0);
+        std::fill(J_buffer_lu.begin(), J_buffer_lu.end(), 0);
+        std::fill(Work2.begin(), Work2.end(), 0.0);
+        if (qrcp_wide == 1) {
+            geqp3(sampling_dimension, cols, A_sk, d, J_buffer.data(), Work2.data());          // :336
+        } else {
+            transposition(sampling_dimension, cols, A_sk, d, A_sk_trans.data(), n, 0);        // :341
+            getrf(cols, sampling_dimension, A_sk_trans.data(), n, J_buffer_lu.data());        // :343
+            for (int64_t i = 0; i < cols; ++i) J_buffer[i] = i + 1;                            // :345
+            for (int64_t i = 0; i < std::min(sampling_dimension, cols); ++i)                   // :346-350
+                std::swap(J_buffer[J_buffer_lu[i] - 1], J_buffer[i]);
+            col_swap_matrix(sampling_dimension, cols, cols, A_sk, d, J_buffer.data());         // :352
+            geqrf(sampling_dimension, cols, A_sk, d, Work2.data());                            // :354
+        }
+        col_swap_matrix(m, cols, cols, A + lda * curr_sz, lda, J_buffer.data());               // :369
+        bool block_zero = true;                                                                // :373-379
+        for (int64_t i = 0; i < rows; ++i)
+            if (std::abs(A_work[i]) > std::numeric_limits<double>::epsilon()) { block_zero = false; break; }
+        if (iter == 0) std::copy(J_buffer.begin(), J_buffer.begin() + cols, J);                // :383-387 / :402-406
+        else col_swap_int(cols, cols, J + curr_sz, J_buffer.data());
+        if (block_zero) { *rank_out = curr_sz; return 0; }                                     // :380-399
+        double* Work1 = A_work + lda * b_sz;
+        double* R_sk = A_sk;
+        for (int64_t i = 0; i < b_sz; ++i) {                                                   // :421-427
+            if (std::abs(R_sk[i * d + i]) / std::abs(R_sk[0]) < tol) {
+                block_rank = i;
+                internal_nb = std::min(internal_nb, block_rank);
+                break;
+            }
+        }
+        double* tau_sub = tau + curr_sz;
+        double* R11 = A_work;
+        if (qr_tall == 0) {                                                                    // geqrt :438-446
+            geqrt(rows, b_sz, internal_nb, A_work, lda, T_dat.data(), b_sz_const);
+            for (int64_t i = 0; i < block_rank; ++i) tau_sub[i] = T_dat[b_sz_const * i + (i % internal_nb)];
+        } else if (qr_tall == 1) {                                                             // cholqr :454-505
+            trsm_right_upper(rows, block_rank, 1.0, R_sk, d, A_work, lda);
+            syrk_upper_trans(block_rank, rows, 1.0, A_work, lda, 0.0, R_tall_qr.data(), b_sz_const);
+            potrf_upper(block_rank, R_tall_qr.data(), b_sz_const);
+            trsm_right_upper(rows, block_rank, 1.0, R_tall_qr.data(), b_sz_const, A_work, lda);
+            orhr_col(rows, block_rank, internal_nb, A_work, lda, T_dat.data(), b_sz_const, Work2.data());
+            for (int64_t i = 0; i < block_rank; ++i)
+                for (int64_t j = 0; j < i + 1; ++j) R_tall_qr[b_sz_const * i + j] *= Work2[j];
+            for (int64_t i = 0; i < block_rank; ++i) tau_sub[i] = T_dat[b_sz_const * i + (i % internal_nb)];
+            trmm_right_upper(block_rank, b_sz, 1.0, R_sk, d, R_tall_qr.data(), b_sz_const);
+            lacpy('U', block_rank, b_sz, R_tall_qr.data(), b_sz_const, A_work, lda);
+        } else {                                                                               // geqrf :513-517
+            geqrf(rows, b_sz, A_work, lda, tau_sub);
+        }
+        const bool use_gemqrt = (apply_trans_q == 1) && (qr_tall == 0 || qr_tall == 1);       // :535-547
+        const int64_t q_rows = (block_rank != b_sz_const) ? block_rank : rows;
+        if (cols - b_sz > 0) {
+            if (use_gemqrt) gemqrt_lt(q_rows, cols - b_sz, block_rank, internal_nb, A_work, lda, T_dat.data(), b_sz_const, Work1, lda);
+            else ormqr_lt(q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda);
+        }
+        double* R12 = R11 + lda * b_sz;
+        curr_sz += b_sz;
+        if (curr_sz >= mn || block_rank != b_sz_const) { *rank_out = curr_sz; return 0; }      // :576-618
+        A_work = Work1 + b_sz;                                                                 // :624
+        get_U(b_sz, b_sz, R_sk, d);                                                            // :633
+        trsm_right_upper(b_sz, b_sz, 1.0, R11, lda, R_sk, d);                                  // :634
+        gemm('N', 'N', b_sz, cols - b_sz, b_sz, -1.0, R_sk, d, R12, lda, 1.0, R_sk + d * b_sz, d);   // :638
+        sampling_dimension = std::min(sampling_dimension, cols);                               // :641
+        if (sampling_dimension - b_sz > 0)                                                     // :645-646
+            get_U(sampling_dimension - b_sz, sampling_dimension - b_sz, R_sk + (d + 1) * b_sz, d);
+        A_sk = A_sk + d * b_sz;                                                                // :651
+        rows -= b_sz;
+        cols -= b_sz;
+    }
+    return 0;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -586,6 +719,24 @@ int oracle_cqrrpt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, i
     trmm_right_upper(new_rank, n, 1.0, A_hat, d, R, ldr);                                     // :345
     return 0;
 }
+
+// BQRRP::call (drivers/rl_bqrrp.hh:155).  A (m x n, lda) -> GEQP3-format output, tau (min(m,n)), J (n).
+int oracle_bqrrp_f64(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz, int64_t internal_nb,
+                     double tol, int qrcp_wide, int qr_tall, int apply_trans_q, double* tau, int64_t* J, uint32_t state[6],
+                     const double* A_sk_in, int64_t* rank_out) {
+    RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+    int rc = bqrrp_call(m, n, A, lda, d_factor, b_sz, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, tau, J, st, A_sk_in,
+                        rank_out);
+    std::memcpy(state, st.ctr, 16);
+    return rc;
+}
+// ungqr on a GEQP3-format result (what the reference's tests do to verify, test/drivers/test_bqrrp.cc:138)
+int oracle_ungqr_f64(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau) { return orgqr(m, n, k, A, lda, tau); }
+int oracle_orhr_col_f64(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt, double* D) {
+    return orhr_col(m, n, nb, A, lda, T, ldt, D);
+}
+int oracle_getrf_f64(int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv) { return getrf(m, n, A, lda, ipiv); }
+int oracle_geqrf_f64(int64_t m, int64_t n, double* A, int64_t lda, double* tau) { return geqrf(m, n, A, lda, tau); }
 
 // plain LAPACK entry points used by tests as independent references for single kernels
 int oracle_gesdd_f64(char jobz, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,

@@ -38,6 +38,13 @@ def _blas3(T):
         "col_swap": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "geqp3": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
         "get_diag": [c_vp, c_i64, c_vp, c_i64, C.POINTER(T)],
+        "orhr_col": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+        "gemqrt": [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64],
+        "larft": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64],
+        "row_sign": [c_vp, c_i64, c_vp, c_i64, c_vp],
+        "tau_from_t": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "any_abs_gt": [c_vp, c_i64, c_vp, T, C.POINTER(c_int)],
+        "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "add_diag": [c_vp, c_i64, T, c_vp, c_i64],
         "gesdd": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_int)],
         "transpose": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
@@ -73,6 +80,7 @@ SIGNATURES = {
     "rlhip_saso_create": (c_int, [c_vp, c_i64, c_i64, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
     "rlhip_saso_destroy": (c_int, [c_vp, c_vp]),
     "rlhip_col_swap_i64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "rlhip_luqrcp_piv": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }
@@ -98,6 +106,8 @@ SIGNATURES.update({
                                  c_int, c_int, dpp, dpp, u32p]),
     "rlhip_drv_cqrrpt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_i64, c_dbl, u32p, c_vp,
                                      c_vp, C.POINTER(c_i64), C.POINTER(C.c_long)]),
+    "rlhip_drv_bqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_dbl, c_i64, c_i64, c_dbl, c_vp, c_vp, u32p, c_vp, c_vp,
+                                    C.POINTER(c_i64), C.POINTER(C.c_long)]),
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })

@@ -15,44 +15,75 @@ template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, 
 template <typename T> int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx);
 int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev);
 template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
+template <typename T> int orhr_col(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);
+template <typename T> int gemqrt_lt(rlhip_ctx*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
+template <typename T> int larft_gram(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);
+template <typename T> int row_sign(rlhip_ctx*, int64_t, T*, int64_t, const T*);
+template <typename T> int tau_from_t(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, T*);
+template <typename T> int any_abs_gt(rlhip_ctx*, int64_t, const T*, T, int*);
+template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*);
+int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]);
 }
 
 // ------------------------------------------------------------------ scratch arena
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
-    bytes = align_up(bytes ? bytes : 1, 256);
-    if (c->ws_off + bytes <= c->ws_bytes) {
-        void* p = c->ws + c->ws_off;
-        c->ws_off += bytes;
-        if (c->ws_off > c->ws_highwater) c->ws_highwater = c->ws_off;
-        return p;
-    }
-    // arena exhausted: serve from a dedicated allocation now, grow the arena at release time
-    if (c->n_overflow >= 64) return nullptr;
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    c->overflow[c->n_overflow++] = p;
-    c->ws_off += bytes;  // virtual accounting so the high-water mark reflects the true need
-    if (c->ws_off > c->ws_highwater) c->ws_highwater = c->ws_off;
-    return p;
+static size_t seg_vstart(const rlhip_ctx* c, int k) {
+    size_t v = 0;
+    for (int i = 0; i < k; ++i) v += c->segs[i].size;
+    return v;
 }
 
-size_t rlhip_ws_mark(rlhip_ctx* c) { return c->ws_off; }
+void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    for (;;) {
+        if (c->cur_seg < c->nsegs && c->cur_used + bytes <= c->segs[c->cur_seg].size) {
+            void* p = c->segs[c->cur_seg].base + c->cur_used;
+            c->cur_used += bytes;
+            size_t v = seg_vstart(c, c->cur_seg) + c->cur_used;
+            if (v > c->ws_highwater) c->ws_highwater = v;
+            return p;
+        }
+        if (c->cur_seg + 1 < c->nsegs) { ++c->cur_seg; c->cur_used = 0; continue; }   // reuse a later segment
+        if (c->nsegs >= 32) return nullptr;
+        size_t total = seg_vstart(c, c->nsegs);
+        size_t want = bytes > total ? bytes : total;          // at least double the arena
+        if (want < ((size_t)256 << 20)) want = (size_t)256 << 20;
+        want = align_up(want, 1 << 20);
+        char* p = nullptr;
+        if (hipMalloc((void**)&p, want) != hipSuccess) {
+            want = align_up(bytes, 1 << 20);                   // memory is tight: take exactly what is needed
+            if (hipMalloc((void**)&p, want) != hipSuccess) return nullptr;
+        }
+        c->segs[c->nsegs].base = p;
+        c->segs[c->nsegs].size = want;
+        c->cur_seg = c->nsegs++;
+        c->cur_used = 0;
+    }
+}
+
+size_t rlhip_ws_mark(rlhip_ctx* c) { return c->nsegs ? seg_vstart(c, c->cur_seg) + c->cur_used : 0; }
 
 void rlhip_ws_release(rlhip_ctx* c, size_t mark) {
-    c->ws_off = mark;
-    if (mark == 0 && c->n_overflow > 0) {
-        // all scratch users are done: drop the overflow blocks and regrow the arena to the high-water mark
+    // find the segment holding `mark`
+    size_t v = 0;
+    int k = 0;
+    for (; k < c->nsegs; ++k) {
+        if (mark <= v + c->segs[k].size) break;
+        v += c->segs[k].size;
+    }
+    if (k >= c->nsegs) k = c->nsegs ? c->nsegs - 1 : 0;
+    c->cur_seg = k;
+    c->cur_used = (c->nsegs && mark >= v) ? (mark - v) : 0;
+    if (mark == 0 && c->nsegs > 1) {
+        // stack empty: merge the segments into one arena of the high-water size
         hipStreamSynchronize(c->stream);
-        for (int i = 0; i < c->n_overflow; ++i) hipFree(c->overflow[i]);
-        c->n_overflow = 0;
-        if (c->ws) hipFree(c->ws);
-        c->ws = nullptr;
-        c->ws_bytes = 0;
+        for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
+        c->nsegs = 0; c->cur_seg = 0; c->cur_used = 0;
         size_t want = align_up(c->ws_highwater + (c->ws_highwater >> 3), 1 << 20);
-        if (hipMalloc((void**)&c->ws, want) == hipSuccess) c->ws_bytes = want;
+        char* p = nullptr;
+        if (hipMalloc((void**)&p, want) == hipSuccess) { c->segs[0].base = p; c->segs[0].size = want; c->nsegs = 1; }
     }
 }
 
@@ -90,8 +121,11 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
     RLHIP_CHECK(hipMalloc((void**)&c->d_mail, 64 * sizeof(int64_t)));
     RLHIP_CHECK(hipEventCreate(&c->ev0));
     RLHIP_CHECK(hipEventCreate(&c->ev1));
-    c->ws_bytes = (size_t)64 << 20;
-    RLHIP_CHECK(hipMalloc((void**)&c->ws, c->ws_bytes));
+    {
+        char* p = nullptr;
+        RLHIP_CHECK(hipMalloc((void**)&p, (size_t)64 << 20));
+        c->segs[0].base = p; c->segs[0].size = (size_t)64 << 20; c->nsegs = 1;
+    }
     *out = c;
     return 0;
 }
@@ -101,8 +135,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     rlhip_comm_destroy(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    for (int i = 0; i < c->n_overflow; ++i) hipFree(c->overflow[i]);
-    if (c->ws) hipFree(c->ws);
+    for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
     if (c->d_mail) hipFree(c->d_mail);
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -145,15 +178,17 @@ int rlhip_memset(rlhip_ctx* c, void* dst, int byte, size_t bytes) {
     return 0;
 }
 int rlhip_reserve_workspace(rlhip_ctx* c, size_t bytes) {
-    if (bytes <= c->ws_bytes) return 0;
-    if (c->ws_off != 0) return -2;  // only legal between top-level calls
+    if (rlhip_ws_mark(c) != 0) return -2;  // only legal between top-level calls
+    size_t total = 0;
+    for (int i = 0; i < c->nsegs; ++i) total += c->segs[i].size;
+    if (c->nsegs == 1 && bytes <= total) return 0;
     RLHIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->ws) RLHIP_CHECK(hipFree(c->ws));
-    c->ws = nullptr;
-    c->ws_bytes = 0;
-    bytes = align_up(bytes, 1 << 20);
-    RLHIP_CHECK(hipMalloc((void**)&c->ws, bytes));
-    c->ws_bytes = bytes;
+    for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
+    c->nsegs = 0; c->cur_seg = 0; c->cur_used = 0;
+    bytes = align_up(bytes > total ? bytes : total, 1 << 20);
+    char* p = nullptr;
+    RLHIP_CHECK(hipMalloc((void**)&p, bytes));
+    c->segs[0].base = p; c->segs[0].size = bytes; c->nsegs = 1;
     return 0;
 }
 size_t rlhip_workspace_highwater(rlhip_ctx* c) { return c->ws_highwater; }
@@ -195,6 +230,10 @@ int rlhip_saso_create(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_
 int rlhip_saso_destroy(rlhip_ctx* c, rlhip_saso* S) { return rlhip::saso_destroy(c, (rlhip::SasoOp*)S); }
 int rlhip_col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx) {
     return rlhip::col_swap_i64(c, n, k, A, idx);
+}
+
+int rlhip_luqrcp_piv(rlhip_ctx* c, int64_t sd, int64_t cols, const int64_t* ipiv, int64_t* J) {
+    return rlhip::luqrcp_piv(c, sd, cols, ipiv, J);
 }
 
 // ------------------------------------------------------------------ BLAS-3
@@ -272,6 +311,32 @@ static inline int op_flag(char t, int* out) {
                                      hipMemcpyDeviceToHost, c->stream));                                        \
         RLHIP_CHECK(hipStreamSynchronize(c->stream));                                                           \
         return 0;                                                                                               \
+    }                                                                                                           \
+    int rlhip_orhr_col_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* D) { \
+        return rlhip::orhr_col<T>(c, m, n, nb, A, lda, Tm, ldt, D);                                              \
+    }                                                                                                           \
+    int rlhip_gemqrt_##SUF(rlhip_ctx* c, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const T* V, \
+                           int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc) {                          \
+        if (side != 'L' && side != 'l') return -2;                                                              \
+        if (trans != 'T' && trans != 't') return -3;                                                            \
+        return rlhip::gemqrt_lt<T>(c, m, n, k, nb, V, ldv, Tm, ldt, C, ldc);                                     \
+    }                                                                                                           \
+    int rlhip_larft_##SUF(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt) { \
+        return rlhip::larft_gram<T>(c, m, k, V, ldv, tau, Tm, ldt);                                              \
+    }                                                                                                           \
+    int rlhip_row_sign_##SUF(rlhip_ctx* c, int64_t n, T* R, int64_t ldr, const T* D) {                          \
+        return rlhip::row_sign<T>(c, n, R, ldr, D);                                                              \
+    }                                                                                                           \
+    int rlhip_tau_from_t_##SUF(rlhip_ctx* c, int64_t k, int64_t nb, const T* Tm, int64_t ldt, T* tau) {         \
+        return rlhip::tau_from_t<T>(c, k, nb, Tm, ldt, tau);                                                     \
+    }                                                                                                           \
+    int rlhip_any_abs_gt_##SUF(rlhip_ctx* c, int64_t n, const T* x, T thr, int* any_host) {                     \
+        return rlhip::any_abs_gt<T>(c, n, x, thr, any_host);                                                     \
+    }                                                                                                           \
+    int rlhip_getrf_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv) {               \
+        int info = 0;                                                                                           \
+        int rc = rlhip::getrf<T>(c, m, n, A, lda, ipiv, &info);                                                  \
+        return rc ? rc : info;                                                                                  \
     }                                                                                                           \
     int rlhip_add_diag_##SUF(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda) {                             \
         return rlhip::add_diag<T>(c, n, alpha, A, lda);                                                          \

@@ -153,4 +153,24 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
     });
 }
 
+int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,
+                        int64_t internal_nb, double tol, double* tau, int64_t* J, uint32_t state[6],
+                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::BQRRP<double, RNG> alg(q, times_us != nullptr, b_sz);
+        if (internal_nb > 0) alg.internal_nb = internal_nb;
+        if (tol > 0) alg.tol = tol;
+        alg.sketch_override = A_sk_in;
+        alg.sketch_export = A_sk_out;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A, lda, d_factor, tau, J, st);
+        store_state(st, state);
+        if (rank_out) *rank_out = alg.rank;
+        if (times_us && alg.times.size() == 9)
+            for (int i = 0; i < 9; ++i) times_us[i] = alg.times[i];
+        return rc;
+    });
+}
+
 }  // extern "C"

@@ -1,0 +1,310 @@
+// Householder reconstruction and block-reflector application for the BQRRP / HQRRP part of the path.
+//
+//   orhr_col   lapack::orhr_col (drivers/rl_bqrrp.hh:480, rl_hqrrp.hh:537), util::rl_orhr_col (misc/rl_util.hh:339-379),
+//              the reference's CUDA orhr_col_gpu = 3*n launches of BLAS-1/2 kernels (rl_cuda_kernels.cuh:772-803).
+//              Here: LAPACK's dorhr_col organisation -- sign-modified LU without pivoting of the top n x n block
+//              (blocked, NB = 32: one fused "diagonal block + block row" kernel and one MFMA update per step),
+//              ONE wide triangular solve V2 = Q2 * U^-1 for all rows below (MFMA path of tri.hip), and the
+//              T factors as  T = (-U * diag(D)) * V1^-T  per nb-block.
+//   gemqrt_lt  lapack::gemqrt(Side::Left, Op::Trans, ...) (rl_bqrrp.hh:543): C <- Q^T C with the compact-WY
+//              blocks (V, T).  Three dense contractions per block on the MFMA GEMMs:
+//                  W = V^T C ;  W <- T^T W ;  C <- C - V W
+//              V's top nb x nb block is read through a cleaned unit-lower copy, the rest of V in place.
+//   larft_gram T from (V, tau) in LAPACK geqrf format, via  T^-1 = striu(V^T V) + diag(1/tau)  and one triangular
+//              solve -- lets the same block apply serve lapack::ormqr (rl_bqrrp.hh:545).
+#include "rlhip_internal.h"
+
+namespace rlhip {
+template <typename T>
+int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+              const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev = nullptr, int* ssq_done = nullptr);
+}
+
+namespace {
+
+constexpr int LB = 32;
+
+// Sign-modified LU step (dlaorhr_col_getrfnp semantics) on the diagonal block [j0, j0+jb) and its block row:
+//   for i: D(i) = -sign(a_ii) (1 if a_ii == 0); a_ii -= D(i); column below /= a_ii; trailing -= col * row
+// Every workgroup re-factors the jb x jb block in LDS; workgroup 0 writes it back (+ D); every workgroup then
+// computes its slice of U12 = L11^-1 A12 (one column per thread).
+template <typename T>
+__global__ __launch_bounds__(256) void lunp_panel_kernel(int64_t n, int64_t j0, int jb, T* __restrict__ A, int64_t lda,
+                                                         T* __restrict__ D) {
+    __shared__ T sA[LB][LB + 1];
+    __shared__ T sD[LB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < LB * LB; e += 256) {
+        int i = e % LB, j = e / LB;
+        sA[i][j] = (i < jb && j < jb) ? A[(j0 + i) + (j0 + j) * lda] : T(0);
+    }
+    __syncthreads();
+    for (int k = 0; k < jb; ++k) {
+        if (tid == 0) {
+            T a = sA[k][k];
+            T dd = (a == T(0)) ? T(1) : ((a > T(0)) ? T(-1) : T(1));
+            sD[k] = dd;
+            sA[k][k] = a - dd;
+        }
+        __syncthreads();
+        const T piv = sA[k][k];
+        if (tid > k && tid < jb) sA[tid][k] = sA[tid][k] / piv;
+        __syncthreads();
+        for (int e = tid; e < LB * LB; e += 256) {
+            int i = e % LB, j = e / LB;
+            if (i > k && j > k && i < jb && j < jb) sA[i][j] -= sA[i][k] * sA[k][j];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < LB * LB; e += 256) {
+            int i = e % LB, j = e / LB;
+            if (i < jb && j < jb) A[(j0 + i) + (j0 + j) * lda] = sA[i][j];
+        }
+        if (tid < jb) D[j0 + tid] = sD[tid];
+    }
+    // U12: column c of A12, forward substitution with unit-lower L11
+    int64_t c = j0 + jb + (int64_t)blockIdx.x * 256 + tid;
+    if (c < n) {
+        T x[LB];
+        T* col = A + j0 + c * lda;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) x[i] = (i < jb) ? col[i] : T(0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            if (i < jb) {
+                T s = x[i];
+#pragma unroll
+                for (int l = 0; l < LB; ++l)
+                    if (l < i) s -= sA[i][l] * x[l];
+                x[i] = s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            if (i < jb) col[i] = x[i];
+    }
+}
+
+// T(0:i+1, j) = -D(j) * U(jb0 : jb0+i+1, j) for the columns of one nb-block (upper triangle), zero below
+template <typename T>
+__global__ void tfac_init_kernel(int64_t n, int64_t nb, const T* __restrict__ A, int64_t lda, const T* __restrict__ D,
+                                 T* __restrict__ Tm, int64_t ldt) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb * n) return;
+    int64_t i = idx % nb, j = idx / nb;            // T is nb x n
+    int64_t jb0 = (j / nb) * nb;                   // block start
+    int64_t jl = j - jb0;                          // column inside the block
+    T v = 0;
+    if (i <= jl) v = -D[j] * A[(jb0 + i) + j * lda];
+    Tm[i + j * ldt] = v;
+}
+
+// unit-lower-triangular nb x nb block of V -> dense copy with explicit ones / zeros (dst ld = nb)
+template <typename T>
+__global__ void unit_lower_copy_kernel(int64_t nb, const T* __restrict__ V, int64_t ldv, T* __restrict__ out, int transpose) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nb * nb) return;
+    int64_t i = idx % nb, j = idx / nb;
+    T v = (i > j) ? V[i + j * ldv] : ((i == j) ? T(1) : T(0));
+    if (transpose) out[j + i * nb] = v; else out[i + j * nb] = v;
+}
+
+// R(j, i) *= D(j) for j <= i (row scaling of an upper-triangular n x n matrix)   rl_bqrrp.hh:485-487
+template <typename T>
+__global__ void row_sign_kernel(int64_t n, T* __restrict__ R, int64_t ldr, const T* __restrict__ D) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t j = idx % n, i = idx / n;
+    if (j <= i) R[j + i * ldr] *= D[j];
+}
+
+// tau(i) = T(i % nb, i)                                                            rl_bqrrp.hh:490-491
+template <typename T>
+__global__ void tau_from_t_kernel(int64_t k, int64_t nb, const T* __restrict__ Tm, int64_t ldt, T* __restrict__ tau) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) tau[i] = Tm[(i % nb) + i * ldt];
+}
+
+// M = striu(G) + diag(1/tau); tau == 0 (H = I) -> a huge diagonal so that the column of T vanishes
+template <typename T>
+__global__ void larft_m_kernel(int64_t k, T* __restrict__ G, int64_t ldg, const T* __restrict__ tau) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k * k) return;
+    int64_t i = idx % k, j = idx / k;
+    T v = G[i + j * ldg];
+    if (i > j) v = 0;
+    else if (i == j) v = (tau[i] != T(0)) ? T(1) / tau[i] : T(1e300);
+    G[i + j * ldg] = v;
+}
+
+// flag |= any(|x[i]| > thr), i < n                                                  rl_bqrrp.hh:373-379
+template <typename T>
+__global__ void any_abs_gt_kernel(int64_t n, const T* __restrict__ x, T thr, int* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = (i < n) && (fabs(x[i]) > thr);
+    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ void zero_int2(int* p) { *p = 0; }
+
+}  // namespace
+
+namespace rlhip {
+
+template <typename T> int laset(rlhip_ctx*, int, int64_t, int64_t, T, T, T*, int64_t);
+template <typename T> int lacpy(rlhip_ctx*, int, int64_t, int64_t, const T*, int64_t, T*, int64_t);
+template <typename T> int trsm_right_upper(rlhip_ctx*, int, int64_t, int64_t, T, const T*, int64_t, T*, int64_t);
+template <typename T> int gemm(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T, T*, int64_t);
+
+// A (m x n, orthonormal columns) -> V (unit lower trapezoidal, in place), T (nb x n), D (n)
+template <typename T>
+int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* D) {
+    if (m < 0) return -2;
+    if (n < 0 || n > m) return -3;
+    if (nb < 1) return -4;
+    if (lda < (m > 1 ? m : 1)) return -6;
+    if (nb > n) nb = n;
+    if (ldt < (nb > 1 ? nb : 1)) return -8;
+    if (n == 0) return 0;
+    // (1) sign-modified LU of the top n x n block
+    for (int64_t j0 = 0; j0 < n; j0 += LB) {
+        const int jb = (int)((n - j0 < LB) ? (n - j0) : LB);
+        const int64_t rest = n - j0 - jb;
+        unsigned blocks = (unsigned)((rest + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(lunp_panel_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, j0, jb, A, lda, D);
+        RLHIP_LAUNCH_CHECK();
+        if (rest > 0) {
+            // L21 = A21 * U11^-1 (rows j0+jb .. n-1)
+            int rc = trsm_right_upper<T>(c, 0, rest, jb, T(1), A + j0 + j0 * lda, lda, A + (j0 + jb) + j0 * lda, lda);
+            if (rc) return rc;
+            // A22 -= L21 * U12
+            rc = gemm<T>(c, 0, 0, rest, rest, jb, T(-1), A + (j0 + jb) + j0 * lda, lda, A + j0 + (j0 + jb) * lda, lda, T(1),
+                         A + (j0 + jb) + (j0 + jb) * lda, lda);
+            if (rc) return rc;
+        }
+    }
+    // (2) V2 = Q2 * U^-1 for the rows below the top block
+    if (m > n) {
+        int rc = trsm_right_upper<T>(c, 0, m - n, n, T(1), A, lda, A + n, lda);
+        if (rc) return rc;
+    }
+    // (3) T = (-U diag(D)) V1^-T, block by block
+    hipLaunchKernelGGL(tfac_init_kernel<T>, dim3((unsigned)((nb * n + 255) / 256)), dim3(256), 0, c->stream, n, nb, A, lda, D,
+                       Tm, ldt);
+    RLHIP_LAUNCH_CHECK();
+    size_t mark = rlhip_ws_mark(c);
+    T* Lt = ws_alloc<T>(c, (size_t)nb * nb);
+    if (!Lt) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    for (int64_t jb0 = 0; jb0 < n; jb0 += nb) {
+        const int64_t jnb = (n - jb0 < nb) ? (n - jb0) : nb;
+        hipLaunchKernelGGL(unit_lower_copy_kernel<T>, dim3((unsigned)((jnb * jnb + 255) / 256)), dim3(256), 0, c->stream, jnb,
+                           A + jb0 + jb0 * lda, lda, Lt, 1);   // Lt = V1^T (unit upper)
+        RLHIP_LAUNCH_CHECK();
+        int rc = trsm_right_upper<T>(c, 1, jnb, jnb, T(1), Lt, jnb, Tm + jb0 * ldt, ldt);
+        if (rc) { rlhip_ws_release(c, mark); return rc; }
+    }
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+// C (m x n) <- Q^T C,  Q = H_1 ... H_k in compact-WY blocks of width nb: V (m x k, unit lower trapezoidal, only the
+// strictly lower part is read), T (nb x k).  Side::Left, Op::Trans.
+template <typename T>
+int gemqrt_lt(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, int64_t nb, const T* V, int64_t ldv, const T* Tm, int64_t ldt,
+              T* C, int64_t ldc) {
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0 || k > m) return -5;
+    if (nb < 1) return -6;
+    if (k == 0 || n == 0 || m == 0) return 0;
+    if (nb > k) nb = k;
+    size_t mark = rlhip_ws_mark(c);
+    T* V1 = ws_alloc<T>(c, (size_t)nb * nb);
+    T* W = ws_alloc<T>(c, (size_t)nb * n);
+    T* W2 = ws_alloc<T>(c, (size_t)nb * n);
+    if (!V1 || !W || !W2) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    int rc = 0;
+    for (int64_t i = 0; i < k && !rc; i += nb) {
+        const int64_t ib = (k - i < nb) ? (k - i) : nb;
+        const int64_t mr = m - i - ib;                      // rows below the block's triangle
+        const T* Vi = V + i + i * ldv;
+        T* Ci = C + i;
+        hipLaunchKernelGGL(unit_lower_copy_kernel<T>, dim3((unsigned)((ib * ib + 255) / 256)), dim3(256), 0, c->stream, ib, Vi, ldv,
+                           V1, 0);
+        RLHIP_LAUNCH_CHECK();
+        // W = V1^T C1 + V2^T C2
+        rc = gemm<T>(c, 1, 0, ib, n, ib, T(1), V1, ib, Ci, ldc, T(0), W, ib);
+        if (!rc && mr > 0) rc = gemm<T>(c, 1, 0, ib, n, mr, T(1), Vi + ib, ldv, Ci + ib, ldc, T(1), W, ib);
+        // W2 = T_i^T W   (T_i upper triangular, strictly lower part is zero)
+        if (!rc) rc = gemm<T>(c, 1, 0, ib, n, ib, T(1), Tm + i * ldt, ldt, W, ib, T(0), W2, ib);
+        // C1 -= V1 W2 ; C2 -= V2 W2
+        if (!rc) rc = gemm<T>(c, 0, 0, ib, n, ib, T(-1), V1, ib, W2, ib, T(1), Ci, ldc);
+        if (!rc && mr > 0) rc = gemm<T>(c, 0, 0, mr, n, ib, T(-1), Vi + ib, ldv, W2, ib, T(1), Ci + ib, ldc);
+    }
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+// T (k x k upper, ldt) from V (m x k unit lower trapezoidal) and tau (k): one compact-WY block for all k reflectors
+template <typename T>
+int larft_gram(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt) {
+    if (k <= 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* V1 = ws_alloc<T>(c, (size_t)k * k);
+    T* G = ws_alloc<T>(c, (size_t)k * k);
+    if (!V1 || !G) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipLaunchKernelGGL(unit_lower_copy_kernel<T>, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, c->stream, k, V, ldv, V1, 0);
+    RLHIP_LAUNCH_CHECK();
+    int rc = gemm<T>(c, 1, 0, k, k, k, T(1), V1, k, V1, k, T(0), G, k);
+    if (!rc && m > k) rc = gemm<T>(c, 1, 0, k, k, m - k, T(1), V + k, ldv, V + k, ldv, T(1), G, k);
+    if (rc) { rlhip_ws_release(c, mark); return rc; }
+    hipLaunchKernelGGL(larft_m_kernel<T>, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, c->stream, k, G, k, tau);
+    RLHIP_LAUNCH_CHECK();
+    rc = laset<T>(c, 2, k, k, T(0), T(1), Tm, ldt);                       // T = I * M^-1
+    if (!rc) rc = trsm_right_upper<T>(c, 0, k, k, T(1), G, k, Tm, ldt);
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+template <typename T>
+int row_sign(rlhip_ctx* c, int64_t n, T* R, int64_t ldr, const T* D) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(row_sign_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, R, ldr, D);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template <typename T>
+int tau_from_t(rlhip_ctx* c, int64_t k, int64_t nb, const T* Tm, int64_t ldt, T* tau) {
+    if (k <= 0) return 0;
+    hipLaunchKernelGGL(tau_from_t_kernel<T>, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, k, nb, Tm, ldt, tau);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+// returns 1 in *any_host if some |x[i]| > thr
+template <typename T>
+int any_abs_gt(rlhip_ctx* c, int64_t n, const T* x, T thr, int* any_host) {
+    *any_host = 0;
+    if (n <= 0) return 0;
+    int* d_flag = (int*)(c->d_mail + 48);
+    hipLaunchKernelGGL(zero_int2, dim3(1), dim3(1), 0, c->stream, d_flag);
+    hipLaunchKernelGGL(any_abs_gt_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, x, thr, d_flag);
+    RLHIP_LAUNCH_CHECK();
+    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 48, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    *any_host = *(int*)(c->h_mail + 48);
+    return 0;
+}
+
+#define INST(T)                                                                                                          \
+    template int orhr_col<T>(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);                       \
+    template int gemqrt_lt<T>(rlhip_ctx*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t); \
+    template int larft_gram<T>(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);                  \
+    template int row_sign<T>(rlhip_ctx*, int64_t, T*, int64_t, const T*);                                                \
+    template int tau_from_t<T>(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, T*);                                     \
+    template int any_abs_gt<T>(rlhip_ctx*, int64_t, const T*, T, int*);
+INST(double)
+INST(float)
+
+}  // namespace rlhip

@@ -1,0 +1,300 @@
+// Row-pivoted LU (lapack::getrf) of a tall-skinny matrix on the device, and the pivot post-processing of BQRRP's
+// LU-based qrcp_wide (RandLAPACK/drivers/rl_bqrrp.hh:341-352; rl_bqrrp_gpu.hh:359-364; PLUL rl_orth.hh:212-230).
+//
+// Partial pivoting is inherently one decision per column, and the decision must equal LAPACK's (first maximum of
+// |a(j:m, j)|) for the pivot order to be bit-identical given the same sketch.  Organisation:
+//   * blocked right-looking, panel width 32: the trailing update and the U12 solve are MFMA / thread-per-column work;
+//   * the panel itself is ONE persistent launch: the rows below the diagonal are dealt out to the workgroups and the
+//     workgroup's piece of the 32-column panel lives in LDS for the whole panel; per column there is a single grid
+//     rendezvous -- before it each workgroup publishes its best local candidate TOGETHER WITH that row's 32 values
+//     (and the owner of the diagonal row publishes that row), after it everybody knows the winner, the two owners
+//     exchange rows inside their LDS pieces and every workgroup eliminates its own rows.  Published data are 8-byte
+//     write-through stores read after one L1 invalidate (no release fences), double-buffered by column parity.
+//   * dlaswp on the columns outside the panel is a thread-per-column kernel walking the 32 swaps in order.
+#include "rlhip_internal.h"
+
+namespace rlhip {
+template <typename T>
+int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+              const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev = nullptr, int* ssq_done = nullptr);
+}
+
+namespace {
+
+constexpr int PB = 32;
+
+template <typename T>
+struct LuArgs {
+    int64_t m, n;             // full matrix
+    T* A; int64_t lda;
+    int64_t j0; int pb;       // panel [j0, j0+pb)
+    int64_t* ipiv;            // 1-based, device
+    T* cand_val; int64_t* cand_row;   // 2 x G
+    T* cand_data;             // 2 x G x PB  : candidate row contents
+    T* diag_data;             // 2 x PB      : contents of the current diagonal row
+    unsigned* bar;
+    int* info;                // first zero pivot (1-based), 0 if none
+    int64_t rpw;              // rows per workgroup
+};
+
+template <typename T>
+__device__ __forceinline__ void pstore(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void lu_barrier(unsigned* bar, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
+    T* P = reinterpret_cast<T*>(lu_smem);                 // [pb][rpw] : local rows of the panel, column-major
+    __shared__ T s_val[256];
+    __shared__ int64_t s_row[256];
+    __shared__ int s_w[256];
+    const int tid = threadIdx.x;
+    const int64_t G = gridDim.x, me = blockIdx.x;
+    const int pb = g.pb;
+    const int64_t j0 = g.j0, rpw = g.rpw;
+    const int64_t lo = j0 + me * rpw;                      // first global row of this workgroup
+    int64_t hi = lo + rpw; if (hi > g.m) hi = g.m;
+    const int64_t nloc = hi > lo ? hi - lo : 0;
+    // stage
+    for (int64_t e = tid; e < (int64_t)pb * rpw; e += 256) {
+        const int64_t r = e % rpw; const int c = (int)(e / rpw);
+        P[c * rpw + r] = (r < nloc) ? g.A[(lo + r) + (j0 + c) * g.lda] : T(0);
+    }
+    __syncthreads();
+    unsigned epoch = 0;
+    for (int c = 0; c < pb; ++c) {
+        const int64_t j = j0 + c;                          // global diagonal row / column
+        const int par = c & 1;
+        // ---- local candidate: first maximum of |P[c][r]| over owned rows >= j
+        T bv = T(-1); int64_t br = g.m;
+        for (int64_t r = tid; r < nloc; r += 256) {
+            const int64_t gr = lo + r;
+            if (gr < j) continue;
+            T v = fabs(P[c * rpw + r]);
+            if (v > bv) { bv = v; br = gr; }               // increasing rows per thread: strict > keeps the first
+        }
+        s_val[tid] = bv; s_row[tid] = br;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                T v2 = s_val[tid + st]; int64_t r2 = s_row[tid + st];
+                if (r2 < g.m && (v2 > s_val[tid] || (v2 == s_val[tid] && r2 < s_row[tid]))) { s_val[tid] = v2; s_row[tid] = r2; }
+            }
+            __syncthreads();
+        }
+        const T lbest = s_val[0]; const int64_t lrow = s_row[0];
+        if (tid == 0) {
+            pstore(g.cand_val + par * G + me, lbest);
+            __hip_atomic_store(g.cand_row + par * G + me, lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lrow < g.m && tid < pb) pstore(g.cand_data + ((int64_t)par * G + me) * PB + tid, P[tid * rpw + (lrow - lo)]);
+        if (j >= lo && j < hi && tid < pb) pstore(g.diag_data + par * PB + tid, P[tid * rpw + (j - lo)]);
+        __syncthreads();
+        lu_barrier(g.bar, (unsigned)(G * (++epoch)));
+        // ---- winner (every workgroup, redundantly): max |value|, ties -> smallest row
+        {
+            T v = T(-1); int64_t r = g.m; int w = 0;
+            for (int64_t ww = tid; ww < G; ww += 256) {
+                T v2 = g.cand_val[par * G + ww]; int64_t r2 = g.cand_row[par * G + ww];
+                if (r2 < g.m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = (int)ww; }
+            }
+            s_val[tid] = v; s_row[tid] = r; s_w[tid] = w;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (tid < st) {
+                    T v2 = s_val[tid + st]; int64_t r2 = s_row[tid + st];
+                    if (r2 < g.m && (v2 > s_val[tid] || (v2 == s_val[tid] && r2 < s_row[tid]))) {
+                        s_val[tid] = v2; s_row[tid] = r2; s_w[tid] = s_w[tid + st];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        int64_t p = s_row[0]; const int wstar = s_w[0];
+        if (p >= g.m) p = j;                                 // empty / NaN column: no exchange
+        const T* prow = g.cand_data + ((int64_t)par * G + wstar) * PB;   // contents of row p (becomes row j)
+        const T* drow = g.diag_data + par * PB;                          // contents of row j (moves to row p)
+        __syncthreads();
+        if (me == 0 && tid == 0) g.ipiv[j] = p + 1;
+        // ---- exchange rows j <-> p inside the LDS pieces
+        if (p != j) {
+            if (j >= lo && j < hi && tid < pb) P[tid * rpw + (j - lo)] = prow[tid];
+            if (p >= lo && p < hi && tid < pb) P[tid * rpw + (p - lo)] = drow[tid];
+        }
+        __syncthreads();
+        const T piv = (p != j) ? prow[c] : ((j >= lo && j < hi) ? P[c * rpw + (j - lo)] : drow[c]);
+        if (piv == T(0)) {
+            if (me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
+        } else {
+            // ---- eliminate: own rows r > j
+            const T rp = T(1) / piv;
+            T u[PB];
+#pragma unroll
+            for (int c2 = 0; c2 < PB; ++c2) u[c2] = (c2 > c && c2 < pb) ? ((p != j) ? prow[c2] : drow[c2]) : T(0);
+            for (int64_t r = tid; r < nloc; r += 256) {
+                if (lo + r <= j) continue;
+                const T l = P[c * rpw + r] * rp;
+                P[c * rpw + r] = l;
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2)
+                    if (c2 > c && c2 < pb) P[c2 * rpw + r] -= l * u[c2];
+            }
+        }
+        __syncthreads();
+    }
+    for (int64_t e = tid; e < (int64_t)pb * rpw; e += 256) {
+        const int64_t r = e % rpw; const int c = (int)(e / rpw);
+        if (r < nloc) g.A[(lo + r) + (j0 + c) * g.lda] = P[c * rpw + r];
+    }
+}
+
+// dlaswp on column range [c_lo, c_hi): for j in [j0, j0+pb): swap rows j and ipiv[j]-1; one thread per column
+template <typename T>
+__global__ void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* __restrict__ A, int64_t lda,
+                             const int64_t* __restrict__ ipiv) {
+    int64_t c = c_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c_hi) return;
+    T* col = A + c * lda;
+    for (int q = 0; q < pb; ++q) {
+        const int64_t j = j0 + q, p = ipiv[j] - 1;
+        if (p != j) { T t = col[j]; col[j] = col[p]; col[p] = t; }
+    }
+}
+
+// U12 = L11^-1 A12 (unit lower, jb x jb at A[j0,j0]); one column per thread
+template <typename T>
+__global__ __launch_bounds__(256) void unit_lower_solve_kernel(int64_t n, int64_t j0, int jb, T* __restrict__ A, int64_t lda) {
+    __shared__ T sL[PB][PB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < PB * PB; e += 256) {
+        int i = e % PB, j = e / PB;
+        sL[i][j] = (i < jb && j < jb && i > j) ? A[(j0 + i) + (j0 + j) * lda] : T(0);
+    }
+    __syncthreads();
+    int64_t c = j0 + jb + (int64_t)blockIdx.x * 256 + tid;
+    if (c >= n) return;
+    T x[PB];
+    T* col = A + j0 + c * lda;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) x[i] = (i < jb) ? col[i] : T(0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        if (i < jb) {
+            T s = x[i];
+#pragma unroll
+            for (int l = 0; l < PB; ++l)
+                if (l < i) s -= sL[i][l] * x[l];
+            x[i] = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+        if (i < jb) col[i] = x[i];
+}
+
+// BQRRP's conversion of LU row pivots into a QRCP permutation (rl_bqrrp.hh:345-350; LUQRCP_piv_process_gpu_global,
+// rl_cuda_kernels.cuh:203-220): J = iota(1..cols); for i < min(sd, cols): swap(J[ipiv[i]-1], J[i]).  Serial, integer-exact.
+__global__ void luqrcp_piv_kernel(int64_t sd, int64_t cols, const int64_t* __restrict__ ipiv, int64_t* __restrict__ J) {
+    for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) J[i] = i + 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t lim = sd < cols ? sd : cols;
+        for (int64_t i = 0; i < lim; ++i) {
+            const int64_t a = ipiv[i] - 1;
+            const int64_t t = J[a]; J[a] = J[i]; J[i] = t;
+        }
+    }
+}
+
+__global__ void lu_zero_kernel(unsigned* bar, int* info, int zero_info) { *bar = 0; if (zero_info) *info = 0; }
+
+}  // namespace
+
+namespace rlhip {
+
+template <typename T>
+int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_dev, int* info_host) {
+    if (info_host) *info_host = 0;
+    if (m < 0) return -2;
+    if (n < 0) return -3;
+    if (lda < (m > 1 ? m : 1)) return -5;
+    const int64_t mn = m < n ? m : n;
+    if (mn == 0) return 0;
+    static int num_cu = 0;
+    if (!num_cu) {
+        hipDeviceProp_t prop;
+        num_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
+        if (num_cu <= 0) num_cu = 256;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)getrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    size_t mark = rlhip_ws_mark(c);
+    const int64_t Gmax = num_cu;
+    LuArgs<T> g;
+    g.m = m; g.n = n; g.A = A; g.lda = lda; g.ipiv = ipiv_dev;
+    g.cand_val = ws_alloc<T>(c, 2 * Gmax); g.cand_row = ws_alloc<int64_t>(c, 2 * Gmax);
+    g.cand_data = ws_alloc<T>(c, (size_t)2 * Gmax * PB); g.diag_data = ws_alloc<T>(c, 2 * PB);
+    g.bar = ws_alloc<unsigned>(c, 4); g.info = (int*)ws_alloc<int>(c, 4);
+    if (!g.cand_val || !g.cand_row || !g.cand_data || !g.diag_data || !g.bar || !g.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    for (int64_t j0 = 0; j0 < mn; j0 += PB) {
+        const int pb = (int)((mn - j0 < PB) ? (mn - j0) : PB);
+        const int64_t rows = m - j0;
+        // rows per workgroup: at least 64, LDS piece pb*rpw*sizeof(T) <= 96 KiB
+        int64_t rpw = (rows + Gmax - 1) / Gmax;
+        if (rpw < 64) rpw = 64;
+        const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
+        if (rpw > rpw_max) { rlhip_ws_release(c, mark); return -2; }   // > num_cu * 384 rows (fp64): not needed on the path
+        const int64_t G = (rows + rpw - 1) / rpw;
+        g.j0 = j0; g.pb = pb; g.rpw = rpw;
+        hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
+        hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
+        RLHIP_LAUNCH_CHECK();
+        // row interchanges outside the panel
+        if (j0 > 0)
+            hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((j0 + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, j0, j0, pb, A, lda, ipiv_dev);
+        const int64_t rest = n - j0 - pb;
+        if (rest > 0) {
+            hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, j0 + pb, n, j0, pb, A, lda, ipiv_dev);
+            hipLaunchKernelGGL(unit_lower_solve_kernel<T>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, n, j0, pb, A, lda);
+            RLHIP_LAUNCH_CHECK();
+            const int64_t mrest = m - j0 - pb;
+            if (mrest > 0) {
+                int rc = gemm_impl<T>(c, 0, 0, mrest, rest, pb, T(-1), A + (j0 + pb) + j0 * lda, lda, A + j0 + (j0 + pb) * lda, lda, T(1),
+                                      A + (j0 + pb) + (j0 + pb) * lda, lda, 0);
+                if (rc) { rlhip_ws_release(c, mark); return rc; }
+            }
+        }
+    }
+    if (info_host) {
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, g.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        *info_host = *(int*)(c->h_mail + 56);
+    }
+    rlhip_ws_release(c, mark);
+    return 0;
+}
+
+int luqrcp_piv(rlhip_ctx* c, int64_t sd, int64_t cols, const int64_t* ipiv_dev, int64_t* J_dev) {
+    if (cols <= 0) return 0;
+    hipLaunchKernelGGL(luqrcp_piv_kernel, dim3(1), dim3(256), 0, c->stream, sd, cols, ipiv_dev, J_dev);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template int getrf<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, int64_t*, int*);
+template int getrf<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, int64_t*, int*);
+
+}  // namespace rlhip

@@ -26,14 +26,16 @@ struct rlhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    // scratch arena (bump allocator, reset per top-level call via ws_mark/ws_release)
-    char* ws = nullptr;
-    size_t ws_bytes = 0;
-    size_t ws_off = 0;
-    // overflow blocks allocated when the arena is too small (freed + arena regrown at release)
-    void* overflow[64];
-    int n_overflow = 0;
-    size_t ws_highwater = 0;
+    // scratch arena: stack-disciplined bump allocator over a short list of device segments.  Marks are virtual
+    // offsets (segment k starts where segment k-1's full size ends); when a request does not fit, a new, larger
+    // segment is appended (hipMalloc once); when the stack returns to empty the segments are merged into one so
+    // that steady-state calls never allocate.
+    struct Seg { char* base; size_t size; };
+    Seg segs[32];
+    int nsegs = 0;
+    int cur_seg = 0;          // segment currently bumped
+    size_t cur_used = 0;      // bytes used inside segs[cur_seg]
+    size_t ws_highwater = 0;  // largest virtual offset ever reached
     // pinned mailbox
     int64_t* h_mail = nullptr;   // 64 x int64 host-pinned
     int64_t* d_mail = nullptr;   // 64 x int64 device

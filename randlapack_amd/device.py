@@ -291,3 +291,28 @@ def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0,
     if timing:
         out["times_us"] = [int(t) for t in times]
     return out
+
+
+def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
+              want_sketch=False, timing=False):
+    """BQRRP::call ({geqp3, cholqr, gemqrt}).  A (column-major tensor (n, m)) is overwritten in GEQP3 format.
+    Returns dict(rc, rank, tau, J, next_ctr[, sketch][, times_us])."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    d = int(d_factor * b_sz)
+    tau = torch.zeros(min(m, n), dtype=torch.float64, device=dev)
+    J = torch.zeros(n, dtype=torch.int64, device=dev)
+    sk_out = cm_empty(d, n, device=dev) if want_sketch else None
+    rank = C.c_int64(0)
+    st = _state_arr(ctr, key)
+    times = (C.c_long * 9)() if timing else None
+    rc = ctx.lib.rlhip_drv_bqrrp_f64(ctx.h, m, n, A.data_ptr(), m, d_factor, b_sz, internal_nb, tol, tau.data_ptr(), J.data_ptr(),
+                                     st, sketch_in.data_ptr() if sketch_in is not None else None,
+                                     sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times)
+    _drv_check(ctx, rc, "bqrrp")
+    out = dict(rc=rc, rank=int(rank.value), tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
+    if want_sketch:
+        out["sketch"] = sk_out
+    if timing:
+        out["times_us"] = [int(t) for t in times]
+    return out
