@@ -2,8 +2,9 @@
 // randomized pivoting, GEQP3-compatible output (R above the diagonal, Householder vectors below, tau, 1-based J).
 //
 // Device status of the sub-routine options (BQRRPSubroutines):
-//   qrcp_wide     geqp3  -> persistent device geqp3 (qrcp.hip)              | luqr  -> not yet (needs device getrf/geqrf)
-//   qr_tall       cholqr -> trsm/syrk/potrf/trsm + orhr_col (house.hip)     | geqrf, geqrt -> not yet
+//   qrcp_wide     geqp3  -> persistent device geqp3 (qrcp.hip)              | luqr  -> device getrf (lu.hip) + wide geqrf
+//   qr_tall       cholqr -> trsm/syrk/potrf/trsm + orhr_col (house.hip)     | geqrf, geqrt -> step-synchronous Householder kernel
+//                                                                              (correct, BLAS-2 bound: cholqr is the fast one)
 //   apply_trans_q gemqrt -> compact-WY block apply on the MFMA GEMMs        | ormqr -> the same apply (tau is the
 //                                                                             diagonal of T, :490-491, so both name one operator)
 // The object therefore DEFAULTS to {geqp3, cholqr, gemqrt}; asking for an option that is not on the device raises
@@ -55,8 +56,6 @@ public:
     /// A (m x n, lda), tau (min(m,n)), J (n, int64): DEVICE buffers.  Returns 0.  `rank` as in the reference (an upper
     /// bound on the numerical rank).  SURVEY.md A.8 is the behavioural spec; line numbers refer to rl_bqrrp.hh.
     int call(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, T* tau, int64_t* J, RandBLAS::RNGState<RNG>& state) override {
-        randlapack_require(qrcp_wide == Subroutines::QRCPWide::geqp3) << "BQRRP on the device: qrcp_wide must be geqp3 (luqr needs getrf/geqrf)";
-        randlapack_require(qr_tall == Subroutines::QRTall::cholqr) << "BQRRP on the device: qr_tall must be cholqr";
         randlapack_require(m >= 0 && n >= 0 && lda >= m) << "bad dimensions";
         const int64_t mn = std::min(m, n);
         if (mn == 0) { rank = 0; return 0; }
@@ -79,6 +78,10 @@ public:
         T* R_tall_qr = ws.alloc<T>(b_sz_const * b_sz_const);
         T* T_dat = ws.alloc<T>(b_sz_const * b_sz_const);
         T* Work2 = ws.alloc<T>(n);
+        const bool lu = (qrcp_wide == Subroutines::QRCPWide::luqr);
+        T* T_ormqr = ws.alloc<T>(b_sz_const * b_sz_const);
+        T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;                                                   // :262-266
+        int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
         T* A_sk = A_sk_base;
 
         auto t0 = stamp();
@@ -100,7 +103,15 @@ public:
             inb = std::min(inb, b_sz);
             block_rank = b_sz;
             auto ta = stamp();
-            lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                           // :336
+            if (!lu) {
+                lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                       // :336
+            } else {                                                                                        // :337-357
+                blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
+                lapack::getrf(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);
+                lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
+                util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
+                lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
+            }
             t_qrcp += us(ta, stamp());
             ta = stamp();
             util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);                             // :369
@@ -116,27 +127,45 @@ public:
             }
             T* tau_sub = &tau[curr_sz];
             T* R11 = A_work;
-            // ---- qr_tall = cholqr (:454-505)
-            blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
-            t_pre += us(ta, stamp());
-            ta = stamp();
-            lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
-            blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
-            lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);   // failure handled "gracefully" as in the reference (:461)
-            blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
-            t_tall += us(ta, stamp());
-            ta = stamp();
-            lapack::orhr_col(rows, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work2, q);               // :480
-            lapack::row_sign(block_rank, R_tall_qr, b_sz_const, Work2, q);                                  // :485-487
-            lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);                             // :490-491
-            blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, block_rank, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // :497
-            lapack::lacpy(MatrixType::Upper, block_rank, b_sz, R_tall_qr, b_sz_const, A_work, lda, q);     // :504
-            t_rec += us(ta, stamp());
+            bool have_T = true;
+            if (qr_tall == Subroutines::QRTall::cholqr) {                                                   // :454-505
+                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
+                t_pre += us(ta, stamp());
+                ta = stamp();
+                lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
+                blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
+                lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);   // failure handled "gracefully" as in the reference (:461)
+                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
+                t_tall += us(ta, stamp());
+                ta = stamp();
+                lapack::orhr_col(rows, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work2, q);           // :480
+                lapack::row_sign(block_rank, R_tall_qr, b_sz_const, Work2, q);                              // :485-487
+                lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);                         // :490-491
+                blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, block_rank, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // :497
+                lapack::lacpy(MatrixType::Upper, block_rank, b_sz, R_tall_qr, b_sz_const, A_work, lda, q); // :504
+                t_rec += us(ta, stamp());
+            } else if (qr_tall == Subroutines::QRTall::geqrt) {                                             // :438-453
+                t_pre += us(ta, stamp());
+                ta = stamp();
+                lapack::geqrt(rows, b_sz, inb, A_work, lda, T_dat, b_sz_const, Work2, q);
+                lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);
+                t_tall += us(ta, stamp());
+            } else {                                                                                        // geqrf :506-523
+                t_pre += us(ta, stamp());
+                ta = stamp();
+                lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
+                have_T = false;
+                t_tall += us(ta, stamp());
+            }
             ta = stamp();
             // ---- apply Q^T to the trailing columns (:535-547)
             const int64_t q_rows = (block_rank != b_sz_const) ? block_rank : rows;
-            if (cols - b_sz > 0 && block_rank > 0)
-                lapack::gemqrt(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work1, lda, q);
+            if (cols - b_sz > 0 && block_rank > 0) {
+                if (apply_trans_q == Subroutines::ApplyTransQ::gemqrt && have_T)                            // :535-547
+                    lapack::gemqrt(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work1, lda, q);
+                else   // ormqr: the same reflectors applied from (V, tau); T_dat is free to hold the k x k block when T is not needed again
+                    lapack::ormqr(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda, T_ormqr, q);
+            }
             t_apply += us(ta, stamp());
             T* R12 = &R11[lda * b_sz];
             curr_sz += b_sz;
@@ -161,6 +190,11 @@ public:
             t_upd += us(ta, stamp());
         }
         return 0;
+    }
+
+    int transpose_call(int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
+        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+        else return rlhip_transpose_f32(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
     }
 
     blas::Queue& q;

@@ -70,6 +70,39 @@ inline void row_sign(int64_t n, double* R, int64_t ldr, double const* D, Queue& 
 inline void row_sign(int64_t n, float* R, int64_t ldr, float const* D, Queue& q) { blas::check(rlhip_row_sign_f32(q.ctx(), n, R, ldr, D), "row_sign"); }
 inline void tau_from_t(int64_t k, int64_t nb, double const* T, int64_t ldt, double* tau, Queue& q) { blas::check(rlhip_tau_from_t_f64(q.ctx(), k, nb, T, ldt, tau), "tau_from_t"); }
 inline void tau_from_t(int64_t k, int64_t nb, float const* T, int64_t ldt, float* tau, Queue& q) { blas::check(rlhip_tau_from_t_f32(q.ctx(), k, nb, T, ldt, tau), "tau_from_t"); }
+// Householder QR / LU building blocks (device tau / ipiv)
+inline int64_t geqrf(int64_t m, int64_t n, double* A, int64_t lda, double* tau, Queue& q) { int rc = rlhip_geqrf_f64(q.ctx(), m, n, A, lda, tau); blas::check(rc, "geqrf"); return rc; }
+inline int64_t geqrf(int64_t m, int64_t n, float* A, int64_t lda, float* tau, Queue& q) { int rc = rlhip_geqrf_f32(q.ctx(), m, n, A, lda, tau); blas::check(rc, "geqrf"); return rc; }
+inline void ungqr(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, double const* tau, Queue& q) { blas::check(rlhip_ungqr_f64(q.ctx(), m, n, k, A, lda, tau), "ungqr"); }
+inline void ungqr(int64_t m, int64_t n, int64_t k, float* A, int64_t lda, float const* tau, Queue& q) { blas::check(rlhip_ungqr_f32(q.ctx(), m, n, k, A, lda, tau), "ungqr"); }
+// returns info (> 0: exactly singular U, factorization still complete)
+inline int64_t getrf(int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_f64(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf"); return rc; }
+inline int64_t getrf(int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_f32(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf"); return rc; }
+inline void laswp(int64_t n, double* A, int64_t lda, int64_t k1, int64_t k2, int64_t const* ipiv, int64_t incx, Queue& q) {
+    if (incx != 1) throw blas::Error("laswp: only incx = 1 is on the path");
+    blas::check(rlhip_laswp_f64(q.ctx(), n, A, lda, k1, k2, ipiv), "laswp");
+}
+inline void laswp(int64_t n, float* A, int64_t lda, int64_t k1, int64_t k2, int64_t const* ipiv, int64_t incx, Queue& q) {
+    if (incx != 1) throw blas::Error("laswp: only incx = 1 is on the path");
+    blas::check(rlhip_laswp_f32(q.ctx(), n, A, lda, k1, k2, ipiv), "laswp");
+}
+// lapack::geqrt(m, n, nb, A, lda, T, ldt): geqrf + one compact-WY T per nb-wide block (T is nb x n); tau is scratch (device, n)
+template <typename T>
+inline void geqrt(int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* tau_scratch, Queue& q) {
+    geqrf(m, n, A, lda, tau_scratch, q);
+    for (int64_t i = 0; i < n; i += nb) {
+        const int64_t ib = std::min(nb, n - i);
+        larft(m - i, ib, A + i + i * lda, lda, tau_scratch + i, Tm + i * ldt, ldt, q);
+    }
+}
+// lapack::ormqr(Side::Left, Op::Trans, m, n, k, V, ldv, tau, C, ldc): one k x k compact-WY block (T_scratch: k*k device)
+template <typename T>
+inline void ormqr(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, T const* V, int64_t ldv, T const* tau, T* C, int64_t ldc, T* T_scratch, Queue& q) {
+    if (k == 0 || n == 0) return;
+    larft(m, k, V, ldv, tau, T_scratch, k, q);
+    gemqrt(s, t, m, n, k, k, V, ldv, T_scratch, k, C, ldc, q);
+}
+inline void luqrcp_piv(int64_t sd, int64_t cols, int64_t const* ipiv, int64_t* J, Queue& q) { blas::check(rlhip_luqrcp_piv(q.ctx(), sd, cols, ipiv, J), "luqrcp_piv"); }
 // Job::SomeVec, tall (m >= n).  Returns info (>0: Jacobi did not converge).
 inline int64_t gesdd(Job job, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,
                      double* VT, int64_t ldvt, Queue& q) {

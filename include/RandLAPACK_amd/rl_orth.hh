@@ -52,4 +52,49 @@ public:
     bool verbose;
 };
 
+/// Householder QR, Q factor only: geqrf -> ungqr.                                         (rl_orth.hh:100-164)
+/// The stabiliser RS/RF fall back on when CholQR's Gram matrix is too ill-conditioned.
+template <typename T>
+class HQRQ : public Stabilization<T> {
+public:
+    HQRQ(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
+        cond_check = c_check;
+        verbose = verb;
+    }
+    int call(int64_t m, int64_t n, T* A) override {
+        randlapack_require(!q.reduce_over_rows()) << "HQRQ is not row-sharded (use CholQRQ across ranks)";
+        blas::Scratch ws(q);
+        T* tau = ws.alloc<T>(n);
+        if (lapack::geqrf(m, n, A, m, tau, q)) return 1;                                                 // :157
+        lapack::ungqr(m, n, n, A, m, tau, q);                                                            // :162
+        return 0;
+    }
+    blas::Queue& q;
+    bool cond_check;
+    bool verbose;
+};
+
+/// Row-pivoted LU stabiliser: A <- L[ipiv, :] (unit lower trapezoidal, rows interchanged).       (rl_orth.hh:166-230)
+/// A singular U is not a failure (U is discarded); returns 0.
+template <typename T>
+class PLUL : public Stabilization<T> {
+public:
+    PLUL(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
+        cond_check = c_check;
+        verbose = verb;
+    }
+    int call(int64_t m, int64_t n, T* A) override {
+        randlapack_require(!q.reduce_over_rows()) << "PLUL is not row-sharded";
+        blas::Scratch ws(q);
+        int64_t* ipiv = ws.alloc<int64_t>(n);
+        lapack::getrf(m, n, A, m, ipiv, q);                                                              // :219
+        lapack::laset(MatrixType::Upper, m, n, T(0), T(1), A, m, q);                                     // util::get_L(m, n, A, 1) :221
+        lapack::laswp(n, A, m, 1, n, ipiv, 1, q);                                                        // :222
+        return 0;
+    }
+    blas::Queue& q;
+    bool cond_check;
+    bool verbose;
+};
+
 }  // namespace RandLAPACK

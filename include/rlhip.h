@@ -176,6 +176,15 @@ int rlhip_get_diag_f32(rlhip_ctx* ctx, int64_t n, const float* A, int64_t lda, f
  * ipiv: DEVICE int64, 1-based, min(m,n) entries.  Returns LAPACK info (first exactly-zero pivot) or 0. */
 int rlhip_getrf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv);
 int rlhip_getrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv);
+/* lapack::geqrf (rl_orth.hh:157, rl_bqrrp.hh:356,515): Householder QR, reflectors below the diagonal, tau: DEVICE.
+ * lapack::ungqr(m, n, k = n) (rl_orth.hh:162): overwrite the reflectors with the first n columns of Q (k must equal n).
+ * lapack::laswp(n, A, lda, k1, k2, ipiv, 1) (rl_orth.hh:226): forward row interchanges, ipiv DEVICE int64 1-based. */
+int rlhip_geqrf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* tau);
+int rlhip_geqrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* tau);
+int rlhip_ungqr_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau);
+int rlhip_ungqr_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, float* A, int64_t lda, const float* tau);
+int rlhip_laswp_f64(rlhip_ctx* ctx, int64_t n, double* A, int64_t lda, int64_t k1, int64_t k2, const int64_t* ipiv);
+int rlhip_laswp_f32(rlhip_ctx* ctx, int64_t n, float* A, int64_t lda, int64_t k1, int64_t k2, const int64_t* ipiv);
 /* J <- iota(1..cols); for i < min(sd, cols): swap(J[ipiv[i]-1], J[i])   (rl_bqrrp.hh:345-350; CUDA twin
  * LUQRCP_piv_process_gpu_global, rl_cuda_kernels.cuh:203-220).  Integer-exact. */
 int rlhip_luqrcp_piv(rlhip_ctx* ctx, int64_t sd, int64_t cols, const int64_t* ipiv, int64_t* J);

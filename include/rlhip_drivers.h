@@ -47,12 +47,14 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
                          int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
                          const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us);
 
-/* BQRRP<double>::call with {qrcp_wide = geqp3, qr_tall = cholqr, apply_trans_q = gemqrt}.  A (m x n, lda) -> GEQP3
+/* BQRRP<double>::call.  qrcp_wide {0 luqr, 1 geqp3}, qr_tall {0 geqrt, 1 cholqr, 2 geqrf}, apply_trans_q {0 ormqr, 1 gemqrt}
+ * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default.  A (m x n, lda) -> GEQP3
  * format, tau (min(m,n)), J (n) all on the device.  A_sk_in / A_sk_out: shared-sketch hooks as for CQRRPT (d x n,
  * ld d, d = (int64)(d_factor * b_sz)).  times_us[9] may be NULL.              drivers/rl_bqrrp.hh:155-665 */
 int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,
                         int64_t internal_nb, double tol, double* tau, int64_t* J, uint32_t state[6],
-                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us);
+                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
+                        int apply_trans_q);
 
 #ifdef __cplusplus
 }

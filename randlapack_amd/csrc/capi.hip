@@ -23,6 +23,9 @@ template <typename T> int tau_from_t(rlhip_ctx*, int64_t, int64_t, const T*, int
 template <typename T> int any_abs_gt(rlhip_ctx*, int64_t, const T*, T, int*);
 template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*);
 int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
+template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
+template <typename T> int ungqr(rlhip_ctx*, int64_t, int64_t, T*, int64_t, const T*);
+template <typename T> int laswp(rlhip_ctx*, int64_t, T*, int64_t, int64_t, int64_t, const int64_t*);
 int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]);
 }
 
@@ -337,6 +340,16 @@ static inline int op_flag(char t, int* out) {
         int info = 0;                                                                                           \
         int rc = rlhip::getrf<T>(c, m, n, A, lda, ipiv, &info);                                                  \
         return rc ? rc : info;                                                                                  \
+    }                                                                                                           \
+    int rlhip_geqrf_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau) {                       \
+        return rlhip::geqrf<T>(c, m, n, A, lda, tau);                                                           \
+    }                                                                                                           \
+    int rlhip_ungqr_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const T* tau) {      \
+        if (k != n) return -4;                                                                                  \
+        return rlhip::ungqr<T>(c, m, n, A, lda, tau);                                                           \
+    }                                                                                                           \
+    int rlhip_laswp_##SUF(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int64_t k1, int64_t k2, const int64_t* ipiv) { \
+        return rlhip::laswp<T>(c, n, A, lda, k1, k2, ipiv);                                                     \
     }                                                                                                           \
     int rlhip_add_diag_##SUF(rlhip_ctx* c, int64_t n, T alpha, T* A, int64_t lda) {                             \
         return rlhip::add_diag<T>(c, n, alpha, A, lda);                                                          \

@@ -29,7 +29,9 @@ template <typename T>
 std::unique_ptr<RandLAPACK::Stabilization<T>> make_stab(blas::Queue& q, int kind, bool cond_check) {
     switch (kind) {
         case 0: return std::make_unique<RandLAPACK::CholQRQ<T>>(q, cond_check, false);
-        default: throw RandLAPACK::Error("stabilization kind " + std::to_string(kind) + " is not available on the device yet");
+        case 1: return std::make_unique<RandLAPACK::HQRQ<T>>(q, cond_check, false);
+        case 2: return std::make_unique<RandLAPACK::PLUL<T>>(q, cond_check, false);
+        default: throw RandLAPACK::Error("unknown stabilization kind " + std::to_string(kind) + " (0 CholQRQ, 1 HQRQ, 2 PLUL)");
     }
 }
 
@@ -155,10 +157,15 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
 
 int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,
                         int64_t internal_nb, double tol, double* tau, int64_t* J, uint32_t state[6],
-                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us) {
+                        const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
+                        int apply_trans_q) {
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::BQRRP<double, RNG> alg(q, times_us != nullptr, b_sz);
+        using Sub = RandLAPACK::BQRRPSubroutines;
+        if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
+        if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
+        if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
         if (internal_nb > 0) alg.internal_nb = internal_nb;
         if (tol > 0) alg.tol = tol;
         alg.sketch_override = A_sk_in;

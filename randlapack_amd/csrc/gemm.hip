@@ -475,6 +475,15 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (lda < (arows > 1 ? arows : 1)) return -8;
     if (ldb < (brows > 1 ? brows : 1)) return -10;
     if (ldc < (m > 1 ? m : 1)) return -13;
+    // contraction lengths that are not a multiple of the k-step (row shards of 200000/8 = 25000 rows): the multiple-of-16
+    // part goes down the persistent path, the < 16 leftover is one accumulate pass of the generic kernel
+    if (!transB && k % 16 != 0 && k >= 1024 && n % 256 == 0 && !ssqA_dev && (tri ? (m == n) : (m >= 128))) {
+        const int64_t k_main = (k / 16) * 16;
+        int rc = gemm_impl<T>(c, transA, transB, m, n, k_main, alpha, A, lda, B, ldb, beta, C, ldc, tri, nullptr, nullptr);
+        if (rc) return rc;
+        const T* A2 = transA ? (A + k_main) : (A + k_main * lda);
+        return gemm_impl<T>(c, transA, transB, m, n, k - k_main, alpha, A2, lda, B + k_main, ldb, T(1), C, ldc, tri, nullptr, nullptr);
+    }
     if (tri && !transB && m == n && n % 256 == 0 && k % 16 == 0) {
         int rc = try_streamk<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 1);
         if (rc < 0) return rc;

@@ -287,6 +287,18 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     return 0;
 }
 
+// lapack::laswp(n, A, lda, k1, k2, ipiv, incx = 1) with 1-based k1..k2 (rl_orth.hh:226)
+template <typename T>
+int laswp(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int64_t k1, int64_t k2, const int64_t* ipiv_dev) {
+    if (n <= 0 || k2 < k1) return 0;
+    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, k1 - 1, (int)(k2 - k1 + 1), A,
+                       lda, ipiv_dev);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int laswp<double>(rlhip_ctx*, int64_t, double*, int64_t, int64_t, int64_t, const int64_t*);
+template int laswp<float>(rlhip_ctx*, int64_t, float*, int64_t, int64_t, int64_t, const int64_t*);
+
 int luqrcp_piv(rlhip_ctx* c, int64_t sd, int64_t cols, const int64_t* ipiv_dev, int64_t* J_dev) {
     if (cols <= 0) return 0;
     hipLaunchKernelGGL(luqrcp_piv_kernel, dim3(1), dim3(256), 0, c->stream, sd, cols, ipiv_dev, J_dev);

@@ -33,6 +33,7 @@ struct QrcpArgs {
     unsigned* bar;            // barrier counter (zeroed by the host)
     T tol3z;
     int use_lds;              // owned columns live in LDS for the whole factorization
+    int pivot;                // 0: plain Householder QR (geqr2 order), jpvt untouched
 };
 
 // ---- cross-workgroup traffic uses agent-scope relaxed atomics on 8-byte granules (sc1 write-through stores /
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
         if (lane == 0) {
             T nr = sqrt(ss);
             l_vn1[j / G] = nr; l_vn2[j / G] = nr;
-            __hip_atomic_store(g.jpvt + j, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.pivot) __hip_atomic_store(g.jpvt + j, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -111,10 +112,14 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
         T* kcol = g.kcol + (int64_t)par * (m + 2);
         // ---- A. local candidate over owned positions >= k (first maximum) and its SPECULATIVE reflector
         T best = T(-1); int64_t bpos = n;
-        for (int64_t j = me; j < n; j += G) {
-            if (j < k) continue;
-            T v = l_vn1[j / G];
-            if (v > best) { best = v; bpos = j; }   // increasing j: strict > keeps the first maximum
+        if (g.pivot) {
+            for (int64_t j = me; j < n; j += G) {
+                if (j < k) continue;
+                T v = l_vn1[j / G];
+                if (v > best) { best = v; bpos = j; }   // increasing j: strict > keeps the first maximum
+            }
+        } else if (me == k % G) {
+            best = 0; bpos = k;
         }
         T my_tau = 0;
         if (bpos < n) {
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
                 w = wave_sum(w) * tauk;
                 for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : l_v[i]);
             }
+            if (!g.pivot) continue;
             // dlaqp2: vn1(j) *= sqrt(max(0, 1 - (|A(k,j)|/vn1(j))^2)), recomputed when cancellation is detected
             T v1 = l_vn1[j / G];
             if (v1 != T(0)) {
@@ -248,7 +254,105 @@ __global__ void zero_u32(unsigned* p) { *p = 0; }
 namespace rlhip {
 
 template <typename T>
+int gemqrt_lt(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, int64_t nb, const T* V, int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc);
+template <typename T>
+int larft_gram(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt);
+template <typename T>
+int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
+         const T* B, int64_t ldb, T beta, T* C, int64_t ldc);
+
+template <typename T>
+static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
+
+template <typename T>
 int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
+    return qr_core<T>(c, 1, m, n, A, lda, jpvt_dev, tau_dev);
+}
+
+// lapack::geqrf: Householder QR without pivoting.  Wide input (n > m, BQRRP's permuted sketch rl_bqrrp.hh:356): only the
+// leading m x m block goes through the step-synchronous kernel; the remaining columns get Q^T applied as ONE compact-WY
+// block (larft + gemqrt on the MFMA path).
+template <typename T>
+int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
+    if (m < 0) return -2;
+    if (n < 0) return -3;
+    if (lda < (m > 1 ? m : 1)) return -5;
+    if (m == 0 || n == 0) return 0;
+    const int64_t nf = n < m ? n : m;
+    int rc = qr_core<T>(c, 0, m, nf, A, lda, nullptr, tau_dev);
+    if (rc || n <= m) return rc;
+    size_t mark = rlhip_ws_mark(c);
+    T* Tm = ws_alloc<T>(c, (size_t)m * m);
+    if (!Tm) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    rc = larft_gram<T>(c, m, m, A, lda, tau_dev, Tm, m);
+    if (!rc) rc = gemqrt_lt<T>(c, m, n - m, m, m, A, lda, Tm, m, A + m * lda, lda);
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+template <typename T>
+__global__ void ungqr_seed_kernel(int64_t n, const T* __restrict__ V, int64_t ldv, T* __restrict__ V1t) {
+    // V1t (n x n) = unit-lower(V[0:n, 0:n])^T
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t i = idx % n, j = idx / n;      // V1t[i, j] = V1[j, i]
+    T v = 0;
+    if (j > i) v = V[j + i * ldv]; else if (j == i) v = 1;
+    V1t[idx] = v;
+}
+template <typename T>
+__global__ void ungqr_finish_kernel(int64_t m, int64_t n, T* __restrict__ Q, int64_t ldq, const T* __restrict__ V, int64_t ldv,
+                                    const T* __restrict__ Wm) {
+    // rows < n of the result: Q[i, j] = delta_ij - sum_l V1[i, l] W[l, j]  (V1 unit lower); one thread per entry.
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int64_t i = idx % n, j = idx / n;
+    T s = (i == j) ? T(1) : T(0);
+    for (int64_t l = 0; l <= i; ++l) s -= ((l == i) ? T(1) : V[i + l * ldv]) * Wm[l + j * n];
+    Q[i + j * ldq] = s;   // NOTE: V's strictly-lower part is stored in Q's own top block; see ungqr() for the ordering
+}
+
+// lapack::ungqr(m, n, k = n, A, lda, tau): A (m x n, reflectors below the diagonal) <- Q[:, 0:n]   (rl_orth.hh:162)
+// Q E = E - V (T V1^T):  W = T V1^T (n x n x n GEMM), bottom rows  Q2 = -V2 W (m x n x n GEMM, out of place into a
+// scratch copy of V2), top block by the finish kernel.
+template <typename T>
+int ungqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, const T* tau_dev) {
+    if (m < 0) return -2;
+    if (n < 0 || n > m) return -3;
+    if (lda < (m > 1 ? m : 1)) return -6;
+    if (n == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* Tm = ws_alloc<T>(c, (size_t)n * n);
+    T* V1t = ws_alloc<T>(c, (size_t)n * n);
+    T* Wm = ws_alloc<T>(c, (size_t)n * n);
+    T* Qtop = ws_alloc<T>(c, (size_t)n * n);
+    T* V2 = (m > n) ? ws_alloc<T>(c, (size_t)(m - n) * n) : nullptr;
+    if (!Tm || !V1t || !Wm || !Qtop || (m > n && !V2)) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    int rc = larft_gram<T>(c, m, n, A, lda, tau_dev, Tm, n);
+    if (rc) { rlhip_ws_release(c, mark); return rc; }
+    const unsigned nb2 = (unsigned)((n * n + 255) / 256);
+    hipLaunchKernelGGL(ungqr_seed_kernel<T>, dim3(nb2), dim3(256), 0, c->stream, n, A, lda, V1t);
+    RLHIP_LAUNCH_CHECK();
+    // T is upper triangular but larft leaves the strictly lower part untouched: Tm was freshly laset to I before the solve
+    rc = gemm<T>(c, 0, 0, n, n, n, T(1), Tm, n, V1t, n, T(0), Wm, n);
+    if (!rc) {
+        hipLaunchKernelGGL(ungqr_finish_kernel<T>, dim3(nb2), dim3(256), 0, c->stream, m, n, Qtop, n, A, lda, Wm);
+        RLHIP_LAUNCH_CHECK();
+    }
+    if (!rc && m > n) {
+        RLHIP_CHECK(hipMemcpy2DAsync(V2, (size_t)(m - n) * sizeof(T), A + n, (size_t)lda * sizeof(T), (size_t)(m - n) * sizeof(T), (size_t)n,
+                                     hipMemcpyDeviceToDevice, c->stream));
+        rc = gemm<T>(c, 0, 0, m - n, n, n, T(-1), V2, m - n, Wm, n, T(0), A + n, lda);
+    }
+    if (!rc)
+        RLHIP_CHECK(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), Qtop, (size_t)n * sizeof(T), (size_t)n * sizeof(T), (size_t)n,
+                                     hipMemcpyDeviceToDevice, c->stream));
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+template <typename T>
+static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
     if (m < 0) return -2;
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
@@ -287,7 +391,7 @@ int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_d
     g.slot = ws_alloc<T>(c, (size_t)2 * G * m); g.kcol = ws_alloc<T>(c, (size_t)2 * (m + 2));
     g.bar = ws_alloc<unsigned>(c, 4);
     g.tol3z = std::sqrt(std::numeric_limits<T>::epsilon());
-    g.use_lds = use_lds;
+    g.use_lds = use_lds; g.pivot = pivot;
     if (!g.vn1 || !g.vn2 || !g.cand_val || !g.cand_pos || !g.cand_tau || !g.slot || !g.kcol || !g.bar) {
         rlhip_ws_release(c, mark);
         return RLHIP_ERR_HIP(hipErrorOutOfMemory);
@@ -303,5 +407,9 @@ int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_d
 
 template int geqp3<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, int64_t*, double*);
 template int geqp3<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, int64_t*, float*);
+template int geqrf<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*);
+template int geqrf<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*);
+template int ungqr<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, const double*);
+template int ungqr<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, const float*);
 
 }  // namespace rlhip

@@ -19,18 +19,63 @@ import numpy as np
 from . import _lib
 
 
-def init_comm(ctx, dist) -> None:
-    """Join this rank's rlhip context to an RCCL communicator spanning dist's world."""
+_keepalive = {}
+
+
+def init_comm(ctx, dist, force_hook: bool = False) -> str:
+    """Join this rank's rlhip context to an RCCL communicator spanning dist's world.  Returns the transport name:
+    "rccl" (librlhip.so issues ncclAllReduce itself, on the context's stream) or "torch.distributed" (the library's
+    all-reduce hook hands the buffer to torch's RCCL communicator -- used only if EVERY rank failed to bind RCCL
+    directly, e.g. a host process with a static RCCL; still a device-side RCCL all-reduce over xGMI)."""
+    import sys
+
     import torch
 
     world, rank = dist.get_world_size(), dist.get_rank()
+    dev = f"cuda:{ctx.device}"
     idbuf = (C.c_ubyte * 128)()
+    ok = 1
     if rank == 0:
-        _lib.check(ctx.lib.rlhip_comm_unique_id(idbuf), "rlhip_comm_unique_id")
-    t = torch.tensor(list(idbuf), dtype=torch.uint8, device=f"cuda:{ctx.device}")
+        ok = int(ctx.lib.rlhip_comm_unique_id(idbuf) == 0)
+    t = torch.tensor([ok] + list(idbuf), dtype=torch.uint8, device=dev)
     dist.broadcast(t, src=0)
-    idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
-    _lib.check(ctx.lib.rlhip_comm_init(ctx.h, world, rank, idbuf), "rlhip_comm_init")
+    vals = t.cpu().tolist()
+    native = 0
+    if vals[0] and not force_hook:
+        idbuf = (C.c_ubyte * 128)(*vals[1:])
+        native = int(ctx.lib.rlhip_comm_init(ctx.h, world, rank, idbuf) == 0)
+    flag = torch.tensor([native], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return "rccl"
+    if native:
+        ctx.lib.rlhip_comm_destroy(ctx.h)
+    if rank == 0:
+        print("[randlapack_amd] direct RCCL binding failed on some rank; all-reduce goes through torch.distributed", file=sys.stderr)
+    staging = {}
+
+    def hook(_user, dev_ptr, count, is_f64):
+        try:
+            dt = torch.float64 if is_f64 else torch.float32
+            buf = staging.get(dt)
+            if buf is None or buf.numel() < count:
+                buf = torch.empty(max(int(count), 1 << 20), dtype=dt, device=dev)
+                staging[dt] = buf
+            nbytes = int(count) * (8 if is_f64 else 4)
+            _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, buf.data_ptr(), dev_ptr, nbytes), "memcpy_d2d")
+            ctx.sync()
+            dist.all_reduce(buf[:count])
+            torch.cuda.synchronize()
+            _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, dev_ptr, buf.data_ptr(), nbytes), "memcpy_d2d")
+            return 0
+        except Exception as e:  # noqa: BLE001 - reported through the C return code
+            print(f"[randlapack_amd] all-reduce hook failed: {e}", file=sys.stderr)
+            return -1
+
+    cb = _lib.HOOK(hook)
+    _keepalive[id(ctx)] = (cb, staging)
+    _lib.check(ctx.lib.rlhip_comm_set_hook(ctx.h, cb, None, world, rank), "rlhip_comm_set_hook")
+    return "torch.distributed"
 
 
 def rsvd_rowsharded(ctx, dist, A_local, m_local, n, k, key=(0, 0), b_sz=None, tol=1e-12, p=0, q=1):
@@ -39,7 +84,7 @@ def rsvd_rowsharded(ctx, dist, A_local, m_local, n, k, key=(0, 0), b_sz=None, to
     from . import device as dev
 
     if ctx.lib.rlhip_comm_size(ctx.h) != dist.get_world_size():
-        init_comm(ctx, dist)
+        ctx.comm_transport = init_comm(ctx, dist)
     return dev.drv_rsvd(ctx, A_local, m_local, n, k, b_sz or k, tol, p, q, key=key)
 
 

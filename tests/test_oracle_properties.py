@@ -132,3 +132,91 @@ def test_orhr_col_matches_lapack_semantics(orc):
     # H[:, :n] = Q * diag(D): reconstructed reflectors reproduce Q up to the sign vector
     np.testing.assert_allclose(H[:, :n], Q * D, atol=1e-12)
     assert set(np.unique(D)).issubset({-1.0, 1.0})
+
+
+# ---------------------------------------------------------------------------------------------------
+# BQRRP (drivers/rl_bqrrp.hh) -- the reference's test/drivers/test_bqrrp.cc cases, scaled down.
+# Checks are the reference's (test_bqrrp.cc:105-145): after ungqr + col_swap,
+#   ||A[:, J] - Q R||_F <= eps^0.75 ||A||_F,  ||Q^T Q - I||_F <= eps^0.75 sqrt(min(m,n)),  all-zero input -> A == 0.
+# ---------------------------------------------------------------------------------------------------
+def _bqrrp_checks(orc, A, r, atol=EPS**0.75):
+    m, n = A.shape
+    mn = min(m, n)
+    Q = orc.ungqr(r["A"], r["tau"])
+    R = np.triu(r["A"])[:mn]
+    J = r["J"]
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= atol * max(np.linalg.norm(A), 1e-300)
+    assert np.linalg.norm(Q.T @ Q - np.eye(mn)) <= atol * np.sqrt(mn)
+
+
+@pytest.mark.parametrize("b_sz", [100, 140])
+@pytest.mark.parametrize("opts", [(0, 2, 0), (1, 1, 1), (0, 0, 1), (0, 1, 0)])
+def test_bqrrp_full_rank(orc, b_sz, opts):
+    # test_bqrrp.cc:151-186 (5000 x 2000, b = 500 / 700) at 1/5 scale, every subroutine family
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((1000, 400))
+    r = orc.bqrrp(A, b_sz, 1.0, qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2], key=(b_sz, 0))
+    assert r["rc"] == 0 and r["rank"] == 400
+    _bqrrp_checks(orc, A, r)
+
+
+def test_bqrrp_low_rank_and_step_spectrum(orc):
+    rng = np.random.default_rng(8)
+    A = poly_mat(600, 300, 120, rng, cond=1e3)                 # test_bqrrp.cc:188-207 (low rank)
+    r = orc.bqrrp(A, 50, 1.0, key=(1, 0))
+    assert r["rc"] == 0 and 120 <= r["rank"] <= 150            # rank is rounded up to a block boundary
+    _bqrrp_checks(orc, A, r)
+    n = 256                                                    # :209-240 step spectrum, cond 1e10, qrcp_wide = geqp3
+    s = np.ones(n); s[n // 2:] = 1e-10
+    A = (np.linalg.qr(rng.standard_normal((n, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    r = orc.bqrrp(A, 32, 1.0, qrcp_wide=1, key=(2, 0))
+    assert r["rc"] == 0
+    _bqrrp_checks(orc, A, r)
+    # the leading half of the pivots must capture the large singular directions: |R[n/2-1, n/2-1]| >> |R[n/2, n/2]|
+    dR = np.abs(np.diag(r["A"]))
+    assert dR[n // 2 - 1] > 1e6 * dR[n // 2]
+
+
+@pytest.mark.parametrize("kind", ["zero", "near_zero", "half_zero"])
+def test_bqrrp_degenerate_inputs(orc, kind):
+    # test_bqrrp.cc:330-412
+    rng = np.random.default_rng(9)
+    m, n, b = 300, 120, 30
+    if kind == "zero":
+        A = np.zeros((m, n))
+    elif kind == "near_zero":
+        A = 1e-20 * rng.standard_normal((m, n))
+    else:
+        A = rng.standard_normal((m, n)); A[:, n // 2:] = 0
+    r = orc.bqrrp(A, b, 1.0, key=(3, 0))
+    assert r["rc"] == 0
+    if kind == "zero":
+        assert r["rank"] == 0 and np.all(r["A"] == 0)
+    if r["rank"] == 0:
+        assert np.abs(r["A"]).max() <= EPS**0.75               # test_bqrrp.cc:126-129: ASSERT_NEAR(A[i], 0, atol)
+    else:
+        _bqrrp_checks(orc, A, r)
+    if kind == "near_zero":
+        assert r["rank"] == 0                                  # every entry is below eps: rl_bqrrp.hh:373-399
+    if kind == "half_zero":
+        assert r["rank"] <= n // 2 + b
+
+
+def test_bqrrp_wide(orc):
+    # test_bqrrp.cc:414-438 (2000 x 5000) at 1/10 scale
+    rng = np.random.default_rng(10)
+    A = rng.standard_normal((200, 500))
+    r = orc.bqrrp(A, 64, 1.0, key=(4, 0))
+    assert r["rc"] == 0 and r["rank"] == 200
+    _bqrrp_checks(orc, A, r)
+
+
+def test_bqrrp_internal_nb_and_state(orc):
+    # cholqr with internal_nb < b (test_bqrrp.cc:300-328) and the RNG-state contract: one d x m fill_dense per call
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((500, 280))
+    r = orc.bqrrp(A, 90, 1.0, qrcp_wide=0, qr_tall=1, apply_trans_q=1, internal_nb=30, key=(5, 0))
+    assert r["rc"] == 0
+    _bqrrp_checks(orc, A, r)
+    assert r["next_ctr"][0] == (90 * 500 + 3) // 4
