@@ -40,6 +40,9 @@ int rlhip_sync(rlhip_ctx* ctx);
 void* rlhip_stream(rlhip_ctx* ctx);
 int rlhip_malloc(rlhip_ctx* ctx, void** dev_ptr, size_t bytes);
 int rlhip_free(rlhip_ctx* ctx, void* dev_ptr);
+/* rlhip_malloc/rlhip_free recycle blocks by exact size (stream-ordered, no synchronisation on free; at most 1/8 of
+ * the device memory idles in the pool).  rlhip_trim returns every idle block to the driver. */
+int rlhip_trim(rlhip_ctx* ctx);
 int rlhip_memcpy_h2d(rlhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int rlhip_memcpy_d2h(rlhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int rlhip_memcpy_d2d(rlhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);

@@ -129,6 +129,10 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
         RLHIP_CHECK(hipMalloc((void**)&p, (size_t)64 << 20));
         c->segs[0].base = p; c->segs[0].size = (size_t)64 << 20; c->nsegs = 1;
     }
+    {
+        size_t fr = 0, tot = 0;
+        c->pool_cap_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? tot / 8 : ((size_t)8 << 30);   // <= 1/8 of HBM idles here
+    }
     *out = c;
     return 0;
 }
@@ -138,6 +142,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     rlhip_comm_destroy(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->npool; ++i) hipFree(c->pool[i].p);
     for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
     if (c->d_mail) hipFree(c->d_mail);
     if (c->h_mail) hipHostFree(c->h_mail);
@@ -151,14 +156,57 @@ int rlhip_destroy(rlhip_ctx* c) {
 int rlhip_sync(rlhip_ctx* c) { RLHIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
 void* rlhip_stream(rlhip_ctx* c) { return (void*)c->stream; }
 
+static void pool_drop(rlhip_ctx* c, int i) {
+    hipFree(c->pool[i].p);
+    c->pool_idle_bytes -= c->pool[i].bytes;
+    c->pool[i] = c->pool[--c->npool];
+}
+int rlhip_trim(rlhip_ctx* c) {
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = c->npool - 1; i >= 0; --i)
+        if (!c->pool[i].in_use) pool_drop(c, i);
+    return 0;
+}
 int rlhip_malloc(rlhip_ctx* c, void** p, size_t bytes) {
     RLHIP_CHECK(hipSetDevice(c->device));
-    RLHIP_CHECK(hipMalloc(p, bytes ? bytes : 1));
+    bytes = bytes ? ((bytes + 255) & ~(size_t)255) : 256;
+    for (int i = 0; i < c->npool; ++i)
+        if (!c->pool[i].in_use && c->pool[i].bytes == bytes) {
+            c->pool[i].in_use = true;
+            c->pool_idle_bytes -= bytes;
+            *p = c->pool[i].p;
+            return 0;
+        }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                       // give the idle blocks back and try once more
+        (void)hipGetLastError();
+        rlhip_trim(c);
+        e = hipMalloc(p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return RLHIP_ERR_HIP(e); }
+    }
+    if (c->npool < 64) c->pool[c->npool++] = {*p, bytes, true, 0};
     return 0;
 }
 int rlhip_free(rlhip_ctx* c, void* p) {
     if (!p) return 0;
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->npool; ++i)
+        if (c->pool[i].p == p) {
+            c->pool[i].in_use = false;
+            c->pool[i].stamp = ++c->pool_clock;
+            c->pool_idle_bytes += c->pool[i].bytes;
+            if (c->pool_idle_bytes > c->pool_cap_bytes) {          // over the cap: release least recently freed blocks
+                RLHIP_CHECK(hipStreamSynchronize(c->stream));
+                while (c->pool_idle_bytes > c->pool_cap_bytes) {
+                    int lru = -1;
+                    for (int j = 0; j < c->npool; ++j)
+                        if (!c->pool[j].in_use && (lru < 0 || c->pool[j].stamp < c->pool[lru].stamp)) lru = j;
+                    if (lru < 0) break;
+                    pool_drop(c, lru);
+                }
+            }
+            return 0;
+        }
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));                 // not one of ours (table was full): plain free
     RLHIP_CHECK(hipFree(p));
     return 0;
 }

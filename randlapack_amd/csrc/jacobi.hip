@@ -15,6 +15,8 @@
 // pre-conditioned factor: Jacobi on R^T of a QR factorisation converges in ~11 sweeps regardless of
 // grading, on R itself it can take 30+ (measured).
 #include "rlhip_internal.h"
+#include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 
@@ -139,14 +141,16 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // LDS: 160 KiB in total, the whole CU), writes the panel back and applies J to the matching 64 columns of
 // V.  An outer tournament over the block pairs (NB-1 launches of NB/2 workgroups) visits every column
 // pair once per outer sweep.
-constexpr int JB = 32;            // block width
-constexpr int JP = 2 * JB;        // panel width
 constexpr int JM = 256;           // panel rows (LDS)
 
-template <typename T>
+// JB = block width (16 or 32), JP = 2*JB = panel width.  Narrow blocks put twice as many workgroups to work per
+// launch and shrink the per-launch pair count 4x; launches per sweep double (measured trade-off in DESIGN.md 4.3).
+template <typename T, int JB>
 __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
                                                             int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
                                                             unsigned* __restrict__ nrot) {
+    constexpr int JP = 2 * JB;
+    constexpr int HALVES = JB / 16;                    // pairs per round = JB, 16 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JM] column-major
     T* Js = Xs + JP * JM;                              // [JP][JP] column-major
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     for (int e = tid; e < JP * JP; e += 1024) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
     __syncthreads();
     unsigned my_rot = 0;
+    float my_cos2 = 0.f;                               // largest squared cosine met before rotating (convergence shortcut)
     const T tol2 = tol * tol;
     // intra = 1: the 2 x 496 pairs INSIDE the two blocks (31 rounds, 16 pairs per block per round)
     // intra = 0: the 32 x 32 CROSS pairs between the blocks (32 rounds of 32 pairs): every column pair of the
@@ -177,11 +182,11 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     const int nrounds = intra ? (JB - 1) : JB;
     for (int round = 0; round < nrounds; ++round) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int sl = wid + 16 * half;            // 32 pairs per round, 16 waves
+        for (int half = 0; half < HALVES; ++half) {
+            const int sl = wid + 16 * half;            // JB pairs per round, 16 waves
             int p, q;
             if (intra) {
-                const int blk = sl >> 4, s16 = sl & 15;
+                const int blk = sl / (JB / 2), s16 = sl % (JB / 2);
                 if (s16 == 0) { p = JB - 1; q = round; }
                 else { p = (round + s16) % (JB - 1); q = (round - s16 + (JB - 1)) % (JB - 1); }
                 if (p > q) { int t = p; p = q; q = t; }
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
             aa = (T)wave_sum_dpp((double)aa);
             bb = (T)wave_sum_dpp((double)bb);
             ab = (T)wave_sum_dpp((double)ab);
+            if (aa > T(0) && bb > T(0)) my_cos2 = fmaxf(my_cos2, (float)((double)ab * (double)ab / ((double)aa * (double)bb)) * 1.000001f);
             if (ab * ab > tol2 * aa * bb && aa > T(0) && bb > T(0)) {      // wave-uniform; |ab| > tol*||x||*||y||
                 const double zeta = (double)(bb - aa) * fast_rcp(2.0 * (double)ab);
                 const double w = fma(zeta, zeta, 1.0);
@@ -213,15 +219,20 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
                     xp[lane + 64 * j] = cs * x[j] - sn * y[j];
                     xq[lane + 64 * j] = sn * x[j] + cs * y[j];
                 }
-                const T jp = Js[lane + p * JP], jq = Js[lane + q * JP];
-                Js[lane + p * JP] = cs * jp - sn * jq;
-                Js[lane + q * JP] = sn * jp + cs * jq;
+                if (JP >= 64 || lane < JP) {
+                    const T jp = Js[lane + p * JP], jq = Js[lane + q * JP];
+                    Js[lane + p * JP] = cs * jp - sn * jq;
+                    Js[lane + q * JP] = sn * jp + cs * jq;
+                }
                 ++my_rot;
             }
         }
         __syncthreads();
     }
-    if (lane == 0 && my_rot) atomicAdd(nrot, my_rot);
+    if (lane == 0 && my_rot) {
+        atomicAdd(nrot, my_rot);
+        atomicMax(nrot + 1, __float_as_uint(my_cos2));   // non-negative floats order like their bit patterns
+    }
     // ---- write the rotated panel back
     for (int e = tid; e < JP * JM; e += 1024) {
         const int r = e % JM, c = e / JM;
@@ -242,21 +253,22 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
             Xs[e] = (r0 + r < n && gc < n) ? V[(r0 + r) + (int64_t)gc * ldv] : T(0);
         }
         __syncthreads();
-        d4_t acc[4];
+        constexpr int NU = JP / 16;
+        d4_t acc[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = d4_t{0, 0, 0, 0};
+        for (int u = 0; u < NU; ++u) acc[u] = d4_t{0, 0, 0, 0};
 #pragma unroll 4
         for (int st = 0; st < JP / 4; ++st) {
             const double vf = (double)Xs[(16 * wid + fr) + (4 * st + fk) * JM];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const double jf = (double)Js[(4 * st + fk) + (16 * u + fr) * JP];
                 acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, vf, acc[u], 0, 0, 0);
             }
         }
         const int row = r0 + 16 * wid + fr;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gc = gcol(16 * u + fk + 4 * r);
@@ -313,7 +325,42 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t m, int n, const T
     if (threadIdx.x == 0) Sout[r] = s;
 }
 
-__global__ void zero_u32_kernel(unsigned* p) { *p = 0; }
+__global__ void zero_u32_kernel(unsigned* p) { p[0] = 0; p[1] = 0; }
+
+template <typename T, int JB>
+int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
+    constexpr int JP = 2 * JB;
+    int NBk = (n + JB - 1) / JB;
+    if (NBk < 2) NBk = 2;
+    if (NBk % 2) ++NBk;
+    constexpr int smem = (JP * JM + JP * JP) * (int)sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T, JB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    int sweep = 0;
+    for (; sweep < max_sweeps; ++sweep) {
+        hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
+        hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
+                           (int64_t)n, tol, d_nrot);
+        for (int oround = 0; oround < NBk - 1; ++oround)
+            hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, oround, 0, A, lda,
+                               V, (int64_t)n, tol, d_nrot);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        const unsigned nrot = *(unsigned*)(c->h_mail + 16);
+        float cos2;
+        memcpy(&cos2, (const char*)(c->h_mail + 16) + sizeof(unsigned), sizeof(float));
+        if (nrot == 0) { ++sweep; break; }
+        // quadratic convergence shortcut (cf. DGESVJ's mxaapq test): every cosine met in this sweep was <= 1e-9, so
+        // the rotations just applied leave cosines of order n * 1e-18 << tol; a further all-idle sweep would only confirm it
+        if (cos2 <= 1e-18f) { ++sweep; break; }
+    }
+    *sweeps_out = sweep;
+    return 0;
+}
 
 }  // namespace
 
@@ -351,29 +398,11 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     int info = 0;
     if (n > 1 && m <= JM && sizeof(T) == 8) {
         // LDS-resident block Jacobi (see jacobi_block_kernel)
-        int NBk = (n + JB - 1) / JB;
-        if (NBk < 2) NBk = 2;
-        if (NBk % 2) ++NBk;
-        constexpr int smem = (JP * JM + JP * JP) * (int)sizeof(T);
-        static bool attr_set = false;
-        if (!attr_set) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
-        }
-        for (; sweep < max_sweeps; ++sweep) {
-            hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
-            hipLaunchKernelGGL(jacobi_block_kernel<T>, dim3(NBk / 2), dim3(1024), smem, c->stream, (int)m, n, NBk, 0, 1,
-                               A, lda, V, (int64_t)n, tol, d_nrot);
-            for (int oround = 0; oround < NBk - 1; ++oround) {
-                hipLaunchKernelGGL(jacobi_block_kernel<T>, dim3(NBk / 2), dim3(1024), smem, c->stream, (int)m, n, NBk,
-                                   oround, 0, A, lda, V, (int64_t)n, tol, d_nrot);
-            }
-            RLHIP_LAUNCH_CHECK();
-            RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(hipStreamSynchronize(c->stream));
-            unsigned nrot = *(unsigned*)(c->h_mail + 16);
-            if (nrot == 0) { ++sweep; break; }
-        }
+        static int jb_sel = 0;
+        if (!jb_sel) { const char* e = getenv("RLHIP_JACOBI_JB"); jb_sel = (e && atoi(e) == 32) ? 32 : 16; }
+        if (jb_sel == 32 || n <= 32) rc = block_jacobi_sweeps<T, 32>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
+        else rc = block_jacobi_sweeps<T, 16>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
+        if (rc) { rlhip_ws_release(c, mark); return rc; }
         if (sweep >= max_sweeps) info = 1;
     } else if (n > 1) {
         for (; sweep < max_sweeps; ++sweep) {

@@ -17,3 +17,10 @@ for (m,n,kind) in [(256,256,'RT'),(256,256,'graded'),(200,100,'gauss'),(256,33,'
     U = cm_to_numpy(Ad); s = S.cpu().numpy(); vt = cm_to_numpy(VT)
     sref = np.linalg.svd(A, compute_uv=False)
     print(f'gesvdj {kind} {m}x{n} info={info} sweeps={sw} t={dt*1e3:.2f}ms recon={np.abs(U*s@vt-A).max()/np.abs(A).max():.2e} sabs={np.max(np.abs(s-sref))/sref[0]:.2e} orthU={np.abs(U.T@U-np.eye(n)).max():.2e} orthV={np.abs(vt@vt.T-np.eye(n)).max():.2e}', flush=True)
+# bench-like: R^T of a CholQR of a Gaussian 20000 x 256
+B = rng.standard_normal((20000,256)); A = np.linalg.qr(B)[1].T.copy()
+for rep in range(3):
+    Ad = cm_from_numpy(A); S = torch.empty(256, dtype=torch.float64, device='cuda'); VT = cm_empty(256,256)
+    ctx.sync(); t0=time.time(); info, sw = ctx.gesvdj(256,256,Ad,256,S,VT,256); ctx.sync(); dt=time.time()-t0
+    s = S.cpu().numpy(); sref = np.linalg.svd(A, compute_uv=False); U = cm_to_numpy(Ad); vt = cm_to_numpy(VT)
+    print(f'bench-like gesvdj sweeps={sw} t={dt*1e3:.2f}ms sabs={np.max(np.abs(s-sref))/sref[0]:.2e} recon={np.abs(U*s@vt-A).max()/np.abs(A).max():.2e} orthU={np.abs(U.T@U-np.eye(256)).max():.2e}')
