@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include "../rlhip.h"
 
 namespace blas {
@@ -61,6 +62,16 @@ public:
     void allreduce_sum(double* buf, int64_t count) { check(rlhip_allreduce_sum_f64(ctx_, buf, count), "allreduce"); }
     void allreduce_sum(float* buf, int64_t count) { check(rlhip_allreduce_sum_f32(ctx_, buf, count), "allreduce"); }
     void allreduce_sum_host(double* x, int64_t n) { check(rlhip_allreduce_sum_host_f64(ctx_, x, n), "allreduce_host"); }
+    // this rank's slice of a row-sharded dimension: (global length, first global row) from the local lengths
+    void shard_extent(int64_t m_local, int64_t& m_global, int64_t& row0) {
+        const int w = world(), r = rank();
+        if (w <= 1) { m_global = m_local; row0 = 0; return; }
+        std::vector<double> len((size_t)w, 0.0);
+        len[(size_t)r] = (double)m_local;
+        allreduce_sum_host(len.data(), w);
+        m_global = 0; row0 = 0;
+        for (int i = 0; i < w; ++i) { if (i < r) row0 += (int64_t)len[(size_t)i]; m_global += (int64_t)len[(size_t)i]; }
+    }
     void* stream() const { return rlhip_stream(ctx_); }
     rlhip_ctx* ctx() const { return ctx_; }
 };

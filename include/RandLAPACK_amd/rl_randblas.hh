@@ -51,6 +51,22 @@ RNGState<RNG> fill_dense(DenseDist const& D, float* buf, RNGState<RNG> const& st
     return next;
 }
 
+// Rows [row0, row0 + loc_rows) of the D.n_rows x D.n_cols operator fill_dense(D, ...) produces, into buf (ld = loc_rows).
+// The returned state is the one the full fill returns.
+template <typename RNG>
+RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, double* buf, RNGState<RNG> const& st, blas::Queue& q) {
+    RNGState<RNG> next = st;
+    blas::check(rlhip_fill_dense_rows_f64(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
+                                          loc_rows, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
+    return next;
+}
+template <typename RNG>
+RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, float* buf, RNGState<RNG> const& st, blas::Queue& q) {
+    RNGState<RNG> next = st;
+    blas::check(rlhip_fill_dense_rows_f32(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
+                                          loc_rows, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
+    return next;
+}
 
 // ---- sparse sketching operator (short-axis-sparse), cf. RandBLAS::SparseDist / SparseSkOp / sketch_general as used at
 //      drivers/rl_cqrrpt.hh:214-222.  n_rows = d (sketch dimension), n_cols = m, vec_nnz nonzeros per column.

@@ -36,8 +36,13 @@ public:
             RandBLAS::DenseDist D(n, k);
             state = RandBLAS::fill_dense(D, Omega, state, q);                                            // :132-135
         } else {
-            RandBLAS::DenseDist D(m, k);
-            state = RandBLAS::fill_dense(D, Omega_1, state, q);                                          // :137-139
+            // row-sharded: every rank regenerates ITS rows of the one global m x k operator, so the result does not
+            // depend on how many ranks hold the matrix
+            int64_t m_glob = m, row0 = 0;
+            q.shard_extent(m, m_glob, row0);
+            RandBLAS::DenseDist D(m_glob, k);
+            if (m_glob == m) state = RandBLAS::fill_dense(D, Omega_1, state, q);                         // :137-139
+            else state = RandBLAS::fill_dense_rows(D, row0, m, Omega_1, state, q);
             blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, n, k, m, T(1), A, m, Omega_1, m, T(0), Omega, n, q);  // :142
             if (q.world() > 1) q.allreduce_sum(Omega, n * k);      // A^T Omega_1 sums over the sharded rows
             ++p_done;

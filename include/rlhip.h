@@ -73,6 +73,14 @@ int rlhip_fill_dense_f64(rlhip_ctx* ctx, int dist, int64_t rows, int64_t cols, d
                          const uint32_t ctr_host[4], const uint32_t key_host[2], uint32_t next_ctr_host[4]);
 int rlhip_fill_dense_f32(rlhip_ctx* ctx, int dist, int64_t rows, int64_t cols, float* buf,
                          const uint32_t ctr_host[4], const uint32_t key_host[2], uint32_t next_ctr_host[4]);
+/* rows [row0, row0 + loc_rows) of the glob_rows x cols operator rlhip_fill_dense_* generates (same stream positions):
+ * a row shard regenerates its slice of the global m x k sketch (odd power-pass counts, rl_rs.hh:137-139, under
+ * row-block sharding); the device counterpart of RandBLAS::fill_dense_unpacked's offsets.  next_ctr advances by the
+ * GLOBAL size, so every rank's state stays identical to the single-device run. */
+int rlhip_fill_dense_rows_f64(rlhip_ctx* ctx, int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows,
+                              double* buf, int64_t ld, const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4]);
+int rlhip_fill_dense_rows_f32(rlhip_ctx* ctx, int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows,
+                              float* buf, int64_t ld, const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4]);
 
 /* ---- BLAS-3 on MFMA.  blas::gemm (rl_rs.hh:142,153,165; rl_rf.hh:123; rl_qb.hh:210-218,260;
  *      rl_rsvd.hh:148), blas::syrk (rl_orth.hh:78; rl_cqrrpt.hh:310; rl_bqrrp.hh:460),

@@ -53,6 +53,7 @@ def _blas3(T):
         "transpose": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
         "gesvdj": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, C.POINTER(c_int)],
         "fill_dense": [c_vp, c_int, c_i64, c_i64, c_vp, u32p, u32p, u32p],
+        "fill_dense_rows": [c_vp, c_int, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, u32p, u32p, u32p],
     }
 
 

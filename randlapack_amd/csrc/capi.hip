@@ -26,6 +26,7 @@ int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
 template <typename T> int ungqr(rlhip_ctx*, int64_t, int64_t, T*, int64_t, const T*);
 template <typename T> int laswp(rlhip_ctx*, int64_t, T*, int64_t, int64_t, int64_t, const int64_t*);
+template <typename T> int fill_dense_rows(rlhip_ctx*, int, int64_t, int64_t, int64_t, int64_t, T*, int64_t, const uint32_t*, const uint32_t*, uint32_t*);
 int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]);
 }
 
@@ -268,6 +269,14 @@ int rlhip_philox4x32_10(rlhip_ctx* c, int64_t nblocks, uint32_t* out_dev, const 
 int rlhip_fill_dense_f64(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, double* buf, const uint32_t ctr[4],
                          const uint32_t key[2], uint32_t next_ctr[4]) {
     return rlhip::fill_dense<double>(c, dist, rows, cols, buf, ctr, key, next_ctr);
+}
+int rlhip_fill_dense_rows_f64(rlhip_ctx* c, int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows, double* buf,
+                              int64_t ld, const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4]) {
+    return rlhip::fill_dense_rows<double>(c, dist, glob_rows, cols, row0, loc_rows, buf, ld, ctr, key, next_ctr);
+}
+int rlhip_fill_dense_rows_f32(rlhip_ctx* c, int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows, float* buf,
+                              int64_t ld, const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4]) {
+    return rlhip::fill_dense_rows<float>(c, dist, glob_rows, cols, row0, loc_rows, buf, ld, ctr, key, next_ctr);
 }
 int rlhip_fill_dense_f32(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, float* buf, const uint32_t ctr[4],
                          const uint32_t key[2], uint32_t next_ctr[4]) {

@@ -86,6 +86,37 @@ __global__ void fill_dense_kernel(int dist, int64_t total, T* __restrict__ buf, 
     }
 }
 
+// Rows [row0, row0 + loc_rows) of the glob_rows x cols matrix that fill_dense_kernel would produce: element (i, j) of
+// the global matrix is stream position i + j*glob_rows, so a row shard regenerates exactly its slice of the global
+// operator (the device counterpart of RandBLAS::fill_dense_unpacked's row/column offsets).
+template <typename T>
+__global__ void fill_dense_rows_kernel(int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows, T* __restrict__ buf,
+                                       int64_t ld, RngState st) {
+    const int64_t total = loc_rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % loc_rows, j = e / loc_rows;
+        const int64_t g = (row0 + i) + j * glob_rows;
+        uint32_t c[4], r[4];
+        ctr_add(st.ctr, (uint64_t)(g >> 2), c);
+        philox4x32_10(c, st.key, r);
+        const int w = (int)(g & 3);
+        double z;
+        if (dist == 0) {
+            const double s32 = 2.3283064365386963e-10;
+            const int h = w >> 1;
+            double u0 = ((double)r[2 * h] + 0.5) * s32;
+            double u1 = ((double)r[2 * h + 1] + 0.5) * s32;
+            double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincospi(2.0 * u0, &sn, &cs);
+            z = (w & 1) ? rad * sn : rad * cs;
+        } else {
+            z = ((double)r[w] + 0.5) * 4.6566128730773926e-10 - 1.0;
+        }
+        buf[i + j * ld] = (T)z;
+    }
+}
+
 __global__ void philox_raw_kernel(int64_t nblk, uint32_t* __restrict__ out, RngState st) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
@@ -118,6 +149,30 @@ int fill_dense(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, T* buf, const
     RLHIP_LAUNCH_CHECK();
     return 0;
 }
+
+template <typename T>
+int fill_dense_rows(rlhip_ctx* c, int dist, int64_t glob_rows, int64_t cols, int64_t row0, int64_t loc_rows, T* buf, int64_t ld,
+                    const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4]) {
+    if (dist != 0 && dist != 1) return -2;
+    if (glob_rows < 0) return -3;
+    if (cols < 0) return -4;
+    if (row0 < 0 || loc_rows < 0 || row0 + loc_rows > glob_rows) return -5;
+    if (ld < (loc_rows > 1 ? loc_rows : 1)) return -8;
+    RngState st;
+    for (int i = 0; i < 4; ++i) st.ctr[i] = ctr[i];
+    st.key[0] = key[0]; st.key[1] = key[1];
+    if (next_ctr) ctr_add(ctr, (uint64_t)((glob_rows * cols + 3) / 4), next_ctr);
+    const int64_t total = loc_rows * cols;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fill_dense_rows_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, c->stream, dist, glob_rows, cols, row0, loc_rows, buf, ld,
+                       st);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int fill_dense_rows<double>(rlhip_ctx*, int, int64_t, int64_t, int64_t, int64_t, double*, int64_t, const uint32_t*, const uint32_t*, uint32_t*);
+template int fill_dense_rows<float>(rlhip_ctx*, int, int64_t, int64_t, int64_t, int64_t, float*, int64_t, const uint32_t*, const uint32_t*, uint32_t*);
 
 int philox_raw(rlhip_ctx* c, int64_t nblk, uint32_t* out_dev, const uint32_t ctr[4], const uint32_t key[2]) {
     if (nblk <= 0) return 0;

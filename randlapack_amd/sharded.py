@@ -33,18 +33,22 @@ def init_comm(ctx, dist, force_hook: bool = False) -> str:
 
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = f"cuda:{ctx.device}"
+    host_pg = dist.get_backend() == "gloo"      # tests: several ranks share one GPU, the exchange runs on the host
+    if host_pg:
+        force_hook = True
+    pg_dev = "cpu" if host_pg else dev
     idbuf = (C.c_ubyte * 128)()
     ok = 1
     if rank == 0:
         ok = int(ctx.lib.rlhip_comm_unique_id(idbuf) == 0)
-    t = torch.tensor([ok] + list(idbuf), dtype=torch.uint8, device=dev)
+    t = torch.tensor([ok] + list(idbuf), dtype=torch.uint8, device=pg_dev)
     dist.broadcast(t, src=0)
     vals = t.cpu().tolist()
     native = 0
     if vals[0] and not force_hook:
         idbuf = (C.c_ubyte * 128)(*vals[1:])
         native = int(ctx.lib.rlhip_comm_init(ctx.h, world, rank, idbuf) == 0)
-    flag = torch.tensor([native], dtype=torch.int32, device=dev)
+    flag = torch.tensor([native], dtype=torch.int32, device=pg_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 1:
         return "rccl"
@@ -59,9 +63,14 @@ def init_comm(ctx, dist, force_hook: bool = False) -> str:
             dt = torch.float64 if is_f64 else torch.float32
             buf = staging.get(dt)
             if buf is None or buf.numel() < count:
-                buf = torch.empty(max(int(count), 1 << 20), dtype=dt, device=dev)
+                buf = torch.empty(max(int(count), 1 << 20), dtype=dt, device=pg_dev)
                 staging[dt] = buf
             nbytes = int(count) * (8 if is_f64 else 4)
+            if host_pg:
+                _lib.check(ctx.lib.rlhip_memcpy_d2h(ctx.h, buf.data_ptr(), dev_ptr, nbytes), "memcpy_d2h")
+                dist.all_reduce(buf[:count])
+                _lib.check(ctx.lib.rlhip_memcpy_h2d(ctx.h, dev_ptr, buf.data_ptr(), nbytes), "memcpy_h2d")
+                return 0
             _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, buf.data_ptr(), dev_ptr, nbytes), "memcpy_d2d")
             ctx.sync()
             dist.all_reduce(buf[:count])

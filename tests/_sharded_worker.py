@@ -1,0 +1,72 @@
+"""Worker for tests/test_gpu_sharded.py: WORLD_SIZE ranks share cuda:0 and run the row-sharded C++ drivers; the
+all-reduce hook exchanges through gloo on the host, so every reduction point of the sharded drivers is exercised
+on a 1-GPU box.  Rank 0 compares with the unsharded device run and the oracle and prints one JSON line."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+
+    from randlapack_amd import device as d
+    from randlapack_amd import sharded
+
+    m, n, k, p = (int(x) for x in sys.argv[1:5])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rng = np.random.default_rng(2024)
+    A = rng.standard_normal((m, n)) @ np.diag(np.linspace(1.0, 0.05, n)) @ np.linalg.qr(rng.standard_normal((n, n)))[0]
+    rows = np.array_split(np.arange(m), world)[rank]
+    ctx = d.Context(0)
+    transport = sharded.init_comm(ctx, dist)
+    assert transport == "torch.distributed"
+    assert ctx.lib.rlhip_comm_size(ctx.h) == world and ctx.lib.rlhip_comm_rank(ctx.h) == rank
+    Aloc = d.cm_from_numpy(np.ascontiguousarray(A[rows]))
+    r = d.drv_rsvd(ctx, Aloc, len(rows), n, k, k, 1e-12, p, 1)
+    Uloc = d.cm_to_numpy(r["U"])
+    # multi-block QB on the shards (b_sz < k exercises the deflation / re-orthogonalisation all-reduces)
+    r2 = d.drv_rsvd(ctx, Aloc, len(rows), n, k, max(k // 4, 1), 1e-12, p, 1)
+    U2loc = d.cm_to_numpy(r2["U"])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc))
+    ctx.lib.rlhip_comm_destroy(ctx.h)
+    if rank == 0:
+        import oracle
+
+        U = np.zeros((m, r["k"])); U2 = np.zeros((m, r2["k"]))
+        for rr, u, u2 in gathered:
+            U[rr] = u; U2[rr] = u2
+        S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
+        S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
+        ctx1 = d.Context(0)
+        r1 = d.drv_rsvd(ctx1, d.cm_from_numpy(A), m, n, k, k, 1e-12, p, 1)
+        S1 = r1["S"].cpu().numpy()
+        ref = oracle.rsvd(A, k, k, 1e-12, p, 1)          # same Philox stream on both sides (oracle/oracle.cpp fill_dense)
+        nA = np.linalg.norm(A)
+        out = dict(
+            k=r["k"], k2=r2["k"], qb_rc=r["qb_rc"], qb_rc2=r2["qb_rc"],
+            S_vs_single=float(np.max(np.abs(S - S1)) / S1[0]),
+            S_vs_oracle=float(np.max(np.abs(S - ref["S"])) / ref["S"][0]),
+            recon=float(np.linalg.norm(A - (U * S) @ V.T) / nA),
+            recon_ref=float(np.linalg.norm(A - (ref["U"] * ref["S"]) @ ref["V"].T) / nA),
+            orthU=float(np.linalg.norm(U.T @ U - np.eye(r["k"]))),
+            orthV=float(np.linalg.norm(V.T @ V - np.eye(r["k"]))),
+            recon2=float(np.linalg.norm(A - (U2 * S2) @ V2.T) / nA),
+            orthU2=float(np.linalg.norm(U2.T @ U2 - np.eye(r2["k"]))),
+        )
+        if os.environ.get("RLHIP_TEST_DEBUG"):
+            print("S", S[:5], "S1", S1[:5], "ref", ref["S"][:5], ref["k"], ref["qb_rc"], file=sys.stderr)
+        print("SHARDED_RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

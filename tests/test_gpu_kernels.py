@@ -509,3 +509,21 @@ def test_larft_and_any_abs_gt(ctx):
     assert ctx.lib.rlhip_any_abs_gt_f64(ctx.h, 1000, x.data_ptr(), EPS, C.byref(flag)) == 0 and flag.value == 0
     x[777] = -3e-16
     assert ctx.lib.rlhip_any_abs_gt_f64(ctx.h, 1000, x.data_ptr(), EPS, C.byref(flag)) == 0 and flag.value == 1
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_fill_dense_rows_is_a_slice_of_the_global_operator(ctx, dist):
+    import ctypes as C
+
+    d = _dev()
+    m, k = 1003, 37
+    full = d.cm_empty(m, k)
+    ctr = (C.c_uint32 * 4)(5, 0, 0, 0); key = (C.c_uint32 * 2)(9, 1); nxt = (C.c_uint32 * 4)()
+    assert ctx.lib.rlhip_fill_dense_f64(ctx.h, dist, m, k, full.data_ptr(), ctr, key, nxt) == 0
+    F = d.cm_to_numpy(full)
+    for row0, rows in [(0, 400), (400, 603), (17, 1), (1002, 1), (0, 1003)]:
+        part = d.cm_empty(rows, k)
+        nxt2 = (C.c_uint32 * 4)()
+        assert ctx.lib.rlhip_fill_dense_rows_f64(ctx.h, dist, m, k, row0, rows, part.data_ptr(), rows, ctr, key, nxt2) == 0
+        np.testing.assert_array_equal(d.cm_to_numpy(part), F[row0:row0 + rows])      # bit-identical
+        assert list(nxt2) == list(nxt)

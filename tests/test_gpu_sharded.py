@@ -1,0 +1,39 @@
+"""-m gpu: the row-sharded C++ drivers with world_size 2 and 3 on ONE GPU (ranks share cuda:0; the library's
+all-reduce hook exchanges over gloo).  This runs the real sharded code path -- every Queue::allreduce_sum in
+CholQRQ / RS / QB / RSVD -- which the round-end 8-GPU bench uses with RCCL as the transport."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,m,n,k,p", [(2, 3001, 256, 32, 0), (3, 2000, 300, 40, 2), (2, 4096, 512, 64, 1)])
+def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_worker.py"), str(m), str(n), str(k), str(p)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("SHARDED_RESULT ")]
+    assert res.returncode == 0 and line, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads(line[-1][len("SHARDED_RESULT "):])
+    assert out["k"] == k and out["k2"] == k
+    assert out["S_vs_single"] <= 1e-12          # same arithmetic up to the order of the cross-rank sums
+    assert out["S_vs_oracle"] <= 1e-10
+    assert out["recon"] <= out["recon_ref"] * (1 + 1e-6) + 1e-12
+    assert out["orthU"] <= 1e-10 and out["orthV"] <= 1e-10
+    assert out["recon2"] <= out["recon_ref"] * 1.5 + 1e-12 and out["orthU2"] <= 1e-9
