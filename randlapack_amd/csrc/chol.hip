@@ -10,6 +10,7 @@
 // the flag and leave the matrix untouched, so the caller gets LAPACK's info and a partially factored
 // matrix, as with dpotrf.
 #include "rlhip_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -88,6 +89,136 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int64_t n, int64_t j0,
 
 __global__ void zero_int_kernel(int* p) { *p = 0; }
 
+// ---- whole factorization in ONE workgroup for n <= 512 (the k x k Gram matrices of CholQR: k = 256 on the RSVD path).
+// The blocked path above costs ~60 us per 32-column panel in launches and barriers (0.5 ms at n = 256, three times per
+// RSVD step, replicated on every rank of a row-sharded run); here a panel is a few microseconds:
+//   * the 32 x 32 diagonal block is factored by ONE wave without workgroup barriers: lane j owns column j in registers,
+//     row k of U travels through LDS once per step;
+//   * the block row U12 = U11^-T A12 is one column per thread (forward substitution from the LDS copy of U11);
+//   * the trailing update A22 -= U12^T U12 reads U12 from LDS (<= 32 x 480 doubles) and touches each upper-triangle
+//     entry of A22 once, 2 x 2 entries per thread per pass.
+constexpr int PS_MAXN = 448;
+constexpr int PS_LD = 34;          // column stride (doubles) of the LDS copy of U12: conflict-free MFMA fragment reads
+
+template <typename T>
+__global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict__ A, int64_t lda, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
+    T* sU11 = reinterpret_cast<T*>(ps_smem);          // [32][33]
+    T* sRow = sU11 + 32 * 33;                          // [32] : row k of the diagonal block during its factorization
+    T* sInv = sRow + 32;                               // [32] : 1 / u_kk
+    T* sU12 = sInv + 32;                               // [rest16][PS_LD] : sU12[c*PS_LD + l] = U12[l, c], zero padded to 16 columns
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int jb = (n - j0 < NB) ? (n - j0) : NB;
+        const int rest = n - j0 - jb;
+        // ---- 1. diagonal block: wave 0, lane j < 32 owns column j (rows 0..j matter).  1/sqrt from the hardware seed +
+        //      Newton, sqrt = d * rsqrt(d) with one correction step; no IEEE divide/sqrt sequences on the serial path.
+        if (wid == 0) {
+            T col[NB];
+            const int j = lane & 31;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) col[i] = (lane < 32 && i < jb && j < jb && i <= j) ? A[(j0 + i) + (int64_t)(j0 + j) * lda] : T(0);
+            int bad = 0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (k < jb && !bad) {
+                    const double ck = (double)col[k];
+                    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ck), k),
+                                                      __builtin_amdgcn_readlane(__double2loint(ck), k));   // pivot a_kk (lane k)
+                    if (!(d > 0.0)) { bad = k + 1; }
+                    else {
+                        double y = __builtin_amdgcn_rsq(d);
+                        y = y * fma(-0.5 * d * y, y, 1.5);
+                        y = y * fma(-0.5 * d * y, y, 1.5);
+                        double r = d * y;
+                        r = fma(0.5 * y, fma(-r, r, d), r);                 // Heron correction: r = sqrt(d) to rounding
+                        const T ukj = (j == k) ? (T)r : (T)((double)col[k] * y);   // row k of U (valid for j >= k)
+                        col[k] = ukj;
+                        if (lane < 32) sRow[j] = (j >= k) ? ukj : T(0);
+                        if (lane == 0) sInv[k] = (T)y;
+                        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the LDS row is written (single wave)
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int i = k + 1; i < NB; ++i) col[i] -= sRow[i] * ukj;   // a_ij -= u_ki u_kj  (i > k, column j)
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            if (bad && lane == 0) s_bad = j0 + bad;
+            if (lane < 32) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    sU11[i * 33 + j] = (i <= j) ? col[i] : T(0);
+                    if (!bad && i < jb && j < jb && i <= j) A[(j0 + i) + (int64_t)(j0 + j) * lda] = col[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (s_bad) break;
+        if (rest <= 0) break;
+        // ---- 2. block row: column c of A12 per thread, solve U11^T x = a
+        for (int c = tid; c < rest; c += 1024) {
+            T x[NB];
+            T* colp = A + j0 + (int64_t)(j0 + jb + c) * lda;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) x[i] = (i < jb) ? colp[i] : T(0);
+            // right-looking substitution: once x[l] is final every later entry is updated independently (ILP, no serial dot)
+#pragma unroll
+            for (int l = 0; l < NB; ++l) {
+                if (l < jb) {
+                    x[l] *= sInv[l];
+#pragma unroll
+                    for (int i = l + 1; i < NB; ++i) x[i] -= sU11[l * 33 + i] * x[l];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i < jb) colp[i] = x[i];
+                sU12[c * PS_LD + i] = x[i];
+            }
+        }
+        for (int e = tid; e < (((rest + 15) / 16) * 16 - rest) * NB; e += 1024)      // zero the padding columns
+            sU12[(rest + e / NB) * PS_LD + (e % NB)] = T(0);
+        __syncthreads();
+        // ---- 3. trailing update on the upper triangle of A22 on the matrix core: 16 x 16 tiles (I <= J), K = 32.
+        //      The operands are swapped (columns of tile J as the MFMA A operand) so that a lane's results run along
+        //      rows of A22 -> 128-byte segments.  sU12's column stride of 34 doubles makes the fragment reads conflict-free.
+        {
+            typedef double d4_t __attribute__((ext_vector_type(4)));
+            const int nt = (rest + 15) / 16;
+            const int ntile = nt * (nt + 1) / 2;
+            const int fr = lane & 15, fk = lane >> 4;
+            T* A22 = A + (j0 + jb) + (int64_t)(j0 + jb) * lda;
+            for (int t = wid; t < ntile; t += 16) {
+                int tj = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while ((tj + 1) * (tj + 2) / 2 <= t) ++tj;
+                while (tj * (tj + 1) / 2 > t) --tj;
+                const int ti = t - tj * (tj + 1) / 2;
+                const int i0 = 16 * ti, c0 = 16 * tj;
+                d4_t acc = {0, 0, 0, 0};
+                const T* pa = sU12 + (c0 + fr) * PS_LD + fk;      // A operand: A[m = fr][k = fk] = U12[l][c0 + m]
+                const T* pb = sU12 + (i0 + fr) * PS_LD + fk;      // B operand: B[k = fk][n = fr] = U12[l][i0 + n]
+#pragma unroll
+                for (int st = 0; st < NB / 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)pa[4 * st], (double)pb[4 * st], acc, 0, 0, 0);
+                // acc[r] = E[row = fk + 4r][col = fr] = D[i0 + fr][c0 + fk + 4r]
+                const int gi = i0 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = c0 + fk + 4 * r;
+                    if (gi < rest && gj < rest && gi <= gj) A22[gi + (int64_t)gj * lda] -= (T)acc[r];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) *info = s_bad;
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -104,6 +235,22 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
     if (lda < (n > 1 ? n : 1)) return -4;
     if (n == 0) return 0;
     int* d_info = (int*)(c->d_mail + 8);
+    static int use_small = -1;
+    if (use_small < 0) { const char* e = getenv("RLHIP_POTRF_SMALL"); use_small = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_small && n <= PS_MAXN) {
+        const size_t smem = (size_t)(32 * 33 + 64 + (size_t)(n + 16) * PS_LD) * sizeof(T);
+        static bool attr_set = false;
+        if (!attr_set) {
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)potrf_small_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, d_info);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        *info_host = *(int*)(c->h_mail + 8);
+        return 0;
+    }
     hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, c->stream, d_info);
     for (int64_t j0 = 0; j0 < n; j0 += NB) {
         int jb = (int)((n - j0 < NB) ? (n - j0) : NB);

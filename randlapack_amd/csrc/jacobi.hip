@@ -125,6 +125,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
     y = fma(fma(-x, y, 1.0), y, y);
     return fma(fma(-x, y, 1.0), y, y);
 }
+__device__ __forceinline__ double rcp1(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ double rsq1(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * fma(-0.5 * x * y, y, 1.5);
@@ -145,16 +153,45 @@ constexpr int JM = 256;           // panel rows (LDS)
 
 // JB = block width (16 or 32), JP = 2*JB = panel width.  Narrow blocks put twice as many workgroups to work per
 // launch and shrink the per-launch pair count 4x; launches per sweep double (measured trade-off in DESIGN.md 4.3).
+//
+// Work assignment inside a round: a column pair is handled by a QUARTER wave (16 lanes, 16 rows per lane as eight
+// 16-byte LDS accesses), four pairs per wavefront.  The rotation parameters are then ordinary per-lane values
+// and the instruction stream (dot products, DPP row-rotate all-reduce, rcp/rsq based rotation, update) is issued once
+// for four pairs.  The earlier one-pair-per-wavefront layout was VALU-issue bound: ~150 instructions per pair with
+// four wavefronts per SIMD = 1.5 us per round; this layout issues ~65 per pair from one or two wavefronts per SIMD.
+__device__ __forceinline__ double dpp_ror_add(double v, const int n) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo2, hi2;
+    switch (n) {   // row_ror:n  (rotate inside each 16-lane row)
+        case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false); break;
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, false); break;
+        case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, false); break;
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false); break;
+    }
+    return v + __hiloint2double(hi2, lo2);
+}
+// every lane of a 16-lane row ends up with the row's sum
+__device__ __forceinline__ double row16_allsum(double v) {
+    v = dpp_ror_add(v, 8);
+    v = dpp_ror_add(v, 4);
+    v = dpp_ror_add(v, 2);
+    return dpp_ror_add(v, 1);
+}
+
 template <typename T, int JB>
 __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
-                                                            int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
-                                                            unsigned* __restrict__ nrot) {
+                                                               int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
+                                                               unsigned* __restrict__ nrot, int dbg) {
     constexpr int JP = 2 * JB;
-    constexpr int HALVES = JB / 16;                    // pairs per round = JB, 16 waves
+    constexpr int NT = 1024;                           // all 16 waves move data; the first 16*JB threads rotate
+    constexpr int NW = NT / 64;
+    constexpr int NROT = 16 * JB;                      // JB pairs per round, 16 lanes each
+    typedef double d2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JM] column-major
     T* Js = Xs + JP * JM;                              // [JP][JP] column-major
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ql = lane & 15;                          // lane inside the quarter
     // block pair of this workgroup (circle method over NB blocks)
     int P, Q;
     {
@@ -166,114 +203,140 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     }
     auto gcol = [&](int c) { return (c < JB) ? (P * JB + c) : (Q * JB + (c - JB)); };   // panel col -> global col
     // ---- load panel (zero padded), J = I
-    for (int e = tid; e < JP * JM; e += 1024) {
+    for (int e = tid; e < JP * JM; e += NT) {
         const int r = e % JM, c = e / JM;
         const int gc = gcol(c);
         Xs[e] = (r < m && gc < n) ? A[r + (int64_t)gc * lda] : T(0);
     }
-    for (int e = tid; e < JP * JP; e += 1024) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
+    for (int e = tid; e < JP * JP; e += NT) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
     __syncthreads();
     unsigned my_rot = 0;
     float my_cos2 = 0.f;                               // largest squared cosine met before rotating (convergence shortcut)
-    const T tol2 = tol * tol;
-    // intra = 1: the 2 x 496 pairs INSIDE the two blocks (31 rounds, 16 pairs per block per round)
-    // intra = 0: the 32 x 32 CROSS pairs between the blocks (32 rounds of 32 pairs): every column pair of the
+    const double tol2 = (double)tol * (double)tol;
+    // intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
+    // intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs): every column pair of the
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
-    const int nrounds = intra ? (JB - 1) : JB;
+    const int nrounds = (dbg & 1) ? 0 : (intra ? (JB - 1) : JB);
+    const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
     for (int round = 0; round < nrounds; ++round) {
+        if (tid >= NROT) { __syncthreads(); continue; }     // wave-uniform: whole wavefronts sit the rounds out
+        int p, q;
+        if (intra) {
+            const int blk = sl / (JB / 2), s16 = sl % (JB / 2);
+            if (s16 == 0) { p = JB - 1; q = round; }
+            else { p = (round + s16) % (JB - 1); q = (round - s16 + (JB - 1)) % (JB - 1); }
+            if (p > q) { int t = p; p = q; q = t; }
+            p += JB * blk; q += JB * blk;
+        } else {
+            p = sl; q = JB + ((sl + round) & (JB - 1));
+        }
+        // rows 2*ql + 32*r, 2*ql + 32*r + 1  (r = 0..7): 16-byte accesses, a quarter wave covers 256 contiguous bytes
+        d2_t* xp = reinterpret_cast<d2_t*>(Xs + p * JM) + ql;
+        d2_t* xq = reinterpret_cast<d2_t*>(Xs + q * JM) + ql;
+        d2_t x[8], y[8];
+        double aa = 0, bb = 0, ab = 0;
 #pragma unroll
-        for (int half = 0; half < HALVES; ++half) {
-            const int sl = wid + 16 * half;            // JB pairs per round, 16 waves
-            int p, q;
-            if (intra) {
-                const int blk = sl / (JB / 2), s16 = sl % (JB / 2);
-                if (s16 == 0) { p = JB - 1; q = round; }
-                else { p = (round + s16) % (JB - 1); q = (round - s16 + (JB - 1)) % (JB - 1); }
-                if (p > q) { int t = p; p = q; q = t; }
-                p += JB * blk; q += JB * blk;
-            } else {
-                p = sl; q = JB + ((sl + round) & (JB - 1));
+        for (int r = 0; r < 8; ++r) {
+            x[r] = xp[16 * r];
+            y[r] = xq[16 * r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            aa = fma(x[r].x, x[r].x, aa); aa = fma(x[r].y, x[r].y, aa);
+            bb = fma(y[r].x, y[r].x, bb); bb = fma(y[r].y, y[r].y, bb);
+            ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab);
+        }
+        aa = row16_allsum(aa);
+        bb = row16_allsum(bb);
+        ab = row16_allsum(ab);
+        const double nn = aa * bb;
+        const bool live = (aa > 0.0) && (bb > 0.0);
+        const bool rot = live && (ab * ab > tol2 * nn);                     // |ab| > tol*||x||*||y||
+        if (live) my_cos2 = fmaxf(my_cos2, (float)(ab * ab * fast_rcp(nn)) * 1.000001f);
+        // t = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)),  d = bb - aa, g = 2ab.  t only has to make the (p,q) inner product small
+        // (one Newton step on the seeds = ~48 bits); cs = rsqrt(1 + t^2) keeps two steps so that cs^2 + sn^2 = 1 to rounding.
+        const double dd = bb - aa, gg = 2.0 * ab;
+        const double h2 = fma(dd, dd, gg * gg);
+        const double h = h2 * rsq1(h2);
+        double tt = gg * rcp1(fabs(dd) + h);
+        tt = (dd < 0.0) ? -tt : tt;
+        tt = rot ? tt : 0.0;                                                // also discards inf/NaN from ab == 0
+        const double cs = fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * tt;
+        if (__builtin_amdgcn_ballot_w64(rot)) {                             // skip the stores when no quarter rotates
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                d2_t xn, yn;
+                xn.x = cs * x[r].x - sn * y[r].x; xn.y = cs * x[r].y - sn * y[r].y;
+                yn.x = sn * x[r].x + cs * y[r].x; yn.y = sn * x[r].y + cs * y[r].y;
+                xp[16 * r] = xn;
+                xq[16 * r] = yn;
             }
-            T* xp = Xs + p * JM;
-            T* xq = Xs + q * JM;
-            T x[4], y[4];
-            T aa = 0, bb = 0, ab = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                x[j] = xp[lane + 64 * j];
-                y[j] = xq[lane + 64 * j];
-                aa += x[j] * x[j]; bb += y[j] * y[j]; ab += x[j] * y[j];
-            }
-            aa = (T)wave_sum_dpp((double)aa);
-            bb = (T)wave_sum_dpp((double)bb);
-            ab = (T)wave_sum_dpp((double)ab);
-            if (aa > T(0) && bb > T(0)) my_cos2 = fmaxf(my_cos2, (float)((double)ab * (double)ab / ((double)aa * (double)bb)) * 1.000001f);
-            if (ab * ab > tol2 * aa * bb && aa > T(0) && bb > T(0)) {      // wave-uniform; |ab| > tol*||x||*||y||
-                const double zeta = (double)(bb - aa) * fast_rcp(2.0 * (double)ab);
-                const double w = fma(zeta, zeta, 1.0);
-                const double den = fabs(zeta) + w * fast_rsqrt(w);
-                const double tt = copysign(fast_rcp(den), zeta);
-                const T cs = (T)fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * (T)tt;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    xp[lane + 64 * j] = cs * x[j] - sn * y[j];
-                    xq[lane + 64 * j] = sn * x[j] + cs * y[j];
-                }
-                if (JP >= 64 || lane < JP) {
-                    const T jp = Js[lane + p * JP], jq = Js[lane + q * JP];
-                    Js[lane + p * JP] = cs * jp - sn * jq;
-                    Js[lane + q * JP] = sn * jp + cs * jq;
-                }
-                ++my_rot;
+            for (int r = 0; r < JP / 16; ++r) {
+                const double jp = Js[ql + 16 * r + p * JP], jq = Js[ql + 16 * r + q * JP];
+                Js[ql + 16 * r + p * JP] = cs * jp - sn * jq;
+                Js[ql + 16 * r + q * JP] = sn * jp + cs * jq;
             }
         }
+        my_rot += (rot && ql == 0) ? 1u : 0u;
         __syncthreads();
     }
-    if (lane == 0 && my_rot) {
-        atomicAdd(nrot, my_rot);
-        atomicMax(nrot + 1, __float_as_uint(my_cos2));   // non-negative floats order like their bit patterns
+    // one atomic pair per wavefront
+    {
+        unsigned r = my_rot;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+        float c2 = my_cos2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
+        if (lane == 0 && r) {
+            atomicAdd(nrot, r);
+            atomicMax(nrot + 1, __float_as_uint(c2));   // non-negative floats order like their bit patterns
+        }
     }
     // ---- write the rotated panel back
-    for (int e = tid; e < JP * JM; e += 1024) {
+    for (int e = tid; e < JP * JM; e += NT) {
         const int r = e % JM, c = e / JM;
         const int gc = gcol(c);
         if (r < m && gc < n) A[r + (int64_t)gc * lda] = Xs[e];
     }
     // ---- V[:, panel] <- V[:, panel] * J on the matrix cores: the panel's LDS is free now, so a 256-row slab of
-    //      V's 64 panel columns is staged there; wave w owns rows 16w..16w+15 of the slab (16 waves = 256
-    //      rows) x all 64 columns = 4 MFMA tiles x 16 k-steps.  Operands are swapped (J as the MFMA A operand)
-    //      so that each lane's results run along rows -> 128-byte store segments.
+    //      V's panel columns is staged there; a wave owns 16-row groups of the slab x all JP columns
+    //      (JP/16 MFMA tiles x JP/4 k-steps each).  Operands are swapped (J as the MFMA A operand) so that each
+    //      lane's results run along rows -> 128-byte store segments.
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int fr = lane & 15, fk = lane >> 4;
-    for (int r0 = 0; r0 < n; r0 += JM) {
+    for (int r0 = 0; r0 < ((dbg & 2) ? 0 : n); r0 += JM) {
         __syncthreads();
-        for (int e = tid; e < JP * JM; e += 1024) {
+        for (int e = tid; e < JP * JM; e += NT) {
             const int r = e % JM, c = e / JM;
             const int gc = gcol(c);
             Xs[e] = (r0 + r < n && gc < n) ? V[(r0 + r) + (int64_t)gc * ldv] : T(0);
         }
         __syncthreads();
         constexpr int NU = JP / 16;
-        d4_t acc[NU];
+        for (int rg = wid; rg < JM / 16; rg += NW) {
+            d4_t acc[NU];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) acc[u] = d4_t{0, 0, 0, 0};
+            for (int u = 0; u < NU; ++u) acc[u] = d4_t{0, 0, 0, 0};
 #pragma unroll 4
-        for (int st = 0; st < JP / 4; ++st) {
-            const double vf = (double)Xs[(16 * wid + fr) + (4 * st + fk) * JM];
+            for (int st = 0; st < JP / 4; ++st) {
+                const double vf = (double)Xs[(16 * rg + fr) + (4 * st + fk) * JM];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const double jf = (double)Js[(4 * st + fk) + (16 * u + fr) * JP];
-                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, vf, acc[u], 0, 0, 0);
+                for (int u = 0; u < NU; ++u) {
+                    const double jf = (double)Js[(4 * st + fk) + (16 * u + fr) * JP];
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(jf, vf, acc[u], 0, 0, 0);
+                }
             }
+            const int row = r0 + 16 * rg + fr;
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gc = gcol(16 * u + fk + 4 * r);
+                    if (row < n && gc < n) V[row + (int64_t)gc * ldv] = (T)acc[u][r];
+                }
         }
-        const int row = r0 + 16 * wid + fr;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gc = gcol(16 * u + fk + 4 * r);
-                if (row < n && gc < n) V[row + (int64_t)gc * ldv] = (T)acc[u][r];
-            }
     }
 }
 
@@ -340,23 +403,26 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
         attr_set = true;
     }
     int sweep = 0;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("RLHIP_JACOBI_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg) max_sweeps = 10;
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
         hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
-                           (int64_t)n, tol, d_nrot);
+                           (int64_t)n, tol, d_nrot, dbg);
         for (int oround = 0; oround < NBk - 1; ++oround)
             hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, oround, 0, A, lda,
-                               V, (int64_t)n, tol, d_nrot);
+                               V, (int64_t)n, tol, d_nrot, dbg);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
         const unsigned nrot = *(unsigned*)(c->h_mail + 16);
         float cos2;
         memcpy(&cos2, (const char*)(c->h_mail + 16) + sizeof(unsigned), sizeof(float));
-        if (nrot == 0) { ++sweep; break; }
+        if (nrot == 0 && !dbg) { ++sweep; break; }
         // quadratic convergence shortcut (cf. DGESVJ's mxaapq test): every cosine met in this sweep was <= 1e-9, so
         // the rotations just applied leave cosines of order n * 1e-18 << tol; a further all-idle sweep would only confirm it
-        if (cos2 <= 1e-18f) { ++sweep; break; }
+        if (cos2 <= 1e-18f && !dbg) { ++sweep; break; }
     }
     *sweeps_out = sweep;
     return 0;
