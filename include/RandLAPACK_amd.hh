@@ -13,3 +13,4 @@
 #include "RandLAPACK_amd/rl_rsvd.hh"
 #include "RandLAPACK_amd/rl_cqrrpt.hh"
 #include "RandLAPACK_amd/rl_bqrrp.hh"
+#include "RandLAPACK_amd/rl_hqrrp.hh"

@@ -10,6 +10,8 @@
 #include "rl_lapackpp.hh"
 #include "rl_randblas.hh"
 #include "rl_util.hh"
+#include "rl_hqrrp.hh"
+#include "rl_bqrrp.hh"
 
 namespace RandLAPACK {
 
@@ -35,6 +37,11 @@ public:
         eps = ep;
         nnz = 2;                       // reference default (rl_cqrrpt.hh constructor)
         qrcp = Subroutines::QRCP::geqp3;
+        bqrrp_block_ratio = 1;         // rl_cqrrpt.hh:59-63
+        nb_alg = 64;
+        oversampling = 10;
+        use_cholqr = 0;
+        panel_pivoting = 1;
         orthogonalization = false;
         rank = 0;
     }
@@ -42,7 +49,7 @@ public:
     /// A (m x n, lda, DEVICE) is overwritten by Q (first `rank` columns orthonormal), R (n x n, ldr, DEVICE) receives
     /// the rank x n upper-trapezoidal factor, J (n, DEVICE int64, 1-based) the pivots.  Return codes as the
     /// reference: 0 ok (also for an all-zero sketch, :256-261), 1 when R_sk has a zero on its diagonal (:296-301).
-    /// SURVEY.md A.6 is the behavioural spec.  Only qrcp == geqp3 (the default) is on the device so far.
+    /// SURVEY.md A.6 is the behavioural spec.  qrcp: geqp3 (default), hqrrp or bqrrp, as in the reference.
     int call(int64_t m, int64_t n, T* A, int64_t lda, T* R, int64_t ldr, int64_t* J, T d_factor,
              RandBLAS::RNGState<RNG>& state) override {
         randlapack_require(m >= 0) << "m=" << m << " must be >= 0";                                      // :161-168
@@ -53,7 +60,6 @@ public:
         randlapack_require(!(A == nullptr && m > 0 && n > 0)) << "A buffer is null but m=" << m << " and n=" << n << " imply a nonempty matrix";
         randlapack_require(!(R == nullptr && n > 0)) << "R buffer is null but n=" << n << " > 0";
         randlapack_require(!(J == nullptr && n > 0)) << "J buffer is null but n=" << n << " > 0";
-        randlapack_require(qrcp == Subroutines::QRCP::geqp3) << "only QRCP::geqp3 is available on the device";
         using clk = std::chrono::steady_clock;
         auto stamp = [&]() { if (timing) q.sync(); return clk::now(); };
         auto t_total0 = stamp();
@@ -83,7 +89,20 @@ public:
         }
         auto t1 = stamp();
         // ---- QRCP of the sketch (:247)
-        lapack::geqp3(d, n, A_hat, d, J, tau, q);
+        if (qrcp == Subroutines::QRCP::hqrrp) {                                                             // :230-231
+            hqrrp(d, n, A_hat, d, J, tau, nb_alg, oversampling, panel_pivoting, use_cholqr, state, q);
+        } else if (qrcp == Subroutines::QRCP::bqrrp) {                                                      // :232-245
+            if (n <= 2000) bqrrp_block_ratio = 1.0;
+            else if (n <= 8000) bqrrp_block_ratio = 0.5;
+            else bqrrp_block_ratio = (T)1 / (T)32;
+            RandLAPACK::BQRRP<T, RNG> bq(q, false, (int64_t)(n * bqrrp_block_ratio));
+            bq.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;      // the reference object's defaults (rl_bqrrp.hh:101-103)
+            bq.qr_tall = BQRRPSubroutines::QRTall::geqrf;
+            bq.apply_trans_q = BQRRPSubroutines::ApplyTransQ::ormqr;
+            bq.call(d, n, A_hat, d, (T)1.0, tau, J, state);
+        } else {
+            lapack::geqp3(d, n, A_hat, d, J, tau, q);
+        }
         auto t2 = stamp();
 
         std::vector<T> diag(n);
@@ -145,6 +164,11 @@ public:
     std::vector<long> times;   // {saso, qrcp, rank_reveal, cholqr, a_mod_piv, a_mod_trsm, rest, total} in microseconds
     int64_t nnz;
     Subroutines::QRCP qrcp;
+    double bqrrp_block_ratio;      // rl_cqrrpt.hh:133-137
+    int64_t nb_alg;
+    int64_t oversampling;
+    int64_t panel_pivoting;
+    int64_t use_cholqr;
     bool orthogonalization;
     // testing hooks (not in the reference): a d x n sketch to use instead of S*A / a buffer receiving the sketch
     const T* sketch_override = nullptr;

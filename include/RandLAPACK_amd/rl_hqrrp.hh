@@ -1,0 +1,120 @@
+// hqrrp (reference: RandLAPACK/drivers/rl_hqrrp.hh:812-1197): Householder QR with randomized pivoting (Martinsson,
+// Quintana-Orti, Heavner, van de Geijn), GEQP3-compatible output: R above the diagonal, Householder vectors below,
+// tau, 1-based jpvt.  Same free-function signature as the reference plus the queue; every buffer is a DEVICE buffer.
+//
+// How the reference's pieces map onto the device:
+//   G = Uniform(-1,1) ((nb+pp) x m), Y = G A                -> fill_dense + MFMA GEMM                       (:929-936)
+//   per block of nb columns (b = actual width):
+//     QRP of the current sketch Y_R, b steps, permutations
+//       carried to A_R and Y_R            (NoFLA_QRPmod_WY_unb_var4 0,1,b :1040-1062)  -> qrp_partial on a copy of Y_R +
+//                                                                                          col_swap of A_R, Y_R, jpvt_R
+//     panel factorization of [A11; A21] + T                   (:1084-1094)
+//       qr_type 0 & panel_pivoting   pivoted Householder QR   -> qrp_partial (all b steps) + col_swap of A01, Y1, jpvt + larft
+//       qr_type 0 | 1, no pivoting   Householder QR           -> geqrf + larft
+//       qr_type 2                    CholQR + orhr_col        -> syrk/potrf/trsm + orhr_col + sign fix (CHOLQR_mod_WY :466-512)
+//     [A12; A22] <- Q^T [A12; A22]   (larfb, :1108-1118)      -> gemqrt (one compact-WY block, MFMA)
+//     Y2 -= (G1 - (G1 U11 + G2 U21) T U11^T) R12 ; G_R <- G_R Q (NoFLA_Downdate_Y :210-295)
+//                                                             -> G_R <- G_R Q first (larfb from the right); the bracket IS
+//                                                                the updated G1, so Y2 -= G1 R12 is one more GEMM.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+#include "rl_exceptions.hh"
+#include "rl_blaspp.hh"
+#include "rl_lapackpp.hh"
+#include "rl_randblas.hh"
+#include "rl_util.hh"
+
+namespace RandLAPACK {
+
+/// returns 0; 1 if a CholQR panel (qr_type == 2) broke down.  `G_export`, when not null, receives the (nb_alg+pp) x m
+/// sketching matrix before it is updated (tests share it with the CPU path, cf. test_bqrrp_gpu.cu:91-110).
+template <typename T, typename RNG>
+int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff_jpvt, T* buff_tau, int64_t nb_alg, int64_t pp,
+              int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, blas::Queue& q, T* G_export = nullptr) {
+    randlapack_require(m_A >= 0) << "hqrrp: m_A is < 0";                                                   // :871-877
+    randlapack_require(n_A >= 0) << "hqrrp: n_A is < 0";
+    randlapack_require(ldim_A >= std::max<int64_t>(1, m_A)) << "hqrrp: ldim_A is < max(1, m_A)";
+    randlapack_require(nb_alg > 0 && pp >= 0) << "hqrrp: nb_alg must be > 0 and pp >= 0";
+    const int64_t mn_A = std::min(m_A, n_A);
+    if (mn_A == 0) return 0;
+    const int64_t m_Y = nb_alg + pp, n_Y = n_A, ldim_Y = m_Y, ldim_V = m_Y, m_G = nb_alg + pp, n_G = m_A, ldim_G = m_G;
+    blas::Scratch ws(q);
+    T* buff_Y = ws.alloc<T>(m_Y * n_Y);
+    T* buff_V = ws.alloc<T>(m_Y * n_Y);
+    T* buff_G = ws.alloc<T>(m_G * n_G);
+    T* T1 = ws.alloc<T>(nb_alg * nb_alg);
+    T* buff_R = ws.alloc<T>(nb_alg * nb_alg);
+    T* buff_D = ws.alloc<T>(nb_alg);
+    T* tau_scr = ws.alloc<T>(n_A);
+    int64_t* Jloc = ws.alloc<int64_t>(n_A);
+    {   // jpvt = 1..n  (:921)
+        std::vector<int64_t> iota_((size_t)n_A);
+        for (int64_t i = 0; i < n_A; ++i) iota_[(size_t)i] = i + 1;
+        blas::copy_to_device(n_A, iota_.data(), buff_jpvt, q);
+    }
+    RandBLAS::DenseDist D(nb_alg + pp, m_A, RandBLAS::ScalarDist::Uniform);                                 // :929-930
+    state = RandBLAS::fill_dense(D, buff_G, state, q);
+    if (G_export) blas::device_copy_vector(m_G * n_G, buff_G, G_export, q);
+    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n_Y, m_A, (T)1, buff_G, ldim_G, buff_A, ldim_A, (T)0, buff_Y, ldim_Y, q);
+
+    for (int64_t j = 0; j < mn_A; j += nb_alg) {
+        const int64_t b = std::min(nb_alg, std::min(n_A - j, m_A - j));
+        const bool last_iter = (j + nb_alg >= m_A) || (j + nb_alg >= n_A);
+        const int64_t n_VR = n_A - j;
+        T* buff_VR = &buff_V[j * ldim_V];
+        T* buff_YR = &buff_Y[j * ldim_Y];
+        int64_t* buff_pB = &buff_jpvt[j];
+        T* buff_sB = &buff_tau[j];
+        T* buff_AR = &buff_A[j * ldim_A];
+        const int64_t m_AB1 = m_A - j;
+        T* buff_AB1 = &buff_A[j + j * ldim_A];
+        T* buff_A01 = &buff_A[j * ldim_A];
+        T* buff_Y1 = &buff_Y[j * ldim_Y];
+        T* buff_A12 = &buff_A[j + std::min(n_A - 1, j + b) * ldim_A];
+        const int64_t n_A12 = std::max<int64_t>(0, n_A - j - b);
+        T* buff_Y2 = &buff_Y[std::min(n_Y - 1, j + b) * ldim_Y];
+        T* buff_G1 = &buff_G[j * ldim_G];
+
+        if (!last_iter) {                                                                                   // :1040-1062
+            lapack::lacpy(MatrixType::General, m_Y, n_VR, buff_YR, ldim_Y, buff_VR, ldim_V, q);
+            lapack::qrp_partial(m_Y, n_VR, b, buff_VR, ldim_V, Jloc, tau_scr, q);
+            util::col_swap(m_A, n_VR, n_VR, buff_AR, ldim_A, Jloc, q);
+            util::col_swap(m_Y, n_VR, n_VR, buff_YR, ldim_Y, Jloc, q);
+            util::col_swap(n_VR, n_VR, buff_pB, Jloc, q);
+        }
+        // ---- panel [A11; A21] (m_AB1 x b) and its T                                                       :1084-1094
+        if (qr_type == 2 && !panel_pivoting) {                                                              // CHOLQR_mod_WY
+            lapack::laset(MatrixType::General, nb_alg, nb_alg, (T)0, (T)0, buff_R, nb_alg, q);
+            blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, b, m_AB1, (T)1, buff_AB1, ldim_A, (T)0, buff_R, nb_alg, q);
+            if (lapack::potrf(Uplo::Upper, b, buff_R, nb_alg, q)) return 1;
+            blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m_AB1, b, (T)1, buff_R, nb_alg, buff_AB1, ldim_A, q);
+            lapack::orhr_col(m_AB1, b, b, buff_AB1, ldim_A, T1, nb_alg, buff_D, q);
+            lapack::row_sign(b, buff_R, nb_alg, buff_D, q);
+            lapack::lacpy(MatrixType::Upper, b, b, buff_R, nb_alg, buff_AB1, ldim_A, q);
+            lapack::tau_from_t(b, b, T1, nb_alg, buff_sB, q);
+        } else if (panel_pivoting) {
+            lapack::qrp_partial(m_AB1, b, std::min(m_AB1, b), buff_AB1, ldim_A, Jloc, buff_sB, q);
+            if (j > 0) util::col_swap(j, b, b, buff_A01, ldim_A, Jloc, q);
+            util::col_swap(m_Y, b, b, buff_Y1, ldim_Y, Jloc, q);
+            util::col_swap(b, b, buff_pB, Jloc, q);
+            lapack::larft(m_AB1, std::min(m_AB1, b), buff_AB1, ldim_A, buff_sB, T1, nb_alg, q);
+        } else {                                                                                            // GEQRF_mod_WY / unpivoted var4
+            lapack::geqrf(m_AB1, b, buff_AB1, ldim_A, buff_sB, q);
+            lapack::larft(m_AB1, std::min(m_AB1, b), buff_AB1, ldim_A, buff_sB, T1, nb_alg, q);
+        }
+        const int64_t kref = std::min(m_AB1, b);
+        if (j + b < n_A)                                                                                    // :1108-1118
+            lapack::gemqrt(Side::Left, Op::Trans, m_AB1, n_A12, kref, kref, buff_AB1, ldim_A, T1, nb_alg, buff_A12, ldim_A, q);
+        if (!last_iter) {                                                                                   // :1135-1145
+            lapack::gemqrt(Side::Right, Op::NoTrans, m_G, n_G - j, kref, kref, buff_AB1, ldim_A, T1, nb_alg, buff_G1, ldim_G, q);
+            const int64_t n_Y2 = std::max<int64_t>(0, n_Y - j - b);
+            if (n_Y2 > 0)
+                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n_Y2, b, (T)-1, buff_G1, ldim_G, buff_A12, ldim_A, (T)1, buff_Y2, ldim_Y, q);
+        }
+    }
+    return 0;
+}
+
+}  // namespace RandLAPACK

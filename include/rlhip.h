@@ -214,6 +214,13 @@ int rlhip_gemqrt_f64(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n
                      int64_t ldv, const double* T, int64_t ldt, double* C, int64_t ldc);
 int rlhip_gemqrt_f32(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const float* V,
                      int64_t ldv, const float* T, int64_t ldt, float* C, int64_t ldc);
+/* (side = 'R', trans = 'N', nb >= k): C (m x n) <- C (I - V T V^T), V n x k -- lapack::larfb(Right, NoTrans, Forward, Columnwise) as
+ * used by HQRRP to carry the sketching matrix along (NoFLA_Apply_Q_WY_rnfc_blk_var4, rl_hqrrp.hh:178-206).
+ * rlhip_qrp_partial_*: pivoted Householder QR of the first `steps` columns only, HQRRP's norm down-date form
+ * (NoFLA_QRPmod_WY_unb_var4 with pivoting = 1, num_stages = steps; rl_hqrrp.hh:516-770); jpvt (device, n, 1-based on exit)
+ * is the complete permutation produced by the swaps. */
+int rlhip_qrp_partial_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau);
+int rlhip_qrp_partial_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau);
 /* lapack::larft(Forward, Columnwise): T (k x k) from V (m x k) and tau (k) */
 int rlhip_larft_f64(rlhip_ctx* ctx, int64_t m, int64_t k, const double* V, int64_t ldv, const double* tau, double* T, int64_t ldt);
 int rlhip_larft_f32(rlhip_ctx* ctx, int64_t m, int64_t k, const float* V, int64_t ldv, const float* tau, float* T, int64_t ldt);

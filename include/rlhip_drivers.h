@@ -38,14 +38,21 @@ int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t*
                        int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** U,
                        double** S, double** V, uint32_t state[6], int* qb_ret);
 
-/* CQRRPT<double>::call with qrcp = geqp3.  A (m x n, lda) -> Q; R (n x n, ldr); J (n, device int64).  If A_hat_in
+/* CQRRPT<double>::call; qrcp {0 hqrrp, 1 bqrrp, 2 geqp3} in the reference's enum order (rl_cqrrpt.hh:41), -1 = default (geqp3).  A (m x n, lda) -> Q; R (n x n, ldr); J (n, device int64).  If A_hat_in
  * is non-NULL it is used as the d x n sketch (ld d) instead of generating a SASO (parity tests share one sketch
  * between this path and the oracle, like test/drivers/test_bqrrp_gpu.cu:91-110); if A_hat_out is non-NULL the
  * sketch that was factored is copied there BEFORE geqp3.  *rank_out = CQRRPT::rank; times_us[8] may be NULL.
  *                                                                         drivers/rl_cqrrpt.hh:147-391 */
 int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr,
                          int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
-                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us);
+                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us, int qrcp);
+
+/* hqrrp (drivers/rl_hqrrp.hh:812): GEQP3-format Householder QR with randomized pivoting.  qr_type 0 Householder panel
+ * (pivoted inside the panel when panel_pivoting != 0), 1 geqrf, 2 CholQR (2 needs panel_pivoting == 0, as in the
+ * reference's dispatch :587-591).  G_out (may be NULL): receives the (nb_alg+pp) x m Uniform(-1,1) sketching matrix.
+ * Returns 0, or 1 if a CholQR panel broke down. */
+int rlhip_drv_hqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg,
+                        int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double* G_out);
 
 /* BQRRP<double>::call.  qrcp_wide {0 luqr, 1 geqp3}, qr_tall {0 geqrt, 1 cholqr, 2 geqrf}, apply_trans_q {0 ormqr, 1 gemqrt}
  * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default.  A (m x n, lda) -> GEQP3

@@ -224,8 +224,9 @@ def rsvd(A, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb_orth=0, orth_check=Fals
                 next_ctr=tuple(int(x) for x in st[:4]))
 
 
-def cqrrpt(A, A_hat, eps_user):
-    """A (m x n) and the precomputed sketch A_hat (d x n).  returns dict(rc, rank, Q, R, J)"""
+def cqrrpt(A, A_hat, eps_user, qrcp=2, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """A (m x n) and the precomputed sketch A_hat (d x n).  qrcp: 0 hqrrp, 1 bqrrp, 2 geqp3 (the reference's enum order,
+    rl_cqrrpt.hh:41); (ctr, key) seeds the inner randomized QRCP.  returns dict(rc, rank, Q, R, J)"""
     lib = load()
     A = _f(A).copy(order="F")
     A_hat = _f(A_hat).copy(order="F")
@@ -234,8 +235,9 @@ def cqrrpt(A, A_hat, eps_user):
     R = np.zeros((n, n), order="F")
     J = np.zeros(n, dtype=np.int64)
     rank = i64(0)
+    st = _state(ctr, key)
     rc = lib.oracle_cqrrpt_f64(i64(m), i64(n), _p(A), i64(m), _p(R), i64(n), _p(J), i64(d), _p(A_hat), dbl(eps_user),
-                               C.byref(rank))
+                               C.byref(rank), C.c_int(qrcp), _p(st))
     return dict(rc=rc, rank=int(rank.value), Q=A, R=R, J=J)
 
 
@@ -299,3 +301,19 @@ def lapack_orhr_col(Q, nb):
     D = np.zeros(n)
     info = lib.oracle_orhr_col_f64(i64(m), i64(n), i64(nb), _p(A), i64(m), _p(T), i64(nb), _p(D))
     return info, A, T, D
+
+
+def hqrrp(A, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), G=None):
+    """hqrrp (drivers/rl_hqrrp.hh:812).  qr_type 0 unblocked Householder (pivoted inside the panel when panel_pivoting),
+    1 geqrf, 2 CholQR (both without panel pivoting).  G: optional (nb_alg+pp) x m sketching matrix to use instead of the
+    oracle's own Uniform(-1,1) stream.  returns dict(rc, A (GEQP3 format), tau, J, next_ctr)"""
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    tau = np.zeros(min(m, n))
+    J = np.zeros(n, dtype=np.int64)
+    st = _state(ctr, key)
+    Gf = None if G is None else _f(G).copy(order="F")
+    rc = lib.oracle_hqrrp_f64(i64(m), i64(n), _p(A), i64(m), _p(J), _p(tau), i64(nb_alg), i64(pp), i64(panel_pivoting), i64(qr_type),
+                              _p(st), _p(Gf) if Gf is not None else None)
+    return dict(rc=rc, A=A, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))

@@ -45,7 +45,10 @@ const char* lapack_open(const char* path) {
               bind(h, prefix, "dlange_", L.dlange) && bind(h, prefix, "dlacpy_", L.dlacpy) &&
               bind(h, prefix, "dlaset_", L.dlaset) && bind(h, prefix, "dlapmt_", L.dlapmt) &&
               bind(h, prefix, "dorhr_col_", L.dorhr_col) && bind(h, prefix, "dgeqrt_", L.dgeqrt) &&
-              bind(h, prefix, "dgemqrt_", L.dgemqrt);
+              bind(h, prefix, "dgemqrt_", L.dgemqrt) && bind(h, prefix, "dlarfg_", L.dlarfg) &&
+              bind(h, prefix, "dlarf_", L.dlarf) && bind(h, prefix, "dlarfb_", L.dlarfb) &&
+              bind(h, prefix, "dlarft_", L.dlarft) && bind(h, prefix, "dnrm2_", L.dnrm2) &&
+              bind(h, prefix, "idamax_", L.idamax) && bind(h, prefix, "dswap_", L.dswap);
     if (!ok) {
         dlclose(h);
         return g_err;

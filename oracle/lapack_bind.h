@@ -53,6 +53,17 @@ struct Lapack {
                    lint*);
     void (*dgemqrt)(const char*, const char*, const lint*, const lint*, const lint*, const lint*, const double*,
                     const lint*, const double*, const lint*, double*, const lint*, double*, lint*, size_t, size_t);
+    void (*dlarfg)(const lint*, double*, double*, const lint*, double*);
+    void (*dlarf)(const char*, const lint*, const lint*, const double*, const lint*, const double*, double*, const lint*,
+                  double*, size_t);
+    void (*dlarfb)(const char*, const char*, const char*, const char*, const lint*, const lint*, const lint*, const double*,
+                   const lint*, const double*, const lint*, double*, const lint*, double*, const lint*, size_t, size_t, size_t,
+                   size_t);
+    void (*dlarft)(const char*, const char*, const lint*, const lint*, const double*, const lint*, const double*, double*,
+                   const lint*, size_t, size_t);
+    double (*dnrm2)(const lint*, const double*, const lint*);
+    lint (*idamax)(const lint*, const double*, const lint*);
+    void (*dswap)(const lint*, double*, const lint*, double*, const lint*);
     void (*set_threads)(int);
     int (*get_threads)(void);
 };

@@ -570,6 +570,192 @@ int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, in
 // =====================================================================================================
 // extern "C" surface for ctypes (tests / smoke / cpu_baseline only)
 // =====================================================================================================
+
+// =====================================================================================================================
+// HQRRP (drivers/rl_hqrrp.hh): Householder QR with randomized pivoting, GEQP3-compatible output.  Restated routine by
+// routine; the LAPACK calls are the ones the reference makes (larfg, larf, larfb, larft, nrm2, iamax, swap).
+// =====================================================================================================================
+namespace hq {
+
+// NoFLA_QRP_downdate_partial_norms (rl_hqrrp.hh:349-396): Drmac-style down-date, (1+t)(1-t) form
+void downdate_partial_norms(int64_t m_A, int64_t n_A, double* d, double* e, const double* wt, int64_t st_wt, const double* A,
+                            int64_t ldim_A) {
+    const double tol3z = std::sqrt(std::numeric_limits<double>::epsilon() * 0.5);   // dlamch('E') = eps/2 (relative machine eps)
+    lint one = 1;
+    for (int64_t j = 0; j < n_A; ++j) {
+        if (d[j] != 0.0) {
+            double temp = std::abs(wt[j * st_wt]) / d[j];
+            temp = std::max(0.0, (1.0 + temp) * (1 - temp));
+            const double temp5 = d[j] / e[j];
+            const double temp2 = temp * temp5 * temp5;
+            if (temp2 <= tol3z) {
+                if (m_A > 0) {
+                    lint mm = (lint)m_A;
+                    d[j] = lapack().dnrm2(&mm, A + j * ldim_A, &one);
+                    e[j] = d[j];
+                } else { d[j] = 0.0; e[j] = 0.0; }
+            } else {
+                d[j] = d[j] * std::sqrt(temp);
+            }
+        }
+    }
+}
+
+// CHOLQR_mod_WY (:466-512)
+int cholqr_mod_wy(int64_t m_A, int64_t n_A, double* A, int64_t ldA, double* t, double* T, int64_t ldT, double* R, int64_t ldR,
+                  double* D) {
+    syrk_upper_trans(n_A, m_A, 1.0, A, ldA, 0.0, R, ldR);
+    if (potrf_upper(n_A, R, ldR)) return 1;
+    trsm_right_upper(m_A, n_A, 1.0, R, ldR, A, ldA);
+    lint mm = (lint)m_A, nn = (lint)n_A, nb = (lint)n_A, lda = (lint)ldA, ldt = (lint)ldT, info = 0;
+    lapack().dorhr_col(&mm, &nn, &nb, A, &lda, T, &ldt, D, &info);
+    for (int64_t i = 0; i < n_A; ++i)
+        for (int64_t j = 0; j < i + 1; ++j) R[ldR * i + j] *= D[j];
+    lacpy('U', n_A, n_A, R, ldR, A, ldA);
+    for (int64_t i = 0; i < n_A; ++i) t[i] = T[(ldT + 1) * i];
+    return 0;
+}
+
+// GEQRF_mod_WY (:431-462)
+int geqrf_mod_wy(int64_t num_stages, int64_t m_A, int64_t n_A, double* A, int64_t ldA, double* t, double* T, int64_t ldT) {
+    if (num_stages < 0) num_stages = std::min(m_A, n_A);
+    geqrf(m_A, n_A, A, ldA, t);
+    lint mm = (lint)m_A, ks = (lint)num_stages, lda = (lint)ldA, ldt = (lint)ldT;
+    lapack().dlarft("F", "C", &mm, &ks, A, &lda, t, T, &ldt, 1, 1);
+    return 0;
+}
+
+// NoFLA_QRPmod_WY_unb_var4 (:516-770)
+int qrpmod_wy_unb_var4(int qr_type, int pivoting, int64_t num_stages, int64_t m_A, int64_t n_A, double* A, int64_t ldA,
+                       int64_t* p, double* t, int pivot_B, int64_t m_B, double* B, int64_t ldB, int pivot_C, int64_t m_C,
+                       double* Cm, int64_t ldC, int build_T, double* T, int64_t ldT, double* R, int64_t ldR, double* D) {
+    if (!pivoting && qr_type == 1) return geqrf_mod_wy(num_stages, m_A, n_A, A, ldA, t, T, ldT);
+    if (!pivoting && qr_type == 2) return cholqr_mod_wy(m_A, n_A, A, ldA, t, T, ldT, R, ldR, D);
+    const int64_t mn_A = std::min(m_A, n_A);
+    if (num_stages < 0) num_stages = mn_A;
+    std::vector<double> d(n_A, 0.0), e(n_A, 0.0), work(std::max<int64_t>(n_A, 1), 0.0);
+    lint one = 1;
+    if (pivoting == 1) {                                                                   // NoFLA_QRP_compute_norms
+        lint mm = (lint)m_A;
+        for (int64_t j = 0; j < n_A; ++j) { d[j] = lapack().dnrm2(&mm, A + j * ldA, &one); e[j] = d[j]; }
+    }
+    for (int64_t j = 0; j < num_stages; ++j) {
+        const int64_t n_dB = n_A - j, m_a21 = m_A - j - 1, m_A22 = m_A - j - 1, n_A22 = n_A - j - 1;
+        if (pivoting == 1) {
+            lint nn = (lint)n_dB;
+            const int64_t jmax = (int64_t)lapack().idamax(&nn, d.data() + j, &one) - 1;     // first maximum
+            if (jmax != 0) {                                                               // NoFLA_QRP_pivot_G_B_C
+                lint mA = (lint)m_A, mB = (lint)m_B, mC = (lint)m_C;
+                lapack().dswap(&mA, A + j * ldA, &one, A + (j + jmax) * ldA, &one);
+                if (pivot_B) lapack().dswap(&mB, B + j * ldB, &one, B + (j + jmax) * ldB, &one);
+                if (pivot_C) lapack().dswap(&mC, Cm + j * ldC, &one, Cm + (j + jmax) * ldC, &one);
+                std::swap(p[j + jmax], p[j]);
+                d[j + jmax] = d[j];
+                e[j + jmax] = e[j];
+            }
+        }
+        lint nh = (lint)(m_a21 + 1);
+        lapack().dlarfg(&nh, &A[j + j * ldA], &A[std::min(m_A - 1, j + 1) + j * ldA], &one, &t[j]);
+        const double diag = A[j + j * ldA];
+        A[j + j * ldA] = 1.0;
+        lint mrest = (lint)(m_A22 + 1), n22 = (lint)n_A22, lda = (lint)ldA;
+        if (n_A22 > 0) lapack().dlarf("L", &mrest, &n22, &A[j + j * ldA], &one, &t[j], &A[j + (j + 1) * ldA], &lda, work.data(), 1);
+        A[j + j * ldA] = diag;
+        if (pivoting == 1 && n_A22 > 0)
+            downdate_partial_norms(m_A22, n_A22, d.data() + j + 1, e.data() + j + 1, &A[j + (j + 1) * ldA], ldA,
+                                   &A[(j + 1) + std::min(n_A - 1, j + 1) * ldA], ldA);
+    }
+    if (build_T) {
+        lint mm = (lint)m_A, ks = (lint)num_stages, lda = (lint)ldA, ldt = (lint)ldT;
+        lapack().dlarft("F", "C", &mm, &ks, A, &lda, t, T, &ldt, 1, 1);
+    }
+    return 0;
+}
+
+void larfb(char side, char trans, int64_t m, int64_t n, int64_t k, const double* V, int64_t ldv, const double* T, int64_t ldt,
+           double* Cm, int64_t ldc) {
+    std::vector<double> W((size_t)std::max<int64_t>(1, (side == 'L' ? n : m) * k), 0.0);
+    lint mm = (lint)m, nn = (lint)n, kk = (lint)k, lv = (lint)ldv, lt = (lint)ldt, lc = (lint)ldc,
+         lw = (lint)std::max<int64_t>(1, side == 'L' ? n : m);
+    lapack().dlarfb(&side, &trans, "F", "C", &mm, &nn, &kk, V, &lv, T, &lt, Cm, &lc, W.data(), &lw, 1, 1, 1, 1);
+}
+
+// NoFLA_Downdate_Y (:210-295):  Y2 -= (G1 - (G1 U11 + G2 U21) T11 U11^T) R12 ;  GR = GR Q
+void downdate_Y(int64_t n_U11, const double* U11, int64_t ldU11, int64_t m_U21, const double* U21, int64_t ldU21, int64_t m_A12,
+                const double* A12, int64_t ldA12, const double* T, int64_t ldT, int64_t m_Y2, int64_t n_Y2, double* Y2,
+                int64_t ldY2, int64_t m_G1, int64_t n_G1, double* G1, int64_t ldG1, int64_t n_G2, double* G2, int64_t ldG2) {
+    const int64_t m_B = m_G1, n_B = n_G1, ldB = m_G1;
+    std::vector<double> B((size_t)std::max<int64_t>(1, m_B * n_B), 0.0);
+    lacpy('A', m_G1, n_G1, G1, ldG1, B.data(), ldB);
+    lint mb = (lint)m_B, nb = (lint)n_B, lu = (lint)ldU11, lb = (lint)ldB, lt = (lint)ldT;
+    const double one = 1.0, mone = -1.0;
+    lapack().dtrmm("R", "L", "N", "U", &mb, &nb, &one, U11, &lu, B.data(), &lb, 1, 1, 1, 1);
+    if (m_U21 > 0) gemm('N', 'N', m_B, n_B, m_U21, 1.0, G2, ldG2, U21, ldU21, 1.0, B.data(), ldB);
+    lapack().dtrmm("R", "U", "N", "N", &mb, &nb, &one, T, &lt, B.data(), &lb, 1, 1, 1, 1);
+    lapack().dtrmm("R", "L", "C", "U", &mb, &nb, &mone, U11, &lu, B.data(), &lb, 1, 1, 1, 1);
+    for (int64_t j = 0; j < n_B; ++j)
+        for (int64_t i = 0; i < m_B; ++i) B[i + j * ldB] += G1[i + j * ldG1];
+    if (n_Y2 > 0) gemm('N', 'N', m_Y2, n_Y2, m_A12, -1.0, B.data(), ldB, A12, ldA12, 1.0, Y2, ldY2);
+    larfb('R', 'N', m_G1, n_G1 + n_G2, n_U11, U11, ldU11, T, ldT, G1, ldG1);                // NoFLA_Apply_Q_WY_rnfc_blk_var4
+    (void)G2;
+}
+
+}  // namespace hq
+
+// hqrrp (rl_hqrrp.hh:812-1197).  qr_type: 0 unblocked (pivoted panel if panel_pivoting), 1 geqrf, 2 CholQR; the sketch
+// G (nb_alg+pp x m, Uniform(-1,1)) comes from the oracle's own stream unless Y_in (the (nb_alg+pp) x n product G*A) AND G_in
+// are supplied (shared-sketch parity with the device path).
+int hqrrp_call(int64_t m_A, int64_t n_A, double* A, int64_t ldA, int64_t* jpvt, double* tau, int64_t nb_alg, int64_t pp,
+               int64_t panel_pivoting, int64_t qr_type, RNGState& st, const double* G_in) {
+    const int64_t mn_A = std::min(m_A, n_A);
+    if (mn_A == 0) return 0;
+    const int64_t m_Y = nb_alg + pp, n_Y = n_A, ldY = m_Y, m_V = nb_alg + pp, n_V = n_A, ldV = m_V, m_W = nb_alg, ldW = m_W,
+                  m_G = nb_alg + pp, n_G = m_A, ldG = m_G, ldR = nb_alg;
+    std::vector<double> Y((size_t)m_Y * n_Y, 0.0), V((size_t)m_V * n_V, 0.0), W((size_t)m_W * n_A, 0.0), G((size_t)m_G * n_G, 0.0),
+        R((size_t)nb_alg * nb_alg, 0.0), D(nb_alg, 0.0);
+    for (int64_t i = 0; i < n_A; ++i) jpvt[i] = i + 1;                                       // :921
+    if (G_in) { std::copy(G_in, G_in + (size_t)m_G * n_G, G.begin()); RNGState tmp = st; std::vector<double> scratch((size_t)m_G * n_G); fill_dense(1, m_G, n_G, scratch.data(), tmp); st = tmp; }
+    else fill_dense(1, m_G, n_G, G.data(), st);                                             // Uniform(-1,1)  :929-930
+    gemm('N', 'N', m_Y, n_Y, m_A, 1.0, G.data(), ldG, A, ldA, 0.0, Y.data(), ldY);           // :932-936
+    for (int64_t j = 0; j < mn_A; j += nb_alg) {
+        const int64_t b = std::min(nb_alg, std::min(n_A - j, m_A - j));
+        const int last_iter = ((j + nb_alg >= m_A) || (j + nb_alg >= n_A)) ? 1 : 0;
+        const int64_t n_VR = n_V - j;
+        double* VR = &V[0 + j * ldV];
+        double* YR = &Y[0 + j * ldY];
+        int64_t* pB = &jpvt[j];
+        double* sB = &tau[j];
+        double* AR = &A[0 + j * ldA];
+        const int64_t m_AB1 = m_A - j, n_AB1 = b;
+        double* AB1 = &A[j + j * ldA];
+        double* A01 = &A[0 + j * ldA];
+        double* Y1 = &Y[0 + j * ldY];
+        double* T1_T = &W[0 + j * ldW];
+        double* A11 = &A[j + j * ldA];
+        const int64_t n_A11 = b;
+        double* A21 = &A[std::min(m_A - 1, j + nb_alg) + j * ldA];
+        const int64_t m_A21 = std::max<int64_t>(0, m_A - j - b);
+        double* A12 = &A[j + std::min(n_A - 1, j + b) * ldA];
+        const int64_t m_A12 = b, n_A12 = std::max<int64_t>(0, n_A - j - b), m_A22 = std::max<int64_t>(0, m_A - j - b);
+        double* Y2 = &Y[0 + std::min(n_Y - 1, j + b) * ldY];
+        double* G1 = &G[0 + j * ldG];
+        double* G2 = &G[0 + std::min(n_G - 1, j + b) * ldG];
+        if (!last_iter) {                                                                   // :1040-1062
+            lacpy('A', m_V, n_VR, YR, ldY, VR, ldV);
+            hq::qrpmod_wy_unb_var4(0, 1, b, m_V, n_VR, VR, ldV, pB, sB, 1, m_A, AR, ldA, 1, m_Y, YR, ldY, 0, nullptr, 0, nullptr, 0,
+                                   nullptr);
+        }
+        hq::qrpmod_wy_unb_var4((int)qr_type, (int)panel_pivoting, -1, m_AB1, n_AB1, AB1, ldA, pB, sB, 1, j, A01, ldA, 1, m_Y, Y1, ldY,
+                               1, T1_T, ldW, R.data(), ldR, D.data());                      // :1084-1094
+        if ((j + b) < n_A)                                                                  // :1108-1118
+            hq::larfb('L', 'T', m_A12 + m_A22, n_A12, n_A11, A11, ldA, T1_T, ldW, A12, ldA);
+        if (!last_iter)                                                                     // :1135-1145
+            hq::downdate_Y(n_A11, A11, ldA, m_A21, A21, ldA, m_A12, A12, ldA, T1_T, ldW, m_Y, std::max<int64_t>(0, n_Y - j - b), Y2, ldY,
+                           m_G, b, G1, ldG, std::max<int64_t>(0, n_G - j - b), G2, ldG);
+    }
+    return 0;
+}
+
 extern "C" {
 
 const char* oracle_init(const char* lapack_path) { return orc::lapack_open(lapack_path); }
@@ -684,14 +870,27 @@ int oracle_rsvd_f64(int64_t m, int64_t n, const double* A, int64_t* k, int64_t b
 // same precomputed sketch.  A (m x n, lda) -> Q in place; R (n x n, ldr); J (n, zero-initialised on entry).
 // eps_user = CQRRPT::eps member (:20-143).  *rank_out = CQRRPT::rank.
 int oracle_cqrrpt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr, int64_t* J, int64_t d,
-                      double* A_hat, double eps_user, int64_t* rank_out) {
+                      double* A_hat, double eps_user, int64_t* rank_out, int qrcp, uint32_t state[6]) {
     if (m < 0 || n < 0 || lda < m || ldr < n) return -1;                                      // :161-168
     int64_t k = n;
     const double eps_mach = std::numeric_limits<double>::epsilon();
     const double eps_initial = 2 * std::pow(eps_mach, 0.95);                                  // :200
     std::vector<double> tau(n, 0.0);
     std::vector<int64_t> J_buf(n, 0);
-    geqp3(d, n, A_hat, d, J, tau.data());                                                     // :247
+    if (qrcp == 0) {                                                                          // QRCP::hqrrp :230-231 (defaults :60-63)
+        RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+        hqrrp_call(d, n, A_hat, d, J, tau.data(), 64, 10, 1, 0, st, nullptr);
+        std::memcpy(state, st.ctr, 16);
+    } else if (qrcp == 1) {                                                                   // QRCP::bqrrp :232-245
+        const double ratio = (n <= 2000) ? 1.0 : (n <= 8000 ? 0.5 : 1.0 / 32.0);
+        RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+        int64_t rk = 0;
+        const int64_t bsz = (int64_t)(n * ratio);
+        bqrrp_call(d, n, A_hat, d, 1.0, bsz, bsz, std::numeric_limits<double>::epsilon(), 0, 2, 0, tau.data(), J, st, nullptr, &rk);
+        std::memcpy(state, st.ctr, 16);
+    } else {
+        geqp3(d, n, A_hat, d, J, tau.data());                                                 // :247
+    }
     if (!A_hat[0]) { *rank_out = 0; return 0; }                                               // :256-261
     for (int64_t i = 0; i < n; ++i) {                                                         // :267-272
         if (std::abs(A_hat[i * d + i]) / std::abs(A_hat[0]) < eps_initial) { k = i; break; }
@@ -718,6 +917,14 @@ int oracle_cqrrpt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, i
     trsm_right_upper(m, new_rank, 1.0, R, ldr, A, lda);                                       // :338
     trmm_right_upper(new_rank, n, 1.0, A_hat, d, R, ldr);                                     // :345
     return 0;
+}
+
+int oracle_hqrrp_f64(int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg, int64_t pp,
+                      int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], const double* G_in) {
+    RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+    int rc = hqrrp_call(m, n, A, lda, jpvt, tau, nb_alg, pp, panel_pivoting, qr_type, st, G_in);
+    std::memcpy(state, st.ctr, 16);
+    return rc;
 }
 
 // BQRRP::call (drivers/rl_bqrrp.hh:155).  A (m x n, lda) -> GEQP3-format output, tau (min(m,n)), J (n).

@@ -45,6 +45,7 @@ def _blas3(T):
         "tau_from_t": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "any_abs_gt": [c_vp, c_i64, c_vp, T, C.POINTER(c_int)],
         "geqrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "qrp_partial": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
         "ungqr": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "laswp": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
         "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
@@ -110,7 +111,8 @@ SIGNATURES.update({
     "rlhip_drv_qb_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int, c_int,
                                  c_int, c_int, dpp, dpp, u32p]),
     "rlhip_drv_cqrrpt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_i64, c_dbl, u32p, c_vp,
-                                     c_vp, C.POINTER(c_i64), C.POINTER(C.c_long)]),
+                                     c_vp, C.POINTER(c_i64), C.POINTER(C.c_long), c_int]),
+    "rlhip_drv_hqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, u32p, c_vp]),
     "rlhip_drv_bqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_dbl, c_i64, c_i64, c_dbl, c_vp, c_vp, u32p, c_vp, c_vp,
                                     C.POINTER(c_i64), C.POINTER(C.c_long), c_int, c_int, c_int]),
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,

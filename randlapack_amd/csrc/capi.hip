@@ -24,6 +24,8 @@ template <typename T> int any_abs_gt(rlhip_ctx*, int64_t, const T*, T, int*);
 template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*);
 int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
+template <typename T> int qrp_partial(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, int64_t*, T*);
+template <typename T> int gemqrt_rn(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int ungqr(rlhip_ctx*, int64_t, int64_t, T*, int64_t, const T*);
 template <typename T> int laswp(rlhip_ctx*, int64_t, T*, int64_t, int64_t, int64_t, const int64_t*);
 template <typename T> int fill_dense_rows(rlhip_ctx*, int, int64_t, int64_t, int64_t, int64_t, T*, int64_t, const uint32_t*, const uint32_t*, uint32_t*);
@@ -377,9 +379,16 @@ static inline int op_flag(char t, int* out) {
     }                                                                                                           \
     int rlhip_gemqrt_##SUF(rlhip_ctx* c, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const T* V, \
                            int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc) {                          \
-        if (side != 'L' && side != 'l') return -2;                                                              \
-        if (trans != 'T' && trans != 't') return -3;                                                            \
-        return rlhip::gemqrt_lt<T>(c, m, n, k, nb, V, ldv, Tm, ldt, C, ldc);                                     \
+        const bool left = (side == 'L' || side == 'l'), tr = (trans == 'T' || trans == 't');                   \
+        if (left && tr) return rlhip::gemqrt_lt<T>(c, m, n, k, nb, V, ldv, Tm, ldt, C, ldc);                    \
+        if (!left && (side == 'R' || side == 'r') && (trans == 'N' || trans == 'n')) {                         \
+            if (nb < k) return -7; /* one compact-WY block on this side */                                      \
+            return rlhip::gemqrt_rn<T>(c, m, n, k, V, ldv, Tm, ldt, C, ldc);                                    \
+        }                                                                                                       \
+        return left ? -3 : -2;                                                                                  \
+    }                                                                                                           \
+    int rlhip_qrp_partial_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt, T* tau) { \
+        return rlhip::qrp_partial<T>(c, m, n, steps, A, lda, jpvt, tau);                                        \
     }                                                                                                           \
     int rlhip_larft_##SUF(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt) { \
         return rlhip::larft_gram<T>(c, m, k, V, ldv, tau, Tm, ldt);                                              \

@@ -138,11 +138,15 @@ int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t*
 
 int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr,
                          int64_t* J, double d_factor, int64_t nnz, double eps, uint32_t state[6],
-                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us) {
+                         const double* A_hat_in, double* A_hat_out, int64_t* rank_out, long* times_us, int qrcp) {
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::CQRRPT<double, RNG> alg(q, times_us != nullptr, eps);
         alg.nnz = nnz;
+        if (qrcp >= 0) {
+            if (qrcp > 2) throw RandLAPACK::Error("qrcp must be 0 (hqrrp), 1 (bqrrp) or 2 (geqp3)");
+            alg.qrcp = (RandLAPACK::CQRRPTSubroutines::QRCP)qrcp;
+        }
         alg.sketch_override = A_hat_in;
         alg.sketch_export = A_hat_out;
         State st = load_state(state);
@@ -151,6 +155,17 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
         if (rank_out) *rank_out = alg.rank;
         if (times_us && alg.times.size() == 8)
             for (int i = 0; i < 8; ++i) times_us[i] = alg.times[i];
+        return rc;
+    });
+}
+
+int rlhip_drv_hqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg,
+                        int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double* G_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        State st = load_state(state);
+        int rc = (int)RandLAPACK::hqrrp<double, RNG>(m, n, A, lda, jpvt, tau, nb_alg, pp, panel_pivoting, qr_type, st, q, G_out);
+        store_state(st, state);
         return rc;
     });
 }

@@ -247,6 +247,33 @@ int gemqrt_lt(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, int64_t nb, const T
     return rc;
 }
 
+// C (m x n) <- C Q,  Q = I - V T V^T one compact-WY block (V: n x k unit lower trapezoidal, T: k x k upper).  Side::Right,
+// Op::NoTrans: HQRRP's update of the sketching matrix G (NoFLA_Apply_Q_WY_rnfc_blk_var4, rl_hqrrp.hh:178-206).
+template <typename T>
+int gemqrt_rn(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc) {
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0 || k > n) return -5;
+    if (k == 0 || n == 0 || m == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* V1 = ws_alloc<T>(c, (size_t)k * k);
+    T* W = ws_alloc<T>(c, (size_t)m * k);
+    T* W2 = ws_alloc<T>(c, (size_t)m * k);
+    if (!V1 || !W || !W2) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipLaunchKernelGGL(unit_lower_copy_kernel<T>, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, c->stream, k, V, ldv, V1, 0);
+    RLHIP_LAUNCH_CHECK();
+    const int64_t nr = n - k;
+    int rc = gemm<T>(c, 0, 0, m, k, k, T(1), C, ldc, V1, k, T(0), W, m);                                   // W = C1 V1 + C2 V2
+    if (!rc && nr > 0) rc = gemm<T>(c, 0, 0, m, k, nr, T(1), C + k * ldc, ldc, V + k, ldv, T(1), W, m);
+    if (!rc) rc = gemm<T>(c, 0, 0, m, k, k, T(1), W, m, Tm, ldt, T(0), W2, m);                              // W2 = W T
+    if (!rc) rc = gemm<T>(c, 0, 1, m, k, k, T(-1), W2, m, V1, k, T(1), C, ldc);                             // C1 -= W2 V1^T
+    if (!rc && nr > 0) rc = gemm<T>(c, 0, 1, m, nr, k, T(-1), W2, m, V + k, ldv, T(1), C + k * ldc, ldc);   // C2 -= W2 V2^T
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+template int gemqrt_rn<double>(rlhip_ctx*, int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t);
+template int gemqrt_rn<float>(rlhip_ctx*, int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t);
+
 // T (k x k upper, ldt) from V (m x k unit lower trapezoidal) and tau (k): one compact-WY block for all k reflectors
 template <typename T>
 int larft_gram(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt) {

@@ -34,6 +34,8 @@ struct QrcpArgs {
     T tol3z;
     int use_lds;              // owned columns live in LDS for the whole factorization
     int pivot;                // 0: plain Householder QR (geqr2 order), jpvt untouched
+    int64_t max_steps;        // number of columns to factor (< min(m,n): partial factorization, HQRRP's sketch step)
+    int hq_formula;           // 1: norm down-date written as (1+t)(1-t) (rl_hqrrp.hh:373), 0: dlaqp2's 1 - t^2
 };
 
 // ---- cross-workgroup traffic uses agent-scope relaxed atomics on 8-byte granules (sc1 write-through stores /
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t G = gridDim.x, me = blockIdx.x;
     const int64_t m = g.m, n = g.n;
-    const int64_t kmax = m < n ? m : n;
+    const int64_t kmin = m < n ? m : n;
+    const int64_t kmax = (g.max_steps >= 0 && g.max_steps < kmin) ? g.max_steps : kmin;
     __shared__ T s_val[4];
     unsigned epoch = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char qr_smem[];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
             if (v1 != T(0)) {
                 T akj = fabs(col[k]);
                 T r = akj / v1;
-                T temp = T(1) - r * r;
+                T temp = g.hq_formula ? (T(1) + r) * (T(1) - r) : T(1) - r * r;
                 temp = temp > T(0) ? temp : T(0);
                 T q = v1 / l_vn2[j / G];
                 T temp2 = temp * q * q;
@@ -262,12 +265,23 @@ int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, 
          const T* B, int64_t ldb, T beta, T* C, int64_t ldc);
 
 template <typename T>
-static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
+static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev, int64_t max_steps = -1,
+                   int hq_formula = 0);
 
 template <typename T>
 int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
     return qr_core<T>(c, 1, m, n, A, lda, jpvt_dev, tau_dev);
 }
+
+// Pivoted Householder QR restricted to the first `steps` columns, with the norm down-date in HQRRP's form: the device
+// counterpart of NoFLA_QRPmod_WY_unb_var4(pivoting = 1, num_stages = steps) (rl_hqrrp.hh:516-770).  jpvt returns the
+// whole permutation (1-based) that the column swaps of those steps produce.
+template <typename T>
+int qrp_partial(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
+    return qr_core<T>(c, 1, m, n, A, lda, jpvt_dev, tau_dev, steps, 1);
+}
+template int qrp_partial<double>(rlhip_ctx*, int64_t, int64_t, int64_t, double*, int64_t, int64_t*, double*);
+template int qrp_partial<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, int64_t, int64_t*, float*);
 
 // lapack::geqrf: Householder QR without pivoting.  Wide input (n > m, BQRRP's permuted sketch rl_bqrrp.hh:356): only the
 // leading m x m block goes through the step-synchronous kernel; the remaining columns get Q^T applied as ONE compact-WY
@@ -352,7 +366,8 @@ int ungqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, const T* tau_de
 }
 
 template <typename T>
-static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
+static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev, int64_t max_steps,
+                   int hq_formula) {
     if (m < 0) return -2;
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
@@ -390,8 +405,8 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     g.cand_val = ws_alloc<T>(c, 2 * G); g.cand_pos = ws_alloc<int64_t>(c, 2 * G); g.cand_tau = ws_alloc<T>(c, 2 * G);
     g.slot = ws_alloc<T>(c, (size_t)2 * G * m); g.kcol = ws_alloc<T>(c, (size_t)2 * (m + 2));
     g.bar = ws_alloc<unsigned>(c, 4);
-    g.tol3z = std::sqrt(std::numeric_limits<T>::epsilon());
-    g.use_lds = use_lds; g.pivot = pivot;
+    g.tol3z = std::sqrt(std::numeric_limits<T>::epsilon() / 2);   // SQRT(DLAMCH('Epsilon')): LAPACK's eps is the rounding unit
+    g.use_lds = use_lds; g.pivot = pivot; g.max_steps = max_steps; g.hq_formula = hq_formula;
     if (!g.vn1 || !g.vn2 || !g.cand_val || !g.cand_pos || !g.cand_tau || !g.slot || !g.kcol || !g.bar) {
         rlhip_ws_release(c, mark);
         return RLHIP_ERR_HIP(hipErrorOutOfMemory);

@@ -266,8 +266,25 @@ def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb
     return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))
 
 
+def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), want_G=False):
+    """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G])."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    tau = torch.zeros(min(m, n), dtype=torch.float64, device=dev)
+    J = torch.zeros(n, dtype=torch.int64, device=dev)
+    G = cm_empty(nb_alg + pp, m, device=dev) if want_G else None
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_hqrrp_f64(ctx.h, m, n, A.data_ptr(), m, J.data_ptr(), tau.data_ptr(), nb_alg, pp, panel_pivoting, qr_type,
+                                     st, G.data_ptr() if G is not None else None)
+    _drv_check(ctx, rc, "hqrrp")
+    out = dict(rc=rc, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
+    if want_G:
+        out["G"] = G
+    return out
+
+
 def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
-               want_sketch=False, timing=False):
+               want_sketch=False, timing=False, qrcp=-1):
     """CQRRPT::call (qrcp = geqp3).  A (column-major tensor (n, m)) is overwritten by Q.  Returns dict(rc, rank, R, J,
     next_ctr[, sketch][, times_us])."""
     torch = _torch()
@@ -283,7 +300,7 @@ def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0,
     times = (C.c_long * 8)() if timing else None
     rc = ctx.lib.rlhip_drv_cqrrpt_f64(ctx.h, m, n, A.data_ptr(), m, R.data_ptr(), n, J.data_ptr(), d_factor, nnz, eps, st,
                                       sketch_in.data_ptr() if sketch_in is not None else None,
-                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times)
+                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times, qrcp)
     _drv_check(ctx, rc, "cqrrpt")
     out = dict(rc=rc, rank=int(rank.value), R=R, J=J, next_ctr=tuple(int(x) for x in st[:4]))
     if want_sketch:

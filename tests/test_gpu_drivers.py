@@ -466,3 +466,69 @@ def test_comm_world1_allreduce_is_identity(ctx, force_hook):
         ctx.lib.rlhip_comm_destroy(ctx.h)
         if created:
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------
+# HQRRP (drivers/rl_hqrrp.hh) vs the oracle sharing the Uniform(-1,1) sketching matrix G
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("qr_type,panel_pivoting", [(0, 1), (0, 0), (1, 0), (2, 0)])
+@pytest.mark.parametrize("m,n,nb,pp", [(300, 120, 32, 5), (200, 200, 64, 10), (150, 260, 32, 8), (500, 70, 16, 4),
+                                       (1280, 1024, 64, 10)])
+def test_hqrrp_vs_oracle_shared_sketch(ctx, orc, m, n, nb, pp, qr_type, panel_pivoting):
+    d = _d()
+    rng = np.random.default_rng(m + n + nb)
+    A = poly_mat(m, n, min(m, n), rng, cond=1e4)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_hqrrp(ctx, Ad, m, n, nb, pp, panel_pivoting, qr_type, key=(7, 0), want_G=True)
+    o = orc.hqrrp(A, nb, pp, panel_pivoting, qr_type, key=(7, 0), G=d.cm_to_numpy(r["G"]))
+    assert r["rc"] == o["rc"] == 0
+    assert r["next_ctr"] == o["next_ctr"]                                    # one (nb+pp) x m fill (rl_hqrrp.hh:929-930)
+    Aout, tau, J = d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy()
+    np.testing.assert_array_equal(J, o["J"])                                 # pivot order: bit-exact
+    mn = min(m, n)
+    Rd, Ro = np.triu(Aout)[:mn], np.triu(o["A"])[:mn]
+    assert np.linalg.norm(Rd - Ro) <= (1e-9 if qr_type == 2 else EPS**0.6) * np.linalg.norm(Ro)
+    _bqrrp_verify(orc, A, Aout, tau, J, atol=(1e-8 if qr_type == 2 else EPS**0.75))
+
+
+def test_hqrrp_own_sketch_and_bad_args(ctx, orc):
+    d = _d()
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((400, 150))
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_hqrrp(ctx, Ad, 400, 150, 32, 6, key=(9, 0))
+    o = orc.hqrrp(A, 32, 6, key=(9, 0))                                      # both sides generate G from the same stream
+    np.testing.assert_array_equal(r["J"].cpu().numpy(), o["J"])
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy())
+    from randlapack_amd import _lib
+
+    with pytest.raises(_lib.RlhipError):
+        d.drv_hqrrp(ctx, Ad, 400, 150, 0, 6)                                 # nb_alg must be positive
+
+
+@pytest.mark.parametrize("qrcp", [0, 1, 2])
+def test_cqrrpt_qrcp_choices_vs_oracle(ctx, orc, qrcp):
+    """CQRRPT with qrcp = hqrrp / bqrrp / geqp3 (rl_cqrrpt.hh:230-247).  The inner randomized QRCP continues from the state the
+    SASO construction leaves behind, so the oracle is started from that state."""
+    import ctypes as C
+
+    d = _d()
+    rng = np.random.default_rng(77)
+    m, n = 6000, 200
+    A = poly_mat(m, n, n, rng, cond=1e5)
+    dd = int(1.25 * n)
+    nxt = (C.c_uint32 * 4)()
+    S = C.c_void_p()
+    assert ctx.lib.rlhip_saso_create(ctx.h, dd, m, 4, (C.c_uint32 * 4)(0, 0, 0, 0), (C.c_uint32 * 2)(11, 0), nxt, C.byref(S)) == 0
+    ctx.lib.rlhip_saso_destroy(ctx.h, S)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, want_sketch=True, key=(11, 0), qrcp=qrcp)
+    o = orc.cqrrpt(A, d.cm_to_numpy(r["sketch"]), EPS**0.85, qrcp=qrcp, ctr=tuple(nxt), key=(11, 0))
+    assert r["rc"] == o["rc"] == 0 and r["rank"] == o["rank"] == n
+    J = r["J"].cpu().numpy()
+    if qrcp != 1:       # bqrrp's inner Gaussian sketch goes through different libm implementations (device vs host): pivots
+        np.testing.assert_array_equal(J, o["J"])            # may differ on near-ties there; hqrrp's uniform sketch is exact
+    k = r["rank"]
+    Q, R = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k]
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= EPS**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS**0.75 * np.sqrt(n)

@@ -220,3 +220,31 @@ def test_bqrrp_internal_nb_and_state(orc):
     assert r["rc"] == 0
     _bqrrp_checks(orc, A, r)
     assert r["next_ctr"][0] == (90 * 500 + 3) // 4
+
+
+# ---------------------------------------------------------------------------------------------------
+# HQRRP (drivers/rl_hqrrp.hh) -- test/drivers/test_hqrrp.cc style checks: GEQP3-format output verified through
+# ungqr + col_swap; plus pivot quality against LAPACK's geqp3 on a graded matrix.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,nb,pp", [(300, 120, 32, 5), (200, 200, 64, 10), (150, 260, 32, 8), (500, 70, 16, 4)])
+@pytest.mark.parametrize("qr_type,panel_pivoting", [(0, 1), (0, 0), (1, 0), (2, 0)])
+def test_hqrrp_factorization(orc, m, n, nb, pp, qr_type, panel_pivoting):
+    rng = np.random.default_rng(m + n + nb)
+    A = poly_mat(m, n, min(m, n), rng, cond=1e4)
+    r = orc.hqrrp(A, nb, pp, panel_pivoting, qr_type, key=(m, 0))
+    assert r["rc"] == 0
+    # same GEQP3-format verification as BQRRP; CholQR panels (qr_type 2, no pivoting inside the panel) lose
+    # cond(panel)^2 * eps of orthogonality by construction -- the reference has the same property
+    _bqrrp_checks(orc, A, r, atol=(1e-8 if qr_type == 2 else EPS**0.75))
+    assert r["next_ctr"][0] == ((nb + pp) * m + 3) // 4
+
+
+def test_hqrrp_pivot_quality_and_rank_reveal(orc):
+    rng = np.random.default_rng(12)
+    n = 96
+    s = np.logspace(0, -10, n)
+    A = (np.linalg.qr(rng.standard_normal((200, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    r = orc.hqrrp(A, 16, 8, 1, 0, key=(3, 0))
+    dR = np.abs(np.diag(r["A"]))
+    # |r_ii| tracks the singular values within a modest factor (randomized pivoting is a strong-RRQR in practice)
+    assert np.all(dR[:60] <= s[:60] * 40) and np.all(dR[:60] >= s[:60] / 40)
