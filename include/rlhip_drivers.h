@@ -63,6 +63,21 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
                         const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
                         int apply_trans_q);
 
+/* fp32 instantiations (same contracts; tol / eps / d_factor are float) */
+int rlhip_drv_stab_f32(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, float* A, int* chol_fail);
+int rlhip_drv_rsvd_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t* k, int64_t b_sz, float tol,
+                       int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, float** U,
+                       float** S, float** V, uint32_t state[6], int* qb_ret);
+int rlhip_drv_cqrrpt_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* R, int64_t ldr,
+                         int64_t* J, float d_factor, int64_t nnz, float eps, uint32_t state[6],
+                         const float* A_hat_in, float* A_hat_out, int64_t* rank_out, long* times_us, int qrcp);
+int rlhip_drv_hqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* jpvt, float* tau, int64_t nb_alg,
+                        int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], float* G_out);
+int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float d_factor, int64_t b_sz,
+                        int64_t internal_nb, float tol, float* tau, int64_t* J, uint32_t state[6],
+                        const float* A_sk_in, float* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
+                        int apply_trans_q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,9 @@ SIGNATURES.update({
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })
+for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp"):      # fp32 instantiations: same shapes, float scalars
+    _rt, _args = SIGNATURES[f"rlhip_drv_{_name}_f64"]
+    SIGNATURES[f"rlhip_drv_{_name}_f32"] = (_rt, [c_flt if a is c_dbl else a for a in _args])
 for _suf, _T in (("f64", c_dbl), ("f32", c_flt)):
     for _name, _args in _blas3(_T).items():
         SIGNATURES[f"rlhip_{_name}_{_suf}"] = (c_int, _args)

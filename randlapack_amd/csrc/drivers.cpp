@@ -195,4 +195,98 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
     });
 }
 
+// ---- fp32 instantiations of the same objects (BASELINE config 4 is fp32)
+int rlhip_drv_stab_f32(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, float* A, int* chol_fail) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto st = make_stab<float>(q, kind, cond_check != 0);
+        int rc = st->call(m, k, A);
+        if (chol_fail) {
+            auto* c = dynamic_cast<RandLAPACK::CholQRQ<float>*>(st.get());
+            *chol_fail = (c && c->chol_fail) ? 1 : 0;
+        }
+        return rc;
+    });
+}
+
+int rlhip_drv_rsvd_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t* k, int64_t b_sz, float tol, int64_t p,
+                       int64_t q_, int rs_stab, int rf_orth, int qb_orth, int orth_check, float** U, float** S,
+                       float** V, uint32_t state[6], int* qb_ret) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        auto s1 = make_stab<float>(q, rs_stab, false);
+        auto s2 = make_stab<float>(q, rf_orth, false);
+        auto s3 = make_stab<float>(q, qb_orth, false);
+        RandLAPACK::RS<float, RNG> rs(q, *s1, p, q_, false, false);
+        RandLAPACK::RF<float, RNG> rf(q, rs, *s2, false, false);
+        RandLAPACK::QB<float, RNG> qb(q, rf, *s3, false, orth_check != 0);
+        RandLAPACK::RSVD<float, RNG> rsvd(q, qb, b_sz);
+        State st = load_state(state);
+        *U = *S = *V = nullptr;
+        int rc = rsvd.call(m, n, A, *k, tol, *U, *S, *V, st);
+        store_state(st, state);
+        if (qb_ret) *qb_ret = rsvd.qb_return;
+        return rc;
+    });
+}
+
+int rlhip_drv_cqrrpt_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* R, int64_t ldr,
+                         int64_t* J, float d_factor, int64_t nnz, float eps, uint32_t state[6],
+                         const float* A_hat_in, float* A_hat_out, int64_t* rank_out, long* times_us, int qrcp) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::CQRRPT<float, RNG> alg(q, times_us != nullptr, eps);
+        alg.nnz = nnz;
+        if (qrcp >= 0) {
+            if (qrcp > 2) throw RandLAPACK::Error("qrcp must be 0 (hqrrp), 1 (bqrrp) or 2 (geqp3)");
+            alg.qrcp = (RandLAPACK::CQRRPTSubroutines::QRCP)qrcp;
+        }
+        alg.sketch_override = A_hat_in;
+        alg.sketch_export = A_hat_out;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A, lda, R, ldr, J, d_factor, st);
+        store_state(st, state);
+        if (rank_out) *rank_out = alg.rank;
+        if (times_us && alg.times.size() == 8)
+            for (int i = 0; i < 8; ++i) times_us[i] = alg.times[i];
+        return rc;
+    });
+}
+
+int rlhip_drv_hqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* jpvt, float* tau, int64_t nb_alg,
+                        int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], float* G_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        State st = load_state(state);
+        int rc = (int)RandLAPACK::hqrrp<float, RNG>(m, n, A, lda, jpvt, tau, nb_alg, pp, panel_pivoting, qr_type, st, q, G_out);
+        store_state(st, state);
+        return rc;
+    });
+}
+
+int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float d_factor, int64_t b_sz,
+                        int64_t internal_nb, float tol, float* tau, int64_t* J, uint32_t state[6],
+                        const float* A_sk_in, float* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
+                        int apply_trans_q) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::BQRRP<float, RNG> alg(q, times_us != nullptr, b_sz);
+        using Sub = RandLAPACK::BQRRPSubroutines;
+        if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
+        if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
+        if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
+        if (internal_nb > 0) alg.internal_nb = internal_nb;
+        if (tol > 0) alg.tol = tol;
+        alg.sketch_override = A_sk_in;
+        alg.sketch_export = A_sk_out;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A, lda, d_factor, tau, J, st);
+        store_state(st, state);
+        if (rank_out) *rank_out = alg.rank;
+        if (times_us && alg.times.size() == 9)
+            for (int i = 0; i < 9; ++i) times_us[i] = alg.times[i];
+        return rc;
+    });
+}
+
 }  // extern "C"

@@ -198,12 +198,12 @@ def _state_arr(ctr, key):
     return (C.c_uint32 * 6)(*[int(v) & 0xFFFFFFFF for v in list(ctr) + list(key)])
 
 
-def _adopt(ctx: "Context", ptr: C.c_void_p, rows: int, cols: int):
+def _adopt(ctx: "Context", ptr: C.c_void_p, rows: int, cols: int, dtype=None):
     """copy a callee-allocated column-major device block into a torch tensor (cols, rows) and free it"""
     torch = _torch()
-    t = torch.empty((cols, rows), dtype=torch.float64, device=f"cuda:{ctx.device}")
+    t = torch.empty((cols, rows), dtype=dtype or torch.float64, device=f"cuda:{ctx.device}")
     if rows * cols > 0:
-        _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, t.data_ptr(), ptr, rows * cols * 8), "memcpy_d2d")
+        _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, t.data_ptr(), ptr, rows * cols * t.element_size()), "memcpy_d2d")
     _lib.check(ctx.lib.rlhip_free(ctx.h, ptr), "rlhip_free")
     return t
 
@@ -216,7 +216,7 @@ def _drv_check(ctx, rc, what):
 
 def drv_stab(ctx: Context, kind: int, A, m: int, k: int, cond_check: bool = False):
     cf = C.c_int(0)
-    rc = ctx.lib.rlhip_drv_stab_f64(ctx.h, kind, int(cond_check), m, k, A.data_ptr(), C.byref(cf))
+    rc = getattr(ctx.lib, f"rlhip_drv_stab_{_suffix(A)[0]}")(ctx.h, kind, int(cond_check), m, k, A.data_ptr(), C.byref(cf))
     return _drv_check(ctx, rc, "stab"), bool(cf.value)
 
 
@@ -255,14 +255,15 @@ def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb
     Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
     qrc = C.c_int(0)
     st = _state_arr(ctr, key)
-    rc = ctx.lib.rlhip_drv_rsvd_f64(ctx.h, m, n, A.data_ptr(), C.byref(kk), b_sz, tol, p, q, rs_stab, rf_orth, qb_orth,
-                                    int(orth_check), C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(qrc))
+    suf, _ = _suffix(A)
+    rc = getattr(ctx.lib, f"rlhip_drv_rsvd_{suf}")(ctx.h, m, n, A.data_ptr(), C.byref(kk), b_sz, tol, p, q, rs_stab, rf_orth, qb_orth,
+                                                   int(orth_check), C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(qrc))
     _drv_check(ctx, rc, "rsvd")
     kf = int(kk.value)
     kal = max(kf, 1)
-    U = _adopt(ctx, Up, m, kal)
-    S = _adopt(ctx, Sp, kal, 1).reshape(-1)
-    V = _adopt(ctx, Vp, n, kal)
+    U = _adopt(ctx, Up, m, kal, A.dtype)
+    S = _adopt(ctx, Sp, kal, 1, A.dtype).reshape(-1)
+    V = _adopt(ctx, Vp, n, kal, A.dtype)
     return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))
 
 
@@ -270,11 +271,11 @@ def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type
     """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G])."""
     torch = _torch()
     dev = f"cuda:{ctx.device}"
-    tau = torch.zeros(min(m, n), dtype=torch.float64, device=dev)
+    tau = torch.zeros(min(m, n), dtype=A.dtype, device=dev)
     J = torch.zeros(n, dtype=torch.int64, device=dev)
-    G = cm_empty(nb_alg + pp, m, device=dev) if want_G else None
+    G = cm_empty(nb_alg + pp, m, dtype=A.dtype, device=dev) if want_G else None
     st = _state_arr(ctr, key)
-    rc = ctx.lib.rlhip_drv_hqrrp_f64(ctx.h, m, n, A.data_ptr(), m, J.data_ptr(), tau.data_ptr(), nb_alg, pp, panel_pivoting, qr_type,
+    rc = getattr(ctx.lib, f"rlhip_drv_hqrrp_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), m, J.data_ptr(), tau.data_ptr(), nb_alg, pp, panel_pivoting, qr_type,
                                      st, G.data_ptr() if G is not None else None)
     _drv_check(ctx, rc, "hqrrp")
     out = dict(rc=rc, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
@@ -289,16 +290,17 @@ def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0,
     next_ctr[, sketch][, times_us])."""
     torch = _torch()
     dev = f"cuda:{ctx.device}"
+    npdt = np.float64 if A.dtype == torch.float64 else np.float32
     if eps is None:
-        eps = float(np.finfo(np.float64).eps ** 0.85)
+        eps = float(np.finfo(npdt).eps ** 0.85)
     d = int(d_factor * n)
-    R = cm_zeros(n, n, device=dev)
+    R = cm_zeros(n, n, dtype=A.dtype, device=dev)
     J = torch.zeros(n, dtype=torch.int64, device=dev)
-    sk_out = cm_empty(d, n, device=dev) if want_sketch else None
+    sk_out = cm_empty(d, n, dtype=A.dtype, device=dev) if want_sketch else None
     rank = C.c_int64(0)
     st = _state_arr(ctr, key)
     times = (C.c_long * 8)() if timing else None
-    rc = ctx.lib.rlhip_drv_cqrrpt_f64(ctx.h, m, n, A.data_ptr(), m, R.data_ptr(), n, J.data_ptr(), d_factor, nnz, eps, st,
+    rc = getattr(ctx.lib, f"rlhip_drv_cqrrpt_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), m, R.data_ptr(), n, J.data_ptr(), d_factor, nnz, eps, st,
                                       sketch_in.data_ptr() if sketch_in is not None else None,
                                       sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times, qrcp)
     _drv_check(ctx, rc, "cqrrpt")
@@ -318,13 +320,13 @@ def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0,
     torch = _torch()
     dev = f"cuda:{ctx.device}"
     d = int(d_factor * b_sz)
-    tau = torch.zeros(min(m, n), dtype=torch.float64, device=dev)
+    tau = torch.zeros(min(m, n), dtype=A.dtype, device=dev)
     J = torch.zeros(n, dtype=torch.int64, device=dev)
-    sk_out = cm_empty(d, n, device=dev) if want_sketch else None
+    sk_out = cm_empty(d, n, dtype=A.dtype, device=dev) if want_sketch else None
     rank = C.c_int64(0)
     st = _state_arr(ctr, key)
     times = (C.c_long * 9)() if timing else None
-    rc = ctx.lib.rlhip_drv_bqrrp_f64(ctx.h, m, n, A.data_ptr(), m, d_factor, b_sz, internal_nb, tol, tau.data_ptr(), J.data_ptr(),
+    rc = getattr(ctx.lib, f"rlhip_drv_bqrrp_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), m, d_factor, b_sz, internal_nb, tol, tau.data_ptr(), J.data_ptr(),
                                      st, sketch_in.data_ptr() if sketch_in is not None else None,
                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times,
                                      qrcp_wide, qr_tall, apply_trans_q)

@@ -532,3 +532,55 @@ def test_cqrrpt_qrcp_choices_vs_oracle(ctx, orc, qrcp):
     Q, R = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k]
     assert np.linalg.norm(A[:, J - 1] - Q @ R) <= EPS**0.75 * np.linalg.norm(A)
     assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS**0.75 * np.sqrt(n)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32 instantiations of the drivers (BASELINE config 4 is fp32).  Tolerances: the reference's eps^0.75 rule with
+# float eps (test_bqrrp.cc is typed on T), checked in float64 arithmetic on the host.
+# ---------------------------------------------------------------------------------------------------
+def _cm32(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a.T.astype(np.float32))).cuda()
+
+
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+@pytest.mark.parametrize("opts", [(0, 1, 1), (1, 1, 1), (0, 2, 0)])
+def test_bqrrp_f32(ctx, orc, opts):
+    d = _d()
+    rng = np.random.default_rng(8)
+    m, n, b = 1000, 400, 100
+    A = rng.standard_normal((m, n)).astype(np.float32).astype(np.float64)
+    Ad = _cm32(A)
+    r = d.drv_bqrrp(ctx, Ad, m, n, b, 1.0, key=(3, 0), qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2])
+    assert r["rc"] == 0 and r["rank"] == n
+    Aout = d.cm_to_numpy(Ad).astype(np.float64)
+    _bqrrp_verify(orc, A, Aout, r["tau"].cpu().numpy().astype(np.float64), r["J"].cpu().numpy(), atol=EPS32**0.75 * 4)
+
+
+def test_cqrrpt_hqrrp_rsvd_f32(ctx, orc):
+    d = _d()
+    rng = np.random.default_rng(9)
+    m, n = 20000, 256
+    A = poly_mat(m, n, n, rng, cond=1e3).astype(np.float32).astype(np.float64)
+    Ad = _cm32(A)
+    r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, key=(1, 0))
+    k = r["rank"]
+    assert r["rc"] == 0 and k == n
+    Q, R, J = d.cm_to_numpy(Ad)[:, :k].astype(np.float64), d.cm_to_numpy(r["R"])[:k].astype(np.float64), r["J"].cpu().numpy()
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= EPS32**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= EPS32**0.75 * np.sqrt(n)
+    Ad = _cm32(A[:2000])
+    r = d.drv_hqrrp(ctx, Ad, 2000, n, 32, 8)
+    _bqrrp_verify(orc, A[:2000], d.cm_to_numpy(Ad).astype(np.float64), r["tau"].cpu().numpy().astype(np.float64), r["J"].cpu().numpy(),
+                  atol=EPS32**0.75)
+    Ad = _cm32(A)
+    r = d.drv_rsvd(ctx, Ad, m, n, 32, 32, 1e-5, 2, 1)
+    U, S, V = (d.cm_to_numpy(r["U"]).astype(np.float64), r["S"].cpu().numpy().astype(np.float64), d.cm_to_numpy(r["V"]).astype(np.float64))
+    assert r["k"] == 32
+    assert np.linalg.norm(U.T @ U - np.eye(32)) <= EPS32**0.75 * 10
+    o = orc.rsvd(A, 32, 32, 1e-5, 2, 1)
+    # same sketch stream in both precisions (the Gaussian is generated in fp64 and rounded): approximation quality equal to fp64's
+    assert np.linalg.norm(A - (U * S) @ V.T) <= np.linalg.norm(A - (o["U"] * o["S"]) @ o["V"].T) * (1 + 1e-3)
