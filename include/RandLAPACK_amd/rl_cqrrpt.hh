@@ -77,12 +77,21 @@ public:
         // ---- sketch: S = SparseSkOp(SparseDist(d, m, nnz), state); state = S.next_state; A_hat = S * A  (:214-222)
         auto t0 = stamp();
         {
-            RandBLAS::SparseDist DS(d, m, nnz);
+            // Row-block sharding (one process per GPU): S is the operator for the GLOBAL row count; every rank applies its
+            // column window of S to its rows and the d x n partial sketches are summed over the ranks.  Everything that
+            // follows on the sketch (QRCP, rank estimate) is replicated, the m-long operations stay local, and the only
+            // other exchange is the k x k Gram matrix of the CholQR step.
+            int64_t m_glob = m, row0 = 0;
+            q.shard_extent(m, m_glob, row0);
+            RandBLAS::SparseDist DS(d, m_glob, nnz);
             RandBLAS::SparseSkOp<T, RNG> S(DS, state, q);
             state = S.next_state;
             if (sketch_override)   // parity-test hook: both sides factor the SAME precomputed sketch
                 lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_hat, d, q);
-            else
+            else if (q.world() > 1) {
+                RandBLAS::sketch_rows(S, n, (T)1.0, A, lda, row0, m, (T)0.0, A_hat, d, q);
+                q.allreduce_sum(A_hat, d * n);
+            } else
                 RandBLAS::sketch_general(Layout::ColMajor, Op::NoTrans, Op::NoTrans, d, n, m, (T)1.0, S, 0, 0, A, lda,
                                          (T)0.0, A_hat, d, q);
             if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_hat, d, sketch_export, d, q);
@@ -127,7 +136,13 @@ public:
         auto t5 = stamp();
 
         blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, A, lda, (T)0.0, R, ldr, q);     // :310
-        if (q.world() > 1) throw blas::Error("CQRRPT: row-sharded execution is not wired yet");
+        if (q.world() > 1) {                    // Gram matrix of the sharded rows: sum the upper triangles over the ranks
+            T* G = ws.alloc<T>(k * k);
+            lapack::laset(MatrixType::General, k, k, (T)0, (T)0, G, k, q);
+            lapack::lacpy(MatrixType::Upper, k, k, R, ldr, G, k, q);
+            q.allreduce_sum(G, k * k);
+            lapack::lacpy(MatrixType::Upper, k, k, G, k, R, ldr, q);
+        }
         if (lapack::potrf(Uplo::Upper, k, R, ldr, q)) {                                                     // :311
             // a-posteriori rank estimate from the (partially factored) diagonal                               :319-331
             std::vector<T> rd(k);

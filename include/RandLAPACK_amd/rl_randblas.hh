@@ -108,4 +108,16 @@ void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t
     blas::check(rlhip_saso_apply_f32(q.ctx(), S.handle, n, alpha, A, lda, beta, B, ldb), "saso_apply");
 }
 
+// one row shard's contribution to S * A: B = alpha * S[:, row0 : row0 + mloc] * A_loc + beta * B  (S built for the global row count)
+template <typename RNG>
+void sketch_rows(SparseSkOp<double, RNG>& S, int64_t n, double alpha, double const* A_loc, int64_t lda, int64_t row0, int64_t mloc,
+                 double beta, double* B, int64_t ldb, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_rows_f64(q.ctx(), S.handle, n, alpha, A_loc, lda, row0, mloc, beta, B, ldb), "saso_apply_rows");
+}
+template <typename RNG>
+void sketch_rows(SparseSkOp<float, RNG>& S, int64_t n, float alpha, float const* A_loc, int64_t lda, int64_t row0, int64_t mloc,
+                 float beta, float* B, int64_t ldb, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_rows_f32(q.ctx(), S.handle, n, alpha, A_loc, lda, row0, mloc, beta, B, ldb), "saso_apply_rows");
+}
+
 }  // namespace RandBLAS

@@ -166,6 +166,12 @@ int rlhip_saso_apply_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, double 
                          double beta, double* B, int64_t ldb);
 int rlhip_saso_apply_f32(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, float alpha, const float* A, int64_t lda,
                          float beta, float* B, int64_t ldb);
+/* contribution of ONE ROW SHARD: B = alpha * S[:, row0 : row0+mloc] * A_loc (mloc x n, lda) + beta * B.  Summed over the
+ * shards (all-reduce) this is S * A; S was created for the GLOBAL row count. */
+int rlhip_saso_apply_rows_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, double alpha, const double* A_loc, int64_t lda,
+                              int64_t row0, int64_t mloc, double beta, double* B, int64_t ldb);
+int rlhip_saso_apply_rows_f32(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, float alpha, const float* A_loc, int64_t lda,
+                              int64_t row0, int64_t mloc, float beta, float* B, int64_t ldb);
 int rlhip_saso_dense_f64(rlhip_ctx* ctx, const rlhip_saso* S, double* dense_d_by_m);   /* tests / debugging */
 int rlhip_saso_dense_f32(rlhip_ctx* ctx, const rlhip_saso* S, float* dense_d_by_m);
 /* util::col_swap (misc/rl_util.hh:151-164 == lapmt forward): on exit column i holds former column idx[i]-1.

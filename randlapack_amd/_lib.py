@@ -34,6 +34,7 @@ def _blas3(T):
         "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "laset": [c_vp, c_char, c_i64, c_i64, T, T, c_vp, c_i64],
         "saso_apply": [c_vp, c_vp, c_i64, T, c_vp, c_i64, T, c_vp, c_i64],
+        "saso_apply_rows": [c_vp, c_vp, c_i64, T, c_vp, c_i64, c_i64, c_i64, T, c_vp, c_i64],
         "saso_dense": [c_vp, c_vp, c_vp],
         "col_swap": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "geqp3": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],

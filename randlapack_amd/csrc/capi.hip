@@ -10,6 +10,8 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4
                uint32_t next_ctr[4], SasoOp** out);
 int saso_destroy(rlhip_ctx* c, SasoOp* op);
 template <typename T> int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S);
+template <typename T> int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, int64_t row0, int64_t mloc,
+                                          T beta, T* B, int64_t ldb);
 template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta,
                                      T* B, int64_t ldb);
 template <typename T> int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx);
@@ -353,6 +355,10 @@ static inline int op_flag(char t, int* out) {
     int rlhip_laset_##SUF(rlhip_ctx* c, char uplo, int64_t m, int64_t n, T offd, T diag, T* A, int64_t lda) {   \
         int u = (uplo == 'U' || uplo == 'u') ? 0 : (uplo == 'L' || uplo == 'l') ? 1 : 2;                        \
         return rlhip::laset<T>(c, u, m, n, offd, diag, A, lda);                                                  \
+    }                                                                                                           \
+    int rlhip_saso_apply_rows_##SUF(rlhip_ctx* c, const rlhip_saso* S, int64_t n, T alpha, const T* A, int64_t lda, int64_t row0, \
+                                    int64_t mloc, T beta, T* B, int64_t ldb) {                                  \
+        return rlhip::saso_apply_rows<T>(c, (const rlhip::SasoOp*)S, n, alpha, A, lda, row0, mloc, beta, B, ldb); \
     }                                                                                                           \
     int rlhip_saso_apply_##SUF(rlhip_ctx* c, const rlhip_saso* S, int64_t n, T alpha, const T* A, int64_t lda, T beta, \
                                T* B, int64_t ldb) {                                                             \

@@ -113,13 +113,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, int64_t m, int64_t Tb, int nnz,
                                                          const int32_t* __restrict__ src, const T* __restrict__ A,
                                                          int64_t lda, int64_t t_per_group, int64_t r_base,
-                                                         T* __restrict__ partial) {
+                                                         T* __restrict__ partial, int64_t row0, int64_t mloc, int64_t tb0,
+                                                         int64_t tb1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);                     // [d][CT] row-major
     const int tid = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CT;
     const int64_t g = blockIdx.y;
-    const int64_t t0 = g * t_per_group, t1 = (t0 + t_per_group < Tb) ? (t0 + t_per_group) : Tb;
+    // A holds global rows [row0, row0 + mloc) only (row-block sharding); row blocks tb0 .. tb1-1 intersect that window
+    const int64_t t0 = tb0 + g * t_per_group, t1 = (t0 + t_per_group < tb1) ? (t0 + t_per_group) : tb1;
+    (void)Tb;
     T acc[RPT][CT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q)
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, i
         // stage A[t*d : t*d+d, c0:c0+CT] (zero padded) -- threads run along rows: coalesced
         for (int64_t e = tid; e < d * CT; e += 256) {
             const int64_t u = e % d, c = e / d;
-            const int64_t j = t * d + u;
-            sA[u * CT + c] = (j < m && c0 + c < n) ? A[j + (c0 + c) * lda] : T(0);
+            const int64_t j = t * d + u - row0;      // local row
+            sA[u * CT + c] = (j >= 0 && j < mloc && t * d + u < m && c0 + c < n) ? A[j + (c0 + c) * lda] : T(0);
         }
         __syncthreads();
 #pragma unroll
@@ -298,13 +301,17 @@ int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S /* d x m, zeroed here */) {
     return 0;
 }
 
-// B (d x n, ldb) = alpha * S * A (m x n, lda) + beta * B
+// B (d x n, ldb) = alpha * S[:, row0 : row0 + mloc] * A_loc (mloc x n, lda) + beta * B : the contribution of one row shard
+// (the whole product when row0 = 0, mloc = m)
 template <typename T>
-int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb) {
+int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, int64_t row0, int64_t mloc, T beta,
+                    T* B, int64_t ldb) {
     const int64_t d = op->d, m = op->m;
     if (n <= 0) return 0;
-    if (lda < (m > 1 ? m : 1)) return -6;
+    if (row0 < 0 || mloc < 0 || row0 + mloc > m) return -6;
+    if (lda < (mloc > 1 ? mloc : 1)) return -6;
     if (ldb < d) return -9;
+    const int64_t tb0 = (mloc > 0) ? row0 / d : 0, tb1 = (mloc > 0) ? (row0 + mloc + d - 1) / d : 0, nTb = tb1 - tb0;
     const size_t smem = sizeof(T) * (size_t)d * CT;
     if (smem > 160 * 1024) return -2;   // d up to 2560 (fp64)
     static bool attr_set = false;
@@ -314,19 +321,19 @@ int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, i
     }
     const int64_t ctiles = (n + CT - 1) / CT;
     int64_t G = (1024 + ctiles - 1) / ctiles;                       // ~4 workgroups per CU in flight
-    if (G > op->T) G = op->T;
+    if (G > nTb) G = nTb;
     if (G < 1) G = 1;
-    const int64_t tpg = (op->T + G - 1) / G;
-    G = (op->T + tpg - 1) / tpg;
+    const int64_t tpg = (nTb + G - 1) / G;
+    G = (nTb + tpg - 1) / tpg;
     if (G < 1) G = 1;
     size_t mark = rlhip_ws_mark(c);
     T* partial = ws_alloc<T>(c, (size_t)G * d * n);
     if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
-    if (op->T == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
+    if (nTb == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
     for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT) {
-        if (op->T > 0)
+        if (nTb > 0)
             hipLaunchKernelGGL(saso_apply_kernel<T>, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m,
-                               op->T, op->nnz, op->src, A, lda, tpg, r_base, partial);
+                               op->T, op->nnz, op->src, A, lda, tpg, r_base, partial, row0, mloc, tb0, tb1);
     }
     RLHIP_LAUNCH_CHECK();
     const int64_t total = d * n;
@@ -335,6 +342,11 @@ int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, i
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);
     return 0;
+}
+
+template <typename T>
+int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb) {
+    return saso_apply_rows<T>(c, op, n, alpha, A, lda, 0, op->m, beta, B, ldb);
 }
 
 // in-place forward column permutation; idx is a DEVICE array of n 1-based indices (left untouched)
@@ -369,6 +381,8 @@ int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* 
 
 template int saso_dense<double>(rlhip_ctx*, const SasoOp*, double*);
 template int saso_dense<float>(rlhip_ctx*, const SasoOp*, float*);
+template int saso_apply_rows<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const double*, int64_t, int64_t, int64_t, double, double*, int64_t);
+template int saso_apply_rows<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const float*, int64_t, int64_t, int64_t, float, float*, int64_t);
 template int saso_apply<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const double*, int64_t, double, double*, int64_t);
 template int saso_apply<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const float*, int64_t, float, float*, int64_t);
 template int col_swap<double>(rlhip_ctx*, int64_t, int64_t, int64_t, double*, int64_t, const int64_t*);

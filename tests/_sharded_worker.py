@@ -35,23 +35,37 @@ def main():
     # multi-block QB on the shards (b_sz < k exercises the deflation / re-orthogonalisation all-reduces)
     r2 = d.drv_rsvd(ctx, Aloc, len(rows), n, k, max(k // 4, 1), 1e-12, p, 1)
     U2loc = d.cm_to_numpy(r2["U"])
+    # CQRRPT on the shards: sketch partial sums and the Gram matrix are the two exchanges
+    ncq = min(n, 96)
+    Acq = A[:, :ncq] * np.logspace(0, -3, ncq)
+    Aq = d.cm_from_numpy(np.ascontiguousarray(Acq[rows]))
+    rq = d.drv_cqrrpt(ctx, Aq, len(rows), ncq, 1.25, 4, key=(5, 0))
+    Qloc, Rq, Jq = d.cm_to_numpy(Aq), d.cm_to_numpy(rq["R"]), rq["J"].cpu().numpy()
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
 
         U = np.zeros((m, r["k"])); U2 = np.zeros((m, r2["k"]))
-        for rr, u, u2 in gathered:
-            U[rr] = u; U2[rr] = u2
+        Qc = np.zeros((m, ncq))
+        for rr, u, u2, qq in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
         r1 = d.drv_rsvd(ctx1, d.cm_from_numpy(A), m, n, k, k, 1e-12, p, 1)
         S1 = r1["S"].cpu().numpy()
         ref = oracle.rsvd(A, k, k, 1e-12, p, 1)          # same Philox stream on both sides (oracle/oracle.cpp fill_dense)
+        Aq1 = d.cm_from_numpy(Acq)
+        rq1 = d.drv_cqrrpt(ctx1, Aq1, m, ncq, 1.25, 4, key=(5, 0))
+        kq = rq["rank"]
         nA = np.linalg.norm(A)
         out = dict(
+            cq_rank=kq, cq_rank1=rq1["rank"], cq_J_equal=bool(np.array_equal(Jq, rq1["J"].cpu().numpy())),
+            cq_R=float(np.linalg.norm(Rq[:kq] - d.cm_to_numpy(rq1["R"])[:kq]) / np.linalg.norm(Rq[:kq])),
+            cq_resid=float(np.linalg.norm(Acq[:, Jq - 1] - Qc[:, :kq] @ Rq[:kq]) / np.linalg.norm(Acq)),
+            cq_orth=float(np.linalg.norm(Qc[:, :kq].T @ Qc[:, :kq] - np.eye(kq))),
             k=r["k"], k2=r2["k"], qb_rc=r["qb_rc"], qb_rc2=r2["qb_rc"],
             S_vs_single=float(np.max(np.abs(S - S1)) / S1[0]),
             S_vs_oracle=float(np.max(np.abs(S - ref["S"])) / ref["S"][0]),

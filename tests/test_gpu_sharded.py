@@ -37,3 +37,6 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     assert out["recon"] <= out["recon_ref"] * (1 + 1e-6) + 1e-12
     assert out["orthU"] <= 1e-10 and out["orthV"] <= 1e-10
     assert out["recon2"] <= out["recon_ref"] * 1.5 + 1e-12 and out["orthU2"] <= 1e-9
+    # row-sharded CQRRPT == single-device CQRRPT (same SASO, same pivots; R to rounding)
+    assert out["cq_rank"] == out["cq_rank1"] and out["cq_J_equal"]
+    assert out["cq_R"] <= 1e-10 and out["cq_resid"] <= 1e-12 and out["cq_orth"] <= 1e-11
