@@ -26,7 +26,9 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
 
 namespace {
 
-constexpr int SB = 32;    // register sub-block
+constexpr int SB = 32;    // sub-block solved by the row-per-lane kernel (SB = 64 halves the passes but its LDS tile allows only
+                          // two waves per CU: measured 714 us per pass against 123 us for SB = 32)
+constexpr int RW = 256;   // rows (= threads) per workgroup of that kernel: LDS tile SB x RW + packed triangle SB x SB
 constexpr int DB = 256;   // diagonal block handled by one fused kernel
 
 // Ut[l * ldp + c] = U[l, c] for l <= c < nb (row-major, zero below the diagonal), padded with the identity
@@ -48,41 +50,59 @@ __global__ void pack_upper_rows_kernel(int nb, int ldp, int unit, const T* __res
     Ut[(int64_t)l * ldp + c] = v;
 }
 
+// One row per lane.  The 32 values of a row are fetched with 32 back-to-back loads (clamped column index, no branches:
+// a branch per column serialised the loads behind s_waitcnt vmcnt(0), and feeding the triangle through SGPR operands
+// spilled thousands of SGPRs to VGPR lanes -- that version ran at 2 TB/s).  The solve then works on 8-column register
+// groups: columns already solved live in an LDS tile (row r of the workgroup = lane r, conflict free), their
+// contribution is a ROLLED loop (tiny code, broadcast 16-byte reads of the packed triangle), the 8 x 8 triangle of the
+// group itself is unrolled.
 template <typename T>
-__global__ __launch_bounds__(256) void trsm_diag_kernel(int64_t m, int nb, int ldp, T alpha,
+__global__ __launch_bounds__(RW) void trsm_diag_kernel(int64_t m, int nb, int ldp, T alpha,
                                                         const T* __restrict__ Ut, T* __restrict__ B,
                                                         int64_t ldb) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    constexpr int GW = 8;                                  // register group width
+    __shared__ __attribute__((aligned(16))) T sU[SB * SB]; // packed rows of the triangle, reciprocal diagonal
+    __shared__ T sX[SB * RW];                              // sX[c * RW + lane]: solved columns of this workgroup's rows
+    const int tid = threadIdx.x;
+    for (int e = tid; e < SB * SB; e += RW) sU[e] = Ut[e];
+    const int64_t r = (int64_t)blockIdx.x * RW + tid;
     const bool live = r < m;
-    const int64_t rr = live ? r : 0;  // dead lanes shadow row 0 without storing (keeps control flow uniform)
-    T* __restrict__ row = B + rr;
-    const int nsb = ldp / SB;
-    for (int sb = 0; sb < nsb; ++sb) {
-        const int c0 = sb * SB;
-        T acc[SB];
-#pragma unroll
-        for (int c = 0; c < SB; ++c) acc[c] = (c0 + c < nb) ? alpha * row[(int64_t)(c0 + c) * ldb] : T(0);
-        // contribution of the already solved columns of this diagonal block
-        for (int l = 0; l < c0; ++l) {
-            const T xl = row[(int64_t)l * ldb];
-            const T* __restrict__ u = Ut + (int64_t)l * ldp + c0;
-#pragma unroll
-            for (int c = 0; c < SB; ++c) acc[c] -= xl * u[c];
-        }
-        // triangular solve inside the sub-block
+    T* __restrict__ row = B + (live ? r : m - 1);          // dead lanes shadow the last row without storing
+    {
+        T v[SB];
 #pragma unroll
         for (int c = 0; c < SB; ++c) {
-            const T* __restrict__ u = Ut + (int64_t)(c0 + c) * ldp + c0;
-            acc[c] *= u[c];  // reciprocal diagonal
-#pragma unroll
-            for (int c2 = c + 1; c2 < SB; ++c2) acc[c2] -= acc[c] * u[c2];
+            const int cc = (c < nb) ? c : (nb - 1);
+            v[c] = row[(int64_t)cc * ldb];
         }
-        if (live) {
 #pragma unroll
-            for (int c = 0; c < SB; ++c)
-                if (c0 + c < nb) row[(int64_t)(c0 + c) * ldb] = acc[c];
-        }
+        for (int c = 0; c < SB; ++c) sX[c * RW + tid] = alpha * v[c];
     }
+    __syncthreads();                                       // sU complete (sX is only touched by its own lane)
+    for (int g0 = 0; g0 < SB; g0 += GW) {
+        T x[GW];
+#pragma unroll
+        for (int j = 0; j < GW; ++j) x[j] = sX[(g0 + j) * RW + tid];
+        for (int l = 0; l < g0; ++l) {                     // earlier columns of the block (rolled)
+            const T xl = sX[l * RW + tid];
+            const T* u = sU + l * SB + g0;
+#pragma unroll
+            for (int j = 0; j < GW; ++j) x[j] -= xl * u[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GW; ++j) {                     // the group's own 8 x 8 triangle
+            const T* u = sU + (g0 + j) * SB + g0;
+            x[j] *= u[j];
+#pragma unroll
+            for (int j2 = j + 1; j2 < GW; ++j2) x[j2] -= x[j] * u[j2];
+        }
+#pragma unroll
+        for (int j = 0; j < GW; ++j) sX[(g0 + j) * RW + tid] = x[j];
+    }
+    if (live) {
+        for (int c = 0; c < nb; ++c) row[(int64_t)c * ldb] = sX[c * RW + tid];
+    }
+    (void)ldp;
 }
 
 template <typename T>
@@ -141,7 +161,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             }
             hipLaunchKernelGGL(pack_upper_rows_kernel<T>, dim3((SB * SB + 255) / 256), dim3(256), 0, c->stream, sbw, SB, diag,
                                A + jc + jc * lda, lda, Ut);
-            hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, sbw, SB, a2,
+            hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + RW - 1) / RW)), dim3(RW), 0, c->stream, m, sbw, SB, a2,
                                Ut, B + jc * ldb, ldb);
             RLHIP_LAUNCH_CHECK();
         }
