@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int64_t n, int64_t j0,
         T x[NB];
         T* col = A + j0 + c * lda;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) x[i] = (i < jb) ? col[i] : T(0);
+        for (int i = 0; i < NB; ++i) { const T t = col[(i < jb) ? i : (jb - 1)]; x[i] = (i < jb) ? t : T(0); }   // clamped, not branched: the loads stay batched
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i < jb) {
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
             T col[NB];
             const int j = lane & 31;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) col[i] = (lane < 32 && i < jb && j < jb && i <= j) ? A[(j0 + i) + (int64_t)(j0 + j) * lda] : T(0);
+            for (int i = 0; i < NB; ++i) {    // clamped addresses + select: 32 loads in flight instead of 32 branch-separated round trips
+                const T t = A[(j0 + ((i < jb) ? i : (jb - 1))) + (int64_t)(j0 + ((j < jb) ? j : (jb - 1))) * lda];
+                col[i] = (lane < 32 && i < jb && j < jb && i <= j) ? t : T(0);
+            }
             int bad = 0;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
             T x[NB];
             T* colp = A + j0 + (int64_t)(j0 + jb + c) * lda;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) x[i] = (i < jb) ? colp[i] : T(0);
+            for (int i = 0; i < NB; ++i) { const T t = colp[(i < jb) ? i : (jb - 1)]; x[i] = (i < jb) ? t : T(0); }
             // right-looking substitution: once x[l] is final every later entry is updated independently (ILP, no serial dot)
 #pragma unroll
             for (int l = 0; l < NB; ++l) {

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void lunp_panel_kernel(int64_t n, int64_t j0, 
         T x[LB];
         T* col = A + j0 + c * lda;
 #pragma unroll
-        for (int i = 0; i < LB; ++i) x[i] = (i < jb) ? col[i] : T(0);
+        for (int i = 0; i < LB; ++i) { const T t = col[(i < jb) ? i : (jb - 1)]; x[i] = (i < jb) ? t : T(0); }   // clamped, not branched
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             if (i < jb) {

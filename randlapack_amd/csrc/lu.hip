@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
     __shared__ T s_val[256];
     __shared__ int64_t s_row[256];
     __shared__ int s_w[256];
+    __shared__ T s_piv[PB];
     const int tid = threadIdx.x;
     const int64_t G = gridDim.x, me = blockIdx.x;
     const int pb = g.pb;
@@ -132,7 +133,11 @@ __global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
             if (p >= lo && p < hi && tid < pb) P[tid * rpw + (p - lo)] = drow[tid];
         }
         __syncthreads();
-        const T piv = (p != j) ? prow[c] : ((j >= lo && j < hi) ? P[c * rpw + (j - lo)] : drow[c]);
+        // the pivot row (the row that now sits at position j) goes through LDS: one parallel fetch by 32 lanes instead of up
+        // to 31 branch-separated global loads per thread
+        if (tid < PB) s_piv[tid] = (tid < pb) ? ((p != j) ? prow[tid] : drow[tid]) : T(0);
+        __syncthreads();
+        const T piv = s_piv[c];
         if (piv == T(0)) {
             if (me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
         } else {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
             const T rp = T(1) / piv;
             T u[PB];
 #pragma unroll
-            for (int c2 = 0; c2 < PB; ++c2) u[c2] = (c2 > c && c2 < pb) ? ((p != j) ? prow[c2] : drow[c2]) : T(0);
+            for (int c2 = 0; c2 < PB; ++c2) u[c2] = (c2 > c) ? s_piv[c2] : T(0);
             for (int64_t r = tid; r < nloc; r += 256) {
                 if (lo + r <= j) continue;
                 const T l = P[c * rpw + r] * rp;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void unit_lower_solve_kernel(int64_t n, int64_
     T x[PB];
     T* col = A + j0 + c * lda;
 #pragma unroll
-    for (int i = 0; i < PB; ++i) x[i] = (i < jb) ? col[i] : T(0);
+    for (int i = 0; i < PB; ++i) { const T t = col[(i < jb) ? i : (jb - 1)]; x[i] = (i < jb) ? t : T(0); }   // clamped, not branched
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         if (i < jb) {
@@ -254,7 +259,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         const int64_t rows = m - j0;
         // rows per workgroup: at least 64, LDS piece pb*rpw*sizeof(T) <= 96 KiB
         int64_t rpw = (rows + Gmax - 1) / Gmax;
-        if (rpw < 64) rpw = 64;
+        if (rpw < 256) rpw = 256;   // fewer, fatter workgroups: the per-column rendezvous and winner search shrink with G
         const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
         if (rpw > rpw_max) { rlhip_ws_release(c, mark); return -2; }   // > num_cu * 384 rows (fp64): not needed on the path
         const int64_t G = (rows + rpw - 1) / rpw;
