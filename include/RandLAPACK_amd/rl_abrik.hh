@@ -1,0 +1,176 @@
+// ABRIK (reference: RandLAPACK/drivers/rl_abrik.hh:30-768): randomized block Krylov iteration for a truncated SVD of any
+// linear operator (BASELINE config 5).  Same object shape as the reference; buffers are DEVICE buffers and the
+// operator is a device linop (rl_linops.hh).  The reference grows X_ev / Y_od / R / S with realloc after every block;
+// here they live in `Grow` (amortised doubling, contents preserved, new columns zeroed) so that an unbounded
+// max_krylov_iters (the default INT_MAX) does not force an n x n allocation up front.
+//   qr_exp = geqrf_ungqr  -> device geqrf + ungqr;   qr_exp = cqrrt -> raises (CQRRT is a "next" row).
+// Row-sharded operators are next round's work (X-side QR needs a sharded panel QR); a sharded queue raises.
+#pragma once
+#include <climits>
+#include <cmath>
+#include <limits>
+#include <vector>
+#include "rl_exceptions.hh"
+#include "rl_blaspp.hh"
+#include "rl_lapackpp.hh"
+#include "rl_randblas.hh"
+#include "rl_util.hh"
+#include "rl_linops.hh"
+
+namespace RandLAPACK {
+
+struct ABRIKSubroutines {
+    enum QR_explicit { geqrf_ungqr, cqrrt };
+};
+
+template <typename T, typename RNG = RandBLAS::DefaultRNG>
+class ABRIK {
+    // column-growing device matrix with a fixed leading dimension (realloc semantics of the reference, :371-375,461-484)
+    struct Grow {
+        blas::Queue& q; int64_t ld; int64_t cap = 0; T* p = nullptr;
+        Grow(blas::Queue& queue, int64_t ld_, int64_t cols) : q(queue), ld(ld_) { ensure(cols); }
+        ~Grow() { if (p) blas::device_free(p, q); }
+        void ensure(int64_t cols) {
+            if (cols <= cap) return;
+            const int64_t ncap = std::max<int64_t>(cols, 2 * cap);
+            T* np_ = blas::device_malloc<T>(ld * ncap, q);
+            if (cap > 0) blas::device_copy_vector(ld * cap, p, np_, q);
+            blas::device_memset(np_ + ld * cap, 0, ld * (ncap - cap), q);
+            if (p) { q.sync(); blas::device_free(p, q); }
+            p = np_; cap = ncap;
+        }
+    };
+
+public:
+    using Subroutines = ABRIKSubroutines;
+
+    ABRIK(blas::Queue& queue, bool verb, bool time_subroutines, T ep) : q(queue) {                               // :64-77
+        qr_exp = Subroutines::QR_explicit::geqrf_ungqr;
+        verbose = verb;
+        timing = time_subroutines;
+        tol = ep;
+        max_krylov_iters = INT_MAX;
+        num_krylov_iters = 0;
+        norm_R_end = 0;
+        singular_triplets_found = 0;
+    }
+
+    /// A: linear operator (rl_linops.hh).  U (m x triplets), V (n x triplets), Sigma (triplets): allocated HERE on the
+    /// device, owned by the caller afterwards (blas::device_free), like the reference's new[] (:678-680).  Returns 0.
+    template <typename GLO>
+    int call(GLO& A, int64_t k, T*& U, T*& V, T*& Sigma, RandBLAS::RNGState<RNG>& state) {
+        randlapack_require(k > 0) << "target rank k=" << k << " must be > 0";                                   // :176
+        randlapack_require(qr_exp == Subroutines::QR_explicit::geqrf_ungqr) << "ABRIK on the device: qr_exp = cqrrt is not available yet";
+        randlapack_require(q.world() == 1) << "ABRIK on the device: row-sharded operators are not wired yet";
+        const int64_t m = A.n_rows, n = A.n_cols;
+        int64_t iter = 0, iter_od = 0, iter_ev = 0, end_rows = 0, end_cols = 0;
+        T norm_R = 0;
+        const int max_iters = max_krylov_iters;
+        Grow Y_od(q, n, k), X_ev(q, m, k), R(q, n, k), S(q, n + k, k);
+        blas::Scratch ws(q);
+        T* Y_orth_buf = nullptr;          // k x (iter_ev k), ld k      -- sized on demand (reference: k x n up front, :247)
+        T* X_orth_buf = nullptr;          // (iter_od k) x k, ld n + k  -- idem (:248)
+        T* tau = ws.alloc<T>(k);
+        int64_t curr_Y_cols = k, curr_X_cols = k;
+        int64_t Y_i = 0, X_i = 0, R_i = -1, R_ii = 0, S_i = 0, S_ii = k;      // element offsets (the reference's moving pointers)
+        const T norm_A = A.fro_nrm();                                                                           // :272
+        const T sq_tol = tol * tol;
+        const T threshold = std::sqrt(1 - sq_tol) * norm_A;
+        const T sqrt_eps = std::sqrt(std::numeric_limits<T>::epsilon());
+        auto elem = [&](const T* p) { T v; blas::copy_to_host(1, p, &v, q); return v; };
+
+        RandBLAS::DenseDist D(n, k);                                                                            // :298-299
+        state = RandBLAS::fill_dense(D, Y_od.p + Y_i, state, q);
+        A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, (T)1.0, Y_od.p + Y_i, n, (T)0.0, X_ev.p + X_i, m);   // :311
+        lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                           // :333
+        lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                        // :342
+        ++iter_od;
+        ++iter;
+        while (1) {
+            if (iter % 2 != 0) {
+                A(Side::Left, Layout::ColMajor, Op::Trans, Op::NoTrans, n, k, m, (T)1.0, X_ev.p + X_i, m, (T)0.0, Y_od.p + Y_i, n);   // :364
+                curr_X_cols += k;                                                                               // :371-375
+                X_ev.ensure(curr_X_cols);
+                X_i = m * (curr_X_cols - k);
+                if (iter != 1) {                                                                                // :384-394
+                    blas::Scratch w2(q);
+                    Y_orth_buf = w2.alloc<T>(k * iter_ev * k);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, k, iter_ev * k, n, (T)1.0, Y_od.p + Y_i, n, Y_od.p, n, (T)0.0, R.p + R_i, n, q);
+                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, k, iter_ev * k, (T)-1.0, Y_od.p, n, R.p + R_i, n, (T)1.0, Y_od.p + Y_i, n, q);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, k, iter_ev * k, n, (T)1.0, Y_od.p + Y_i, n, Y_od.p, n, (T)0.0, Y_orth_buf, k, q);
+                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, k, iter_ev * k, (T)-1.0, Y_od.p, n, Y_orth_buf, k, (T)1.0, Y_od.p + Y_i, n, q);
+                }
+                lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                                   // :420
+                util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                                // :432 (upper triangle, transposed)
+                lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                                // :444
+                if (std::abs(elem(R.p + R_ii + (n + 1) * (k - 1))) < sqrt_eps) break;                           // :455-458
+                R.ensure(curr_X_cols);                                                                          // :461-484
+                R_i = (iter_ev + 1) * k;
+                R_ii = (n * k * (iter_ev + 1)) + k + (k * iter_ev);
+                ++iter_ev;
+            } else {
+                A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, (T)1.0, Y_od.p + Y_i, n, (T)0.0, X_ev.p + X_i, m);   // :494
+                curr_Y_cols += k;                                                                               // :501-505
+                Y_od.ensure(curr_Y_cols);
+                Y_i = n * (curr_Y_cols - k);
+                {                                                                                               // :515-522
+                    blas::Scratch w2(q);
+                    const int64_t ldx = iter_od * k;
+                    X_orth_buf = w2.alloc<T>(ldx * k);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, iter_od * k, k, m, (T)1.0, X_ev.p, m, X_ev.p + X_i, m, (T)0.0, S.p + S_i, n + k, q);
+                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, iter_od * k, (T)-1.0, X_ev.p, m, S.p + S_i, n + k, (T)1.0, X_ev.p + X_i, m, q);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, iter_od * k, k, m, (T)1.0, X_ev.p, m, X_ev.p + X_i, m, (T)0.0, X_orth_buf, ldx, q);
+                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, iter_od * k, (T)-1.0, X_ev.p, m, X_orth_buf, ldx, (T)1.0, X_ev.p + X_i, m, q);
+                }
+                lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                   // :552
+                lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);                  // :561
+                lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                // :570
+                if (std::abs(elem(S.p + S_ii + ((n + k) + 1) * (k - 1))) < sqrt_eps) break;                     // :595-598
+                S.ensure(curr_Y_cols);                                                                          // :604-630
+                S_i = (n + k) * k * iter_od;
+                S_ii = (n + k) * k * iter_od + k + (iter_od * k);
+                ++iter_od;
+            }
+            if (iter % 2 != 0) {                                                                                // :641-642 lantr(Fro, Upper)
+                blas::Scratch w2(q);
+                const int64_t nn = iter_ev * k;
+                T* Tri = w2.alloc<T>(nn * nn);
+                lapack::laset(MatrixType::General, nn, nn, (T)0, (T)0, Tri, nn, q);
+                lapack::lacpy(MatrixType::Upper, nn, nn, R.p, n, Tri, nn, q);
+                norm_R = lapack::lange(Norm::Fro, nn, nn, Tri, nn, q);
+            }
+            if (iter >= max_iters) break;                                                                       // :650-653
+            ++iter;
+            if (norm_R > threshold) break;                                                                      // :659-662
+        }
+        norm_R_end = norm_R;
+        num_krylov_iters = (int)iter;
+        end_cols = num_krylov_iters * k / 2;                                                                    // :668-669
+        end_rows = (iter % 2 == 0) ? end_cols + k : end_cols;
+        T* U_hat = ws.alloc<T>(end_rows * end_cols);
+        T* VT_hat = ws.alloc<T>(end_cols * end_cols);
+        Sigma = blas::device_malloc<T>(std::min(end_cols, end_rows), q);                                        // :678-680
+        U = blas::device_malloc<T>(m * end_cols, q);
+        V = blas::device_malloc<T>(n * end_cols, q);
+        if (iter % 2 != 0) lapack::gesdd(Job::SomeVec, end_rows, end_cols, R.p, n, Sigma, U_hat, end_rows, VT_hat, end_cols, q);       // :685
+        else lapack::gesdd(Job::SomeVec, end_rows, end_cols, S.p, n + k, Sigma, U_hat, end_rows, VT_hat, end_cols, q);                 // :688
+        blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, end_cols, end_rows, (T)1.0, X_ev.p, m, U_hat, end_rows, (T)0.0, U, m, q);   // :696
+        blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, end_cols, end_cols, (T)1.0, Y_od.p, n, VT_hat, end_cols, (T)0.0, V, n, q);    // :698
+        singular_triplets_found = end_cols;
+        q.sync();
+        return 0;
+    }
+
+    blas::Queue& q;
+    Subroutines::QR_explicit qr_exp;
+    bool verbose;
+    bool timing;
+    T tol;
+    int num_krylov_iters;
+    int max_krylov_iters;
+    std::vector<long> times;
+    T norm_R_end;
+    int64_t singular_triplets_found;
+};
+
+}  // namespace RandLAPACK

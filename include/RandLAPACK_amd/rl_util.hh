@@ -49,6 +49,15 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
 /// Forward column permutation (== lapack::lapmt(true, ...)): on exit column i of A holds former column idx[i]-1.
 /// idx is a DEVICE vector of n 1-based indices and is left untouched (the reference's lapmt restores it).
 /// k > n throws std::runtime_error like the reference.                               (rl_util.hh:151-164)
+/// util::transposition (misc/rl_util.hh:315-334): AT (ld ldat) = A^T; copy_upper_triangle != 0 moves only the upper triangle of the
+/// leading n x n block (the reference ignores m in that mode).
+template <typename T>
+void transposition(int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat, int copy_upper_triangle, blas::Queue& q) {
+    const int64_t mm = copy_upper_triangle ? n : m;
+    if constexpr (sizeof(T) == 8) blas::check(rlhip_transpose_f64(q.ctx(), mm, n, (const double*)A, lda, (double*)AT, ldat, copy_upper_triangle), "transposition");
+    else blas::check(rlhip_transpose_f32(q.ctx(), mm, n, (const float*)A, lda, (float*)AT, ldat, copy_upper_triangle), "transposition");
+}
+
 template <typename T>
 void col_swap(int64_t m, int64_t n, int64_t k, T* A, int64_t lda, int64_t const* idx, blas::Queue& q) {
     if (k > n) throw std::runtime_error("Invalid rank parameter.");

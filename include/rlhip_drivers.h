@@ -63,6 +63,12 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
                         const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
                         int apply_trans_q);
 
+/* ABRIK<double>::call on a dense operator (drivers/rl_abrik.hh:166; linops::DenseLinOp rl_dense_linop.hh).  A (m x n, lda) is not
+ * modified.  *U (m x triplets), *Sigma (triplets), *V (n x triplets) are allocated by the callee (rlhip_malloc), freed by the caller.
+ * max_krylov_iters <= 0 keeps the object's default (INT_MAX). */
+int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,
+                        double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end);
+
 /* fp32 instantiations (same contracts; tol / eps / d_factor are float) */
 int rlhip_drv_stab_f32(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, float* A, int* chol_fail);
 int rlhip_drv_rsvd_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t* k, int64_t b_sz, float tol,

@@ -317,3 +317,23 @@ def hqrrp(A, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), ke
     rc = lib.oracle_hqrrp_f64(i64(m), i64(n), _p(A), i64(m), _p(J), _p(tau), i64(nb_alg), i64(pp), i64(panel_pivoting), i64(qr_type),
                               _p(st), _p(Gf) if Gf is not None else None)
     return dict(rc=rc, A=A, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def abrik(A, k, tol, max_krylov_iters, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """ABRIK::call on a dense operator (drivers/rl_abrik.hh:166; qr_exp = geqrf_ungqr).  returns dict(rc, U, S, V,
+    triplets, iters, norm_R_end, next_ctr); U/V have `triplets` columns."""
+    lib = load()
+    A = _f(A).copy(order="F")
+    m, n = A.shape
+    cap = max_krylov_iters * k // 2 + k
+    U = np.zeros((m, cap), order="F")
+    V = np.zeros((n, cap), order="F")
+    S = np.zeros(cap)
+    st = _state(ctr, key)
+    trip, iters = i64(0), i64(0)
+    nre = dbl(0.0)
+    rc = lib.oracle_abrik_f64(i64(m), i64(n), _p(A), i64(m), i64(k), dbl(tol), i64(max_krylov_iters), _p(U), _p(V), _p(S), _p(st),
+                              C.byref(trip), C.byref(iters), C.byref(nre))
+    t = int(trip.value)
+    return dict(rc=rc, U=U[:, :t], S=S[:t], V=V[:, :t], triplets=t, iters=int(iters.value), norm_R_end=float(nre.value),
+                next_ctr=tuple(int(x) for x in st[:4]))

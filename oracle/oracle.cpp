@@ -756,6 +756,99 @@ int hqrrp_call(int64_t m_A, int64_t n_A, double* A, int64_t ldA, int64_t* jpvt, 
     return 0;
 }
 
+
+// =====================================================================================================================
+// ABRIK (drivers/rl_abrik.hh:166-768): randomized block Krylov truncated SVD of a linear operator, here a dense matrix
+// (linops::DenseLinOp, rl_dense_linop.hh: operator() = gemm, fro_nrm = lange).  qr_exp = geqrf_ungqr (the default, :69).
+// Buffers that the reference grows with realloc are std::vectors grown by resize (contents preserved, new part zeroed where
+// the reference zeroes it); pointers are kept as offsets.  Debug code marked "REMOVE ME" (:578-591) is not restated.
+// U (m x end_cols), V (n x end_cols), Sigma (end_cols) must be large enough for end_cols <= max_iters * k / 2.
+// =====================================================================================================================
+int abrik_call(int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters, double* U,
+               double* V, double* Sigma, RNGState& st, int64_t* triplets_out, int64_t* iters_out, double* norm_R_end_out) {
+    if (k <= 0) return -1;                                                                        // :176
+    int64_t iter = 0, iter_od = 0, iter_ev = 0, end_rows = 0, end_cols = 0;
+    double norm_R = 0;
+    const int64_t max_iters = max_krylov_iters;
+    std::vector<double> Y_od((size_t)n * k, 0.0), X_ev((size_t)m * k, 0.0), R((size_t)n * k, 0.0), S((size_t)(n + k) * k, 0.0),
+        Y_orth_buf((size_t)k * n, 0.0), X_orth_buf((size_t)k * (n + k), 0.0), tau(k, 0.0);
+    int64_t curr_Y_cols = k, curr_X_cols = k;
+    int64_t Y_i = 0, X_i = 0;                      // offsets into Y_od / X_ev
+    int64_t R_i = -1, R_ii = 0, S_i = 0, S_ii = k;  // offsets into R / S
+    const double norm_A = lange_fro(m, n, A, lda);                                                // A.fro_nrm() :272
+    const double sq_tol = tol * tol;
+    const double threshold = std::sqrt(1 - sq_tol) * norm_A;
+    fill_dense(0, n, k, Y_od.data() + Y_i, st);                                                   // :298-299
+    gemm('N', 'N', m, k, n, 1.0, A, lda, Y_od.data() + Y_i, n, 0.0, X_ev.data() + X_i, m);        // :311
+    geqrf(m, k, X_ev.data() + X_i, m, tau.data());                                                // :333
+    orgqr(m, k, k, X_ev.data() + X_i, m, tau.data());                                             // :342
+    ++iter_od;
+    ++iter;
+    const double sqrt_eps = std::sqrt(std::numeric_limits<double>::epsilon());
+    while (1) {
+        if (iter % 2 != 0) {
+            gemm('T', 'N', n, k, m, 1.0, A, lda, X_ev.data() + X_i, m, 0.0, Y_od.data() + Y_i, n);   // :364
+            curr_X_cols += k;                                                                     // :371-375
+            X_ev.resize((size_t)m * curr_X_cols, 0.0);
+            X_i = m * (curr_X_cols - k);
+            if (iter != 1) {                                                                      // :384-394
+                gemm('T', 'N', k, iter_ev * k, n, 1.0, Y_od.data() + Y_i, n, Y_od.data(), n, 0.0, R.data() + R_i, n);
+                gemm('N', 'T', n, k, iter_ev * k, -1.0, Y_od.data(), n, R.data() + R_i, n, 1.0, Y_od.data() + Y_i, n);
+                gemm('T', 'N', k, iter_ev * k, n, 1.0, Y_od.data() + Y_i, n, Y_od.data(), n, 0.0, Y_orth_buf.data(), k);
+                gemm('N', 'T', n, k, iter_ev * k, -1.0, Y_od.data(), n, Y_orth_buf.data(), k, 1.0, Y_od.data() + Y_i, n);
+            }
+            std::fill(tau.begin(), tau.end(), 0.0);                                               // :419-444
+            geqrf(n, k, Y_od.data() + Y_i, n, tau.data());
+            transposition(0, k, Y_od.data() + Y_i, n, R.data() + R_ii, n, 1);
+            orgqr(n, k, k, Y_od.data() + Y_i, n, tau.data());
+            if (std::abs(R[R_ii + (n + 1) * (k - 1)]) < sqrt_eps) break;                          // :455-458
+            R.resize((size_t)n * curr_X_cols, 0.0);                                               // :461-484 (new part zero)
+            R_i = (iter_ev + 1) * k;
+            R_ii = (n * k * (iter_ev + 1)) + k + (k * iter_ev);
+            ++iter_ev;
+        } else {
+            gemm('N', 'N', m, k, n, 1.0, A, lda, Y_od.data() + Y_i, n, 0.0, X_ev.data() + X_i, m);  // :494
+            curr_Y_cols += k;                                                                     // :501-505
+            Y_od.resize((size_t)n * curr_Y_cols, 0.0);
+            Y_i = n * (curr_Y_cols - k);
+            gemm('T', 'N', iter_od * k, k, m, 1.0, X_ev.data(), m, X_ev.data() + X_i, m, 0.0, S.data() + S_i, n + k);   // :515-522
+            gemm('N', 'N', m, k, iter_od * k, -1.0, X_ev.data(), m, S.data() + S_i, n + k, 1.0, X_ev.data() + X_i, m);
+            gemm('T', 'N', iter_od * k, k, m, 1.0, X_ev.data(), m, X_ev.data() + X_i, m, 0.0, X_orth_buf.data(), n + k);
+            gemm('N', 'N', m, k, iter_od * k, -1.0, X_ev.data(), m, X_orth_buf.data(), n + k, 1.0, X_ev.data() + X_i, m);
+            std::fill(tau.begin(), tau.end(), 0.0);                                               // :549-570
+            geqrf(m, k, X_ev.data() + X_i, m, tau.data());
+            lacpy('U', k, k, X_ev.data() + X_i, m, S.data() + S_ii, n + k);
+            orgqr(m, k, k, X_ev.data() + X_i, m, tau.data());
+            if (std::abs(S[S_ii + ((n + k) + 1) * (k - 1)]) < sqrt_eps) break;                    // :595-598
+            S.resize((size_t)(n + k) * curr_Y_cols, 0.0);                                         // :604-630
+            S_i = (n + k) * k * iter_od;
+            S_ii = (n + k) * k * iter_od + k + (iter_od * k);
+            ++iter_od;
+        }
+        if (iter % 2 != 0) {                                                                      // :641-642 lantr(Fro, Upper)
+            double ss = 0;
+            const int64_t nn = iter_ev * k;
+            for (int64_t j = 0; j < nn; ++j)
+                for (int64_t i = 0; i <= j; ++i) ss += R[i + j * n] * R[i + j * n];
+            norm_R = std::sqrt(ss);
+        }
+        if (iter >= max_iters) break;                                                             // :650-653
+        ++iter;
+        if (norm_R > threshold) break;                                                            // :659-662
+    }
+    *norm_R_end_out = norm_R;
+    *iters_out = iter;
+    end_cols = iter * k / 2;                                                                      // :668-669
+    end_rows = (iter % 2 == 0) ? end_cols + k : end_cols;
+    std::vector<double> U_hat((size_t)end_rows * end_cols, 0.0), VT_hat((size_t)end_cols * end_cols, 0.0);
+    if (iter % 2 != 0) gesdd('S', end_rows, end_cols, R.data(), n, Sigma, U_hat.data(), end_rows, VT_hat.data(), end_cols);          // :685
+    else gesdd('S', end_rows, end_cols, S.data(), n + k, Sigma, U_hat.data(), end_rows, VT_hat.data(), end_cols);                    // :688
+    gemm('N', 'N', m, end_cols, end_rows, 1.0, X_ev.data(), m, U_hat.data(), end_rows, 0.0, U, m);            // :696
+    gemm('N', 'T', n, end_cols, end_cols, 1.0, Y_od.data(), n, VT_hat.data(), end_cols, 0.0, V, n);           // :698
+    *triplets_out = end_cols;
+    return 0;
+}
+
 extern "C" {
 
 const char* oracle_init(const char* lapack_path) { return orc::lapack_open(lapack_path); }
@@ -923,6 +1016,14 @@ int oracle_hqrrp_f64(int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt
                       int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], const double* G_in) {
     RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
     int rc = hqrrp_call(m, n, A, lda, jpvt, tau, nb_alg, pp, panel_pivoting, qr_type, st, G_in);
+    std::memcpy(state, st.ctr, 16);
+    return rc;
+}
+
+int oracle_abrik_f64(int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,
+                     double* U, double* V, double* Sigma, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end) {
+    RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+    int rc = abrik_call(m, n, A, lda, k, tol, max_krylov_iters, U, V, Sigma, st, triplets, iters, norm_R_end);
     std::memcpy(state, st.ctr, 16);
     return rc;
 }

@@ -195,6 +195,24 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
     });
 }
 
+int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,
+                        double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::linops::DenseLinOp<double> Aop(m, n, A, lda, RandLAPACK::Layout::ColMajor, q);
+        RandLAPACK::ABRIK<double, RNG> alg(q, false, false, tol);
+        if (max_krylov_iters > 0) alg.max_krylov_iters = (int)std::min<int64_t>(max_krylov_iters, INT_MAX);
+        State st = load_state(state);
+        *U = nullptr; *Sigma = nullptr; *V = nullptr;
+        int rc = alg.call(Aop, k, *U, *V, *Sigma, st);
+        store_state(st, state);
+        if (triplets) *triplets = alg.singular_triplets_found;
+        if (iters) *iters = alg.num_krylov_iters;
+        if (norm_R_end) *norm_R_end = alg.norm_R_end;
+        return rc;
+    });
+}
+
 // ---- fp32 instantiations of the same objects (BASELINE config 4 is fp32)
 int rlhip_drv_stab_f32(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int64_t k, float* A, int* chol_fail) {
     return guarded([&] {

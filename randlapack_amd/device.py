@@ -267,6 +267,24 @@ def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb
     return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))
 
 
+def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """ABRIK::call on the dense operator A (column-major tensor (n, m), not modified).  Returns dict(rc, U, S, V, triplets, iters,
+    norm_R_end, next_ctr); U/V are column-major tensors (triplets, m)/(triplets, n)."""
+    Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    trip, iters = C.c_int64(0), C.c_int64(0)
+    nre = C.c_double(0)
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_abrik_f64(ctx.h, m, n, A.data_ptr(), m, k, tol, max_krylov_iters, C.byref(Up), C.byref(Sp), C.byref(Vp), st,
+                                     C.byref(trip), C.byref(iters), C.byref(nre))
+    _drv_check(ctx, rc, "abrik")
+    t = int(trip.value)
+    U = _adopt(ctx, Up, m, t)
+    S = _adopt(ctx, Sp, t, 1).reshape(-1)
+    V = _adopt(ctx, Vp, n, t)
+    return dict(rc=rc, U=U, S=S, V=V, triplets=t, iters=int(iters.value), norm_R_end=float(nre.value),
+                next_ctr=tuple(int(x) for x in st[:4]))
+
+
 def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), want_G=False):
     """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G])."""
     torch = _torch()

@@ -584,3 +584,41 @@ def test_cqrrpt_hqrrp_rsvd_f32(ctx, orc):
     o = orc.rsvd(A, 32, 32, 1e-5, 2, 1)
     # same sketch stream in both precisions (the Gaussian is generated in fp64 and rounded): approximation quality equal to fp64's
     assert np.linalg.norm(A - (U * S) @ V.T) <= np.linalg.norm(A - (o["U"] * o["S"]) @ o["V"].T) * (1 + 1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ABRIK (drivers/rl_abrik.hh) on a dense device operator vs the oracle (same Philox stream on both sides)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,iters", [(400, 300, 8, 2), (400, 300, 8, 5), (400, 300, 8, 12), (300, 500, 4, 9), (2000, 2000, 32, 8)])
+def test_abrik_vs_oracle(ctx, orc, m, n, k, iters):
+    d = _d()
+    rng = np.random.default_rng(m + k + iters)
+    s = np.logspace(0, -6, min(m, n))
+    A = (np.linalg.qr(rng.standard_normal((m, len(s))))[0] * s) @ np.linalg.qr(rng.standard_normal((n, len(s))))[0].T
+    r = d.drv_abrik(ctx, d.cm_from_numpy(A), m, n, k, 1e-12, iters, key=(1, 0))
+    o = orc.abrik(A, k, 1e-12, iters, key=(1, 0))
+    assert r["rc"] == o["rc"] == 0
+    assert (r["iters"], r["triplets"], r["next_ctr"]) == (o["iters"], o["triplets"], o["next_ctr"])
+    U, S, V = d.cm_to_numpy(r["U"]), r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
+    t = r["triplets"]
+    kk = min(k, t)
+    assert np.max(np.abs(S[:kk] - o["S"][:kk]) / o["S"][:kk]) <= 1e-9     # leading block: same numbers as the reference path
+    assert np.max(np.abs(S - o["S"])) <= 1e-6 * o["S"][0]                  # whole Ritz spectrum (the tail is not converged)
+    assert abs(r["norm_R_end"] - o["norm_R_end"]) <= 1e-8 * o["norm_R_end"]
+    assert np.linalg.norm(U.T @ U - np.eye(t)) <= 1e-10 and np.linalg.norm(V.T @ V - np.eye(t)) <= 1e-10
+    assert min(np.linalg.norm(A.T @ U - V * S), np.linalg.norm(A @ V - U * S)) <= 1e-10
+
+
+def test_abrik_early_termination_and_bad_args(ctx, orc):
+    d = _d()
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 20)) @ rng.standard_normal((20, 200))
+    r = d.drv_abrik(ctx, d.cm_from_numpy(A), 300, 200, 8, 1e-12, 50, key=(2, 0))
+    o = orc.abrik(A, 8, 1e-12, 50, key=(2, 0))
+    assert (r["iters"], r["triplets"]) == (o["iters"], o["triplets"])
+    assert r["iters"] <= 8
+    np.testing.assert_allclose(r["S"].cpu().numpy(), o["S"], rtol=1e-8, atol=1e-10 * o["S"][0])
+    from randlapack_amd import _lib
+
+    with pytest.raises(_lib.RlhipError):
+        d.drv_abrik(ctx, d.cm_from_numpy(A), 300, 200, 0, 1e-12, 5)         # k must be > 0 (rl_abrik.hh:176)

@@ -248,3 +248,41 @@ def test_hqrrp_pivot_quality_and_rank_reveal(orc):
     dR = np.abs(np.diag(r["A"]))
     # |r_ii| tracks the singular values within a modest factor (randomized pivoting is a strong-RRQR in practice)
     assert np.all(dR[:60] <= s[:60] * 40) and np.all(dR[:60] >= s[:60] / 40)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ABRIK (drivers/rl_abrik.hh) -- test/drivers/test_abrik.cc style: leading singular triplets against a full SVD,
+# residual ||A^T U - V S|| or ||A V - U S|| (the side the last half-step closes exactly), early termination.
+# ---------------------------------------------------------------------------------------------------
+def _decay_mat(m, n, rng, lo=-6):
+    s = np.logspace(0, lo, min(m, n))
+    return (np.linalg.qr(rng.standard_normal((m, len(s))))[0] * s) @ np.linalg.qr(rng.standard_normal((n, len(s))))[0].T, s
+
+
+@pytest.mark.parametrize("m,n,k,iters", [(400, 300, 8, 2), (400, 300, 8, 5), (400, 300, 8, 12), (300, 500, 4, 9), (600, 600, 16, 6)])
+def test_abrik_dense_operator(orc, m, n, k, iters):
+    rng = np.random.default_rng(m + k + iters)
+    A, s = _decay_mat(m, n, rng)
+    r = orc.abrik(A, k, 1e-12, iters, key=(1, 0))
+    assert r["rc"] == 0 and r["iters"] == iters and r["triplets"] == iters * k // 2
+    U, S, V = r["U"], r["S"], r["V"]
+    t = r["triplets"]
+    assert np.linalg.norm(U.T @ U - np.eye(t)) <= 1e-10 and np.linalg.norm(V.T @ V - np.eye(t)) <= 1e-10
+    # one of the two residuals is at rounding level (which one depends on the parity of the last half-step, rl_abrik.hh:683-689)
+    res = min(np.linalg.norm(A.T @ U - V * S), np.linalg.norm(A @ V - U * S))
+    assert res <= 1e-10
+    if iters >= 12:
+        kk = min(k, t)
+        assert np.max(np.abs(S[:kk] - s[:kk]) / s[:kk]) <= 1e-6      # leading block converged
+    assert np.all(S <= s[:t] * (1 + 1e-12))                              # Ritz values never overshoot (Cauchy interlacing)
+    assert r["next_ctr"][0] == (n * k + 3) // 4                          # one n x k Gaussian (:298-299)
+
+
+def test_abrik_early_termination_on_exact_rank(orc):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 20)) @ rng.standard_normal((20, 200))
+    r = orc.abrik(A, 8, 1e-12, 50, key=(2, 0))
+    # rank 20, block 8: the loop must stop long before max_krylov_iters = 50 (threshold :659-662 or diagonal test :455-458)
+    assert r["rc"] == 0 and r["iters"] <= 8
+    sref = np.linalg.svd(A, compute_uv=False)
+    assert abs(r["S"][0] - sref[0]) <= 0.05 * sref[0]
