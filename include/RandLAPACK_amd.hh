@@ -14,5 +14,6 @@
 #include "RandLAPACK_amd/rl_cqrrpt.hh"
 #include "RandLAPACK_amd/rl_bqrrp.hh"
 #include "RandLAPACK_amd/rl_hqrrp.hh"
+#include "RandLAPACK_amd/rl_cqrrt.hh"
 #include "RandLAPACK_amd/rl_linops.hh"
 #include "RandLAPACK_amd/rl_abrik.hh"

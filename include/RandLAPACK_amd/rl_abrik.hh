@@ -3,8 +3,10 @@
 // operator is a device linop (rl_linops.hh).  The reference grows X_ev / Y_od / R / S with realloc after every block;
 // here they live in `Grow` (amortised doubling, contents preserved, new columns zeroed) so that an unbounded
 // max_krylov_iters (the default INT_MAX) does not force an n x n allocation up front.
-//   qr_exp = geqrf_ungqr  -> device geqrf + ungqr;   qr_exp = cqrrt -> raises (CQRRT is a "next" row).
-// Row-sharded operators are next round's work (X-side QR needs a sharded panel QR); a sharded queue raises.
+//   qr_exp = geqrf_ungqr  -> device geqrf + ungqr;   qr_exp = cqrrt -> CQRRT panels (rl_cqrrt.hh).
+// Row-sharded operator (one process per GPU, linop.row_sharded): X_ev / U are sharded by rows, everything n-long or k-sized is
+// replicated; exchanges: A^T X (n x k, inside the linop), the two re-orthogonalisation inner products of the X side, and
+// CQRRT's sketch + Gram all-reduces.  Needs qr_exp = cqrrt.
 #pragma once
 #include <climits>
 #include <cmath>
@@ -16,6 +18,7 @@
 #include "rl_randblas.hh"
 #include "rl_util.hh"
 #include "rl_linops.hh"
+#include "rl_cqrrt.hh"
 
 namespace RandLAPACK {
 
@@ -60,8 +63,30 @@ public:
     template <typename GLO>
     int call(GLO& A, int64_t k, T*& U, T*& V, T*& Sigma, RandBLAS::RNGState<RNG>& state) {
         randlapack_require(k > 0) << "target rank k=" << k << " must be > 0";                                   // :176
-        randlapack_require(qr_exp == Subroutines::QR_explicit::geqrf_ungqr) << "ABRIK on the device: qr_exp = cqrrt is not available yet";
-        randlapack_require(q.world() == 1) << "ABRIK on the device: row-sharded operators are not wired yet";
+        const bool use_cqrrt = (qr_exp == Subroutines::QR_explicit::cqrrt);
+        const bool sharded = q.world() > 1;       // the operator's rows (and every m-long object: X_ev, U) are sharded; n-long ones are replicated
+        randlapack_require(!sharded || use_cqrrt) << "ABRIK on a row-sharded operator needs qr_exp = cqrrt (Householder panels do not shard)";
+        RandLAPACK::CQRRT<T, RNG> cqrrt(q, false, tol);                                                        // :281-285
+        cqrrt.nnz = 2;
+        const T d_factor = (T)1.25;
+        T* R_11_trans = nullptr;
+        // explicit QR of a panel P (rows x k, ld rows): Q in place, R (k x k upper) to Rout (ld ldr)
+        auto panel_qr = [&](int64_t rows, T* P, T* Rout, int64_t ldr, bool m_long, RandBLAS::RNGState<RNG>& st) {
+            if (use_cqrrt) {
+                cqrrt.rows_replicated = !m_long;
+                const int rc = cqrrt.call(rows, k, P, rows, Rout, ldr, d_factor, st);
+                randlapack_require(rc == 0) << "ABRIK: CQRRT panel factorization failed (code " << rc << ")";
+            }
+        };
+        auto reduce_m = [&](T* buf, int64_t rows_, int64_t cols_, int64_t ld_) {      // sum an inner product over the row shards
+            if (!sharded) return;
+            if (ld_ == rows_) { q.allreduce_sum(buf, rows_ * cols_); return; }
+            blas::Scratch w3(q);
+            T* tmp = w3.alloc<T>(rows_ * cols_);
+            lapack::lacpy(MatrixType::General, rows_, cols_, buf, ld_, tmp, rows_, q);
+            q.allreduce_sum(tmp, rows_ * cols_);
+            lapack::lacpy(MatrixType::General, rows_, cols_, tmp, rows_, buf, ld_, q);
+        };
         const int64_t m = A.n_rows, n = A.n_cols;
         int64_t iter = 0, iter_od = 0, iter_ev = 0, end_rows = 0, end_cols = 0;
         T norm_R = 0;
@@ -71,6 +96,7 @@ public:
         T* Y_orth_buf = nullptr;          // k x (iter_ev k), ld k      -- sized on demand (reference: k x n up front, :247)
         T* X_orth_buf = nullptr;          // (iter_od k) x k, ld n + k  -- idem (:248)
         T* tau = ws.alloc<T>(k);
+        if (use_cqrrt) R_11_trans = ws.alloc<T>(k * k);
         int64_t curr_Y_cols = k, curr_X_cols = k;
         int64_t Y_i = 0, X_i = 0, R_i = -1, R_ii = 0, S_i = 0, S_ii = k;      // element offsets (the reference's moving pointers)
         const T norm_A = A.fro_nrm();                                                                           // :272
@@ -82,8 +108,12 @@ public:
         RandBLAS::DenseDist D(n, k);                                                                            // :298-299
         state = RandBLAS::fill_dense(D, Y_od.p + Y_i, state, q);
         A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, (T)1.0, Y_od.p + Y_i, n, (T)0.0, X_ev.p + X_i, m);   // :311
-        lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                           // :333
-        lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                        // :342
+        if (use_cqrrt) {                                                                                        // :318-319
+            panel_qr(m, X_ev.p + X_i, R_11_trans, k, true, state);
+        } else {
+            lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                       // :333
+            lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                    // :342
+        }
         ++iter_od;
         ++iter;
         while (1) {
@@ -100,9 +130,15 @@ public:
                     blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, k, iter_ev * k, n, (T)1.0, Y_od.p + Y_i, n, Y_od.p, n, (T)0.0, Y_orth_buf, k, q);
                     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, k, iter_ev * k, (T)-1.0, Y_od.p, n, Y_orth_buf, k, (T)1.0, Y_od.p + Y_i, n, q);
                 }
-                lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                                   // :420
-                util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                                // :432 (upper triangle, transposed)
-                lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                                // :444
+                if (use_cqrrt) {                                                                                // :402-410
+                    lapack::laset(MatrixType::General, k, k, (T)0, (T)0, R_11_trans, k, q);
+                    panel_qr(n, Y_od.p + Y_i, R_11_trans, k, false, state);
+                    util::transposition(k, k, R_11_trans, k, R.p + R_ii, n, 1, q);
+                } else {
+                    lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                               // :420
+                    util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                            // :432 (upper triangle, transposed)
+                    lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                            // :444
+                }
                 if (std::abs(elem(R.p + R_ii + (n + 1) * (k - 1))) < sqrt_eps) break;                           // :455-458
                 R.ensure(curr_X_cols);                                                                          // :461-484
                 R_i = (iter_ev + 1) * k;
@@ -118,13 +154,19 @@ public:
                     const int64_t ldx = iter_od * k;
                     X_orth_buf = w2.alloc<T>(ldx * k);
                     blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, iter_od * k, k, m, (T)1.0, X_ev.p, m, X_ev.p + X_i, m, (T)0.0, S.p + S_i, n + k, q);
+                    reduce_m(S.p + S_i, iter_od * k, k, n + k);
                     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, iter_od * k, (T)-1.0, X_ev.p, m, S.p + S_i, n + k, (T)1.0, X_ev.p + X_i, m, q);
                     blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, iter_od * k, k, m, (T)1.0, X_ev.p, m, X_ev.p + X_i, m, (T)0.0, X_orth_buf, ldx, q);
+                    reduce_m(X_orth_buf, iter_od * k, k, ldx);
                     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, iter_od * k, (T)-1.0, X_ev.p, m, X_orth_buf, ldx, (T)1.0, X_ev.p + X_i, m, q);
                 }
-                lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                   // :552
-                lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);                  // :561
-                lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                // :570
+                if (use_cqrrt) {                                                                                // :530-531
+                    panel_qr(m, X_ev.p + X_i, S.p + S_ii, n + k, true, state);
+                } else {
+                    lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                               // :552
+                    lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);              // :561
+                    lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                            // :570
+                }
                 if (std::abs(elem(S.p + S_ii + ((n + k) + 1) * (k - 1))) < sqrt_eps) break;                     // :595-598
                 S.ensure(curr_Y_cols);                                                                          // :604-630
                 S_i = (n + k) * k * iter_od;

@@ -3,6 +3,7 @@
 // operator on the left, `fro_nrm()` its Frobenius norm.  Device flavour: A_buff, B and C are DEVICE pointers and the
 // operator carries the queue.  Only ColMajor / Side::Left is on the path (that is all ABRIK uses, rl_abrik.hh:311,364,494).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include "rl_exceptions.hh"
 #include "rl_blaspp.hh"
@@ -26,7 +27,17 @@ struct DenseLinOp {
         randlapack_require(lda >= n_rows) << "lda=" << lda << " < n_rows=" << n_rows << " (lda must be >= n_rows under ColMajor)";   // :59
     }
 
-    T fro_nrm() { return lapack::lange(Norm::Fro, n_rows, n_cols, A_buff, lda, q); }                              // :67-70
+    /// `row_sharded`: this rank holds a row block of the operator (one process per GPU); A^T X is then summed over the ranks and
+    /// the norm is the global one.  n_rows is the LOCAL row count.
+    bool row_sharded = false;
+
+    T fro_nrm() {                                                                                                // :67-70
+        const T loc = lapack::lange(Norm::Fro, n_rows, n_cols, A_buff, lda, q);
+        if (!(row_sharded && q.world() > 1)) return loc;
+        double ss = (double)loc * (double)loc;
+        q.allreduce_sum_host(&ss, 1);
+        return (T)std::sqrt(ss);
+    }
 
     /// C := alpha * op(A) * op(B) + beta * C                                                                     (:94-147)
     void operator()(Side side, Layout layout, Op trans_A, Op trans_B, int64_t m, int64_t n, int64_t k, T alpha, const T* B, int64_t ldb,
@@ -36,6 +47,10 @@ struct DenseLinOp {
         randlapack_require(rows_A == n_rows) << "op(A) row dim inferred from (m, k, trans_A) is " << rows_A << " but operator n_rows=" << n_rows;
         randlapack_require(cols_A == n_cols) << "op(A) col dim inferred from (m, k, trans_A) is " << cols_A << " but operator n_cols=" << n_cols;
         blas::gemm(layout, trans_A, trans_B, m, n, k, alpha, A_buff, lda, B, ldb, beta, C, ldc, q);
+        if (row_sharded && q.world() > 1 && trans_A != Op::NoTrans) {     // A^T X sums over the row blocks
+            randlapack_require(beta == (T)0 && ldc == m) << "sharded A^T X needs beta = 0 and a contiguous result";
+            q.allreduce_sum(C, m * n);
+        }
     }
     void operator()(Layout layout, Op trans_A, Op trans_B, int64_t m, int64_t n, int64_t k, T alpha, const T* B, int64_t ldb, T beta, T* C,
                     int64_t ldc) {

@@ -337,3 +337,15 @@ def abrik(A, k, tol, max_krylov_iters, ctr=(0, 0, 0, 0), key=(0, 0)):
     t = int(trip.value)
     return dict(rc=rc, U=U[:, :t], S=S[:t], V=V[:, :t], triplets=t, iters=int(iters.value), norm_R_end=float(nre.value),
                 next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def cqrrt(A, A_hat):
+    """CQRRT::call with the precomputed sketch A_hat (d x n).  returns dict(rc, Q, R)"""
+    lib = load()
+    A = _f(A).copy(order="F")
+    A_hat = _f(A_hat).copy(order="F")
+    m, n = A.shape
+    d = A_hat.shape[0]
+    R = np.zeros((n, n), order="F")
+    rc = lib.oracle_cqrrt_f64(i64(m), i64(n), _p(A), i64(m), _p(R), i64(n), i64(d), _p(A_hat))
+    return dict(rc=rc, Q=A, R=np.triu(R))

@@ -1012,6 +1012,22 @@ int oracle_cqrrpt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, i
     return 0;
 }
 
+// CQRRT::call (drivers/rl_cqrrt.hh:124-288) with the sketch A_hat = S*A supplied (d x n, ld d), compute_Q = true,
+// orthogonalization = false.  A (m x n, lda) -> Q; R (n x n, ldr) upper triangle.
+int oracle_cqrrt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr, int64_t d, double* A_hat) {
+    if (m < 0 || n < 0 || lda < m || ldr < n) return -1;
+    std::vector<double> tau(std::max<int64_t>(n, 1), 0.0);
+    geqrf(d, n, A_hat, d, tau.data());                                                        // :155
+    lacpy('U', n, n, A_hat, d, R, ldr);                                                       // :157
+    if (!diag_is_nonzero(n, R, ldr)) return 1;                                                // :160-164
+    trsm_right_upper(m, n, 1.0, R, ldr, A, lda);                                              // :165
+    syrk_upper_trans(n, m, 1.0, A, lda, 0.0, R, ldr);                                         // :169
+    if (potrf_upper(n, R, ldr)) return 1;                                                     // :176-180
+    trsm_right_upper(m, n, 1.0, R, ldr, A, lda);                                              // :184
+    trmm_right_upper(n, n, 1.0, A_hat, d, R, ldr);                                            // :190
+    return 0;
+}
+
 int oracle_hqrrp_f64(int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg, int64_t pp,
                       int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], const double* G_in) {
     RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);

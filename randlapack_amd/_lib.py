@@ -117,7 +117,8 @@ SIGNATURES.update({
     "rlhip_drv_bqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_dbl, c_i64, c_i64, c_dbl, c_vp, c_vp, u32p, c_vp, c_vp,
                                     C.POINTER(c_i64), C.POINTER(C.c_long), c_int, c_int, c_int]),
     "rlhip_drv_abrik_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_dbl, c_i64, dpp, dpp, dpp, u32p, C.POINTER(c_i64),
-                                    C.POINTER(c_i64), C.POINTER(c_dbl)]),
+                                    C.POINTER(c_i64), C.POINTER(c_dbl), c_int]),
+    "rlhip_drv_cqrrt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_dbl, c_i64, c_dbl, u32p, c_vp, c_vp]),
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })

@@ -195,12 +195,33 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
     });
 }
 
+int rlhip_drv_cqrrt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr, double d_factor, int64_t nnz,
+                        double eps, uint32_t state[6], const double* A_hat_in, double* A_hat_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::CQRRT<double, RNG> alg(q, false, eps);
+        if (nnz > 0) alg.nnz = nnz;
+        alg.sketch_override = A_hat_in;
+        alg.sketch_export = A_hat_out;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A, lda, R, ldr, d_factor, st);
+        store_state(st, state);
+        return rc;
+    });
+}
+
 int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,
-                        double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end) {
+                        double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end,
+                        int qr_exp) {
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::linops::DenseLinOp<double> Aop(m, n, A, lda, RandLAPACK::Layout::ColMajor, q);
+        Aop.row_sharded = q.world() > 1;
         RandLAPACK::ABRIK<double, RNG> alg(q, false, false, tol);
+        if (qr_exp >= 0) {
+            if (qr_exp > 1) throw RandLAPACK::Error("qr_exp must be 0 (geqrf_ungqr) or 1 (cqrrt)");
+            alg.qr_exp = (RandLAPACK::ABRIKSubroutines::QR_explicit)qr_exp;
+        }
         if (max_krylov_iters > 0) alg.max_krylov_iters = (int)std::min<int64_t>(max_krylov_iters, INT_MAX);
         State st = load_state(state);
         *U = nullptr; *Sigma = nullptr; *V = nullptr;

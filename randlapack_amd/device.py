@@ -267,7 +267,26 @@ def drv_rsvd(ctx: Context, A, m, n, k, b_sz, tol, p, q, rs_stab=0, rf_orth=0, qb
     return dict(rc=rc, qb_rc=int(qrc.value), k=kf, U=U[:kf], S=S[:kf], V=V[:kf], next_ctr=tuple(int(x) for x in st[:4]))
 
 
-def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+def drv_cqrrt(ctx: Context, A, m, n, d_factor=1.25, nnz=2, eps=None, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None, want_sketch=False):
+    """CQRRT::call.  A (column-major tensor (n, m)) is overwritten by Q.  Returns dict(rc, R, next_ctr[, sketch])."""
+    dev = f"cuda:{ctx.device}"
+    if eps is None:
+        eps = float(np.finfo(np.float64).eps ** 0.85)
+    d = int(d_factor * n)
+    R = cm_zeros(n, n, device=dev)
+    sk_out = cm_empty(d, n, device=dev) if want_sketch else None
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_cqrrt_f64(ctx.h, m, n, A.data_ptr(), m, R.data_ptr(), n, d_factor, nnz, eps, st,
+                                     sketch_in.data_ptr() if sketch_in is not None else None,
+                                     sk_out.data_ptr() if sk_out is not None else None)
+    _drv_check(ctx, rc, "cqrrt")
+    out = dict(rc=rc, R=R, next_ctr=tuple(int(x) for x in st[:4]))
+    if want_sketch:
+        out["sketch"] = sk_out
+    return out
+
+
+def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0), qr_exp=-1):
     """ABRIK::call on the dense operator A (column-major tensor (n, m), not modified).  Returns dict(rc, U, S, V, triplets, iters,
     norm_R_end, next_ctr); U/V are column-major tensors (triplets, m)/(triplets, n)."""
     Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -275,7 +294,7 @@ def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0
     nre = C.c_double(0)
     st = _state_arr(ctr, key)
     rc = ctx.lib.rlhip_drv_abrik_f64(ctx.h, m, n, A.data_ptr(), m, k, tol, max_krylov_iters, C.byref(Up), C.byref(Sp), C.byref(Vp), st,
-                                     C.byref(trip), C.byref(iters), C.byref(nre))
+                                     C.byref(trip), C.byref(iters), C.byref(nre), qr_exp)
     _drv_check(ctx, rc, "abrik")
     t = int(trip.value)
     U = _adopt(ctx, Up, m, t)

@@ -41,27 +41,40 @@ def main():
     Aq = d.cm_from_numpy(np.ascontiguousarray(Acq[rows]))
     rq = d.drv_cqrrpt(ctx, Aq, len(rows), ncq, 1.25, 4, key=(5, 0))
     Qloc, Rq, Jq = d.cm_to_numpy(Aq), d.cm_to_numpy(rq["R"]), rq["J"].cpu().numpy()
+    # ABRIK on the row-sharded operator (CQRRT panels)
+    ka, ita = 8, 8
+    ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
+    Ua_loc = d.cm_to_numpy(ra["U"])
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
 
         U = np.zeros((m, r["k"])); U2 = np.zeros((m, r2["k"]))
         Qc = np.zeros((m, ncq))
-        for rr, u, u2, qq in gathered:
-            U[rr] = u; U2[rr] = u2; Qc[rr] = qq
+        Ua = np.zeros((m, ra["triplets"]))
+        for rr, u, u2, qq, ua in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
         r1 = d.drv_rsvd(ctx1, d.cm_from_numpy(A), m, n, k, k, 1e-12, p, 1)
         S1 = r1["S"].cpu().numpy()
         ref = oracle.rsvd(A, k, k, 1e-12, p, 1)          # same Philox stream on both sides (oracle/oracle.cpp fill_dense)
+        ra1 = d.drv_abrik(ctx1, d.cm_from_numpy(A), m, n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
+        Sa, Sa1, Va = ra["S"].cpu().numpy(), ra1["S"].cpu().numpy(), d.cm_to_numpy(ra["V"])
+        sv = np.linalg.svd(A, compute_uv=False)
         Aq1 = d.cm_from_numpy(Acq)
         rq1 = d.drv_cqrrpt(ctx1, Aq1, m, ncq, 1.25, 4, key=(5, 0))
         kq = rq["rank"]
         nA = np.linalg.norm(A)
         out = dict(
+            ab_iters=ra["iters"], ab_iters1=ra1["iters"], ab_trip=ra["triplets"], ab_trip1=ra1["triplets"],
+            ab_S_vs_single=float(np.max(np.abs(Sa[:ka] - Sa1[:ka]) / Sa1[:ka])),
+            ab_S_vs_exact=float(np.max(np.abs(Sa[:ka] - sv[:ka]) / sv[:ka])),
+            ab_orthU=float(np.linalg.norm(Ua.T @ Ua - np.eye(ra["triplets"]))),
+            ab_res=float(min(np.linalg.norm(A.T @ Ua - Va * Sa), np.linalg.norm(A @ Va - Ua * Sa))),
             cq_rank=kq, cq_rank1=rq1["rank"], cq_J_equal=bool(np.array_equal(Jq, rq1["J"].cpu().numpy())),
             cq_R=float(np.linalg.norm(Rq[:kq] - d.cm_to_numpy(rq1["R"])[:kq]) / np.linalg.norm(Rq[:kq])),
             cq_resid=float(np.linalg.norm(Acq[:, Jq - 1] - Qc[:, :kq] @ Rq[:kq]) / np.linalg.norm(Acq)),

@@ -622,3 +622,40 @@ def test_abrik_early_termination_and_bad_args(ctx, orc):
 
     with pytest.raises(_lib.RlhipError):
         d.drv_abrik(ctx, d.cm_from_numpy(A), 300, 200, 0, 1e-12, 5)         # k must be > 0 (rl_abrik.hh:176)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CQRRT (drivers/rl_cqrrt.hh) and ABRIK with CQRRT panels (qr_exp = cqrrt)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,cond", [(5000, 200, 1e2), (2000, 64, 1e8), (300, 300, 1e3)])
+def test_cqrrt_vs_oracle_shared_sketch(ctx, orc, m, n, cond):
+    d = _d()
+    rng = np.random.default_rng(m + n)
+    A = poly_mat(m, n, n, rng, cond=cond)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_cqrrt(ctx, Ad, m, n, 1.25, 2, want_sketch=True, key=(4, 0))
+    o = orc.cqrrt(A, d.cm_to_numpy(r["sketch"]))
+    assert r["rc"] == o["rc"] == 0
+    Q, R = d.cm_to_numpy(Ad), np.triu(d.cm_to_numpy(r["R"]))
+    assert np.linalg.norm(R - o["R"]) <= EPS**0.6 * np.linalg.norm(o["R"])
+    assert np.linalg.norm(A - Q @ R) <= EPS**0.75 * np.linalg.norm(A)                  # test_cqrrt.cc error check
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= EPS**0.75 * np.sqrt(n)
+
+
+def test_abrik_cqrrt_panels_match_householder_panels(ctx, orc):
+    d = _d()
+    rng = np.random.default_rng(21)
+    m, n, k, iters = 1500, 1200, 16, 10
+    s = np.logspace(0, -5, n)
+    A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    Ad = d.cm_from_numpy(A)
+    r0 = d.drv_abrik(ctx, Ad, m, n, k, 1e-12, iters, key=(1, 0), qr_exp=0)
+    r1 = d.drv_abrik(ctx, Ad, m, n, k, 1e-12, iters, key=(1, 0), qr_exp=1)
+    assert (r0["iters"], r0["triplets"]) == (r1["iters"], r1["triplets"])
+    S0, S1 = r0["S"].cpu().numpy(), r1["S"].cpu().numpy()
+    # same Krylov subspaces whatever the panel QR: the converged Ritz values coincide
+    assert np.max(np.abs(S0[:k] - S1[:k]) / S0[:k]) <= 1e-9
+    assert np.all(S1 <= s[:len(S1)] * (1 + 1e-10))                          # Ritz values stay below the singular values
+    U, V = d.cm_to_numpy(r1["U"]), d.cm_to_numpy(r1["V"])
+    t = r1["triplets"]
+    assert np.linalg.norm(U.T @ U - np.eye(t)) <= 1e-9 and np.linalg.norm(V.T @ V - np.eye(t)) <= 1e-9

@@ -40,3 +40,6 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded CQRRPT == single-device CQRRPT (same SASO, same pivots; R to rounding)
     assert out["cq_rank"] == out["cq_rank1"] and out["cq_J_equal"]
     assert out["cq_R"] <= 1e-10 and out["cq_resid"] <= 1e-12 and out["cq_orth"] <= 1e-11
+    # row-sharded ABRIK (CQRRT panels): same iteration count, same leading Ritz values as on one device
+    assert (out["ab_iters"], out["ab_trip"]) == (out["ab_iters1"], out["ab_trip1"])
+    assert out["ab_S_vs_single"] <= 1e-9 and out["ab_orthU"] <= 1e-9 and out["ab_res"] <= 1e-9
