@@ -221,4 +221,29 @@ private:
     }
 };
 
+/// BQRRP_GPU (reference: drivers/rl_bqrrp_gpu.hh:27-149): the reference's device driver takes the SKETCH as an input
+/// (A_sk_dev, d x n, ld d) instead of generating it; same thing here on top of BQRRP (qr_tall in {cholqr, geqrf} as there).
+template <typename T, typename RNG = RandBLAS::DefaultRNG>
+class BQRRP_GPU {
+public:
+    BQRRP_GPU(blas::Queue& queue, bool time_subroutines, int64_t b_sz) : impl(queue, time_subroutines, b_sz), rank(0), block_size(b_sz) {
+        impl.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;                                        // LU-QR only (:354-399)
+        impl.qr_tall = BQRRPSubroutines::QRTall::cholqr;
+        impl.apply_trans_q = BQRRPSubroutines::ApplyTransQ::gemqrt;
+    }
+    int call(int64_t m, int64_t n, T* A, int64_t lda, T* A_sk, int64_t d, T* tau, int64_t* J) {
+        randlapack_require(block_size > 0 && d % block_size == 0) << "BQRRP_GPU: d=" << d << " must be a multiple of the block size";
+        impl.sketch_override = A_sk;
+        RandBLAS::RNGState<RNG> unused;
+        const int rc = impl.call(m, n, A, lda, (T)d / (T)block_size, tau, J, unused);
+        rank = impl.rank;
+        times = impl.times;
+        return rc;
+    }
+    BQRRP<T, RNG> impl;
+    int64_t rank;
+    int64_t block_size;
+    std::vector<long> times;
+};
+
 }  // namespace RandLAPACK

@@ -49,6 +49,33 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
 /// Forward column permutation (== lapack::lapmt(true, ...)): on exit column i of A holds former column idx[i]-1.
 /// idx is a DEVICE vector of n 1-based indices and is left untouched (the reference's lapmt restores it).
 /// k > n throws std::runtime_error like the reference.                               (rl_util.hh:151-164)
+/// util::eye (misc/rl_util.hh:60-70): A (m x n, ld m, DEVICE) <- identity pattern
+template <typename T>
+void eye(int64_t m, int64_t n, T* A, blas::Queue& q) { lapack::laset(MatrixType::General, m, n, (T)0, (T)1, A, m, q); }
+
+/// util::get_L (misc/rl_util.hh:102-115): zero the strictly upper triangle of A (m x n, ld m), optionally set the diagonal to one
+template <typename T>
+void get_L(int64_t m, int64_t n, T* A, int overwrite_diagonal, blas::Queue& q) {
+    if (overwrite_diagonal) lapack::laset(MatrixType::Upper, m, n, (T)0, (T)1, A, m, q);
+    else if (n > 1) lapack::laset(MatrixType::Upper, m, n - 1, (T)0, (T)0, A + m, m, q);
+}
+
+/// util::get_U (misc/rl_util.hh:119-131): zero the strictly lower triangle of A (m x n, lda)
+template <typename T>
+void get_U(int64_t m, int64_t n, T* A, int64_t lda, blas::Queue& q) {
+    if (m > 1) lapack::laset(MatrixType::Lower, m - 1, n, (T)0, (T)0, A + 1, lda, q);
+}
+
+/// util::diag_is_nonzero (misc/rl_util.hh:138-142) on a DEVICE matrix: exact comparison with zero, as the reference
+template <typename T>
+bool diag_is_nonzero(int64_t n, const T* R, int64_t ldr, blas::Queue& q) {
+    std::vector<T> d((size_t)std::max<int64_t>(n, 1));
+    lapack::get_diag(n, R, ldr, d.data(), q);
+    for (int64_t i = 0; i < n; ++i)
+        if (d[(size_t)i] == (T)0) return false;
+    return true;
+}
+
 /// util::transposition (misc/rl_util.hh:315-334): AT (ld ldat) = A^T; copy_upper_triangle != 0 moves only the upper triangle of the
 /// leading n x n block (the reference ignores m in that mode).
 template <typename T>

@@ -181,7 +181,7 @@ __device__ __forceinline__ double row16_allsum(double v) {
 template <typename T, int JB>
 __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
                                                                int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
-                                                               unsigned* __restrict__ nrot, int dbg) {
+                                                               unsigned* __restrict__ nrot) {
     constexpr int JP = 2 * JB;
     constexpr int NT = 1024;                           // all 16 waves move data; the first 16*JB threads rotate
     constexpr int NW = NT / 64;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     // intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
     // intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs): every column pair of the
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
-    const int nrounds = (dbg & 1) ? 0 : (intra ? (JB - 1) : JB);
+    const int nrounds = intra ? (JB - 1) : JB;
     const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
     for (int round = 0; round < nrounds; ++round) {
         if (tid >= NROT) { __syncthreads(); continue; }     // wave-uniform: whole wavefronts sit the rounds out
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     //      lane's results run along rows -> 128-byte store segments.
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int fr = lane & 15, fk = lane >> 4;
-    for (int r0 = 0; r0 < ((dbg & 2) ? 0 : n); r0 += JM) {
+    for (int r0 = 0; r0 < n; r0 += JM) {
         __syncthreads();
         for (int e = tid; e < JP * JM; e += NT) {
             const int r = e % JM, c = e / JM;
@@ -403,26 +403,23 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
         attr_set = true;
     }
     int sweep = 0;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("RLHIP_JACOBI_DBG"); dbg = e ? atoi(e) : 0; }
-    if (dbg) max_sweeps = 10;
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
         hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
-                           (int64_t)n, tol, d_nrot, dbg);
+                           (int64_t)n, tol, d_nrot);
         for (int oround = 0; oround < NBk - 1; ++oround)
             hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, oround, 0, A, lda,
-                               V, (int64_t)n, tol, d_nrot, dbg);
+                               V, (int64_t)n, tol, d_nrot);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
         const unsigned nrot = *(unsigned*)(c->h_mail + 16);
         float cos2;
         memcpy(&cos2, (const char*)(c->h_mail + 16) + sizeof(unsigned), sizeof(float));
-        if (nrot == 0 && !dbg) { ++sweep; break; }
+        if (nrot == 0) { ++sweep; break; }
         // quadratic convergence shortcut (cf. DGESVJ's mxaapq test): every cosine met in this sweep was <= 1e-9, so
         // the rotations just applied leave cosines of order n * 1e-18 << tol; a further all-idle sweep would only confirm it
-        if (cos2 <= 1e-18f && !dbg) { ++sweep; break; }
+        if (cos2 <= 1e-18f) { ++sweep; break; }
     }
     *sweeps_out = sweep;
     return 0;

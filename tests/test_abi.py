@@ -59,6 +59,24 @@ def test_product_never_imports_oracle():
 
 def test_cxx_driver_headers_compile_standalone():
     # the C++ object layer must compile against the C ABI alone (host compiler, no HIP headers)
-    src = '#include "RandLAPACK_amd.hh"\nint main(){return 0;}\n'
+    # ... and every class of SURVEY.md 8b instantiates in both precisions
+    src = """#include "RandLAPACK_amd.hh"
+using RNG = r123::Philox4x32;
+#define INST(T) \\
+  template class RandLAPACK::CholQRQ<T>; template class RandLAPACK::HQRQ<T>; template class RandLAPACK::PLUL<T>; \\
+  template class RandLAPACK::RS<T, RNG>; template class RandLAPACK::RF<T, RNG>; template class RandLAPACK::QB<T, RNG>; \\
+  template class RandLAPACK::RSVD<T, RNG>; template class RandLAPACK::CQRRPT<T, RNG>; template class RandLAPACK::CQRRT<T, RNG>; \\
+  template class RandLAPACK::BQRRP<T, RNG>; template class RandLAPACK::BQRRP_GPU<T, RNG>; template class RandLAPACK::CQRRPT_GPU<T, RNG>; \\
+  template int64_t RandLAPACK::hqrrp<T, RNG>(int64_t, int64_t, T*, int64_t, int64_t*, T*, int64_t, int64_t, int64_t, int64_t, \\
+                                             RandBLAS::RNGState<RNG>&, blas::Queue&, T*); \\
+  template int RandLAPACK::ABRIK<T, RNG>::call(RandLAPACK::linops::DenseLinOp<T>&, int64_t, T*&, T*&, T*&, RandBLAS::RNGState<RNG>&); \\
+  template void RandLAPACK::util::eye<T>(int64_t, int64_t, T*, blas::Queue&); \\
+  template void RandLAPACK::util::get_L<T>(int64_t, int64_t, T*, int, blas::Queue&); \\
+  template void RandLAPACK::util::get_U<T>(int64_t, int64_t, T*, int64_t, blas::Queue&); \\
+  template bool RandLAPACK::util::diag_is_nonzero<T>(int64_t, const T*, int64_t, blas::Queue&);
+INST(double)
+INST(float)
+int main(){return 0;}
+"""
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(ROOT / "include"), "-x", "c++", "-"], input=src,
                    text=True, check=True)
