@@ -140,8 +140,17 @@ def main():
         ctx.gemm("N", "N", mloc, k, n, 1.0, A, mloc, Om, n, 0.0, Y, mloc)
     kernel_ms = ctx.timer_stop_ms() / reps
     achieved = 2.0 * mloc * n * k / (kernel_ms * 1e-3) / 1e12
+    # L2<->fabric bytes of this kernel from the PMC passes committed under profiles/ (collected at exactly this shape on one
+    # GPU; separate --pmc passes, gfx950 x2 correction on FETCH_SIZE); other shapes / rank counts: not measured -> null
+    traffic = None
+    try:
+        if world == 1 and (m, n, k) == (M, N, K):
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")) as fh:
+                traffic = float(json.load(fh)["traffic_bytes"])
+    except Exception:
+        traffic = None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=traffic,
                     kernel="gemm_sk_kernel<NN> stream-K 128x256x16 (Y = A*Omega) + fix-up",
                     launch_ms=round(kernel_ms, 3), flops_per_launch=2.0 * mloc * n * k)
 
