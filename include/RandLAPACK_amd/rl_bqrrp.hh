@@ -7,8 +7,8 @@
 //                                                                              (correct, BLAS-2 bound: cholqr is the fast one)
 //   apply_trans_q gemqrt -> compact-WY block apply on the MFMA GEMMs        | ormqr -> the same apply (tau is the
 //                                                                             diagonal of T, :490-491, so both name one operator)
-// The object therefore DEFAULTS to {geqp3, cholqr, gemqrt}; asking for an option that is not on the device raises
-// RandLAPACK::Error instead of silently computing something else.
+// Every option of the reference is available.  The object DEFAULTS to {luqr, cholqr, gemqrt}: luqr is the reference's own
+// default, cholqr/gemqrt are the BLAS-3 choices (the reference's CPU defaults geqrf/ormqr are supported, just slower here).
 #pragma once
 #include <chrono>
 #include <cmath>
@@ -47,8 +47,8 @@ public:
         tol = std::numeric_limits<T>::epsilon();
         block_size = b_sz;
         internal_nb = b_sz;
-        qrcp_wide = Subroutines::QRCPWide::geqp3;
-        qr_tall = Subroutines::QRTall::cholqr;
+        qrcp_wide = Subroutines::QRCPWide::luqr;       // the reference's default (rl_bqrrp.hh:74) and the faster one here
+        qr_tall = Subroutines::QRTall::cholqr;         // reference CPU default: geqrf (:75); cholqr is the BLAS-3 panel on the device
         apply_trans_q = Subroutines::ApplyTransQ::gemqrt;
         rank = 0;
     }
