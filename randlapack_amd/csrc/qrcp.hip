@@ -15,6 +15,7 @@
 // at most one rendezvous ahead).  Measured 1280 x 1024: two-rendezvous/global-memory version 61 ms -> LDS
 // columns 36 ms -> single rendezvous + fence-free publication: see DESIGN.md.
 #include "rlhip_internal.h"
+#include <cstdlib>
 #include <cmath>
 #include <limits>
 
@@ -380,8 +381,8 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     }
     // Fewer, fatter workgroups make the two rendezvous per step cheaper; the owned columns are kept in LDS when
     // they fit (<= 150 KiB per workgroup), which also keeps the release fences of the grid barrier clean.
-    int64_t G = (n + 7) / 8;           // ~8 columns (two per wave) per workgroup
-    if (G > num_cu / 2) G = num_cu / 2;
+    int64_t G = (n + 7) / 8;           // ~8 columns (two per wave) per workgroup (4 and 16 measured: no better)
+    if (G > num_cu) G = num_cu;        // wide sketches: one workgroup per CU (2560 x 2048: 94 -> 78 ms against num_cu / 2)
     if (G < 1) G = 1;
     const int64_t cols_per_wg = (n + G - 1) / G;
     size_t lds_bytes = (size_t)cols_per_wg * (size_t)m * sizeof(T);
