@@ -140,7 +140,13 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     // finishes the 32 x 32 triangle entirely in registers.  (A single VALU kernel for the whole 256-block ran at
     // ~8 % of the fp64 vector peak -- its inner loop re-reads x from L2 and U through the scalar cache.  Two fused
     // MFMA kernels were also tried and REJECTED at m = 1e6, k = 1024: 64-row slab in LDS + U from L2: 60 ms;
-    // wave-owned rows with X fragments from L2 + staged U chunks: 38 ms; this two-level scheme: 36 ms.)
+    // wave-owned rows with X fragments from L2 + staged U chunks: 38 ms; this two-level scheme: 36 ms (31 ms after the
+    // substitution kernel was fixed).  A third fused design -- 32-row slab of a whole 256-block resident in LDS, two
+    // workgroups per CU, right-looking with the eight tile accumulators in registers and block row s of U in flight during
+    // the substitution of sub-block s -- was correct but ran 7.0 ms per 256-block against 3.85 ms here: with only one wave
+    // of a workgroup substituting (32 rows), the 8 x ~1000 dependent LDS/FMA instructions per slab (2.2 ms per block)
+    // and the U fragment loads (1.7 ms) cannot hide behind the 0.7 ms of MFMA work; the unfused kernels spread the same
+    // substitution over every wave of every CU.)
     for (int64_t j0 = 0; j0 < n; j0 += DB) {
         const int nb = (int)((n - j0 < DB) ? (n - j0) : DB);
         T a = alpha;
