@@ -70,6 +70,7 @@ public:
         int64_t new_rank;
         if (n == 0 || m == 0) { rank = 0; return 0; }
 
+        randlapack_require(nnz >= 1 && nnz <= d) << "nnz=" << nnz << " nonzeros per column do not fit a sketch of d=" << d << " rows (RandBLAS::SparseDist requires vec_nnz <= d)";
         blas::Scratch ws(q);
         T* A_hat = ws.alloc<T>(d * n);
         T* tau = ws.alloc<T>(n);

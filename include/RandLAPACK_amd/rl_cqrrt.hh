@@ -45,6 +45,7 @@ public:
         if (n == 0) return 0;
         const bool sharded = q.world() > 1 && !rows_replicated;
         const int64_t d = (int64_t)(d_factor * n);                                                              // :143
+        randlapack_require(nnz >= 1 && nnz <= d) << "nnz=" << nnz << " nonzeros per column do not fit a sketch of d=" << d << " rows";
         blas::Scratch ws(q);
         T* A_hat = ws.alloc<T>(d * n);
         T* tau = ws.alloc<T>(n);

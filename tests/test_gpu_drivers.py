@@ -659,3 +659,66 @@ def test_abrik_cqrrt_panels_match_householder_panels(ctx, orc):
     U, V = d.cm_to_numpy(r1["U"]), d.cm_to_numpy(r1["V"])
     t = r1["triplets"]
     assert np.linalg.norm(U.T @ U - np.eye(t)) <= 1e-9 and np.linalg.norm(V.T @ V - np.eye(t)) <= 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# Degenerate shapes through every driver (block larger than the matrix, single columns, wide inputs, one iteration)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,b,kw", [(300, 40, 64, {}), (50, 20, 1, {}), (50, 1, 4, {}), (64, 64, 64, {}), (20, 100, 32, {}),
+                                      (301, 97, 25, dict(qrcp_wide=1))])
+def test_bqrrp_degenerate_shapes(ctx, orc, m, n, b, kw):
+    d = _d()
+    rng = np.random.default_rng(m * 7 + n + b)
+    A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_bqrrp(ctx, Ad, m, n, b, 1.0, **kw)
+    assert r["rc"] == 0 and r["rank"] == min(m, n)
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy())
+
+
+@pytest.mark.parametrize("m,n,nb,pp", [(100, 10, 32, 5), (100, 1, 8, 2), (100, 40, 8, 0), (30, 100, 16, 4)])
+def test_hqrrp_degenerate_shapes(ctx, orc, m, n, nb, pp):
+    d = _d()
+    rng = np.random.default_rng(m + n + nb)
+    A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_hqrrp(ctx, Ad, m, n, nb, pp)
+    o = orc.hqrrp(A, nb, pp)
+    np.testing.assert_array_equal(r["J"].cpu().numpy(), o["J"])
+    _bqrrp_verify(orc, A, d.cm_to_numpy(Ad), r["tau"].cpu().numpy(), r["J"].cpu().numpy())
+
+
+def test_small_shapes_rsvd_cqrrpt_abrik_stabilisers(ctx, orc):
+    d = _d()
+    from randlapack_amd import _lib
+
+    rng = np.random.default_rng(4)
+    for (m, n, k, b) in [(100, 50, 1, 1), (100, 20, 20, 20), (100, 50, 5, 16), (30, 80, 10, 10)]:
+        A = rng.standard_normal((m, n))
+        r = d.drv_rsvd(ctx, d.cm_from_numpy(A), m, n, k, b, 1e-12, 2, 1)
+        o = orc.rsvd(A, k, b, 1e-12, 2, 1)
+        assert (r["rc"], r["qb_rc"], r["k"]) == (o["rc"], o["qb_rc"], o["k"])
+        np.testing.assert_allclose(r["S"].cpu().numpy(), o["S"], rtol=1e-9, atol=1e-10 * o["S"][0])
+    for (m, n) in [(10, 8), (1000, 3)]:
+        A = rng.standard_normal((m, n))
+        Ad = d.cm_from_numpy(A)
+        r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 2)
+        k = r["rank"]
+        Q, R, J = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k], r["J"].cpu().numpy()
+        assert r["rc"] == 0 and k == n and np.linalg.norm(A[:, J - 1] - Q @ R) <= 1e-13 * np.linalg.norm(A)
+    with pytest.raises(_lib.RlhipError):       # d = (int)(1.25 * 1) = 1 row cannot hold 2 nonzeros per column (RandBLAS rejects it too)
+        d.drv_cqrrpt(ctx, d.cm_from_numpy(rng.standard_normal((100, 1))), 100, 1, 1.25, 2)
+    for (m, n, k, it) in [(100, 80, 4, 1), (60, 40, 20, 6), (40, 100, 4, 6)]:
+        A = rng.standard_normal((m, n))
+        r = d.drv_abrik(ctx, d.cm_from_numpy(A), m, n, k, 1e-12, it)
+        o = orc.abrik(A, k, 1e-12, it)
+        assert (r["iters"], r["triplets"]) == (o["iters"], o["triplets"])
+        np.testing.assert_allclose(r["S"].cpu().numpy()[:k], o["S"][:k], rtol=1e-8)
+    for kind in (0, 1, 2):
+        for (m, k) in [(50, 1), (16, 16)]:
+            Y = rng.standard_normal((m, k))
+            Yd = d.cm_from_numpy(Y)
+            rc, _ = d.drv_stab(ctx, kind, Yd, m, k)
+            rco, Qo = orc.stab(kind, Y)
+            assert rc == rco == 0
+            np.testing.assert_allclose(d.cm_to_numpy(Yd), Qo, atol=1e-11, rtol=0)
