@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Secondary benchmark lines (NOT the driver's contract -- that is /bench.py): CQRRPT at BASELINE config 3 and BQRRP at a
+single-GPU cut of config 4, same JSON shape as bench.py (metric/value/roofline/cpu_baseline).  Outputs are committed under
+profiles/.   python scripts/bench_other.py [cqrrpt|bqrrp] [--steps K]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from randlapack_amd import device as d
+
+PEAK = {torch.float64: 78.6, torch.float32: 157.3}
+
+
+def cqrrpt(steps):
+    ctx = d.Context(0)
+    m, n, dd, nnz = 1048576, 1024, 1280, 4
+    A = d.cm_empty(m, n)
+    flops = 2.0 * nnz * m * n + (2.0 * dd * n * n - 2.0 / 3 * n**3) + 3.0 * m * n * n + n**3 / 3.0 + n**3
+    best = None
+    for it in range(steps + 1):
+        ctx.fill_dense(A, m, n, key=(3, 0)); ctx.sync()
+        t0 = time.perf_counter(); r = d.drv_cqrrpt(ctx, A, m, n, 1.25, nnz, timing=(it == steps)); ctx.sync(); dt = time.perf_counter() - t0
+        if it > 0: best = dt if best is None else min(best, dt)
+    # dominant kernel: the stream-K Gram kernel (syrk, upper tiles): 1.1e12 flop
+    ctx.fill_dense(A, m, n, key=(3, 0)); G = d.cm_zeros(n, n)
+    ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n)
+    kms = ctx.timer_stop_ms() / 3
+    ach = 1.0 * m * n * n / (kms * 1e-3) / 1e12
+    # CPU baseline: oracle CQRRPT (sketch supplied, so the reference's SASO apply is excluded) on a 131072-row sample
+    import oracle
+    oracle.load(); oracle.set_threads(os.cpu_count() or 1)
+    ms = 131072
+    rng = np.random.default_rng(0)
+    As = np.asfortranarray(rng.standard_normal((ms, n)))
+    Sk = rng.standard_normal((dd, 4096)) @ As[:4096]           # any valid d x n sketch of a Gaussian matrix is Gaussian-like
+    t0 = time.perf_counter(); o = oracle.cqrrpt(As, Sk, np.finfo(float).eps ** 0.85); tc = time.perf_counter() - t0
+    fl_s = (2.0 * dd * n * n - 2.0 / 3 * n**3) + 3.0 * ms * n * n + n**3 / 3.0 + n**3
+    print(json.dumps({"metric": "GFLOP/s CQRRPT 1048576 x 1024 fp64 (BASELINE configs[2])", "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s",
+                      "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 2), "best_of": steps, "dtype": "f64", "data": "synthetic iid N(0,1), generated on-device",
+                      "config": {"workload": "CQRRPT m=1048576 n=1024 d=1280 nnz=4 qrcp=geqp3", "rank": r["rank"], "times_us": r.get("times_us")},
+                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
+                                   "kernel": "gemm_sk_kernel<TN, tri> (Gram matrix A^T A, upper tiles)", "launch_ms": round(kms, 3)},
+                      "cpu_baseline": {"value": round(fl_s / tc / 1e9, 1), "unit": "GFLOP/s", "cores": oracle.get_threads(), "kind": "port",
+                                       "sample": f"oracle CQRRPT (geqp3 onward, sketch supplied) on {ms}x{n}, {tc:.2f} s"}}))
+
+
+def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
+    ctx = d.Context(0)
+    n = m
+    A = d.cm_empty(m, n, dtype=dtype)
+    flops = 2.0 * b * m * n + 2.0 * m * n * n - 2.0 / 3 * n**3
+    best = None
+    for it in range(steps + 1):
+        ctx.fill_dense(A, m, n, key=(4, 0)); ctx.sync()
+        t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps)); ctx.sync(); dt = time.perf_counter() - t0
+        if it > 0: best = dt if best is None else min(best, dt)
+    apply_us = r["times_us"][5]
+    ach = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
+    pk = PEAK[dtype]
+    print(json.dumps({"metric": f"GFLOP/s BQRRP {m} x {n} {'fp32' if dtype == torch.float32 else 'fp64'}, b={b} (single-GPU cut of BASELINE configs[3])",
+                      "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 1), "best_of": steps,
+                      "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic iid N(0,1), generated on-device",
+                      "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"]},
+                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": None,
+                                   "kernel": "compact-WY apply (gemqrt: generic MFMA GEMMs), wall time of the apply phase over all iterations"},
+                      "cpu_baseline": None}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64"]); ap.add_argument("--steps", type=int, default=3)
+    a = ap.parse_args()
+    if a.what == "cqrrpt": cqrrpt(a.steps)
+    elif a.what == "bqrrp": bqrrp(a.steps)
+    else: bqrrp(a.steps, torch.float64, 16384, 512)
