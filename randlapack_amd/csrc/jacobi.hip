@@ -20,6 +20,13 @@
 #include <cmath>
 #include <limits>
 
+namespace rlhip {
+template <typename T>
+int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb,
+         T beta, T* C, int64_t ldc);
+}
+using rlhip::gemm;
+
 namespace {
 
 template <typename T>
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(int64_t m, int n, int
         ap[i] = swap ? yn : xn;
         aq[i] = swap ? xn : yn;
     }
+    if (!V) return;                      // caller does not want the rotations accumulated
     T* __restrict__ vp = V + (int64_t)p * ldv;
     T* __restrict__ vq = V + (int64_t)q * ldv;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     //      lane's results run along rows -> 128-byte store segments.
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int fr = lane & 15, fk = lane >> 4;
-    for (int r0 = 0; r0 < n; r0 += JM) {
+    for (int r0 = 0; V != nullptr && r0 < n; r0 += JM) {
         __syncthreads();
         for (int e = tid; e < JP * JM; e += NT) {
             const int r = e % JM, c = e / JM;
@@ -383,12 +391,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t m, int n, const T
     const T* col = A + (int64_t)j * lda;
     T* dst = Uout + (int64_t)r * ldu;
     for (int64_t i = threadIdx.x; i < m; i += 256) dst[i] = col[i] * inv;
-    const T* vcol = V + (int64_t)j * ldv;
-    for (int i = threadIdx.x; i < n; i += 256) VT[r + (int64_t)i * ldvt] = vcol[i];
+    if (V != nullptr && VT != nullptr) {
+        const T* vcol = V + (int64_t)j * ldv;
+        for (int i = threadIdx.x; i < n; i += 256) VT[r + (int64_t)i * ldvt] = vcol[i];
+    }
     if (threadIdx.x == 0) Sout[r] = s;
 }
 
 __global__ void zero_u32_kernel(unsigned* p) { p[0] = 0; p[1] = 0; }
+
+// flag |= any |G_ij| > tol * sqrt(G_ii G_jj), i < j   (G = A^T A)
+template <typename T>
+__global__ void gram_offdiag_kernel(int n, const T* __restrict__ G, T tol, unsigned* __restrict__ flag) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx % n, j = idx / n;
+    if (i >= j) return;
+    const double g = (double)G[i + (int64_t)j * n], gi = (double)G[i + (int64_t)i * n], gj = (double)G[j + (int64_t)j * n];
+    if (gi > 0 && gj > 0 && g * g > (double)tol * (double)tol * gi * gj) atomicOr(flag, 1u);
+}
 
 template <typename T, int JB>
 int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
@@ -417,9 +438,28 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
         float cos2;
         memcpy(&cos2, (const char*)(c->h_mail + 16) + sizeof(unsigned), sizeof(float));
         if (nrot == 0) { ++sweep; break; }
-        // quadratic convergence shortcut (cf. DGESVJ's mxaapq test): every cosine met in this sweep was <= 1e-9, so
-        // the rotations just applied leave cosines of order n * 1e-18 << tol; a further all-idle sweep would only confirm it
-        if (cos2 <= 1e-18f) { ++sweep; break; }
+        // Every cosine met in this sweep was <= 1e-9: for separated singular values the rotations just applied leave cosines
+        // of order n * 1e-18 (quadratic convergence) and a further all-idle sweep would only confirm it.  For CLUSTERED
+        // singular values that argument fails (tiny cosines still rotate by large angles), so the claim is VERIFIED with one
+        // Gram matrix (2 launches instead of a 16-launch sweep): converged iff every off-diagonal cosine of A^T A is <= tol.
+        if (cos2 <= 1e-18f) {
+            size_t gm = rlhip_ws_mark(c);
+            T* G = ws_alloc<T>(c, (size_t)n * n);
+            unsigned* flag = d_nrot + 1;
+            bool ok = false;
+            if (G) {
+                int grc = gemm<T>(c, 1, 0, n, n, m, T(1), A, lda, A, lda, T(0), G, n);
+                if (!grc) {
+                    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
+                    hipLaunchKernelGGL(gram_offdiag_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, G, tol, flag);
+                    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+                    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+                    ok = (*((unsigned*)(c->h_mail + 16) + 1) == 0u);
+                }
+            }
+            rlhip_ws_release(c, gm);
+            if (ok) { ++sweep; break; }
+        }
     }
     *sweeps_out = sweep;
     return 0;
@@ -441,19 +481,19 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     if (n64 < 0) return -3;
     if (m < n64) return -2;  // tall only (the path's factor is n x k with n >= k)
     if (lda < (m > 1 ? m : 1)) return -5;
-    if (ldvt < (n64 > 1 ? n64 : 1)) return -8;
+    if (VT != nullptr && ldvt < (n64 > 1 ? n64 : 1)) return -8;   // VT == nullptr: singular values and left vectors only
     if (sweeps_host) *sweeps_host = 0;
     if (n64 == 0) return 0;
     const int n = (int)n64;
     const int N = (n % 2) ? n + 1 : n;
     size_t mark = rlhip_ws_mark(c);
-    T* V = ws_alloc<T>(c, (size_t)n * n);
+    T* V = (VT != nullptr) ? ws_alloc<T>(c, (size_t)n * n) : nullptr;
     T* W = ws_alloc<T>(c, (size_t)m * n);
     T* Sraw = ws_alloc<T>(c, (size_t)n);
     int* rank = ws_alloc<int>(c, (size_t)n);
-    if (!V || !W || !Sraw || !rank) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    if ((VT != nullptr && !V) || !W || !Sraw || !rank) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
     unsigned* d_nrot = (unsigned*)(c->d_mail + 16);
-    int rc = laset<T>(c, 2, n, n, T(0), T(1), V, n);
+    int rc = V ? laset<T>(c, 2, n, n, T(0), T(1), V, n) : 0;
     if (rc) { rlhip_ws_release(c, mark); return rc; }
     const T tol = std::sqrt((T)m) * std::numeric_limits<T>::epsilon();
     const int max_sweeps = 60;

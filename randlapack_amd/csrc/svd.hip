@@ -9,6 +9,7 @@
 // If either Cholesky fails or diag(R1) spans more than 1e7 (CholQR2 no longer guaranteed orthonormal)
 // the routine falls back to Jacobi on A itself (slower, unconditionally accurate).
 #include "rlhip_internal.h"
+#include <cstdlib>
 #include <limits>
 
 namespace {
@@ -31,6 +32,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(int64_t m, int64_t n, co
         int64_t i = i0 + ii, j = j0 + tx;
         if (i < m && j < n && (!upper_only || i <= j)) out[j + i * ldo] = tile[tx][ii];
     }
+}
+
+// A[:, j] /= s[j]
+template <typename T>
+__global__ void scale_cols_inv_kernel(int64_t m, int64_t n, T* __restrict__ A, int64_t lda, const T* __restrict__ s) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * n) return;
+    int64_t i = idx % m, j = idx / m;
+    A[i + j * lda] /= s[j];
 }
 
 // max|d_i| / min|d_i| over the diagonal of an n x n matrix -> out[0] (one workgroup)
@@ -85,6 +95,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
     if (!R1 || !R2 || !X || !VTx) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
     int rc = 0, info = 0;
     bool fallback = false;
+    double ratio = 0;
     // ---- pass 1
     rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
     if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
@@ -96,7 +107,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
         hipLaunchKernelGGL(diag_ratio_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R1, (int64_t)n, d_ratio);
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 24, d_ratio, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
-        double ratio = *(double*)(c->h_mail + 24);
+        ratio = *(double*)(c->h_mail + 24);
         const double lim = (sizeof(T) == 8) ? 1e7 : 1e3;
         if (!(ratio < lim)) fallback = true;
     }
@@ -132,11 +143,38 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
     if (!rc) rc = transpose<T>(c, n, n, R2, n, X, n, 1);               // X = R^T (lower triangular)
     if (rc) { rlhip_ws_release(c, mark); return rc; }
     int sw = 0;
-    int jinfo = gesvdj<T>(c, n, n, X, n, S, VTx, n, &sw);              // X = Ux S VTx
+    // Well-conditioned R (diag ratio < 1e3): the rotations need not be accumulated -- R Ux = Vx S gives Vx = (R Ux) S^-1 to
+    // eps * cond(R); that removes the V-panel update (a quarter of every Jacobi launch).  Otherwise accumulate as usual.
+    // The diagonal ratio is only a LOWER bound on cond(R); the decision uses a rigorous upper bound instead:
+    // cond_2(R) <= ||R||_F ||R^-1||_F, with R^-1 from one k x k substitution (I R^-1).
+    bool recover_v = false;
+    static int rv_on = -1;
+    if (rv_on < 0) { const char* e = getenv("RLHIP_RECOVER_V"); rv_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (rv_on && ratio < 1e3) {
+        T nr = 0, ni = 0;
+        rc = laset<T>(c, 2, n, n, T(0), T(1), VTx, n);
+        if (!rc) rc = trsm_right_upper<T>(c, NonUnit, n, n, T(1), R2, n, VTx, n);
+        if (!rc) rc = lange_fro<T>(c, n, n, R2, n, &nr);
+        if (!rc) rc = lange_fro<T>(c, n, n, VTx, n, &ni);
+        if (rc) { rlhip_ws_release(c, mark); return rc; }
+        recover_v = ((double)nr * (double)ni < ((sizeof(T) == 8) ? 1e3 : 30.0));
+    }
+    int jinfo = gesvdj<T>(c, n, n, X, n, S, recover_v ? (T*)nullptr : VTx, n, &sw);   // X = Ux S VTx
     if (sweeps_host) *sweeps_host = sw;
     if (jinfo < 0) { rlhip_ws_release(c, mark); return jinfo; }
-    // U_out = Q * Vx = Q * VTx^T ;  VT_out = Ux^T
-    rc = gemm<T>(c, 0, 1, m, n, n, T(1), A, lda, VTx, n, T(0), U, ldu);
+    if (recover_v) {
+        // VTx (used as scratch for Vx, NOT transposed here) = R * Ux, columns scaled by 1 / sigma;  U_out = Q * Vx
+        rc = gemm<T>(c, 0, 0, n, n, n, T(1), R2, n, X, n, T(0), VTx, n);
+        if (!rc) {
+            hipLaunchKernelGGL(scale_cols_inv_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, n, VTx, (int64_t)n, S);
+            RLHIP_LAUNCH_CHECK();
+            rc = gemm<T>(c, 0, 0, m, n, n, T(1), A, lda, VTx, n, T(0), U, ldu);
+        }
+    } else {
+        // U_out = Q * Vx = Q * VTx^T
+        rc = gemm<T>(c, 0, 1, m, n, n, T(1), A, lda, VTx, n, T(0), U, ldu);
+    }
+    // VT_out = Ux^T
     if (!rc) rc = transpose<T>(c, n, n, X, n, VT, ldvt, 0);
     rlhip_ws_release(c, mark);
     return rc ? rc : jinfo;

@@ -527,3 +527,31 @@ def test_fill_dense_rows_is_a_slice_of_the_global_operator(ctx, dist):
         assert ctx.lib.rlhip_fill_dense_rows_f64(ctx.h, dist, m, k, row0, rows, part.data_ptr(), rows, ctr, key, nxt2) == 0
         np.testing.assert_array_equal(d.cm_to_numpy(part), F[row0:row0 + rows])      # bit-identical
         assert list(nxt2) == list(nxt)
+
+
+@pytest.mark.parametrize("m,n,kind", [(400, 32, "cluster"), (2000, 64, "cluster"), (256, 256, "identity-like"), (5000, 128, "two-clusters")])
+def test_gesdd_clustered_singular_values(ctx, m, n, kind):
+    """Nearly multiple singular values: tiny cosines still need large rotation angles, so a cosine-based early exit must be
+    verified (regression: the unverified shortcut left U^T U - I at 1e-9 on the B factor of an RSVD with sigma_1..32 ~ 1)."""
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    if kind == "cluster":
+        s = 1.0 - 1e-7 * rng.random(n)
+    elif kind == "identity-like":
+        s = np.ones(n)
+    else:
+        s = np.concatenate([np.full(n // 2, 3.0), 1.0 + 1e-9 * rng.random(n - n // 2)])
+    s = np.sort(s)[::-1]
+    A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    Ad = d.cm_from_numpy(A)
+    S = torch.zeros(n, dtype=torch.float64, device="cuda")
+    U = d.cm_empty(m, n)
+    VT = d.cm_empty(n, n)
+    assert ctx.lib.rlhip_gesdd_f64(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n, None) == 0
+    Un, Sn, VTn = d.cm_to_numpy(U), S.cpu().numpy(), d.cm_to_numpy(VT)
+    assert np.linalg.norm(Un.T @ Un - np.eye(n)) <= 1e-12 * np.sqrt(n)
+    assert np.linalg.norm(VTn @ VTn.T - np.eye(n)) <= 1e-12 * np.sqrt(n)
+    assert np.linalg.norm((Un * Sn) @ VTn - A) <= 1e-13 * np.linalg.norm(A)
+    np.testing.assert_allclose(Sn, s, rtol=1e-12)
