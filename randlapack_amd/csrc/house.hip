@@ -334,4 +334,71 @@ int any_abs_gt(rlhip_ctx* c, int64_t n, const T* x, T thr, int* any_host) {
 INST(double)
 INST(float)
 
+
+// geqrf of a TALL-SKINNY matrix through the BLAS-3 route: Cholesky-QR twice (Q orthonormal to rounding when cond(A) <~ 1e8),
+// then Householder reconstruction (orhr_col) turns Q into the unit-lower V and tau, and R = D R2 R1 goes above the diagonal --
+// the geqrf output format, the same reflectors Householder QR would produce (they are unique for a given sign convention), at
+// GEMM speed instead of one grid-wide step per column.  *done = 0 (A restored to its input up to rounding) when a Cholesky breaks
+// down or the second R factor is not close to the identity, i.e. when CholQR cannot be trusted: the caller then runs the
+// Householder pipeline.  rl_orth.hh:157 (HQRQ), rl_abrik.hh:333,420,552 (ABRIK panels), rl_hqrrp.hh GEQRF_mod_WY.
+template <typename T>
+__global__ void r2_identity_dev_kernel(int n, const T* __restrict__ R, int64_t ldr, T* __restrict__ out) {
+    // out[0] = max over the upper triangle of |R - I|  (one workgroup)
+    __shared__ T red[256];
+    T v = 0;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e % n, j = e / n;
+        if (i <= j) { T d = fabs(R[i + (int64_t)j * ldr] - (i == j ? T(1) : T(0))); v = d > v ? d : v; }
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + st] ? red[threadIdx.x] : red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+template <typename T>
+int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done) {
+    *done = 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* R1 = ws_alloc<T>(c, (size_t)n * n);
+    T* R2 = ws_alloc<T>(c, (size_t)n * n);
+    T* Tm = ws_alloc<T>(c, (size_t)n * n);
+    T* D = ws_alloc<T>(c, (size_t)n);
+    T* dev1 = ws_alloc<T>(c, 4);
+    if (!R1 || !R2 || !Tm || !D || !dev1) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    int info = 0;
+    int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
+    if (!rc) rc = potrf_upper<T>(c, n, R1, n, &info);
+    if (rc || info) { rlhip_ws_release(c, mark); return rc; }                       // A untouched so far
+    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
+    if (!rc) rc = laset<T>(c, 2, n, n, T(0), T(0), R2, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R2, n);
+    if (!rc) rc = potrf_upper<T>(c, n, R2, n, &info);
+    bool good = !rc && !info;
+    if (good) {
+        hipLaunchKernelGGL(r2_identity_dev_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R2, (int64_t)n, dev1);
+        T dev_h = 0;
+        RLHIP_CHECK(hipMemcpyAsync(&dev_h, dev1, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        good = (dev_h <= T(1e-2));                                                  // Q1 was orthonormal to ~1e-2: pass 2 is accurate
+    }
+    if (!good) {                                                                    // restore A = Q1 R1 and let Householder do it
+        int rc2 = trmm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
+        rlhip_ws_release(c, mark);
+        return rc ? rc : rc2;
+    }
+    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R2, n, A, lda);                // A = Q
+    if (!rc) rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R1, n, R2, n);        // R2 <- R2 R1 = R (upper; lower part is zero)
+    if (!rc) rc = orhr_col<T>(c, m, n, n, A, lda, Tm, n, D);                        // V below the diagonal, T, sign vector D
+    if (!rc) rc = row_sign<T>(c, n, R2, n, D);                                      // R <- D R
+    if (!rc) rc = tau_from_t<T>(c, n, n, Tm, n, tau);
+    if (!rc) rc = lacpy<T>(c, 0, n, n, R2, n, A, lda);                              // upper triangle incl. diagonal
+    rlhip_ws_release(c, mark);
+    if (!rc) *done = 1;
+    return rc;
+}
+template int geqrf_cholqr<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*, int*);
+template int geqrf_cholqr<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*, int*);
+
 }  // namespace rlhip

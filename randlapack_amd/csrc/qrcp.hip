@@ -253,6 +253,174 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
 
 __global__ void zero_u32(unsigned* p) { *p = 0; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Unpivoted Householder QR (geqrf / geqr2 order) as a PIPELINE instead of a step-synchronous sweep.  Without pivoting
+// there is no all-to-all decision per step: the owner of column k computes H_k and publishes it (the finished column goes
+// to its final place in A with write-through stores, then a per-step flag is raised); every workgroup applies H_0, H_1,
+// ... to its own columns in order, waiting only on the flag of the reflector it needs next.  Nobody waits for the slowest
+// workgroup of the PREVIOUS step, and the owner of column k+1 updates that column first and publishes H_{k+1} before it
+// finishes applying H_k to the rest of its columns (look-ahead).  Critical path per step: flag poll + one column read + one
+// column update + reflector + publish (~5 us) against ~10-16 us for the rendezvous version.
+template <typename T>
+struct QrPipeArgs {
+    int64_t m, n;
+    T* A; int64_t lda;
+    T* tau;
+    unsigned* flag;           // kmax entries, zeroed by the host
+    int use_lds;
+    int v_in_lds;             // the current reflector fits in LDS (m doubles); otherwise it is read from its column of A
+    int wg_per_col;           // tall-skinny: few columns per workgroup -> the whole workgroup updates one column at a time
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t G = gridDim.x, me = blockIdx.x;
+    const int64_t m = g.m, n = g.n;
+    const int64_t kmax = m < n ? m : n;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qp_smem[];
+    T* l_v = reinterpret_cast<T*>(qp_smem);              // current reflector (m), when it fits
+    T* lds_cols = l_v + (g.v_in_lds ? m : 0);
+    __shared__ T s_val[4];
+    __shared__ T s_tau;
+    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + (j / G) * m) : (g.A + j * g.lda); };
+    if (g.use_lds) {
+        for (int64_t j = me; j < n; j += G) {
+            T* dst = lds_cols + (j / G) * m;
+            const T* src = g.A + j * g.lda;
+            for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    // compute H_k from (already updated) column k, publish it, leave v in l_v and tau in s_tau
+    auto make_reflector = [&](int64_t k) {
+        T* col = colptr(k);
+        T ss = 0;
+#pragma unroll 8
+        for (int64_t i = k + 1 + tid; i < m; i += 256) ss += col[i] * col[i];
+        ss = wave_sum(ss);
+        __syncthreads();
+        if (lane == 0) s_val[wid] = ss;
+        __syncthreads();
+        const T xnorm = sqrt(s_val[0] + s_val[1] + s_val[2] + s_val[3]);
+        const T alpha = col[k];
+        T beta = alpha, scale = 0, tk = 0;
+        if (xnorm != T(0)) {
+            beta = -copysign(hypot(alpha, xnorm), alpha);
+            tk = (beta - alpha) / beta;
+            scale = T(1) / (alpha - beta);
+        }
+        T* gcol = g.A + k * g.lda;
+#pragma unroll 8
+        for (int64_t i = tid; i < m; i += 256) {
+            T v = col[i];
+            if (i == k) v = beta; else if (i > k) v *= scale;
+            if (g.v_in_lds) l_v[i] = v;
+            if (g.use_lds) col[i] = v;
+            pub_store(gcol + i, v);                       // final content of column k of A (R above, beta, v below)
+        }
+        if (tid == 0) { pub_store(g.tau + k, tk); s_tau = tk; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(g.flag + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // tall matrices read v back from its column of A with ordinary loads: drop this CU's stale L1 lines of that column
+            if (!g.v_in_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (!g.v_in_lds) __syncthreads();
+    };
+    // apply H (v in l_v, tau = tk, pivot row k) to column j
+    auto apply_one = [&](int64_t k, T tk, T* col) {       // one wave per column
+        const T* gv = g.A + k * g.lda;                    // (tall matrices: v straight from its published column)
+        T w = 0;
+#pragma unroll 4
+        for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i])) * col[i];
+        w = wave_sum(w) * tk;
+#pragma unroll 4
+        for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i]));
+    };
+    auto apply_wg = [&](int64_t k, T tk, T* col) {        // whole workgroup on one (long) column
+        const T* gv = g.A + k * g.lda;
+        T w = 0;
+#pragma unroll 8
+        for (int64_t i = k + tid; i < m; i += 256) w += ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i])) * col[i];
+        w = wave_sum(w);
+        __syncthreads();
+        if (lane == 0) s_val[wid] = w;
+        __syncthreads();
+        w = (s_val[0] + s_val[1] + s_val[2] + s_val[3]) * tk;
+#pragma unroll 8
+        for (int64_t i = k + tid; i < m; i += 256) col[i] -= w * ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i]));
+    };
+    bool have_next = false;                               // reflector k already made by the look-ahead of step k-1
+    for (int64_t k = 0; k < kmax; ++k) {
+        const int64_t own_k = k % G;
+        T tk;
+        if (me == own_k) {
+            if (!have_next) make_reflector(k);            // (k = 0, or G == 1 handled by the look-ahead below)
+            tk = s_tau;
+        } else {
+            if (tid == 0) {
+                while (__hip_atomic_load(g.flag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const T* gcol = g.A + k * g.lda;
+            if (g.v_in_lds)
+                for (int64_t i = k + tid; i < m; i += 256) l_v[i] = gcol[i];
+            if (tid == 0) s_tau = g.tau[k];
+            __syncthreads();
+            tk = s_tau;
+        }
+        have_next = false;
+        if (tk != T(0)) {
+            // look-ahead: the owner of column k+1 brings that column up to date first and publishes H_{k+1} right away
+            const int64_t kn = k + 1;
+            const bool own_next = (kn < kmax) && (me == kn % G);
+            if (own_next) {
+                if (g.wg_per_col) apply_wg(k, tk, colptr(kn));
+                else if (wid == 0) apply_one(k, tk, colptr(kn));
+                __syncthreads();
+            }
+            // remaining owned columns j > k (all of them when this workgroup does not own k+1)
+            // H_k for the remaining owned columns (still from l_v: make_reflector(k+1) overwrites it afterwards)
+            const T saved_tau = tk;
+            if (g.wg_per_col) {
+                for (int64_t j = me; j < n; j += G) {
+                    if (j <= k || (own_next && j == kn)) continue;
+                    apply_wg(k, saved_tau, colptr(j));
+                }
+            } else {
+                for (int64_t j = me + G * wid; j < n; j += 4 * G) {
+                    if (j <= k || (own_next && j == kn)) continue;
+                    apply_one(k, saved_tau, colptr(j));
+                }
+            }
+            __syncthreads();
+            if (own_next) { make_reflector(kn); have_next = true; }
+        } else {
+            const int64_t kn = k + 1;
+            if ((kn < kmax) && (me == kn % G)) { make_reflector(kn); have_next = true; }
+        }
+    }
+    // columns that never became a pivot (n > m) or global-path bookkeeping: write back what lives only in LDS
+    if (g.use_lds) {
+        __syncthreads();
+        for (int64_t j = me; j < n; j += G) {
+            if (j < kmax) continue;                       // pivot columns were published in place
+            const T* src = lds_cols + (j / G) * m;
+            T* dst = g.A + j * g.lda;
+            for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
+        }
+    }
+}
+
+__global__ void zero_u32_n(unsigned* p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+
 }  // namespace
 
 namespace rlhip {
@@ -264,6 +432,9 @@ int larft_gram(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, cons
 template <typename T>
 int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda,
          const T* B, int64_t ldb, T beta, T* C, int64_t ldc);
+
+template <typename T>
+int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done);
 
 template <typename T>
 static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev, int64_t max_steps = -1,
@@ -294,6 +465,12 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     if (lda < (m > 1 ? m : 1)) return -5;
     if (m == 0 || n == 0) return 0;
     const int64_t nf = n < m ? n : m;
+    if (m >= 16 * n && n >= 8 && n <= 4096 && (size_t)m * sizeof(T) > 64 * 1024 && sizeof(T) == 8) {   // tall-skinny: BLAS-3 route first
+        int done = 0;
+        int rcq = geqrf_cholqr<T>(c, m, n, A, lda, tau_dev, &done);
+        if (rcq) return rcq;
+        if (done) return 0;
+    }
     int rc = qr_core<T>(c, 0, m, nf, A, lda, nullptr, tau_dev);
     if (rc || n <= m) return rc;
     size_t mark = rlhip_ws_mark(c);
@@ -397,7 +574,32 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     static bool attr_set = false;
     if (!attr_set) {
         RLHIP_CHECK(hipFuncSetAttribute((const void*)qrcp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)qr_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
+    }
+    static int pipe_on = -1;
+    if (pipe_on < 0) { const char* e = getenv("RLHIP_QR_PIPE"); pipe_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!pivot && max_steps < 0 && pipe_on) {
+        size_t mark2 = rlhip_ws_mark(c);
+        const int64_t kmax = m < n ? m : n;
+        QrPipeArgs<T> pa;
+        pa.m = m; pa.n = n; pa.A = A; pa.lda = lda; pa.tau = tau_dev; pa.use_lds = use_lds;
+        pa.v_in_lds = use_lds || ((size_t)m * sizeof(T) <= 64 * 1024);
+        pa.wg_per_col = 0;
+        int64_t Gp = G;
+        if (!use_lds && m > 8 * n) {          // tall-skinny: spread the columns over as many workgroups as there are CUs
+            Gp = n < num_cu ? n : num_cu;
+            pa.wg_per_col = 1;
+        }
+        pa.flag = ws_alloc<unsigned>(c, (size_t)kmax + 4);
+        if (!pa.flag) { rlhip_ws_release(c, mark2); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        hipLaunchKernelGGL(zero_u32_n, dim3((unsigned)((kmax + 255) / 256)), dim3(256), 0, c->stream, pa.flag, kmax);
+        const size_t cpw2 = (size_t)((n + Gp - 1) / Gp);
+        const size_t dyn2 = (pa.v_in_lds ? (size_t)m * sizeof(T) : 0) + (use_lds ? cpw2 * (size_t)m * sizeof(T) : 0);
+        hipLaunchKernelGGL(qr_pipe_kernel<T>, dim3((unsigned)Gp), dim3(256), dyn2, c->stream, pa);
+        RLHIP_LAUNCH_CHECK();
+        rlhip_ws_release(c, mark2);
+        return 0;
     }
     size_t mark = rlhip_ws_mark(c);
     QrcpArgs<T> g;
@@ -415,6 +617,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     hipLaunchKernelGGL(zero_u32, dim3(1), dim3(1), 0, c->stream, g.bar);
     const size_t cpw_final = (size_t)((n + G - 1) / G);
     const size_t dyn = (2 * cpw_final + (size_t)m) * sizeof(T) + (use_lds ? cpw_final * (size_t)m * sizeof(T) : 0);
+    if (dyn > 150 * 1024) { rlhip_ws_release(c, mark); return -2; }   // pivoted / partial factorizations keep the reflector in LDS: m <= ~18000 rows
     hipLaunchKernelGGL(qrcp_kernel<T>, dim3((unsigned)G), dim3(256), dyn, c->stream, g);
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);

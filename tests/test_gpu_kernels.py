@@ -555,3 +555,32 @@ def test_gesdd_clustered_singular_values(ctx, m, n, kind):
     assert np.linalg.norm(VTn @ VTn.T - np.eye(n)) <= 1e-12 * np.sqrt(n)
     assert np.linalg.norm((Un * Sn) @ VTn - A) <= 1e-13 * np.linalg.norm(A)
     np.testing.assert_allclose(Sn, s, rtol=1e-12)
+
+
+@pytest.mark.parametrize("m,n,cond", [(20000, 128, 1e2), (20000, 64, 1e12), (100000, 32, 1.0), (9000, 16, 1e9)])
+def test_geqrf_tall_skinny_matches_lapack(ctx, m, n, cond):
+    """Tall-skinny geqrf: Cholesky-QR twice + Householder reconstruction when it can be trusted, the Householder pipeline
+    otherwise (cond 1e9 / 1e12 force the fallback).  Either way the GEQRF-format output equals LAPACK's to rounding."""
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    s = np.logspace(0, -np.log10(cond), n) if cond > 1 else np.ones(n)
+    A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    Ad = d.cm_from_numpy(A)
+    tau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    assert ctx.lib.rlhip_geqrf_f64(ctx.h, m, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
+    ctx.sync()
+    qr_ref, tau_ref, _, _ = ll.dgeqrf(A)
+    out = d.cm_to_numpy(Ad)
+    # R rows scale with the singular values: compare relative to each row of R; V and tau absolutely
+    Rg, Rr = np.triu(out[:n]), np.triu(qr_ref[:n])
+    assert np.linalg.norm(Rg - Rr) <= 1e-9 * np.linalg.norm(Rr)
+    if cond < 1e9:   # reflectors of an ill-conditioned matrix are sensitive to eps * cond perturbations: two correct Householder QRs
+        np.testing.assert_allclose(np.tril(out, -1), np.tril(qr_ref, -1), atol=1e-9, rtol=0)   # need not agree entrywise there
+        np.testing.assert_allclose(tau.cpu().numpy(), tau_ref, atol=1e-9, rtol=0)
+    assert ctx.lib.rlhip_ungqr_f64(ctx.h, m, n, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
+    Q = d.cm_to_numpy(Ad)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 1e-12 * np.sqrt(n)
+    assert np.linalg.norm(Q @ Rg - A) <= 1e-13 * np.linalg.norm(A)
