@@ -8,6 +8,7 @@
 // (torch.distributed in bench.py).  Alternatively a host callback can be installed
 // (rlhip_comm_set_hook) -- used by hosts that own their collectives.
 #include "rlhip_internal.h"
+#include <cstdlib>
 #include "../../include/rlhip.h"
 #include <dlfcn.h>
 #include <cstring>
@@ -80,7 +81,9 @@ int rlhip_comm_init(rlhip_ctx* c, int nranks, int rank, const unsigned char id[1
     rlhip_comm* cm = comm_of(c);
     cm->rank = rank;
     cm->nranks = nranks;
-    if (nranks == 1) return 0;
+    // one rank needs no communicator; RLHIP_COMM_SINGLE_RANK_NCCL=1 builds one anyway so that a 1-GPU box can exercise the real
+    // ncclCommInitRank / ncclAllReduce bindings (tests/test_gpu_drivers.py::test_comm_world1_allreduce_is_identity)
+    if (nranks == 1 && !getenv("RLHIP_COMM_SINGLE_RANK_NCCL")) return 0;
     if (load_rccl()) return -1001;
     RLHIP_CHECK(hipSetDevice(c->device));
     NcclId nid;
@@ -121,7 +124,7 @@ int rlhip_comm_destroy(rlhip_ctx* c) {
 static int allreduce_impl(rlhip_ctx* c, void* buf, int64_t count, int is_f64) {
     if (count <= 0 || !c->comm) return 0;
     rlhip_comm* cm = comm_of(c);
-    if (cm->nranks <= 1) return 0;
+    if (cm->nranks <= 1 && !cm->comm) return 0;
     if (cm->hook) return cm->hook(cm->hook_user, buf, count, is_f64);
     if (!cm->comm) return -1002;
     int rc = g_rccl.allreduce(buf, buf, (size_t)count, is_f64 ? 8 /*ncclFloat64*/ : 7 /*ncclFloat32*/, 0 /*ncclSum*/,

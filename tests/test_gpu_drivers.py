@@ -445,6 +445,7 @@ def test_comm_world1_allreduce_is_identity(ctx, force_hook):
     d = _d()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29731")
+    os.environ["RLHIP_COMM_SINGLE_RANK_NCCL"] = "1"       # build a REAL one-rank RCCL communicator: ncclCommInitRank + ncclAllReduce run
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -455,8 +456,15 @@ def test_comm_world1_allreduce_is_identity(ctx, force_hook):
         assert ctx.lib.rlhip_comm_size(ctx.h) == 1 and ctx.lib.rlhip_comm_rank(ctx.h) == 0
         x = torch.arange(1000, dtype=torch.float64, device="cuda")
         assert ctx.lib.rlhip_allreduce_sum_f64(ctx.h, x.data_ptr(), 1000) == 0
+        y = torch.arange(777, dtype=torch.float32, device="cuda")
+        assert ctx.lib.rlhip_allreduce_sum_f32(ctx.h, y.data_ptr(), 777) == 0
+        import ctypes as C
+
+        h = (C.c_double * 3)(1.5, -2.0, 4.0)
+        assert ctx.lib.rlhip_allreduce_sum_host_f64(ctx.h, h, 3) == 0 and list(h) == [1.5, -2.0, 4.0]
         ctx.sync()
         assert torch.equal(x, torch.arange(1000, dtype=torch.float64, device="cuda"))
+        assert torch.equal(y, torch.arange(777, dtype=torch.float32, device="cuda"))
         # a driver call with a communicator attached (size 1: the reductions are skipped)
         A = d.cm_empty(2048, 256)
         ctx.fill_dense(A, 2048, 256, key=(1, 0))
@@ -464,6 +472,7 @@ def test_comm_world1_allreduce_is_identity(ctx, force_hook):
         assert r["rc"] == 0
     finally:
         ctx.lib.rlhip_comm_destroy(ctx.h)
+        os.environ.pop("RLHIP_COMM_SINGLE_RANK_NCCL", None)
         if created:
             dist.destroy_process_group()
 
