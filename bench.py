@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("RLHIP_BENCH_SHAPE"):      # tests: torch.distributed.run's own parser chokes on unknown short-looking options
+        args.m, args.n, args.k = (int(x) for x in os.environ["RLHIP_BENCH_SHAPE"].split(","))
 
     import torch
 
@@ -81,12 +83,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # RLHIP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (tests): the ranks then share
+    # the visible devices and the library's all-reduce hook exchanges through the host.  The driver's runs use nccl (= RCCL).
+    backend = os.environ.get("RLHIP_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
+    pg_dev = "cpu" if backend == "gloo" else f"cuda:{local_rank}"
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     from randlapack_amd import device as dev
     from randlapack_amd import sharded
@@ -116,7 +127,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok = 0
             print(f"[bench rank {rank}] direct RCCL path failed ({e}); retrying through torch.distributed", file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+        flag = torch.tensor([ok], dtype=torch.int32, device=pg_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             ctx.lib.rlhip_comm_destroy(ctx.h)
@@ -138,7 +149,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([dt], device=pg_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

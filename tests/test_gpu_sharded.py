@@ -43,3 +43,20 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded ABRIK (CQRRT panels): same iteration count, same leading Ritz values as on one device
     assert (out["ab_iters"], out["ab_trip"]) == (out["ab_iters1"], out["ab_trip1"])
     assert out["ab_S_vs_single"] <= 1e-9 and out["ab_orthU"] <= 1e-9 and out["ab_res"] <= 1e-9
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 end to end (row sharding, barrier + max-over-ranks timing, JSON line) with two ranks sharing the GPU and
+    gloo as the process group; the driver's real runs differ only in the transport (RCCL)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    env = dict(os.environ)
+    env["RLHIP_BENCH_BACKEND"] = "gloo"
+    env["RLHIP_BENCH_SHAPE"] = "16384,2048,64"
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-1500:] + res.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["k_out"] == 64 and out["config"]["collectives"] == "torch.distributed"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(out["roofline"])
