@@ -27,7 +27,6 @@ struct QrcpArgs {
     T* A; int64_t lda;
     int64_t* jpvt;            // device, 1-based on exit; entry values are ignored (no "fixed" columns)
     T* tau;
-    T* vn1; T* vn2;           // n each
     T* cand_val; int64_t* cand_pos; T* cand_tau;   // 2 x G each (step parity)
     T* slot;                  // 2 x G x m : each workgroup's speculative "finished pivot column"
     T* kcol;                  // 2 x m     : column currently at position k (moves to position p)
@@ -604,13 +603,12 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     size_t mark = rlhip_ws_mark(c);
     QrcpArgs<T> g;
     g.m = m; g.n = n; g.A = A; g.lda = lda; g.jpvt = jpvt_dev; g.tau = tau_dev;
-    g.vn1 = ws_alloc<T>(c, n); g.vn2 = ws_alloc<T>(c, n);   // (kept for ABI of the args struct; norms live in LDS)
     g.cand_val = ws_alloc<T>(c, 2 * G); g.cand_pos = ws_alloc<int64_t>(c, 2 * G); g.cand_tau = ws_alloc<T>(c, 2 * G);
     g.slot = ws_alloc<T>(c, (size_t)2 * G * m); g.kcol = ws_alloc<T>(c, (size_t)2 * (m + 2));
     g.bar = ws_alloc<unsigned>(c, 4);
     g.tol3z = std::sqrt(std::numeric_limits<T>::epsilon() / 2);   // SQRT(DLAMCH('Epsilon')): LAPACK's eps is the rounding unit
     g.use_lds = use_lds; g.pivot = pivot; g.max_steps = max_steps; g.hq_formula = hq_formula;
-    if (!g.vn1 || !g.vn2 || !g.cand_val || !g.cand_pos || !g.cand_tau || !g.slot || !g.kcol || !g.bar) {
+    if (!g.cand_val || !g.cand_pos || !g.cand_tau || !g.slot || !g.kcol || !g.bar) {
         rlhip_ws_release(c, mark);
         return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     }

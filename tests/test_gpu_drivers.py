@@ -731,3 +731,36 @@ def test_small_shapes_rsvd_cqrrpt_abrik_stabilisers(ctx, orc):
             rco, Qo = orc.stab(kind, Y)
             assert rc == rco == 0
             np.testing.assert_allclose(d.cm_to_numpy(Yd), Qo, atol=1e-11, rtol=0)
+
+
+def test_no_device_memory_growth_over_repeated_calls(ctx, orc):
+    """Steady state allocates nothing: scratch comes from the context's arena, outputs from the caching pool behind rlhip_malloc."""
+    import torch
+
+    d = _d()
+    rng = np.random.default_rng(2)
+    A = d.cm_from_numpy(rng.standard_normal((3000, 400)))
+    Aq = rng.standard_normal((3000, 64))
+
+    def one_round():
+        r = d.drv_rsvd(ctx, A, 3000, 400, 32, 16, 1e-12, 1, 1)
+        del r
+        Ad = d.cm_from_numpy(Aq)
+        d.drv_cqrrpt(ctx, Ad, 3000, 64, 1.25, 2)
+        Ab = d.cm_from_numpy(Aq)
+        d.drv_bqrrp(ctx, Ab, 3000, 64, 16, 1.0)
+        Ah = d.cm_from_numpy(Aq)
+        d.drv_hqrrp(ctx, Ah, 3000, 64, 16, 4)
+        d.drv_abrik(ctx, A, 3000, 400, 8, 1e-12, 4)
+
+    for _ in range(3):
+        one_round()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        one_round()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 8 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 rounds"
