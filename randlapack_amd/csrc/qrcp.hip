@@ -463,20 +463,41 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
     if (m == 0 || n == 0) return 0;
-    const int64_t nf = n < m ? n : m;
-    if (m >= 16 * n && n >= 8 && n <= 4096 && (size_t)m * sizeof(T) > 64 * 1024 && sizeof(T) == 8) {   // tall-skinny: BLAS-3 route first
-        int done = 0;
-        int rcq = geqrf_cholqr<T>(c, m, n, A, lda, tau_dev, &done);
-        if (rcq) return rcq;
-        if (done) return 0;
+    // Blocked right-looking Householder QR, panel width 128.  A panel is factored by the BLAS-3 route (Cholesky-QR twice +
+    // Householder reconstruction: same reflectors, GEMM speed) whenever it is at least twice as tall as wide and the route can be
+    // trusted (verified inside geqrf_cholqr), by the flag-pipelined Householder kernel otherwise; the trailing columns get
+    // Q_panel^T as one compact-WY block on the MFMA GEMMs.  One panel covers the tall-skinny case; wide inputs (n > m) simply
+    // have trailing columns beyond the last reflector.
+    constexpr int64_t NBQ = 256;       // a BLAS-3 panel costs ~1.3 ms of launch latency whatever its width: few, wide panels
+    const int64_t kmax = m < n ? m : n;
+    if (kmax <= 1280 && m < 16 * kmax) {  // sketch-sized problems: the pipelined kernel alone beats blocking (1280 x 1024: 11.0 vs 12.2 ms)
+        int rc0 = qr_core<T>(c, 0, m, kmax, A, lda, nullptr, tau_dev);
+        if (rc0 || n <= kmax) return rc0;
+        size_t mark0 = rlhip_ws_mark(c);
+        T* T0 = ws_alloc<T>(c, (size_t)kmax * kmax);
+        if (!T0) { rlhip_ws_release(c, mark0); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        rc0 = larft_gram<T>(c, m, kmax, A, lda, tau_dev, T0, kmax);
+        if (!rc0) rc0 = gemqrt_lt<T>(c, m, n - kmax, kmax, kmax, A, lda, T0, kmax, A + kmax * lda, lda);
+        rlhip_ws_release(c, mark0);
+        return rc0;
     }
-    int rc = qr_core<T>(c, 0, m, nf, A, lda, nullptr, tau_dev);
-    if (rc || n <= m) return rc;
     size_t mark = rlhip_ws_mark(c);
-    T* Tm = ws_alloc<T>(c, (size_t)m * m);
-    if (!Tm) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    rc = larft_gram<T>(c, m, m, A, lda, tau_dev, Tm, m);
-    if (!rc) rc = gemqrt_lt<T>(c, m, n - m, m, m, A, lda, Tm, m, A + m * lda, lda);
+    T* Tm = (n > NBQ || n > kmax) ? ws_alloc<T>(c, (size_t)NBQ * NBQ) : nullptr;
+    int rc = 0;
+    for (int64_t j0 = 0; j0 < kmax && !rc; j0 += NBQ) {
+        const int64_t jb = (kmax - j0 < NBQ) ? (kmax - j0) : NBQ;
+        const int64_t rows = m - j0;
+        T* P = A + j0 + j0 * lda;
+        int done = 0;
+        if (rows >= 2 * jb && jb >= 8 && (size_t)rows * jb >= 16384) rc = geqrf_cholqr<T>(c, rows, jb, P, lda, tau_dev + j0, &done);
+        if (!rc && !done) rc = qr_core<T>(c, 0, rows, jb, P, lda, nullptr, tau_dev + j0);
+        const int64_t rest = n - j0 - jb;
+        if (!rc && rest > 0) {
+            if (!Tm) { rc = RLHIP_ERR_HIP(hipErrorOutOfMemory); break; }
+            rc = larft_gram<T>(c, rows, jb, P, lda, tau_dev + j0, Tm, jb);
+            if (!rc) rc = gemqrt_lt<T>(c, rows, rest, jb, jb, P, lda, Tm, jb, A + j0 + (j0 + jb) * lda, lda);
+        }
+    }
     rlhip_ws_release(c, mark);
     return rc;
 }
