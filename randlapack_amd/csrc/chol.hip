@@ -204,15 +204,23 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
                 d4_t acc = {0, 0, 0, 0};
                 const T* pa = sU12 + (c0 + fr) * PS_LD + fk;      // A operand: A[m = fr][k = fk] = U12[l][c0 + m]
                 const T* pb = sU12 + (i0 + fr) * PS_LD + fk;      // B operand: B[k = fk][n = fr] = U12[l][i0 + n]
-#pragma unroll
-                for (int st = 0; st < NB / 4; ++st)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)pa[4 * st], (double)pb[4 * st], acc, 0, 0, 0);
-                // acc[r] = E[row = fk + 4r][col = fr] = D[i0 + fr][c0 + fk + 4r]
+                // acc[r] = E[row = fk + 4r][col = fr] = D[i0 + fr][c0 + fk + 4r].  The four old values are requested first with clamped
+                // addresses (no branch between the loads; their latency overlaps the eight MFMAs).
                 const int gi = i0 + fr;
+                const int gic = gi < rest ? gi : rest - 1;
+                T oldv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int gj = c0 + fk + 4 * r;
-                    if (gi < rest && gj < rest && gi <= gj) A22[gi + (int64_t)gj * lda] -= (T)acc[r];
+                    oldv[r] = A22[gic + (int64_t)(gj < rest ? gj : rest - 1) * lda];
+                }
+#pragma unroll
+                for (int st = 0; st < NB / 4; ++st)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)pa[4 * st], (double)pb[4 * st], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gj = c0 + fk + 4 * r;
+                    if (gi < rest && gj < rest && gi <= gj) A22[gi + (int64_t)gj * lda] = oldv[r] - (T)acc[r];
                 }
             }
         }
