@@ -57,6 +57,7 @@ public:
     /// bound on the numerical rank).  SURVEY.md A.8 is the behavioural spec; line numbers refer to rl_bqrrp.hh.
     int call(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, T* tau, int64_t* J, RandBLAS::RNGState<RNG>& state) override {
         randlapack_require(m >= 0 && n >= 0 && lda >= m) << "bad dimensions";
+        if (q.world() > 1) return call_sharded(m, n, A, lda, d_factor, tau, J, state);
         const int64_t mn = std::min(m, n);
         if (mn == 0) { rank = 0; return 0; }
         using clk = std::chrono::steady_clock;
@@ -188,6 +189,156 @@ public:
             rows -= b_sz;
             cols -= b_sz;
             t_upd += us(ta, stamp());
+        }
+        return 0;
+    }
+
+
+    /// Row-block sharded BQRRP (BASELINE config 4): this rank holds rows [row0, row0 + m) of the global matrix.
+    /// Replicated on every rank: the sketch A_sk and everything derived from it (pivots J, rank estimates, R_sk), the b x b factors
+    /// (Gram matrix, R11, T, D), tau.  Sharded by rows: A itself, i.e. the reflectors V and the trailing matrix.  Exchanges per
+    /// block iteration (all-reduces over RCCL): the b x b Gram matrix of the panel ("R-factor all-reduce"), the b x b top block of
+    /// the orthonormal panel (so that every rank can run the Householder reconstruction on [top block; its own rows]), W = V^T C
+    /// (b x (cols - b)) for the compact-WY apply, and the b x (cols - b) block row R12 for the sketch down-date; once at the start the
+    /// d x n sketch.  Options: qrcp_wide free (it acts on the replicated sketch), qr_tall = cholqr, apply_trans_q = gemqrt, internal_nb = b.
+    int call_sharded(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, T* tau, int64_t* J, RandBLAS::RNGState<RNG>& state) {
+        randlapack_require(qr_tall == Subroutines::QRTall::cholqr) << "row-sharded BQRRP needs qr_tall = cholqr (Householder panels do not shard)";
+        int64_t m_glob = m, row0 = 0;
+        q.shard_extent(m, m_glob, row0);
+        const int64_t mn = std::min(m_glob, n);
+        if (mn == 0) { rank = 0; return 0; }
+        int64_t cols = n, curr_sz = 0, b_sz = block_size;
+        const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);
+        const int64_t b_sz_const = b_sz;
+        const int64_t d = (int64_t)(d_factor * b_sz);
+        int64_t sampling_dimension = d, block_rank = b_sz;
+        blas::Scratch ws(q);
+        int64_t* J_buffer = ws.alloc<int64_t>(n);
+        T* A_sk_base = ws.alloc<T>(d * n);
+        T* R_tall_qr = ws.alloc<T>(b_sz_const * b_sz_const);
+        T* T_dat = ws.alloc<T>(b_sz_const * b_sz_const);
+        T* Q1buf = ws.alloc<T>(b_sz_const * b_sz_const);
+        T* Work2 = ws.alloc<T>(n);
+        const bool lu = (qrcp_wide == Subroutines::QRCPWide::luqr);
+        T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;
+        int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
+        T* A_sk = A_sk_base;
+        // ---- sketch: S (d x m_glob) is ONE global Gaussian operator; this rank generates its column block S[:, row0 : row0 + m]
+        //      (stream positions d*row0 ... of the same fill) and contributes S_g A_g; the state advances as for the full fill
+        if (sketch_override) {
+            lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_sk, d, q);
+        } else {
+            blas::Scratch w2(q);
+            T* S = w2.alloc<T>(std::max<int64_t>(d * m, 1));
+            RandBLAS::DenseDist Dall(d * m_glob, 1);
+            state = RandBLAS::fill_dense_rows(Dall, d * row0, d * m, S, state, q);
+            if (m > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, d, n, m, (T)1.0, S, d, A, lda, (T)0.0, A_sk, d, q);
+            else lapack::laset(MatrixType::General, d, n, (T)0, (T)0, A_sk, d, q);
+            q.allreduce_sum(A_sk, d * n);
+        }
+        if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_sk, d, sketch_export, d, q);
+        std::vector<T> diag(b_sz_const);
+
+        for (int64_t iter = 0; iter < maxiter; ++iter) {
+            b_sz = std::min(b_sz, mn - curr_sz);
+            block_rank = b_sz;
+            if (!lu) {
+                lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);
+            } else {
+                blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
+                lapack::getrf(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);
+                lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
+                util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
+                lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
+            }
+            if (m > 0) util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);
+            // local row bookkeeping for this iteration (global rows [curr_sz, m_glob) are active)
+            const int64_t act_lo = std::max(curr_sz, row0), act_hi = row0 + m;              // my active global rows [act_lo, act_hi)
+            const int64_t loc_rows = std::max<int64_t>(0, act_hi - act_lo);
+            T* A_work = (loc_rows > 0) ? &A[(act_lo - row0) + lda * curr_sz] : nullptr;       // my active rows of the panel / trailing matrix
+            double nz = 0;                                                                      // zero test on the panel's first column
+            if (loc_rows > 0) nz = lapack::any_abs_gt(loc_rows, A_work, std::numeric_limits<T>::epsilon(), q) ? 1.0 : 0.0;
+            q.allreduce_sum_host(&nz, 1);
+            const bool block_zero = (nz == 0.0);
+            if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);
+            else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
+            if (block_zero) { rank = curr_sz; return 0; }
+            T* R_sk = A_sk;
+            lapack::get_diag(b_sz, R_sk, d, diag.data(), q);
+            for (int64_t i = 0; i < b_sz; ++i)
+                if (std::abs(diag[i]) / std::abs(diag[0]) < tol) { block_rank = i; break; }
+            const int64_t br = block_rank;
+            T* tau_sub = &tau[curr_sz];
+            // ---- CholQR of the sharded panel: the Gram matrix is summed over the ranks
+            if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_sk, d, A_work, lda, q);
+            lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
+            if (loc_rows > 0) blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, br, loc_rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
+            q.allreduce_sum(R_tall_qr, b_sz_const * b_sz_const);
+            lapack::potrf(Uplo::Upper, br, R_tall_qr, b_sz_const, q);
+            if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
+            // ---- Householder reconstruction on [top block (gathered); my rows below it]
+            const int64_t top_hi = curr_sz + br;                                             // global rows [curr_sz, top_hi) form the top block
+            const int64_t t_lo = std::max(curr_sz, row0), t_hi = std::min(top_hi, row0 + m);
+            const int64_t tcnt = std::max<int64_t>(0, t_hi - t_lo), toff = t_lo - curr_sz;   // my rows of the top block, and where they sit in it
+            const int64_t b_lo = std::max(top_hi, row0);                                      // my rows strictly below the top block
+            const int64_t below = std::max<int64_t>(0, row0 + m - b_lo);
+            lapack::laset(MatrixType::General, br, br, (T)0, (T)0, Q1buf, br, q);
+            if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, &A[(t_lo - row0) + lda * curr_sz], lda, Q1buf + toff, br, q);
+            q.allreduce_sum(Q1buf, br * br);
+            {
+                blas::Scratch w3(q);
+                const int64_t ldp = br + below;
+                T* Pst = w3.alloc<T>(ldp * br);
+                T* Dv = w3.alloc<T>(br);
+                lapack::lacpy(MatrixType::General, br, br, Q1buf, br, Pst, ldp, q);
+                if (below > 0) lapack::lacpy(MatrixType::General, below, br, &A[(b_lo - row0) + lda * curr_sz], lda, Pst + br, ldp, q);
+                lapack::orhr_col(ldp, br, br, Pst, ldp, T_dat, b_sz_const, Dv, q);            // one br x br T block (internal_nb = b)
+                lapack::row_sign(br, R_tall_qr, b_sz_const, Dv, q);
+                lapack::tau_from_t(br, br, T_dat, b_sz_const, tau_sub, q);
+                blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 (replicated)
+                // my rows of V back into A (strictly lower part of the top block is V1, the rest of my rows V2) ...
+                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, Pst + toff, ldp, &A[(t_lo - row0) + lda * curr_sz], lda, q);
+                if (below > 0) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, &A[(b_lo - row0) + lda * curr_sz], lda, q);
+                // ... and my rows of R11 on and above the diagonal of the top block
+                if (tcnt > 0) lapack::lacpy(MatrixType::Upper, tcnt, b_sz - toff, R_tall_qr + toff + toff * b_sz_const, b_sz_const,
+                                            &A[(t_lo - row0) + lda * (curr_sz + toff)], lda, q);
+                // ---- compact-WY apply to the trailing columns: W = sum over ranks of V_g^T C_g, C_g -= V_g (T^T W)
+                const int64_t rest = cols - b_sz;
+                const int64_t vrows = (br != b_sz_const) ? tcnt : (tcnt + below);             // reference: a deficient block acts on the top rows only
+                if (rest > 0 && br > 0) {
+                    T* Vexp = w3.alloc<T>(std::max<int64_t>(vrows, 1) * br);
+                    T* W = w3.alloc<T>(br * rest);
+                    T* W2 = w3.alloc<T>(br * rest);
+                    const int64_t ldvx = std::max<int64_t>(vrows, 1);
+                    if (tcnt > 0) lapack::vrows_explicit(br, toff, tcnt, Pst, ldp, Vexp, ldvx, q);
+                    if (vrows > tcnt) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, Vexp + tcnt, ldvx, q);
+                    T* Cg = (vrows > 0) ? &A[(act_lo - row0) + lda * (curr_sz + b_sz)] : nullptr;
+                    if (vrows > 0) blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, vrows, (T)1.0, Vexp, ldvx, Cg, lda, (T)0.0, W, br, q);
+                    else lapack::laset(MatrixType::General, br, rest, (T)0, (T)0, W, br, q);
+                    q.allreduce_sum(W, br * rest);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, br, (T)1.0, T_dat, b_sz_const, W, br, (T)0.0, W2, br, q);
+                    if (vrows > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, vrows, rest, br, (T)-1.0, Vexp, ldvx, W2, br, (T)1.0, Cg, lda, q);
+                }
+            }
+            curr_sz += b_sz;
+            if (curr_sz >= mn || block_rank != b_sz_const) { rank = curr_sz; return 0; }
+            // ---- sketch down-date: R12 = the b_sz rows just finished of the updated trailing matrix, gathered from their owners
+            {
+                blas::Scratch w4(q);
+                const int64_t rest = cols - b_sz;
+                T* R12 = w4.alloc<T>(b_sz * rest);
+                lapack::laset(MatrixType::General, b_sz, rest, (T)0, (T)0, R12, b_sz, q);
+                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, &A[(t_lo - row0) + lda * curr_sz], lda, R12 + toff, b_sz, q);
+                q.allreduce_sum(R12, b_sz * rest);
+                if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);
+                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R_tall_qr, b_sz_const, R_sk, d, q);
+                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, rest, b_sz, (T)-1.0, R_sk, d, R12, b_sz, (T)1.0, &R_sk[d * b_sz], d, q);
+            }
+            sampling_dimension = std::min(sampling_dimension, cols);
+            if (sampling_dimension - b_sz > 1)
+                lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0, &R_sk[(d + 1) * b_sz] + 1, d, q);
+            A_sk = &A_sk[d * b_sz];
+            cols -= b_sz;
         }
         return 0;
     }

@@ -100,11 +100,13 @@ public:
         auto t1 = stamp();
         // ---- QRCP of the sketch (:247)
         if (qrcp == Subroutines::QRCP::hqrrp) {                                                             // :230-231
+            randlapack_require(q.world() == 1) << "CQRRPT with qrcp = hqrrp / bqrrp on a row-sharded queue: the inner QRCP would treat the replicated sketch as sharded; use geqp3";
             hqrrp(d, n, A_hat, d, J, tau, nb_alg, oversampling, panel_pivoting, use_cholqr, state, q);
         } else if (qrcp == Subroutines::QRCP::bqrrp) {                                                      // :232-245
             if (n <= 2000) bqrrp_block_ratio = 1.0;
             else if (n <= 8000) bqrrp_block_ratio = 0.5;
             else bqrrp_block_ratio = (T)1 / (T)32;
+            randlapack_require(q.world() == 1) << "CQRRPT with qrcp = bqrrp on a row-sharded queue is not supported (the sketch is replicated); use geqp3";
             RandLAPACK::BQRRP<T, RNG> bq(q, false, (int64_t)(n * bqrrp_block_ratio));
             bq.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;      // the reference object's defaults (rl_bqrrp.hh:101-103)
             bq.qr_tall = BQRRPSubroutines::QRTall::geqrf;

@@ -37,6 +37,7 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
     randlapack_require(n_A >= 0) << "hqrrp: n_A is < 0";
     randlapack_require(ldim_A >= std::max<int64_t>(1, m_A)) << "hqrrp: ldim_A is < max(1, m_A)";
     randlapack_require(nb_alg > 0 && pp >= 0) << "hqrrp: nb_alg must be > 0 and pp >= 0";
+    randlapack_require(q.world() == 1) << "hqrrp is not row-sharded (inside CQRRPT it runs on the replicated sketch: use CQRRPT)";
     const int64_t mn_A = std::min(m_A, n_A);
     if (mn_A == 0) return 0;
     const int64_t m_Y = nb_alg + pp, n_Y = n_A, ldim_Y = m_Y, ldim_V = m_Y, m_G = nb_alg + pp, n_G = m_A, ldim_G = m_G;

@@ -104,6 +104,8 @@ inline void ormqr(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, T c
 }
 inline void qrp_partial(int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau, Queue& q) { blas::check(rlhip_qrp_partial_f64(q.ctx(), m, n, steps, A, lda, jpvt, tau), "qrp_partial"); }
 inline void qrp_partial(int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau, Queue& q) { blas::check(rlhip_qrp_partial_f32(q.ctx(), m, n, steps, A, lda, jpvt, tau), "qrp_partial"); }
+inline void vrows_explicit(int64_t br, int64_t toff, int64_t tcnt, double const* Vtop, int64_t ldv, double* out, int64_t ldo, Queue& q) { blas::check(rlhip_vrows_explicit_f64(q.ctx(), br, toff, tcnt, Vtop, ldv, out, ldo), "vrows_explicit"); }
+inline void vrows_explicit(int64_t br, int64_t toff, int64_t tcnt, float const* Vtop, int64_t ldv, float* out, int64_t ldo, Queue& q) { blas::check(rlhip_vrows_explicit_f32(q.ctx(), br, toff, tcnt, Vtop, ldv, out, ldo), "vrows_explicit"); }
 inline void luqrcp_piv(int64_t sd, int64_t cols, int64_t const* ipiv, int64_t* J, Queue& q) { blas::check(rlhip_luqrcp_piv(q.ctx(), sd, cols, ipiv, J), "luqrcp_piv"); }
 // Job::SomeVec, tall (m >= n).  Returns info (>0: Jacobi did not converge).
 inline int64_t gesdd(Job job, int64_t m, int64_t n, double* A, int64_t lda, double* S, double* U, int64_t ldu,

@@ -227,6 +227,10 @@ int rlhip_gemqrt_f32(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n
  * is the complete permutation produced by the swaps. */
 int rlhip_qrp_partial_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau);
 int rlhip_qrp_partial_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau);
+/* rows [toff, toff + tcnt) of the unit-lower-triangular V1 held implicitly in Vtop (br x br), written explicitly (0 above, 1 on the
+ * diagonal) into out (tcnt x br): a rank's own rows of a reflector block under row sharding (BQRRP). */
+int rlhip_vrows_explicit_f64(rlhip_ctx* ctx, int64_t br, int64_t toff, int64_t tcnt, const double* Vtop, int64_t ldv, double* out, int64_t ldo);
+int rlhip_vrows_explicit_f32(rlhip_ctx* ctx, int64_t br, int64_t toff, int64_t tcnt, const float* Vtop, int64_t ldv, float* out, int64_t ldo);
 /* lapack::larft(Forward, Columnwise): T (k x k) from V (m x k) and tau (k) */
 int rlhip_larft_f64(rlhip_ctx* ctx, int64_t m, int64_t k, const double* V, int64_t ldv, const double* tau, double* T, int64_t ldt);
 int rlhip_larft_f32(rlhip_ctx* ctx, int64_t m, int64_t k, const float* V, int64_t ldv, const float* tau, float* T, int64_t ldt);

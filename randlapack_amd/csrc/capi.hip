@@ -26,6 +26,7 @@ template <typename T> int any_abs_gt(rlhip_ctx*, int64_t, const T*, T, int*);
 template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*);
 int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
+template <typename T> int vrows_explicit(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int qrp_partial(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, int64_t*, T*);
 template <typename T> int gemqrt_rn(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int ungqr(rlhip_ctx*, int64_t, int64_t, T*, int64_t, const T*);
@@ -392,6 +393,9 @@ static inline int op_flag(char t, int* out) {
             return rlhip::gemqrt_rn<T>(c, m, n, k, V, ldv, Tm, ldt, C, ldc);                                    \
         }                                                                                                       \
         return left ? -3 : -2;                                                                                  \
+    }                                                                                                           \
+    int rlhip_vrows_explicit_##SUF(rlhip_ctx* c, int64_t br, int64_t toff, int64_t tcnt, const T* Vtop, int64_t ldv, T* out, int64_t ldo) { \
+        return rlhip::vrows_explicit<T>(c, br, toff, tcnt, Vtop, ldv, out, ldo);                                \
     }                                                                                                           \
     int rlhip_qrp_partial_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt, T* tau) { \
         return rlhip::qrp_partial<T>(c, m, n, steps, A, lda, jpvt, tau);                                        \

@@ -401,4 +401,28 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
 template int geqrf_cholqr<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*, int*);
 template int geqrf_cholqr<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*, int*);
 
+
+// Rows [toff, toff + tcnt) of the unit-lower-triangular factor stored implicitly in Vtop (br x br: strictly lower part significant)
+// written out explicitly (zeros above the diagonal, ones on it): the local rows of the reflector block a rank needs when the rows
+// of a BQRRP panel are sharded across ranks.
+template <typename T>
+__global__ void vrows_explicit_kernel(int64_t br, int64_t toff, int64_t tcnt, const T* __restrict__ Vtop, int64_t ldv, T* __restrict__ out,
+                                      int64_t ldo) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= tcnt * br) return;
+    const int64_t i = idx % tcnt, j = idx / tcnt, t = toff + i;
+    T v = 0;
+    if (j < t) v = Vtop[t + j * ldv]; else if (j == t) v = 1;
+    out[i + j * ldo] = v;
+}
+template <typename T>
+int vrows_explicit(rlhip_ctx* c, int64_t br, int64_t toff, int64_t tcnt, const T* Vtop, int64_t ldv, T* out, int64_t ldo) {
+    if (tcnt <= 0 || br <= 0) return 0;
+    hipLaunchKernelGGL(vrows_explicit_kernel<T>, dim3((unsigned)((tcnt * br + 255) / 256)), dim3(256), 0, c->stream, br, toff, tcnt, Vtop, ldv, out, ldo);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int vrows_explicit<double>(rlhip_ctx*, int64_t, int64_t, int64_t, const double*, int64_t, double*, int64_t);
+template int vrows_explicit<float>(rlhip_ctx*, int64_t, int64_t, int64_t, const float*, int64_t, float*, int64_t);
+
 }  // namespace rlhip

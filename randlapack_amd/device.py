@@ -350,14 +350,15 @@ def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0,
 
 
 def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
-              want_sketch=False, timing=False, qrcp_wide=-1, qr_tall=-1, apply_trans_q=-1):
+              want_sketch=False, timing=False, qrcp_wide=-1, qr_tall=-1, apply_trans_q=-1, m_global=None):
     """BQRRP::call; options as in the reference's enums (qrcp_wide 0 luqr | 1 geqp3; qr_tall 0 geqrt | 1 cholqr | 2 geqrf;
     apply_trans_q 0 ormqr | 1 gemqrt; -1 = object default).  A (column-major tensor (n, m)) is overwritten in GEQP3 format.
     Returns dict(rc, rank, tau, J, next_ctr[, sketch][, times_us])."""
     torch = _torch()
     dev = f"cuda:{ctx.device}"
     d = int(d_factor * b_sz)
-    tau = torch.zeros(min(m, n), dtype=A.dtype, device=dev)
+    # row-sharded call (context joined to a communicator): m is the LOCAL row count, tau has min(global rows, n) entries
+    tau = torch.zeros(min(m_global or m, n), dtype=A.dtype, device=dev)
     J = torch.zeros(n, dtype=torch.int64, device=dev)
     sk_out = cm_empty(d, n, dtype=A.dtype, device=dev) if want_sketch else None
     rank = C.c_int64(0)

@@ -41,12 +41,18 @@ def main():
     Aq = d.cm_from_numpy(np.ascontiguousarray(Acq[rows]))
     rq = d.drv_cqrrpt(ctx, Aq, len(rows), ncq, 1.25, 4, key=(5, 0))
     Qloc, Rq, Jq = d.cm_to_numpy(Aq), d.cm_to_numpy(rq["R"]), rq["J"].cpu().numpy()
+    # BQRRP on the shards (config 4's layout): Gram / top-block / W / R12 exchanges
+    nbq, bb = min(n, 120), 32
+    Abq = A[:, :nbq] * np.logspace(0, -2, nbq)
+    Ab = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
+    rb = d.drv_bqrrp(ctx, Ab, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m)
+    Ab_loc, tau_b, J_b = d.cm_to_numpy(Ab), rb["tau"].cpu().numpy(), rb["J"].cpu().numpy()
     # ABRIK on the row-sharded operator (CQRRT panels)
     ka, ita = 8, 8
     ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
     Ua_loc = d.cm_to_numpy(ra["U"])
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
@@ -54,14 +60,20 @@ def main():
         U = np.zeros((m, r["k"])); U2 = np.zeros((m, r2["k"]))
         Qc = np.zeros((m, ncq))
         Ua = np.zeros((m, ra["triplets"]))
-        for rr, u, u2, qq, ua in gathered:
-            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua
+        Abq_out = np.zeros((m, nbq))
+        for rr, u, u2, qq, ua, ab in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
         r1 = d.drv_rsvd(ctx1, d.cm_from_numpy(A), m, n, k, k, 1e-12, p, 1)
         S1 = r1["S"].cpu().numpy()
         ref = oracle.rsvd(A, k, k, 1e-12, p, 1)          # same Philox stream on both sides (oracle/oracle.cpp fill_dense)
+        Ab1 = d.cm_from_numpy(Abq)
+        rb1 = d.drv_bqrrp(ctx1, Ab1, m, nbq, bb, 1.0, key=(8, 0))
+        Ab1n = d.cm_to_numpy(Ab1)
+        Qb = oracle.ungqr(Abq_out, tau_b)
+        Rb = np.triu(Abq_out)[:nbq]
         ra1 = d.drv_abrik(ctx1, d.cm_from_numpy(A), m, n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
         Sa, Sa1, Va = ra["S"].cpu().numpy(), ra1["S"].cpu().numpy(), d.cm_to_numpy(ra["V"])
         sv = np.linalg.svd(A, compute_uv=False)
@@ -70,6 +82,9 @@ def main():
         kq = rq["rank"]
         nA = np.linalg.norm(A)
         out = dict(
+            bq_rank=rb["rank"], bq_rank1=rb1["rank"], bq_J_equal=bool(np.array_equal(J_b, rb1["J"].cpu().numpy())),
+            bq_A=float(np.linalg.norm(Abq_out - Ab1n) / np.linalg.norm(Ab1n)), bq_tau=float(np.max(np.abs(tau_b - rb1["tau"].cpu().numpy()))),
+            bq_resid=float(np.linalg.norm(Abq[:, J_b - 1] - Qb @ Rb) / np.linalg.norm(Abq)), bq_orth=float(np.linalg.norm(Qb.T @ Qb - np.eye(nbq))),
             ab_iters=ra["iters"], ab_iters1=ra1["iters"], ab_trip=ra["triplets"], ab_trip1=ra1["triplets"],
             ab_S_vs_single=float(np.max(np.abs(Sa[:ka] - Sa1[:ka]) / Sa1[:ka])),
             ab_S_vs_exact=float(np.max(np.abs(Sa[:ka] - sv[:ka]) / sv[:ka])),

@@ -21,7 +21,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,m,n,k,p", [(2, 3001, 256, 32, 0), (3, 2000, 300, 40, 2), (2, 4096, 512, 64, 1)])
+@pytest.mark.parametrize("world,m,n,k,p", [(2, 3001, 256, 32, 0), (3, 2000, 300, 40, 2), (2, 4096, 512, 64, 1),
+                                            (3, 210, 160, 16, 0)])  # last: row blocks shorter than n -> BQRRP top blocks straddle ranks, ranks run dry
 def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_worker.py"), str(m), str(n), str(k), str(p)]
@@ -40,6 +41,10 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded CQRRPT == single-device CQRRPT (same SASO, same pivots; R to rounding)
     assert out["cq_rank"] == out["cq_rank1"] and out["cq_J_equal"]
     assert out["cq_R"] <= 1e-10 and out["cq_resid"] <= 1e-12 and out["cq_orth"] <= 1e-11
+    # row-sharded BQRRP == single-device BQRRP: same pivots, GEQP3-format output (V, R, tau) equal to rounding, valid factorization
+    assert out["bq_rank"] == out["bq_rank1"] and out["bq_J_equal"]
+    assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
+    assert out["bq_resid"] <= 1e-12 and out["bq_orth"] <= 1e-11
     # row-sharded ABRIK (CQRRT panels): same iteration count, same leading Ritz values as on one device
     assert (out["ab_iters"], out["ab_trip"]) == (out["ab_iters1"], out["ab_trip1"])
     assert out["ab_S_vs_single"] <= 1e-9 and out["ab_orthU"] <= 1e-9 and out["ab_res"] <= 1e-9
