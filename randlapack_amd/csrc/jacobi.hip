@@ -279,11 +279,13 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
                 xp[16 * r] = xn;
                 xq[16 * r] = yn;
             }
+            if (V != nullptr) {                // the rotation accumulator is only needed when V is wanted
 #pragma unroll
-            for (int r = 0; r < JP / 16; ++r) {
-                const double jp = Js[ql + 16 * r + p * JP], jq = Js[ql + 16 * r + q * JP];
-                Js[ql + 16 * r + p * JP] = cs * jp - sn * jq;
-                Js[ql + 16 * r + q * JP] = sn * jp + cs * jq;
+                for (int r = 0; r < JP / 16; ++r) {
+                    const double jp = Js[ql + 16 * r + p * JP], jq = Js[ql + 16 * r + q * JP];
+                    Js[ql + 16 * r + p * JP] = cs * jp - sn * jq;
+                    Js[ql + 16 * r + q * JP] = sn * jp + cs * jq;
+                }
             }
         }
         my_rot += (rot && ql == 0) ? 1u : 0u;
