@@ -162,9 +162,28 @@ public:
         rank = new_rank;                                                                                     // :335
         blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, new_rank, (T)1.0, R, ldr, A, lda, q);   // :338
         auto t6 = stamp();
-        randlapack_require(!orthogonalization) << "orthogonalization mode needs the device geqrf/orgqr (not built yet)";
-        // R <- R_chol * R_sk (rows 0..new_rank-1, all n columns)                                               :345
-        blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, new_rank, n, (T)1.0, A_hat, d, R, ldr, q);
+        if (!orthogonalization) {
+            // R <- R_chol * R_sk (rows 0..new_rank-1, all n columns)                                           :345
+            blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, new_rank, n, (T)1.0, A_hat, d, R, ldr, q);
+        } else if (new_rank != n) {                                                                         // :347-367
+            // complete the orthonormal set: Gaussian trailing columns, projected against Q, Householder-orthogonalised.
+            // (the reference passes &A[new_rank*lda] to fill_dense as an m x cols buffer with ld m and DISCARDS the returned
+            //  state, :351-352 -- both kept: the fill goes through a packed scratch and `state` is left alone)
+            randlapack_require(q.world() == 1) << "CQRRPT orthogonalization mode is not row-sharded";
+            const int64_t cols_to_fill = n - new_rank;
+            blas::Scratch w2(q);
+            T* Gs = w2.alloc<T>(m * cols_to_fill);
+            T* temp = w2.alloc<T>(new_rank * cols_to_fill);
+            T* tau_orth = w2.alloc<T>(cols_to_fill);
+            RandBLAS::DenseDist Dg(m, cols_to_fill);
+            (void)RandBLAS::fill_dense(Dg, Gs, state, q);
+            T* Gc = &A[new_rank * lda];
+            lapack::lacpy(MatrixType::General, m, cols_to_fill, Gs, m, Gc, lda, q);
+            blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, new_rank, cols_to_fill, m, (T)1.0, A, lda, Gc, lda, (T)0.0, temp, new_rank, q);
+            blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, cols_to_fill, new_rank, (T)-1.0, A, lda, temp, new_rank, (T)1.0, Gc, lda, q);
+            lapack::geqrf(m, cols_to_fill, Gc, lda, tau_orth, q);
+            lapack::ungqr(m, cols_to_fill, cols_to_fill, Gc, lda, tau_orth, q);
+        }
         if (timing) {                                                                                        // :370-384
             auto t7 = stamp();
             auto us = [](clk::time_point a, clk::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };

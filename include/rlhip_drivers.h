@@ -38,7 +38,8 @@ int rlhip_drv_rsvd_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t*
                        int64_t p, int64_t q, int rs_stab, int rf_orth, int qb_orth, int orth_check, double** U,
                        double** S, double** V, uint32_t state[6], int* qb_ret);
 
-/* CQRRPT<double>::call; qrcp {0 hqrrp, 1 bqrrp, 2 geqp3} in the reference's enum order (rl_cqrrpt.hh:41), -1 = default (geqp3).  A (m x n, lda) -> Q; R (n x n, ldr); J (n, device int64).  If A_hat_in
+/* CQRRPT<double>::call; qrcp {0 hqrrp, 1 bqrrp, 2 geqp3} in the reference's enum order (rl_cqrrpt.hh:41), -1 = default (geqp3); add 16 for
+ * CQRRPT::orthogonalization = true (the trailing n - rank columns of A become an orthonormal completion, R is left as R_chol; :347-367).  A (m x n, lda) -> Q; R (n x n, ldr); J (n, device int64).  If A_hat_in
  * is non-NULL it is used as the d x n sketch (ld d) instead of generating a SASO (parity tests share one sketch
  * between this path and the oracle, like test/drivers/test_bqrrp_gpu.cu:91-110); if A_hat_out is non-NULL the
  * sketch that was factored is copied there BEFORE geqp3.  *rank_out = CQRRPT::rank; times_us[8] may be NULL.

@@ -143,6 +143,7 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
         blas::Queue q(ctx);
         RandLAPACK::CQRRPT<double, RNG> alg(q, times_us != nullptr, eps);
         alg.nnz = nnz;
+        if (qrcp >= 16) { alg.orthogonalization = true; qrcp -= 16; }      // +16: CQRRPT::orthogonalization = true (rl_cqrrpt.hh:347-367)
         if (qrcp >= 0) {
             if (qrcp > 2) throw RandLAPACK::Error("qrcp must be 0 (hqrrp), 1 (bqrrp) or 2 (geqp3)");
             alg.qrcp = (RandLAPACK::CQRRPTSubroutines::QRCP)qrcp;
@@ -276,6 +277,7 @@ int rlhip_drv_cqrrpt_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t
         blas::Queue q(ctx);
         RandLAPACK::CQRRPT<float, RNG> alg(q, times_us != nullptr, eps);
         alg.nnz = nnz;
+        if (qrcp >= 16) { alg.orthogonalization = true; qrcp -= 16; }      // +16: CQRRPT::orthogonalization = true (rl_cqrrpt.hh:347-367)
         if (qrcp >= 0) {
             if (qrcp > 2) throw RandLAPACK::Error("qrcp must be 0 (hqrrp), 1 (bqrrp) or 2 (geqp3)");
             alg.qrcp = (RandLAPACK::CQRRPTSubroutines::QRCP)qrcp;

@@ -764,3 +764,21 @@ def test_no_device_memory_growth_over_repeated_calls(ctx, orc):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 <= 8 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 rounds"
+
+
+def test_cqrrpt_orthogonalization_mode(ctx, orc):
+    """CQRRPT::orthogonalization (rl_cqrrpt.hh:347-367): rank-deficient input -> all n columns of A come back orthonormal, the
+    first `rank` of them spanning range(A[:, J])."""
+    d = _d()
+    rng = np.random.default_rng(15)
+    m, n, r0 = 3000, 80, 50
+    A = poly_mat(m, n, r0, rng, cond=1e3)
+    Ad = d.cm_from_numpy(A)
+    r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, key=(2, 0), qrcp=16 + 2)
+    k = r["rank"]
+    assert r["rc"] == 0 and abs(k - r0) <= 5
+    Q = d.cm_to_numpy(Ad)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= EPS**0.75 * np.sqrt(n) * 10
+    J = r["J"].cpu().numpy()
+    AP = A[:, J - 1]
+    assert np.linalg.norm(AP - Q[:, :k] @ (Q[:, :k].T @ AP)) <= 1e-9 * np.linalg.norm(A)     # the leading columns carry the range
