@@ -1,6 +1,7 @@
 // RandLAPACK::util helpers that steer control flow on the path (reference: RandLAPACK/misc/rl_util.hh),
 // operating on device buffers.
 #pragma once
+#include <stdexcept>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -52,6 +53,13 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
 /// util::eye (misc/rl_util.hh:60-70): A (m x n, ld m, DEVICE) <- identity pattern
 template <typename T>
 void eye(int64_t m, int64_t n, T* A, blas::Queue& q) { lapack::laset(MatrixType::General, m, n, (T)0, (T)1, A, m, q); }
+
+/// util::diag (misc/rl_util.hh:84-96): overwrite the first k diagonal entries of S (m x n, ld m, DEVICE) with s (k, DEVICE)
+template <typename T>
+void diag(int64_t m, int64_t n, const T* s_vec, int64_t k, T* S, blas::Queue& q) {
+    if (k > std::min(m, n)) throw std::runtime_error("Invalid rank parameter.");
+    if (k > 0) lapack::lacpy(MatrixType::General, 1, k, s_vec, 1, S, m + 1, q);     // a 1 x k matrix with ld 1 -> stride m + 1
+}
 
 /// util::get_L (misc/rl_util.hh:102-115): zero the strictly upper triangle of A (m x n, ld m), optionally set the diagonal to one
 template <typename T>

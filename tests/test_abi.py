@@ -71,6 +71,7 @@ using RNG = r123::Philox4x32;
                                              RandBLAS::RNGState<RNG>&, blas::Queue&, T*); \\
   template int RandLAPACK::ABRIK<T, RNG>::call(RandLAPACK::linops::DenseLinOp<T>&, int64_t, T*&, T*&, T*&, RandBLAS::RNGState<RNG>&); \\
   template void RandLAPACK::util::eye<T>(int64_t, int64_t, T*, blas::Queue&); \\
+  template void RandLAPACK::util::diag<T>(int64_t, int64_t, const T*, int64_t, T*, blas::Queue&); \\
   template void RandLAPACK::util::get_L<T>(int64_t, int64_t, T*, int, blas::Queue&); \\
   template void RandLAPACK::util::get_U<T>(int64_t, int64_t, T*, int64_t, blas::Queue&); \\
   template bool RandLAPACK::util::diag_is_nonzero<T>(int64_t, const T*, int64_t, blas::Queue&);
