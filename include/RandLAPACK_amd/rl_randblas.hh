@@ -68,6 +68,30 @@ RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows
     return next;
 }
 
+// Dense sketching operator (RandBLAS::DenseSkOp as used at drivers/rl_cqrrt_linops.hh:196-200): owns its n_rows x n_cols
+// column-major DEVICE buffer once fill_dense(S) has run.
+template <typename T, typename RNG = DefaultRNG>
+struct DenseSkOp {
+    DenseDist dist;
+    RNGState<RNG> seed_state, next_state;
+    T* buff = nullptr;
+    blas::Queue& q;
+    DenseSkOp(DenseDist const& D, RNGState<RNG> const& st, blas::Queue& queue) : dist(D), seed_state(st), next_state(st), q(queue) {
+        // the state a fill advances to depends on (dist, seed) only: compute it without touching memory
+        blas::check(rlhip_fill_dense_rows_f64(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, 0, 0, nullptr, 1,
+                                              st.counter.data(), st.key.data(), next_state.counter.data()), "DenseSkOp");
+    }
+    DenseSkOp(DenseSkOp const&) = delete;
+    DenseSkOp& operator=(DenseSkOp const&) = delete;
+    ~DenseSkOp() { if (buff) blas::device_free(buff, q); }
+};
+template <typename T, typename RNG>
+void fill_dense(DenseSkOp<T, RNG>& S) {
+    if (S.buff) return;
+    S.buff = blas::device_malloc<T>(S.dist.n_rows * S.dist.n_cols, S.q);
+    fill_dense(S.dist, S.buff, S.seed_state, S.q);
+}
+
 // ---- sparse sketching operator (short-axis-sparse), cf. RandBLAS::SparseDist / SparseSkOp / sketch_general as used at
 //      drivers/rl_cqrrpt.hh:214-222.  n_rows = d (sketch dimension), n_cols = m, vec_nnz nonzeros per column.
 struct SparseDist {

@@ -108,7 +108,8 @@ int rlhip_trsm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, 
                    double alpha, const double* A, int64_t lda, double* B, int64_t ldb);
 int rlhip_trsm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
                    float alpha, const float* A, int64_t lda, float* B, int64_t ldb);
-/* B <- alpha * B * A, A n x n upper triangular, B m x n (side 'R', uplo 'U', trans 'N' only) */
+/* side 'R': B <- alpha * B * A, A n x n upper triangular, B m x n (trans 'N' only);
+ * side 'L': B <- alpha * op(A) * B, A m x m upper triangular (trans 'N' or 'T').  uplo 'U' only. */
 int rlhip_trmm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
                    double alpha, const double* A, int64_t lda, double* B, int64_t ldb);
 int rlhip_trmm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
@@ -244,6 +245,24 @@ int rlhip_tau_from_t_f32(rlhip_ctx* ctx, int64_t k, int64_t nb, const float* T, 
  * reference's CUDA all_of only honours its first block) */
 int rlhip_any_abs_gt_f64(rlhip_ctx* ctx, int64_t n, const double* x, double thr, int* any_host);
 int rlhip_any_abs_gt_f32(rlhip_ctx* ctx, int64_t n, const float* x, float thr, int* any_host);
+
+/* ---- sparse linear operator kernels (linops::SparseLinOp; reference RandLAPACK/linops/rl_sparse_linop.hh:125-330 forwards to
+ *      RandBLAS left_spmm/right_spmm).  CSR with int64 indices, all arrays DEVICE pointers.
+ *      csr_spmm: C (m x n) = alpha * A (m x k, CSR) * B (k x n) + beta * C; layout 'C' (column-major B, C) or 'R' (row-major).
+ *      csr_transpose: CSR of A^T (construction time; staged through the host, deterministic entry order).
+ *      csr_densify_cols: out (m x b, column-major) = A[:, c0 : c0 + b], read from the CSR of A^T. ---- */
+int rlhip_csr_spmm_f64(rlhip_ctx* ctx, char layout, int64_t m, int64_t n, int64_t k, double alpha, const int64_t* rowptr,
+                       const int64_t* colidx, const double* vals, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+int rlhip_csr_spmm_f32(rlhip_ctx* ctx, char layout, int64_t m, int64_t n, int64_t k, float alpha, const int64_t* rowptr,
+                       const int64_t* colidx, const float* vals, const float* B, int64_t ldb, float beta, float* C, int64_t ldc);
+int rlhip_csr_transpose_f64(rlhip_ctx* ctx, int64_t m, int64_t k, const int64_t* rowptr, const int64_t* colidx, const double* vals,
+                            int64_t* rowptrT, int64_t* colidxT, double* valsT);
+int rlhip_csr_transpose_f32(rlhip_ctx* ctx, int64_t m, int64_t k, const int64_t* rowptr, const int64_t* colidx, const float* vals,
+                            int64_t* rowptrT, int64_t* colidxT, float* valsT);
+int rlhip_csr_densify_cols_f64(rlhip_ctx* ctx, int64_t m, const int64_t* rowptrT, const int64_t* colidxT, const double* valsT,
+                               int64_t c0, int64_t b, double* out, int64_t ldo);
+int rlhip_csr_densify_cols_f32(rlhip_ctx* ctx, int64_t m, const int64_t* rowptrT, const int64_t* colidxT, const float* valsT,
+                               int64_t c0, int64_t b, float* out, int64_t ldo);
 
 /* ---- row-block sharding across the GPUs of a node (new design; the reference has no
  *      distributed code).  One process per GPU.  Sum all-reduces run on the context's stream through RCCL

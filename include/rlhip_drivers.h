@@ -92,6 +92,42 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
                         const float* A_sk_in, float* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
                         int apply_trans_q);
 
+/* ---- drivers over abstract linear operators (include/RandLAPACK_amd/rl_linops.hh, rl_qr_linops.hh).
+ * An operator is described by plain arrays: kind 0 = dense column-major (dense, ld); kind 1 = CSR with int64 indices
+ * (rowptr, colidx, vals; nnz entries).  All arrays are DEVICE pointers.  `right` == NULL: the operator is `left`;
+ * otherwise it is the implicit product left * right (linops::CompositeOperator, rl_composite_linop.hh:43). */
+typedef struct rlhip_linop_desc {
+    int kind;
+    int64_t rows, cols;
+    const void* dense;
+    int64_t ld;
+    int64_t nnz;
+    const int64_t* rowptr;
+    const int64_t* colidx;
+    const void* vals;
+} rlhip_linop_desc;
+
+/* alg: 0 CholQR_linops (rl_cholqr_linops.hh:60), 1 sCholQR3_linops (rl_scholqr3_linops.hh:182), 2 sCholQR3_linops_basic (:600),
+ *      3 CQRRT_linops (rl_cqrrt_linops.hh:144).  R (n x n, ldr) receives the upper-triangular factor.  block_size as the classes'
+ *      member.  Q_out != NULL turns test_mode on and receives a library-owned copy of Q (m x n; free with rlhip_free).
+ *      d_factor, nnz, use_dense_sketch, state, A_hat_in/out (d x n sketch injection / export): CQRRT_linops only.
+ *      Returns the class's return value (0 ok, >0 Cholesky breakdown index), negative on argument / device errors. */
+int rlhip_drv_qr_linops_f64(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const rlhip_linop_desc* right, double* R, int64_t ldr,
+                            int64_t block_size, double** Q_out, double d_factor, int64_t nnz, int use_dense_sketch, uint32_t state[6],
+                            const double* A_hat_in, double* A_hat_out);
+int rlhip_drv_qr_linops_f32(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const rlhip_linop_desc* right, float* R, int64_t ldr,
+                            int64_t block_size, float** Q_out, float d_factor, int64_t nnz, int use_dense_sketch, uint32_t state[6],
+                            const float* A_hat_in, float* A_hat_out);
+/* ABRIK<double>::call on an operator given by descriptor(s) (rl_abrik.hh:166; sparse / composite operators as in
+ * benchmark/bench_ABRIK/ABRIK_speed_comparisons_sparse.cc).  Outputs as rlhip_drv_abrik_f64. */
+int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right /* must be NULL */, int64_t k, double tol,
+                              int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
+                              int64_t* iters, double* norm_R_end, int qr_exp);
+/* C (m x n, ldc) = alpha * op(A) * B + beta * C for an operator given by descriptor(s): the raw operator call, for tests and for
+ * callers that only want the SpMM / composite product.  side 'L' or 'R', trans 'N' or 'T', column-major B and C. */
+int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,
+                          int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,3 +349,114 @@ def cqrrt(A, A_hat):
     R = np.zeros((n, n), order="F")
     rc = lib.oracle_cqrrt_f64(i64(m), i64(n), _p(A), i64(m), _p(R), i64(n), i64(d), _p(A_hat))
     return dict(rc=rc, Q=A, R=np.triu(R))
+
+
+# ---- linop QR drivers (numpy restatement; the operator is a dense ndarray, a scipy.sparse matrix, or a (left, right) tuple for the
+#      implicit product -- reference: RandLAPACK/linops/rl_composite_linop.hh:168-230) -------------------------------------------------
+def _op_shape(A):
+    if isinstance(A, tuple):
+        return A[0].shape[0], A[1].shape[1]
+    return A.shape
+
+
+def _op_mul(A, X, trans=False):
+    """op(A) @ X through the operator interface (Side::Left)"""
+    if isinstance(A, tuple):
+        L, Rr = A
+        return _op_mul(Rr, _op_mul(L, X, True), True) if trans else _op_mul(L, _op_mul(Rr, X))
+    return np.asarray((A.T if trans else A) @ X)
+
+
+def _gram_through_operator(A, M, b_eff, post=None):
+    """G[:, blk] = A^T (A M[:, blk])  (post: G[:, blk] = post^T that) -- the column-block loop of rl_cholqr_linops.hh:108-150,
+    rl_cqrrt_linops.hh:264-318, rl_scholqr3_linops.hh:224-236 / 296-312"""
+    n = M.shape[0]
+    G = np.zeros((n, n))
+    for j in range(0, n, b_eff):
+        bj = min(b_eff, n - j)
+        Z = _op_mul(A, _op_mul(A, M[:, j:j + bj]), True)
+        G[:, j:j + bj] = post.T @ Z if post is not None else Z
+    return G
+
+
+def _chol_upper(G):
+    """laset(Lower, 0) + potrf(Upper): returns (info != 0, R)"""
+    import scipy.linalg as sla
+    try:
+        return False, sla.cholesky(np.triu(G) + np.triu(G, 1).T, lower=False)
+    except np.linalg.LinAlgError:
+        return True, None
+
+
+def _b_eff(block_size, n):
+    return block_size if 0 < block_size < n else n
+
+
+def cholqr_linops(A, block_size=0, test_mode=True):
+    """CholQR_linops::call (drivers/rl_cholqr_linops.hh:60-322).  returns dict(rc, R[, Q])"""
+    import scipy.linalg as sla
+    m, n = _op_shape(A)
+    G = _gram_through_operator(A, np.eye(n), _b_eff(block_size, n))
+    fail, R = _chol_upper(G)
+    if fail:
+        return dict(rc=1, R=None, Q=None)
+    out = dict(rc=0, R=R)
+    if test_mode:
+        out["Q"] = sla.solve_triangular(R, _op_mul(A, np.eye(n)).T, trans="T", lower=False).T      # Q = (A I) R^-1
+    return out
+
+
+def scholqr3_linops(A, block_size=0, test_mode=True, basic=False):
+    """sCholQR3_linops::call (drivers/rl_scholqr3_linops.hh:182-520) and, basic=True, sCholQR3_linops_basic::call (:600-786).
+    returns dict(rc, R, G1, G2, G3[, Q])"""
+    import scipy.linalg as sla
+    m, n = _op_shape(A)
+    b_eff = n if basic else _b_eff(block_size, n)
+    eps = np.finfo(np.float64).eps
+    rsolve = lambda X, U: sla.solve_triangular(U, X.T, trans="T", lower=False).T                    # X U^-1
+    M = np.eye(n)
+    G = _gram_through_operator(A, M, b_eff)
+    G = G + 11 * eps * n * np.trace(G) * np.eye(n)                                                   # :243-251
+    fail, G1 = _chol_upper(G)
+    if fail:
+        return dict(rc=1)
+    R = G1.copy()
+    M = rsolve(M, G1)
+    facs = [G1]
+    Q = _op_mul(A, M) if basic else None
+    for it in (2, 3):
+        G = (Q.T @ Q) if basic else _gram_through_operator(A, M, b_eff, post=M)
+        fail, Gi = _chol_upper(G)
+        if fail:
+            return dict(rc=it)
+        facs.append(Gi)
+        R = np.triu(Gi @ R)
+        if it == 2 or test_mode:
+            if basic:
+                Q = rsolve(Q, Gi)
+            else:
+                M = rsolve(M, Gi)
+    out = dict(rc=0, R=R, G1=facs[0], G2=facs[1], G3=facs[2])
+    if test_mode:
+        out["Q"] = Q if basic else _op_mul(A, M)
+    return out
+
+
+def cqrrt_linops(A, A_hat, block_size=0, test_mode=True):
+    """CQRRT_linops::call (drivers/rl_cqrrt_linops.hh:144-449) with the sketch A_hat = S*A (d x n) given.  returns dict(rc, R[, Q])"""
+    import scipy.linalg as sla
+    m, n = _op_shape(A)
+    R_sk = np.linalg.qr(np.asarray(A_hat, dtype=np.float64), mode="r")                               # geqrf, :217
+    if np.any(np.diag(R_sk) == 0):
+        return dict(rc=1)
+    R_sk_inv = np.triu(sla.solve_triangular(R_sk, np.eye(n), trans="T", lower=False).T)              # I R_sk^-1, :237-241
+    G = _gram_through_operator(A, R_sk_inv, _b_eff(block_size, n))
+    G = R_sk_inv.T @ G                                                                               # trmm, :322
+    fail, R_chol = _chol_upper(G)
+    if fail:
+        return dict(rc=1)
+    out = dict(rc=0, R=np.triu(R_chol @ R_sk))                                                       # :386
+    if test_mode:
+        A_pre = _op_mul(A, R_sk_inv)
+        out["Q"] = sla.solve_triangular(R_chol, A_pre.T, trans="T", lower=False).T
+    return out

@@ -51,6 +51,9 @@ def _blas3(T):
         "ungqr": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "laswp": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
         "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "csr_spmm": [c_vp, c_char, c_i64, c_i64, c_i64, T, c_vp, c_vp, c_vp, c_vp, c_i64, T, c_vp, c_i64],
+        "csr_transpose": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+        "csr_densify_cols": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64],
         "add_diag": [c_vp, c_i64, T, c_vp, c_i64],
         "gesdd": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_int)],
         "transpose": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_int],
@@ -123,7 +126,22 @@ SIGNATURES.update({
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })
-for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp"):      # fp32 instantiations: same shapes, float scalars
+
+
+class LinOpDesc(C.Structure):
+    """rlhip_linop_desc (include/rlhip_drivers.h)"""
+    _fields_ = [("kind", c_int), ("rows", c_i64), ("cols", c_i64), ("dense", c_vp), ("ld", c_i64), ("nnz", c_i64),
+                ("rowptr", c_vp), ("colidx", c_vp), ("vals", c_vp)]
+
+
+_ldp = C.POINTER(LinOpDesc)
+SIGNATURES.update({
+    "rlhip_drv_qr_linops_f64": (c_int, [c_vp, c_int, _ldp, _ldp, c_vp, c_i64, c_i64, dpp, c_dbl, c_i64, c_int, u32p, c_vp, c_vp]),
+    "rlhip_drv_abrik_linop_f64": (c_int, [c_vp, _ldp, _ldp, c_i64, c_dbl, c_i64, dpp, dpp, dpp, u32p, C.POINTER(c_i64),
+                                          C.POINTER(c_i64), C.POINTER(c_dbl), c_int]),
+    "rlhip_linop_apply_f64": (c_int, [c_vp, _ldp, _ldp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
+})
+for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp", "qr_linops"):      # fp32 instantiations: same shapes, float scalars
     _rt, _args = SIGNATURES[f"rlhip_drv_{_name}_f64"]
     SIGNATURES[f"rlhip_drv_{_name}_f32"] = (_rt, [c_flt if a is c_dbl else a for a in _args])
 for _suf, _T in (("f64", c_dbl), ("f32", c_flt)):

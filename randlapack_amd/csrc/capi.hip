@@ -333,10 +333,12 @@ static inline int op_flag(char t, int* out) {
     }                                                                                                           \
     int rlhip_trmm_##SUF(rlhip_ctx* c, char side, char uplo, char trans, char diag, int64_t m, int64_t n,       \
                          T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {                                 \
-        if (side != 'R' && side != 'r') return -2;                                                              \
         if (uplo != 'U' && uplo != 'u') return -3;                                                              \
-        if (trans != 'N' && trans != 'n') return -4;                                                            \
         int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
+        if (side == 'L' || side == 'l')                                                                         \
+            return rlhip::trmm_left_upper<T>(c, (trans != 'N' && trans != 'n') ? 1 : 0, fd, m, n, alpha, A, lda, B, ldb); \
+        if (side != 'R' && side != 'r') return -2;                                                              \
+        if (trans != 'N' && trans != 'n') return -4;                                                            \
         return rlhip::trmm_right_upper<T>(c, fd, m, n, alpha, A, lda, B, ldb);                                   \
     }                                                                                                           \
     int rlhip_potrf_##SUF(rlhip_ctx* c, char uplo, int64_t n, T* A, int64_t lda) {                              \

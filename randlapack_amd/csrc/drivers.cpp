@@ -3,6 +3,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <climits>
 #include "../../include/RandLAPACK_amd.hh"
 #include "../../include/rlhip_drivers.h"
 
@@ -46,6 +47,106 @@ int guarded(F&& f) {
         g_last_error = e.what();
         return -101;
     }
+}
+
+
+// ---- operators from descriptors: run `f` on the concrete operator type the descriptor(s) name
+namespace lo = RandLAPACK::linops;
+template <typename T>
+std::unique_ptr<lo::DenseLinOp<T>> make_dense(blas::Queue& q, const rlhip_linop_desc& d) {
+    auto op = std::make_unique<lo::DenseLinOp<T>>(d.rows, d.cols, (const T*)d.dense, d.ld, RandLAPACK::Layout::ColMajor, q);
+    op->row_sharded = q.world() > 1;
+    return op;
+}
+template <typename T>
+std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_linop_desc& d) {
+    return std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
+}
+template <typename T, typename F>
+int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_linop_desc* right, F&& f) {
+    if (!left) throw RandLAPACK::Error("operator descriptor is null");
+    auto kind_ok = [](const rlhip_linop_desc* d) { return d->kind == 0 || d->kind == 1; };
+    if (!kind_ok(left) || (right && !kind_ok(right))) throw RandLAPACK::Error("operator kind must be 0 (dense) or 1 (CSR)");
+    if (!right) {
+        if (left->kind == 0) { auto A = make_dense<T>(q, *left); return f(*A); }
+        auto A = make_sparse<T>(q, *left);
+        return f(*A);
+    }
+    const int64_t m = left->rows, n = right->cols;
+    if (left->kind == 0 && right->kind == 0) {
+        auto L = make_dense<T>(q, *left); auto Rr = make_dense<T>(q, *right); Rr->row_sharded = false;
+        lo::CompositeOperator<lo::DenseLinOp<T>, lo::DenseLinOp<T>> A(m, n, *L, *Rr);
+        return f(A);
+    }
+    if (left->kind == 0 && right->kind == 1) {
+        auto L = make_dense<T>(q, *left); auto Rr = make_sparse<T>(q, *right);
+        lo::CompositeOperator<lo::DenseLinOp<T>, lo::SparseLinOp<T>> A(m, n, *L, *Rr);
+        return f(A);
+    }
+    if (left->kind == 1 && right->kind == 0) {
+        auto L = make_sparse<T>(q, *left); auto Rr = make_dense<T>(q, *right); Rr->row_sharded = false;
+        lo::CompositeOperator<lo::SparseLinOp<T>, lo::DenseLinOp<T>> A(m, n, *L, *Rr);
+        return f(A);
+    }
+    auto L = make_sparse<T>(q, *left); auto Rr = make_sparse<T>(q, *right);
+    lo::CompositeOperator<lo::SparseLinOp<T>, lo::SparseLinOp<T>> A(m, n, *L, *Rr);
+    return f(A);
+}
+
+template <typename T>
+void export_q(blas::Queue& q, const T* Q, int64_t rows, int64_t cols, T** Q_out) {
+    *Q_out = nullptr;
+    if (!Q) return;
+    *Q_out = blas::device_malloc<T>(rows * cols, q);
+    blas::device_copy_vector(rows * cols, Q, *Q_out, q);
+}
+
+template <typename T>
+int drv_qr_linops(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const rlhip_linop_desc* right, T* R, int64_t ldr, int64_t block_size,
+                  T** Q_out, T d_factor, int64_t nnz, int use_dense_sketch, uint32_t state[6], const T* A_hat_in, T* A_hat_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        const bool tm = Q_out != nullptr;
+        const T eps = std::pow(std::numeric_limits<T>::epsilon(), (T)0.75);
+        return with_operator<T>(q, left, right, [&](auto& A) -> int {
+            switch (alg) {
+                case 0: {
+                    RandLAPACK::CholQR_linops<T> a(false, eps, tm);
+                    a.block_size = block_size;
+                    int rc = a.call(A, R, ldr);
+                    if (tm) export_q(q, a.Q, a.Q_rows, a.Q_cols, Q_out);
+                    return rc;
+                }
+                case 1: {
+                    RandLAPACK::sCholQR3_linops<T> a(false, eps, tm);
+                    a.block_size = block_size;
+                    int rc = a.call(A, R, ldr);
+                    if (tm) export_q(q, a.Q, a.Q_rows, a.Q_cols, Q_out);
+                    return rc;
+                }
+                case 2: {
+                    RandLAPACK::sCholQR3_linops_basic<T> a(false, eps, tm);
+                    int rc = a.call(A, R, ldr);
+                    if (tm) export_q(q, a.Q, a.Q_rows, a.Q_cols, Q_out);
+                    return rc;
+                }
+                case 3: {
+                    RandLAPACK::CQRRT_linops<T, RNG> a(false, eps, tm);
+                    a.block_size = block_size;
+                    if (nnz > 0) a.nnz = nnz;
+                    a.use_dense_sketch = use_dense_sketch != 0;
+                    a.sketch_override = A_hat_in;
+                    a.sketch_export = A_hat_out;
+                    State st = load_state(state);
+                    int rc = a.call(A, R, ldr, d_factor, st);
+                    store_state(st, state);
+                    if (tm) export_q(q, a.Q, a.Q_rows, a.Q_cols, Q_out);
+                    return rc;
+                }
+                default: throw RandLAPACK::Error("alg must be 0 (CholQR), 1 (sCholQR3), 2 (sCholQR3 basic) or 3 (CQRRT)");
+            }
+        });
+    });
 }
 
 }  // namespace
@@ -327,6 +428,60 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
         if (times_us && alg.times.size() == 9)
             for (int i = 0; i < 9; ++i) times_us[i] = alg.times[i];
         return rc;
+    });
+}
+
+
+int rlhip_drv_qr_linops_f64(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const rlhip_linop_desc* right, double* R, int64_t ldr,
+                            int64_t block_size, double** Q_out, double d_factor, int64_t nnz, int use_dense_sketch, uint32_t state[6],
+                            const double* A_hat_in, double* A_hat_out) {
+    return drv_qr_linops<double>(ctx, alg, left, right, R, ldr, block_size, Q_out, d_factor, nnz, use_dense_sketch, state, A_hat_in, A_hat_out);
+}
+int rlhip_drv_qr_linops_f32(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const rlhip_linop_desc* right, float* R, int64_t ldr,
+                            int64_t block_size, float** Q_out, float d_factor, int64_t nnz, int use_dense_sketch, uint32_t state[6],
+                            const float* A_hat_in, float* A_hat_out) {
+    return drv_qr_linops<float>(ctx, alg, left, right, R, ldr, block_size, Q_out, d_factor, nnz, use_dense_sketch, state, A_hat_in, A_hat_out);
+}
+
+int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int64_t k, double tol,
+                              int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
+                              int64_t* iters, double* norm_R_end, int qr_exp) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if (right) throw RandLAPACK::Error("ABRIK needs fro_nrm(): single dense / sparse operators only (composites have none, as in the reference)");
+        if (!left || (left->kind != 0 && left->kind != 1)) throw RandLAPACK::Error("operator kind must be 0 (dense) or 1 (CSR)");
+        auto run = [&](auto& A) -> int {
+            RandLAPACK::ABRIK<double, RNG> alg(q, false, false, tol);
+            if (qr_exp >= 0) {
+                if (qr_exp > 1) throw RandLAPACK::Error("qr_exp must be 0 (geqrf_ungqr) or 1 (cqrrt)");
+                alg.qr_exp = (RandLAPACK::ABRIKSubroutines::QR_explicit)qr_exp;
+            }
+            if (max_krylov_iters > 0) alg.max_krylov_iters = (int)std::min<int64_t>(max_krylov_iters, INT_MAX);
+            State st = load_state(state);
+            *U = nullptr; *Sigma = nullptr; *V = nullptr;
+            int rc = alg.call(A, k, *U, *V, *Sigma, st);
+            store_state(st, state);
+            if (triplets) *triplets = alg.singular_triplets_found;
+            if (iters) *iters = alg.num_krylov_iters;
+            if (norm_R_end) *norm_R_end = alg.norm_R_end;
+            return rc;
+        };
+        if (left->kind == 0) { auto A = make_dense<double>(q, *left); return run(*A); }
+        auto A = make_sparse<double>(q, *left);
+        return run(*A);
+    });
+}
+
+int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,
+                          int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if ((side != 'L' && side != 'R') || (trans != 'N' && trans != 'T')) throw RandLAPACK::Error("side must be L or R, trans N or T");
+        return with_operator<double>(q, left, right, [&](auto& A) -> int {
+            A(side == 'L' ? RandLAPACK::Side::Left : RandLAPACK::Side::Right, RandLAPACK::Layout::ColMajor,
+              trans == 'N' ? RandLAPACK::Op::NoTrans : RandLAPACK::Op::Trans, RandLAPACK::Op::NoTrans, m, n, k, alpha, B, ldb, beta, C, ldc);
+            return 0;
+        });
     });
 }
 

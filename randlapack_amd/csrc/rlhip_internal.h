@@ -91,6 +91,9 @@ int trmm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
                      T* B, int64_t ldb);
 
 template <typename T>
+int trmm_left_upper(rlhip_ctx* c, int trans, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B, int64_t ldb);
+
+template <typename T>
 int fill_dense(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, T* buf, const uint32_t ctr[4],
                const uint32_t key[2], uint32_t next_ctr[4]);
 

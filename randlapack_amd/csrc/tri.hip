@@ -197,6 +197,29 @@ int trmm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     return rc;
 }
 
+// B <- alpha * op(A) * B, A m x m upper triangular (Side::Left, Uplo::Upper), B m x n: the small n x n products of the
+// linop QR drivers (rl_cqrrt_linops.hh:322, rl_scholqr3_linops.hh:352).  Same masked-copy + MFMA GEMM as the right-side form.
+template <typename T>
+int trmm_left_upper(rlhip_ctx* c, int trans, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {
+    if (m < 0) return -6;
+    if (n < 0) return -7;
+    if (lda < (m > 1 ? m : 1)) return -10;
+    if (ldb < (m > 1 ? m : 1)) return -12;
+    if (m == 0 || n == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* W = ws_alloc<T>(c, (size_t)m * m);
+    T* Bc = ws_alloc<T>(c, (size_t)m * n);
+    if (!W || !Bc) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipLaunchKernelGGL(copy_triu_kernel<T>, dim3((unsigned)((m * m + 255) / 256)), dim3(256), 0, c->stream, m, diag, A, lda, W);
+    RLHIP_LAUNCH_CHECK();
+    int rc = lacpy<T>(c, 2, m, n, B, ldb, Bc, m);
+    if (!rc) rc = gemm_impl<T>(c, trans ? 1 : 0, 0, m, n, m, alpha, W, m, Bc, m, T(0), B, ldb, 0);
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+template int trmm_left_upper<double>(rlhip_ctx*, int, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
+template int trmm_left_upper<float>(rlhip_ctx*, int, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
+
 template int trsm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trsm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
 template int trmm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);

@@ -304,6 +304,105 @@ def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0
                 next_ctr=tuple(int(x) for x in st[:4]))
 
 
+class DenseOperator:
+    """linops::DenseLinOp over a column-major device tensor (n, m) (rows m, cols n)."""
+
+    def __init__(self, A, m, n):
+        self.A, self.rows, self.cols = A, m, n
+        self.dtype = A.dtype
+
+    def desc(self):
+        from ._lib import LinOpDesc
+        return LinOpDesc(0, self.rows, self.cols, self.A.data_ptr(), self.rows, 0, None, None, None)
+
+
+class CsrOperator:
+    """linops::SparseLinOp over device CSR arrays (int64 rowptr / colidx).  Build from scipy with `from_scipy`."""
+
+    def __init__(self, rows, cols, rowptr, colidx, vals):
+        self.rows, self.cols = rows, cols
+        self.rowptr, self.colidx, self.vals = rowptr, colidx, vals
+        self.dtype = vals.dtype
+
+    @classmethod
+    def from_scipy(cls, sp, device="cuda:0", dtype=None):
+        torch = _torch()
+        csr = sp.tocsr()
+        dt = dtype or torch.float64
+        return cls(csr.shape[0], csr.shape[1], torch.as_tensor(csr.indptr.astype(np.int64), device=device),
+                   torch.as_tensor(csr.indices.astype(np.int64), device=device),
+                   torch.as_tensor(csr.data, device=device).to(dt))
+
+    def desc(self):
+        from ._lib import LinOpDesc
+        return LinOpDesc(1, self.rows, self.cols, None, 0, int(self.vals.numel()), self.rowptr.data_ptr(), self.colidx.data_ptr(),
+                         self.vals.data_ptr())
+
+
+def _op_descs(op):
+    """op: DenseOperator | CsrOperator | (left, right) -> (left desc, right desc or None, rows, cols, dtype)"""
+    if isinstance(op, tuple):
+        left, right = op
+        return left.desc(), right.desc(), left.rows, right.cols, left.dtype
+    return op.desc(), None, op.rows, op.cols, op.dtype
+
+
+QR_LINOPS_ALGS = {"cholqr": 0, "scholqr3": 1, "scholqr3_basic": 2, "cqrrt": 3}
+
+
+def drv_qr_linops(ctx: Context, alg, op, block_size=0, want_Q=False, d_factor=2.0, nnz=2, use_dense_sketch=False, ctr=(0, 0, 0, 0),
+                  key=(0, 0), sketch_in=None, want_sketch=False):
+    """CholQR_linops / sCholQR3_linops / sCholQR3_linops_basic / CQRRT_linops ::call on a dense, CSR or composite (tuple) operator.
+    Returns dict(rc, R[, Q][, sketch], next_ctr); R and Q are column-major tensors (n, n) / (n, m)."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    ld, rd, m, n, dtype = _op_descs(op)
+    suf = "f64" if dtype == torch.float64 else "f32"
+    R = cm_zeros(n, n, dtype=dtype, device=dev)
+    d = int(d_factor * n)
+    sk_out = cm_empty(d, n, dtype=dtype, device=dev) if want_sketch else None
+    Qp = C.c_void_p()
+    st = _state_arr(ctr, key)
+    rc = getattr(ctx.lib, f"rlhip_drv_qr_linops_{suf}")(
+        ctx.h, QR_LINOPS_ALGS[alg] if isinstance(alg, str) else alg, C.byref(ld), C.byref(rd) if rd is not None else None, R.data_ptr(), n,
+        block_size, C.byref(Qp) if want_Q else None, d_factor, nnz, 1 if use_dense_sketch else 0, st,
+        sketch_in.data_ptr() if sketch_in is not None else None, sk_out.data_ptr() if sk_out is not None else None)
+    _drv_check(ctx, rc, "qr_linops")
+    out = dict(rc=rc, R=R, next_ctr=tuple(int(x) for x in st[:4]))
+    if want_Q:
+        out["Q"] = _adopt(ctx, Qp, m, n, dtype=dtype) if Qp.value else None
+    if want_sketch:
+        out["sketch"] = sk_out
+    return out
+
+
+def drv_abrik_linop(ctx: Context, op, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0), qr_exp=-1):
+    """ABRIK::call on a DenseOperator / CsrOperator.  Same outputs as drv_abrik."""
+    ld, rd, m, n, _ = _op_descs(op)
+    Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    trip, iters = C.c_int64(0), C.c_int64(0)
+    nre = C.c_double(0)
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_abrik_linop_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, k, tol, max_krylov_iters,
+                                           C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(trip), C.byref(iters), C.byref(nre), qr_exp)
+    _drv_check(ctx, rc, "abrik_linop")
+    t = int(trip.value)
+    return dict(rc=rc, U=_adopt(ctx, Up, m, t), S=_adopt(ctx, Sp, t, 1).reshape(-1), V=_adopt(ctx, Vp, n, t), triplets=t,
+                iters=int(iters.value), norm_R_end=float(nre.value), next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def linop_apply(ctx: Context, op, side, trans, B, m, n, k, alpha=1.0, beta=0.0, C_in=None):
+    """C (m x n) = alpha * op(A) * B + beta * C (side 'L') or alpha * B * op(A) + beta * C (side 'R'); column-major tensors."""
+    dev = f"cuda:{ctx.device}"
+    ld, rd, _, _, _ = _op_descs(op)
+    Cout = C_in if C_in is not None else cm_zeros(m, n, device=dev)
+    ldb = B.shape[1]
+    rc = ctx.lib.rlhip_linop_apply_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, side.encode(), trans.encode(), m, n, k,
+                                       alpha, B.data_ptr(), ldb, beta, Cout.data_ptr(), m)
+    _drv_check(ctx, rc, "linop_apply")
+    return Cout
+
+
 def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), want_G=False):
     """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G])."""
     torch = _torch()

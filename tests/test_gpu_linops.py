@@ -1,0 +1,250 @@
+"""-m gpu: linear operators (dense / CSR / composite), the SpMM kernels behind them, and the linop QR drivers
+(CholQR_linops, sCholQR3_linops[_basic], CQRRT_linops) against the numpy oracle.  The test matrix follows the reference's
+test/drivers/test_orth_linop.cc (dense, dense float, sparse, composite dense*sparse / sparse*dense, blocked), with its tolerance
+eps^0.75 on ||A - QR|| / ||A|| and ||Q^T Q - I|| / sqrt(n) (verify_qr, testing/rl_test_utils.hh)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+TOL = EPS**0.75
+
+
+def _d():
+    from randlapack_amd import device
+
+    return device
+
+
+def _sparse(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    return sp.random(m, n, density, random_state=rng, format="csr", data_rvs=rng.standard_normal)
+
+
+def _ops(kind, seed=0):
+    """-> (device operator, numpy oracle operator, dense ndarray)"""
+    d = _d()
+    rng = np.random.default_rng(seed)
+    if kind == "dense":
+        A = rng.standard_normal((300, 50))
+        return d.DenseOperator(d.cm_from_numpy(A), 300, 50), A, A
+    if kind == "sparse":
+        S = _sparse(400, 50, 0.2, seed)
+        return d.CsrOperator.from_scipy(S), S, S.toarray()
+    if kind == "dense*sparse":
+        L = rng.standard_normal((300, 60))
+        S = _sparse(60, 20, 0.3, seed)
+        return (d.DenseOperator(d.cm_from_numpy(L), 300, 60), d.CsrOperator.from_scipy(S)), (L, S), L @ S.toarray()
+    if kind == "sparse*dense":
+        S = _sparse(500, 70, 0.1, seed)
+        Rm = rng.standard_normal((70, 30))
+        return (d.CsrOperator.from_scipy(S), d.DenseOperator(d.cm_from_numpy(Rm), 70, 30)), (S, Rm), S.toarray() @ Rm
+    if kind == "sparse*sparse":
+        S1 = _sparse(500, 80, 0.1, seed)
+        S2 = _sparse(80, 25, 0.4, seed + 1)
+        return (d.CsrOperator.from_scipy(S1), d.CsrOperator.from_scipy(S2)), (S1, S2), S1.toarray() @ S2.toarray()
+    raise ValueError(kind)
+
+
+def _verify_qr(A, Q, R):
+    n = A.shape[1]
+    return np.linalg.norm(A - Q @ R) / np.linalg.norm(A), np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n)
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("nc", [1, 7, 63, 64, 65, 130, 257, 600])
+@pytest.mark.parametrize("layout", ["C", "R"])
+def test_csr_spmm_matches_scipy(ctx, nc, layout):
+    d = _d()
+    import torch
+
+    rng = np.random.default_rng(nc)
+    m, k = 777, 333
+    S = _sparse(m, k, 0.05, nc)
+    S = sp.vstack([S[:100], sp.csr_matrix((5, k)), S[105:]]).tocsr()      # a run of empty rows
+    op = d.CsrOperator.from_scipy(S)
+    B = rng.standard_normal((k, nc))
+    C0 = rng.standard_normal((m, nc))
+    for alpha, beta in ((1.0, 0.0), (-0.5, 2.0)):
+        if layout == "C":
+            Bd, Cd = d.cm_from_numpy(B), d.cm_from_numpy(C0)
+            ldb, ldc = k, m
+        else:
+            Bd, Cd = torch.as_tensor(B, device="cuda:0").contiguous(), torch.as_tensor(C0, device="cuda:0").contiguous()
+            ldb, ldc = nc, nc
+        rc = ctx.lib.rlhip_csr_spmm_f64(ctx.h, layout.encode(), m, nc, k, alpha, op.rowptr.data_ptr(), op.colidx.data_ptr(), op.vals.data_ptr(),
+                                        Bd.data_ptr(), ldb, beta, Cd.data_ptr(), ldc)
+        assert rc == 0
+        got = d.cm_to_numpy(Cd) if layout == "C" else Cd.cpu().numpy()
+        ref = alpha * (S @ B) + beta * C0
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
+
+
+def test_csr_transpose_and_densify(ctx):
+    d = _d()
+    import torch
+
+    m, k = 500, 123
+    S = _sparse(m, k, 0.07, 3)
+    op = d.CsrOperator.from_scipy(S)
+    nnz = S.nnz
+    rpt = torch.zeros(k + 1, dtype=torch.int64, device="cuda:0")
+    cit = torch.zeros(nnz, dtype=torch.int64, device="cuda:0")
+    vt = torch.zeros(nnz, dtype=torch.float64, device="cuda:0")
+    assert ctx.lib.rlhip_csr_transpose_f64(ctx.h, m, k, op.rowptr.data_ptr(), op.colidx.data_ptr(), op.vals.data_ptr(), rpt.data_ptr(),
+                                           cit.data_ptr(), vt.data_ptr()) == 0
+    St = sp.csr_matrix((vt.cpu().numpy(), cit.cpu().numpy(), rpt.cpu().numpy()), shape=(k, m))
+    assert (St != S.T.tocsr()).nnz == 0
+    ci = cit.cpu().numpy()
+    rp = rpt.cpu().numpy()
+    assert all(np.all(np.diff(ci[rp[j]:rp[j + 1]]) > 0) for j in range(k))       # deterministic order: ascending source row
+    out = d.cm_empty(m, 40, device="cuda:0")
+    assert ctx.lib.rlhip_csr_densify_cols_f64(ctx.h, m, rpt.data_ptr(), cit.data_ptr(), vt.data_ptr(), 17, 40, out.data_ptr(), m) == 0
+    np.testing.assert_array_equal(d.cm_to_numpy(out), S.toarray()[:, 17:57])
+    # out-of-range column index is an argument error, not a crash
+    bad = op.colidx.clone()
+    bad[0] = k
+    assert ctx.lib.rlhip_csr_transpose_f64(ctx.h, m, k, op.rowptr.data_ptr(), bad.data_ptr(), op.vals.data_ptr(), rpt.data_ptr(),
+                                           cit.data_ptr(), vt.data_ptr()) == -2
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse", "dense*sparse", "sparse*dense", "sparse*sparse"])
+def test_linop_apply_all_sides(ctx, kind):
+    d = _d()
+    rng = np.random.default_rng(5)
+    op, _, A = _ops(kind, 5)
+    m, n = A.shape
+    nb = 37
+    for side, trans in (("L", "N"), ("L", "T"), ("R", "N"), ("R", "T")):
+        opA = A if trans == "N" else A.T
+        if side == "L":
+            B = rng.standard_normal((opA.shape[1], nb))
+            ref = opA @ B
+            got = d.linop_apply(ctx, op, side, trans, d.cm_from_numpy(B), opA.shape[0], nb, opA.shape[1])
+        else:
+            B = rng.standard_normal((nb, opA.shape[0]))
+            ref = B @ opA
+            got = d.linop_apply(ctx, op, side, trans, d.cm_from_numpy(B), nb, opA.shape[1], opA.shape[0])
+        np.testing.assert_allclose(d.cm_to_numpy(got), ref, rtol=0, atol=1e-11 * np.abs(ref).max(), err_msg=f"{kind} {side} {trans}")
+
+
+def test_trmm_left_upper(ctx):
+    d = _d()
+    rng = np.random.default_rng(2)
+    n, k = 130, 77
+    U = rng.standard_normal((n, n))           # lower triangle is garbage the routine must ignore
+    B = rng.standard_normal((n, k))
+    for trans in ("N", "T"):
+        Bd = d.cm_from_numpy(B)
+        assert ctx.lib.rlhip_trmm_f64(ctx.h, b"L", b"U", trans.encode(), b"N", n, k, 1.5, d.cm_from_numpy(U).data_ptr(), n, Bd.data_ptr(), n) == 0
+        T = np.triu(U)
+        ref = 1.5 * ((T if trans == "N" else T.T) @ B)
+        np.testing.assert_allclose(d.cm_to_numpy(Bd), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ drivers
+KINDS = ["dense", "sparse", "dense*sparse", "sparse*dense"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("alg,block", [("cholqr", 0), ("cholqr", 10), ("scholqr3", 0), ("scholqr3", 10), ("scholqr3_basic", 0)])
+def test_cholqr_family_vs_oracle(ctx, orc, alg, kind, block):
+    d = _d()
+    op, op_np, A = _ops(kind, 11)
+    out = d.drv_qr_linops(ctx, alg, op, block_size=block, want_Q=True)
+    ref = {"cholqr": lambda: orc.cholqr_linops(op_np, block), "scholqr3": lambda: orc.scholqr3_linops(op_np, block),
+           "scholqr3_basic": lambda: orc.scholqr3_linops(op_np, basic=True)}[alg]()
+    assert out["rc"] == ref["rc"] == 0
+    R, Q = np.triu(d.cm_to_numpy(out["R"])), d.cm_to_numpy(out["Q"])
+    fact, orth = _verify_qr(A, Q, R)
+    assert fact <= TOL and orth <= TOL
+    # the Cholesky factor is unique: entrywise agreement with the oracle up to cond^2 * eps
+    np.testing.assert_allclose(R, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())
+    np.testing.assert_allclose(Q, ref["Q"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", KINDS + ["sparse*sparse"])
+@pytest.mark.parametrize("block,dense_sketch", [(0, False), (7, False), (0, True)])
+def test_cqrrt_linops_vs_oracle_shared_sketch(ctx, orc, kind, block, dense_sketch):
+    d = _d()
+    op, op_np, A = _ops(kind, 21)
+    m, n = A.shape
+    out = d.drv_qr_linops(ctx, "cqrrt", op, block_size=block, want_Q=True, d_factor=2.0, use_dense_sketch=dense_sketch, key=(1, 0),
+                          want_sketch=True)
+    A_hat = d.cm_to_numpy(out["sketch"])
+    assert A_hat.shape == (2 * n, n)
+    ref = orc.cqrrt_linops(op_np, A_hat, block)
+    assert out["rc"] == ref["rc"] == 0
+    R, Q = np.triu(d.cm_to_numpy(out["R"])), d.cm_to_numpy(out["Q"])
+    fact, orth = _verify_qr(A, Q, R)
+    assert fact <= TOL and orth <= TOL
+    np.testing.assert_allclose(R, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())
+    np.testing.assert_allclose(Q, ref["Q"], rtol=0, atol=1e-9)
+    # the sketch of an operator equals the sketch of the matrix it represents, and the state advances as in CQRRT (same SkOp)
+    if not dense_sketch:
+        o2 = d.drv_cqrrt(ctx, d.cm_from_numpy(A), m, n, d_factor=2.0, nnz=2, key=(1, 0), want_sketch=True)
+        np.testing.assert_allclose(A_hat, d.cm_to_numpy(o2["sketch"]), rtol=0, atol=1e-12 * np.abs(A_hat).max())
+        assert out["next_ctr"] == o2["next_ctr"]
+    else:
+        S = orc.fill_dense(2 * n, m, key=(1, 0))
+        S = S[0] if isinstance(S, tuple) else S
+        np.testing.assert_allclose(A_hat, S @ A, rtol=0, atol=1e-11 * np.abs(A_hat).max())
+
+
+def test_qr_linops_f32_and_q_less(ctx, orc):
+    d = _d()
+    import torch
+
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((100, 50)).astype(np.float32)
+    op = d.DenseOperator(d.cm_from_numpy(A), 100, 50)
+    tol32 = float(np.finfo(np.float32).eps) ** 0.75
+    for alg in ("cholqr", "scholqr3", "scholqr3_basic", "cqrrt"):
+        out = d.drv_qr_linops(ctx, alg, op, want_Q=True, d_factor=2.0, key=(1, 0))
+        assert out["rc"] == 0 and out["R"].dtype == torch.float32
+        fact, orth = _verify_qr(A.astype(np.float64), d.cm_to_numpy(out["Q"]).astype(np.float64), np.triu(d.cm_to_numpy(out["R"])).astype(np.float64))
+        assert fact <= tol32 and orth <= tol32, (alg, fact, orth)
+        # Q-less call (the default mode of the classes): same R, no Q
+        out2 = d.drv_qr_linops(ctx, alg, op, want_Q=False, d_factor=2.0, key=(1, 0))
+        assert "Q" not in out2
+        np.testing.assert_allclose(d.cm_to_numpy(out2["R"]), d.cm_to_numpy(out["R"]), rtol=0, atol=1e-5 * np.abs(A).max() * 10)
+
+
+def test_qr_linops_failure_codes_and_bad_args(ctx, orc):
+    d = _d()
+    from randlapack_amd._lib import RlhipError
+
+    A = np.ones((60, 4))
+    A[:, 2] = 0                                           # an exactly zero pivot in the Gram matrix
+    op = d.DenseOperator(d.cm_from_numpy(A), 60, 4)
+    assert d.drv_qr_linops(ctx, "cholqr", op)["rc"] == 1 == orc.cholqr_linops(A)["rc"]
+    Z = np.zeros((60, 4))
+    opz = d.DenseOperator(d.cm_from_numpy(Z), 60, 4)
+    assert d.drv_qr_linops(ctx, "cqrrt", opz, d_factor=2.0)["rc"] == 1     # zero diagonal in the sketch's R (rl_cqrrt_linops.hh:231)
+    assert d.drv_qr_linops(ctx, "scholqr3", opz)["rc"] == 1
+    with pytest.raises(RlhipError):
+        d.drv_qr_linops(ctx, 9, op)
+    L = d.DenseOperator(d.cm_from_numpy(np.ones((10, 5))), 10, 5)
+    Rr = d.DenseOperator(d.cm_from_numpy(np.ones((6, 3))), 6, 3)
+    with pytest.raises(RlhipError, match="must match"):
+        d.drv_qr_linops(ctx, "cholqr", (L, Rr))
+
+
+def test_abrik_on_sparse_operator_matches_dense(ctx, orc):
+    d = _d()
+    S = (_sparse(600, 200, 0.05, 8) @ sp.diags(0.85 ** np.arange(200))).tocsr()     # still sparse, decaying spectrum
+    A = S.toarray()
+    k, iters = 8, 8
+    o_s = d.drv_abrik_linop(ctx, d.CsrOperator.from_scipy(S), k, 1e-12, max_krylov_iters=iters, key=(3, 0))
+    o_d = d.drv_abrik(ctx, d.cm_from_numpy(A), 600, 200, k, 1e-12, max_krylov_iters=iters, key=(3, 0))
+    assert o_s["triplets"] == o_d["triplets"] and o_s["iters"] == o_d["iters"]
+    np.testing.assert_allclose(o_s["S"].cpu().numpy(), o_d["S"].cpu().numpy(), rtol=1e-10)
+    sv = np.linalg.svd(A, compute_uv=False)
+    t = o_s["triplets"]
+    U, V, Sg = d.cm_to_numpy(o_s["U"]), d.cm_to_numpy(o_s["V"]), o_s["S"].cpu().numpy()
+    assert np.linalg.norm(U.T @ U - np.eye(t)) < 1e-10 and np.linalg.norm(V.T @ V - np.eye(t)) < 1e-10
+    # residual metric of the reference's ABRIK test (test_abrik.cc:60-96): sqrt(||AV - US||^2 + ||A^T U - VS||^2) / sigma_1 on the leading triplets
+    lead = 4
+    res = np.sqrt(np.linalg.norm(A @ V[:, :lead] - U[:, :lead] * Sg[:lead])**2 + np.linalg.norm(A.T @ U[:, :lead] - V[:, :lead] * Sg[:lead])**2)
+    assert res / sv[0] < 1e-3

@@ -286,3 +286,64 @@ def test_abrik_early_termination_on_exact_rank(orc):
     assert r["rc"] == 0 and r["iters"] <= 8
     sref = np.linalg.svd(A, compute_uv=False)
     assert abs(r["S"][0] - sref[0]) <= 0.05 * sref[0]
+
+
+# ---- linop QR drivers (test/drivers/test_orth_linop.cc: dense, sparse, composite, blocked; tolerance eps^0.75 via verify_qr)
+def _linop_cases():
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((100, 50))
+    S = sp.random(100, 50, 0.2, random_state=rng, format="csr", data_rvs=rng.standard_normal)
+    L = rng.standard_normal((100, 50))
+    Rs = sp.random(50, 20, 0.3, random_state=rng, format="csr", data_rvs=rng.standard_normal)
+    Sl = sp.random(100, 50, 0.2, random_state=rng, format="csr", data_rvs=rng.standard_normal)
+    Rd = rng.standard_normal((50, 20))
+    return [("dense", A, A), ("sparse", S, S.toarray()), ("dense*sparse", (L, Rs), L @ Rs.toarray()),
+            ("sparse*dense", (Sl, Rd), Sl.toarray() @ Rd)]
+
+
+@pytest.mark.parametrize("alg", ["cholqr", "scholqr3", "scholqr3_basic", "cqrrt"])
+@pytest.mark.parametrize("block", [0, 10])
+def test_qr_linops_oracle_properties(orc, alg, block):
+    tol = np.finfo(np.float64).eps ** 0.75
+    rng = np.random.default_rng(1)
+    for name, op, A in _linop_cases():
+        m, n = A.shape
+        if alg == "cholqr":
+            o = orc.cholqr_linops(op, block)
+        elif alg == "scholqr3":
+            o = orc.scholqr3_linops(op, block)
+        elif alg == "scholqr3_basic":
+            o = orc.scholqr3_linops(op, basic=True)
+        else:
+            Sk = rng.standard_normal((2 * n, m)) / np.sqrt(2 * n)
+            o = orc.cqrrt_linops(op, Sk @ A, block)
+        assert o["rc"] == 0, name
+        Q, R = o["Q"], o["R"]
+        assert np.allclose(R, np.triu(R))
+        assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) <= tol, name
+        assert np.linalg.norm(Q.T @ Q - np.eye(n)) / np.sqrt(n) <= tol, name
+        # blocking is a memory optimisation only: same R as the unblocked call
+        if block:
+            o0 = {"cholqr": lambda: orc.cholqr_linops(op, 0), "scholqr3": lambda: orc.scholqr3_linops(op, 0),
+                  "scholqr3_basic": lambda: orc.scholqr3_linops(op, basic=True), "cqrrt": lambda: orc.cqrrt_linops(op, Sk @ A, 0)}[alg]()
+            np.testing.assert_allclose(R, o0["R"], rtol=0, atol=1e-12 * np.abs(R).max())
+
+
+def test_qr_linops_oracle_failure_and_conditioning(orc):
+    Z = np.ones((30, 3)); Z[:, 1] = 0                 # an exactly zero pivot
+    assert orc.cholqr_linops(Z)["rc"] == 1
+    assert orc.cqrrt_linops(np.zeros((30, 3)), np.zeros((6, 3)))["rc"] == 1
+    # At cond 1e9 plain CholQR breaks down; CQRRT_linops and sCholQR3_linops still factor.  Their Q loses orthogonality like
+    # cond * eps (not cond^2 * eps): the operator cannot be overwritten, so the Gram matrix is formed as M^T (A^T (A M)) and the
+    # adjoint product sees the unpreconditioned A -- a property of the reference algorithm (rl_cqrrt_linops.hh:264-322).
+    rng = np.random.default_rng(3)
+    A = poly_mat(400, 40, 40, rng, cond=1e9)
+    Sk = rng.standard_normal((80, 400)) / np.sqrt(80)
+    o = orc.cqrrt_linops(A, Sk @ A)
+    assert o["rc"] == 0 and np.linalg.norm(o["Q"].T @ o["Q"] - np.eye(40)) < 1e-5
+    assert np.linalg.norm(A - o["Q"] @ o["R"]) / np.linalg.norm(A) < 1e-14
+    o3 = orc.scholqr3_linops(A)
+    assert o3["rc"] == 0 and np.linalg.norm(o3["Q"].T @ o3["Q"] - np.eye(40)) < 1e-5
+    assert orc.cholqr_linops(A)["rc"] == 1
