@@ -47,6 +47,14 @@ inline void csr_densify_cols(int64_t m, const int64_t* rpt, const int64_t* cit, 
                              blas::Queue& q) {
     blas::check(rlhip_csr_densify_cols_f32(q.ctx(), m, rpt, cit, vt, c0, b, out, ldo), "csr_densify_cols");
 }
+inline void saso_apply_csr(rlhip_saso* S, int64_t n, double alpha, const int64_t* rpt, const int64_t* cit, const double* vt, double beta, double* C,
+                           int64_t ldc, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_csr_f64(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc), "saso_apply_csr");
+}
+inline void saso_apply_csr(rlhip_saso* S, int64_t n, float alpha, const int64_t* rpt, const int64_t* cit, const float* vt, float beta, float* C,
+                           int64_t ldc, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_csr_f32(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc), "saso_apply_csr");
+}
 }  // namespace detail
 
 // ------------------------------------------------------------------------------------------------ dense
@@ -201,13 +209,18 @@ struct SparseLinOp {
     }
 
     /// sketching operands, Side::Right: C (d x n) = alpha * S * A + beta * C                                     (:292-330)
-    /// Sparse S: column blocks of A are expanded to dense (straight from the transpose's CSR, no atomics on shared entries) and
-    /// pushed through the SASO kernel -- deterministic, and one pass over m x n like the forward product the drivers do anyway.
+    /// Sparse S: a scatter over the nonzeros of A with fixed-point integer LDS atomics (bitwise reproducible, csrc/sketch.hip) --
+    /// nnz(S column) * nnz(A) updates instead of a pass over m x n.  Sketches too tall for LDS (d > 19200) fall back to expanding
+    /// column blocks of A to dense and pushing them through the dense SASO kernel.
     template <typename RNG>
     void operator()(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, T alpha, RandBLAS::SparseSkOp<T, RNG>& S,
                     T beta, T* C, int64_t ldc) {
         check_sketch_call(side, layout, trans_A, trans_S, d, n, m, S.dist.n_rows, S.dist.n_cols, ldc);
         if (n == 0 || d == 0) return;
+        if (d <= 19200 && !force_densified_sketch) {
+            detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, beta, C, ldc, q);
+            return;
+        }
         const int64_t b = std::max<int64_t>(1, std::min<int64_t>(n, densify_budget / std::max<int64_t>(m, 1)));
         blas::Scratch ws(q);
         T* blk = ws.alloc<T>(m * b);
@@ -226,7 +239,8 @@ struct SparseLinOp {
         detail::csr_spmm('R', n, d, m, alpha, rowptr_t, colidx_t, vals_t, S.buff, d, beta, C, ldc, q);
     }
 
-    int64_t densify_budget = (int64_t)1 << 27;   // elements of dense scratch the sparse-sketch path may use (1 GiB in fp64)
+    int64_t densify_budget = (int64_t)1 << 27;   // elements of dense scratch the densified sketch path may use (1 GiB in fp64)
+    bool force_densified_sketch = false;          // tests: take the fallback path regardless of d
 
 private:
     void check_sketch_call(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, int64_t s_rows, int64_t s_cols,

@@ -1,5 +1,6 @@
 // C entry points over the C++ driver/comp objects (include/rlhip_drivers.h).  Host-only C++: everything that
 // touches the GPU goes through the C ABI in rlhip.h.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -60,7 +61,9 @@ std::unique_ptr<lo::DenseLinOp<T>> make_dense(blas::Queue& q, const rlhip_linop_
 }
 template <typename T>
 std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_linop_desc& d) {
-    return std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
+    auto op = std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
+    if (const char* e = std::getenv("RLHIP_SPARSE_SKETCH_DENSIFY")) op->force_densified_sketch = (e[0] == '1');   // test knob: fallback path
+    return op;
 }
 template <typename T, typename F>
 int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_linop_desc* right, F&& f) {

@@ -51,7 +51,7 @@ struct SasoState { uint32_t ctr[4]; uint32_t key[2]; };
 
 // one thread per row block t: parameters a_t^{-1} and b_{t,i}
 __global__ void saso_params_kernel(int64_t d, int64_t T, int nnz, SasoState st, int64_t* __restrict__ ainv,
-                                   int64_t* __restrict__ b) {
+                                   int64_t* __restrict__ b, int64_t* __restrict__ afwd) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     uint32_t c[4], r[4];
@@ -61,6 +61,7 @@ __global__ void saso_params_kernel(int64_t d, int64_t T, int nnz, SasoState st, 
     int64_t a = 1 + (int64_t)(r[0] % (uint32_t)(d > 1 ? d - 1 : 1));
     while (gcd64(a, d) != 1) { a += 1; if (a >= d) a = 1; }
     ainv[t] = (d > 1) ? modinv(a, d) : 0;
+    afwd[t] = (d > 1) ? a : 0;
     // b_i: LCG walk seeded by r[1..3], rejection for distinctness
     uint64_t s = ((uint64_t)r[1] << 32) | r[2];
     for (int i = 0; i < nnz; ++i) {
@@ -103,6 +104,61 @@ __global__ void saso_dense_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, con
     int64_t r = idx % d, t = (idx / d) / nnz;
     int64_t j = t * d + (int64_t)(e & 0x7fffffff);
     S[r + j * d] += (e & 0x80000000) ? T(-1) : T(1);    // distinct (r, j) per entry: no race
+}
+
+// ---- S * A for a SPARSE A (one column of A = one row of the transpose's CSR).  A column holds few nonzeros, so the product is a
+// scatter: entry (j, v) adds +-v to the nnz sketch rows r_i(j).  Floating-point atomics would make the sum order-dependent;
+// instead every value is converted to 64-bit fixed point with a per-column power-of-two scale chosen so that the column cannot
+// overflow (|q| <= 2^61 / len), accumulated with INTEGER LDS atomics (associative => bitwise reproducible), and converted back.
+// Quantisation error per entry: 2^-62 * len * max|v|, below the rounding error of a floating-point sum of the same terms.
+template <typename T>
+__global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, SasoState st,
+                                                             const int64_t* __restrict__ afwd, const int64_t* __restrict__ b,
+                                                             const int64_t* __restrict__ rowptrT, const int64_t* __restrict__ colidxT,
+                                                             const T* __restrict__ valsT, T alpha, T beta, T* __restrict__ B, int64_t ldb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);       // [d]
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int64_t p0 = rowptrT[c], p1 = rowptrT[c + 1], len = p1 - p0;
+    for (int64_t r = tid; r < d; r += 256) acc[r] = 0ull;
+    double mx = 0;
+    for (int64_t p = p0 + tid; p < p1; p += 256) mx = fmax(mx, fabs((double)valsT[p]));
+    for (int off = 32; off; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    int e = 0;
+    if (mx > 0 && len > 0) {
+        int ex;
+        frexp(mx, &ex);                                    // mx < 2^ex
+        int lg = 0;
+        while (((int64_t)1 << lg) < len) ++lg;             // len <= 2^lg
+        e = 61 - lg - ex;
+        for (int64_t p = p0 + tid; p < p1; p += 256) {
+            const int64_t j = colidxT[p];
+            const long long q = llrint(ldexp((double)valsT[p], e));
+            const int64_t t = j / d, u = j - t * d;
+            uint32_t ctr[4], w[4];
+            ctr_add_dev(st.ctr, (uint64_t)(Tb + j), ctr);
+            philox4x32_10_dev(ctr, st.key, w);
+            const int64_t au = (afwd[t] * u) % d;
+            for (int i = 0; i < nnz; ++i) {
+                int64_t r = au + b[t * nnz + i];
+                if (r >= d) r -= d;
+                const uint32_t bit = (w[(i >> 5) & 3] >> (i & 31)) & 1u;
+                atomicAdd(&acc[r], (unsigned long long)(bit ? -q : q));
+            }
+        }
+    }
+    __syncthreads();
+    (void)m;
+    for (int64_t r = tid; r < d; r += 256) {
+        const double v = ldexp((double)(long long)acc[r], -e);
+        T* dst = B + r + c * ldb;
+        *dst = (beta == (T)0) ? (T)(alpha * v) : (T)(alpha * v) + beta * *dst;
+    }
 }
 
 constexpr int CT = 8;     // columns per workgroup
@@ -247,6 +303,8 @@ struct SasoOp {
     int32_t* src;       // T * nnz * d
     int64_t* ainv;      // T
     int64_t* b;         // T * nnz
+    int64_t* afwd;      // T   (the forward multiplier a_t; the sparse-operand path scatters)
+    SasoState st;
 };
 
 int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
@@ -258,12 +316,14 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4
     RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (size_t)(T * nnz * d)));
     RLHIP_CHECK(hipMalloc((void**)&op->ainv, sizeof(int64_t) * (size_t)T));
     RLHIP_CHECK(hipMalloc((void**)&op->b, sizeof(int64_t) * (size_t)(T * nnz)));
+    RLHIP_CHECK(hipMalloc((void**)&op->afwd, sizeof(int64_t) * (size_t)T));
     SasoState st;
     for (int i = 0; i < 4; ++i) st.ctr[i] = ctr[i];
     st.key[0] = key[0]; st.key[1] = key[1];
+    op->st = st;
     if (op->T > 0) {
         hipLaunchKernelGGL(saso_params_kernel, dim3((unsigned)((op->T + 63) / 64)), dim3(64), 0, c->stream, d, op->T, nnz,
-                           st, op->ainv, op->b);
+                           st, op->ainv, op->b, op->afwd);
         int64_t total = op->T * nnz * d;
         hipLaunchKernelGGL(saso_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d, m, op->T,
                            nnz, st, op->ainv, op->b, op->src);
@@ -284,7 +344,7 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4
 int saso_destroy(rlhip_ctx* c, SasoOp* op) {
     if (!op) return 0;
     hipStreamSynchronize(c->stream);
-    hipFree(op->src); hipFree(op->ainv); hipFree(op->b);
+    hipFree(op->src); hipFree(op->ainv); hipFree(op->b); hipFree(op->afwd);
     delete op;
     return 0;
 }
@@ -348,6 +408,27 @@ template <typename T>
 int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb) {
     return saso_apply_rows<T>(c, op, n, alpha, A, lda, 0, op->m, beta, B, ldb);
 }
+
+// B (d x n, ldb) = alpha * S * A + beta * B for a sparse A (m x n) given by the CSR of its transpose
+template <typename T>
+int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int64_t* rowptrT, const int64_t* colidxT, const T* valsT, T beta,
+                   T* B, int64_t ldb) {
+    if (n <= 0) return 0;
+    if (ldb < op->d) return -9;
+    const size_t smem = sizeof(unsigned long long) * (size_t)op->d;
+    if (smem > 150 * 1024) return -2;            // d up to 19200
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)saso_apply_csr_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(saso_apply_csr_kernel<T>, dim3((unsigned)n), dim3(256), smem, c->stream, op->d, op->m, op->T, op->nnz, op->st, op->afwd,
+                       op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int saso_apply_csr<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const int64_t*, const int64_t*, const double*, double, double*, int64_t);
+template int saso_apply_csr<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const int64_t*, const int64_t*, const float*, float, float*, int64_t);
 
 // in-place forward column permutation; idx is a DEVICE array of n 1-based indices (left untouched)
 template <typename T>

@@ -141,51 +141,127 @@ int csr_densify_cols(rlhip_ctx* c, int64_t m, const int64_t* rowptrT, const int6
     return 0;
 }
 
-// CSR of the transpose (k x m) of an m x k CSR matrix.  Construction-time, not on the timed path: staged through the host with a
-// stable counting sort so that the entry order inside every transposed row (= ascending source row) is deterministic.
+// ---- CSR of the transpose (k x m) of an m x k CSR matrix: a STABLE counting sort of the entries by column, entirely on the device.
+// Stability (entries of one transposed row keep the source order = ascending source row) makes the summation order of A^T X
+// independent of scheduling, so results are bit-reproducible.  Three phases over NB contiguous chunks of the entry list:
+//   count    cnt[b][j] = entries of chunk b in column j (integer atomics: order-free)
+//   scan     cnt[b][j] <- entries of column j in chunks < b; rowptrT = exclusive scan of the column totals
+//   scatter  one WAVE per chunk walks its entries 64 at a time in order; a lane's slot is
+//            rowptrT[col] + cnt[b][col] + (number of lower lanes of the tile with the same column)
+__global__ __launch_bounds__(256) void ct_count_kernel(int64_t nnz, int64_t per, int64_t k, const int64_t* __restrict__ colidx,
+                                                       int* __restrict__ cnt, int* __restrict__ bad) {
+    const int64_t b = blockIdx.x;
+    const int64_t p1 = (b + 1) * per < nnz ? (b + 1) * per : nnz;
+    for (int64_t p = b * per + threadIdx.x; p < p1; p += 256) {
+        const int64_t c = colidx[p];
+        if (c < 0 || c >= k) { *bad = 1; continue; }
+        atomicAdd(&cnt[b * k + c], 1);
+    }
+}
+__global__ void ct_chunk_scan_kernel(int64_t nb, int64_t k, int* __restrict__ cnt, int64_t* __restrict__ total) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    int run = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int t = cnt[b * k + j];
+        cnt[b * k + j] = run;
+        run += t;
+    }
+    total[j] = run;
+}
+// rowptrT[0..k] = exclusive scan of total[0..k); one workgroup of 1024 threads, contiguous slice per thread
+__global__ __launch_bounds__(1024) void ct_rowptr_kernel(int64_t k, const int64_t* __restrict__ total, int64_t* __restrict__ rowptrT) {
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (k + 1023) / 1024, j0 = t * per, j1 = (j0 + per < k) ? j0 + per : k;
+    int64_t s = 0;
+    for (int64_t j = j0; j < j1; ++j) s += total[j];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = part[t] - s;
+    for (int64_t j = j0; j < j1; ++j) { rowptrT[j] = run; run += total[j]; }
+    if (t == 1023) rowptrT[k] = part[1023];
+}
+template <typename T>
+__global__ __launch_bounds__(64) void ct_scatter_kernel(int64_t m, int64_t nnz, int64_t per, int64_t k, const int64_t* __restrict__ rowptr,
+                                                        const int64_t* __restrict__ colidx, const T* __restrict__ vals,
+                                                        const int64_t* __restrict__ rowptrT, int* __restrict__ cnt,
+                                                        int64_t* __restrict__ colidxT, T* __restrict__ valsT) {
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t p0 = b * per, p1 = (b + 1) * per < nnz ? (b + 1) * per : nnz;
+    int* mycnt = cnt + b * k;
+    for (int64_t pt = p0; pt < p1; pt += 64) {
+        const int64_t p = pt + lane;
+        const bool valid = p < p1;
+        const int c = valid ? (int)colidx[p] : -1 - lane;          // invalid lanes get distinct sentinels
+        int rank = 0, same = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int cl = __builtin_amdgcn_readlane(c, l);
+            const int eq = (cl == c) ? 1 : 0;
+            rank += (l < lane) ? eq : 0;
+            same += eq;
+        }
+        if (valid) {
+            // per-chunk running offsets live in global memory; this wave is their only writer, agent-scope atomics keep the
+            // read-after-write of the next tile coherent (the vector L1 is not)
+            const int before = __hip_atomic_load(&mycnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t dst = rowptrT[c] + before + rank;
+            // source row of entry p: last r with rowptr[r] <= p
+            int64_t lo = 0, hi = m;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (rowptr[mid] <= p) lo = mid; else hi = mid;
+            }
+            colidxT[dst] = lo;
+            valsT[dst] = vals[p];
+            if (rank == same - 1) __hip_atomic_store(&mycnt[c], before + same, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <typename T>
 int csr_transpose(rlhip_ctx* c, int64_t m, int64_t k, const int64_t* rowptr, const int64_t* colidx, const T* vals, int64_t* rowptrT,
                   int64_t* colidxT, T* valsT) {
-    int64_t* h_rp = (int64_t*)malloc(sizeof(int64_t) * (size_t)(m + 1));
-    if (!h_rp) return -3;
-    RLHIP_CHECK(hipMemcpyAsync(h_rp, rowptr, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
-    const int64_t nnz = h_rp[m];
-    int64_t* h_ci = (int64_t*)malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nnz, 1));
-    T* h_v = (T*)malloc(sizeof(T) * (size_t)std::max<int64_t>(nnz, 1));
-    int64_t* h_rpt = (int64_t*)calloc((size_t)(k + 2), sizeof(int64_t));
-    int64_t* h_cit = (int64_t*)malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nnz, 1));
-    T* h_vt = (T*)malloc(sizeof(T) * (size_t)std::max<int64_t>(nnz, 1));
+    if (k >= ((int64_t)1 << 31)) return -2;
+    int64_t nnz = 0;
+    if (m > 0) {
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 50, rowptr + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        nnz = c->h_mail[50];
+    }
+    if (nnz < 0 || nnz >= ((int64_t)1 << 31)) return -2;      // per-column counters are 32-bit
+    if (k == 0) { RLHIP_CHECK(hipMemsetAsync(rowptrT, 0, sizeof(int64_t), c->stream)); return nnz == 0 ? 0 : -2; }
+    // chunks: enough waves to fill the chip, bounded so that the nb x k counter table stays under 256 MiB
+    int64_t nb = std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)1 << 26) / k));
+    nb = std::max<int64_t>(1, std::min<int64_t>(nb, (nnz + 63) / 64));
+    const int64_t per = std::max<int64_t>(64, ((nnz + nb - 1) / nb + 63) / 64 * 64);
+    nb = std::max<int64_t>(1, (nnz + per - 1) / per);
+    if (per >= ((int64_t)1 << 31)) return -2;
+    const size_t mark = rlhip_ws_mark(c);
+    int* cnt = ws_alloc<int>(c, (size_t)nb * k);
+    int64_t* total = ws_alloc<int64_t>(c, (size_t)k);
+    if (!cnt || !total) { rlhip_ws_release(c, mark); return -3; }
+    int* d_bad = (int*)(c->d_mail + 51);
     int rc = 0;
-    if (!h_ci || !h_v || !h_rpt || !h_cit || !h_vt) rc = -3;
-    if (!rc && nnz > 0) {
-        if (hipMemcpyAsync(h_ci, colidx, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h_v, vals, sizeof(T) * (size_t)nnz, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess)
-            rc = -1;
-    }
-    if (!rc) {
-        for (int64_t p = 0; p < nnz; ++p) {
-            if (h_ci[p] < 0 || h_ci[p] >= k) { rc = -2; break; }
-            h_rpt[h_ci[p] + 2]++;
-        }
-    }
-    if (!rc) {
-        for (int64_t j = 0; j < k; ++j) h_rpt[j + 2] += h_rpt[j + 1];   // h_rpt[j+1] = start of row j while filling
-        for (int64_t i = 0; i < m; ++i)
-            for (int64_t p = h_rp[i]; p < h_rp[i + 1]; ++p) {
-                const int64_t dst = h_rpt[h_ci[p] + 1]++;
-                h_cit[dst] = i;
-                h_vt[dst] = h_v[p];
-            }
-        if (hipMemcpyAsync(rowptrT, h_rpt, sizeof(int64_t) * (size_t)(k + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -1;
-        if (!rc && nnz > 0 &&
-            (hipMemcpyAsync(colidxT, h_cit, sizeof(int64_t) * (size_t)nnz, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-             hipMemcpyAsync(valsT, h_vt, sizeof(T) * (size_t)nnz, hipMemcpyHostToDevice, c->stream) != hipSuccess))
-            rc = -1;
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = -1;
-    }
-    free(h_rp); free(h_ci); free(h_v); free(h_rpt); free(h_cit); free(h_vt);
+    do {
+        if (hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)nb * k, c->stream) != hipSuccess || hipMemsetAsync(d_bad, 0, sizeof(int), c->stream) != hipSuccess) { rc = -1; break; }
+        if (nnz > 0) hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, nnz, per, k, colidx, cnt, d_bad);
+        hipLaunchKernelGGL(ct_chunk_scan_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, nb, k, cnt, total);
+        hipLaunchKernelGGL(ct_rowptr_kernel, dim3(1), dim3(1024), 0, c->stream, k, total, rowptrT);
+        if (hipMemcpyAsync(c->h_mail + 51, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; break; }
+        if (*(int*)(c->h_mail + 51)) { rc = -2; break; }                                   // a column index outside [0, k)
+        if (nnz > 0)
+            hipLaunchKernelGGL(ct_scatter_kernel<T>, dim3((unsigned)nb), dim3(64), 0, c->stream, m, nnz, per, k, rowptr, colidx, vals, rowptrT, cnt, colidxT, valsT);
+        if (hipGetLastError() != hipSuccess) rc = -1;
+    } while (0);
+    rlhip_ws_release(c, mark);
     return rc;
 }
 

@@ -109,6 +109,52 @@ def test_csr_transpose_and_densify(ctx):
                                            cit.data_ptr(), vt.data_ptr()) == -2
 
 
+@pytest.mark.parametrize("d_sk,nnz", [(120, 2), (500, 4), (2000, 8)])
+def test_saso_apply_csr_matches_dense_path_and_is_reproducible(ctx, d_sk, nnz):
+    d = _d()
+    import ctypes as C
+    import torch
+
+    m, n = 3000, 90
+    S = _sparse(m, n, 0.03, d_sk)
+    S = sp.hstack([S[:, :40], sp.csr_matrix((m, 3)), S[:, 43:]]).tocsr()          # three empty columns
+    A = S.toarray()
+    St = S.T.tocsr()
+    rpt = torch.as_tensor(St.indptr.astype(np.int64), device="cuda:0")
+    cit = torch.as_tensor(St.indices.astype(np.int64), device="cuda:0")
+    vt = torch.as_tensor(St.data, device="cuda:0")
+    st = (C.c_uint32 * 4)(3, 0, 0, 0)
+    key = (C.c_uint32 * 2)(7, 0)
+    nxt = (C.c_uint32 * 4)()
+    h = C.c_void_p()
+    assert ctx.lib.rlhip_saso_create(ctx.h, d_sk, m, nnz, st, key, nxt, C.byref(h)) == 0
+    rng = np.random.default_rng(0)
+    B0 = rng.standard_normal((d_sk, n))
+    outs = []
+    for rep in range(2):
+        Bd = d.cm_from_numpy(B0)
+        assert ctx.lib.rlhip_saso_apply_csr_f64(ctx.h, h, n, 1.5, rpt.data_ptr(), cit.data_ptr(), vt.data_ptr(), -0.5, Bd.data_ptr(), d_sk) == 0
+        outs.append(d.cm_to_numpy(Bd))
+    assert np.array_equal(outs[0], outs[1])                                       # integer accumulation: bitwise reproducible
+    Bref = d.cm_from_numpy(B0)
+    assert ctx.lib.rlhip_saso_apply_f64(ctx.h, h, n, 1.5, d.cm_from_numpy(A).data_ptr(), m, -0.5, Bref.data_ptr(), d_sk) == 0
+    ref = d.cm_to_numpy(Bref)
+    np.testing.assert_allclose(outs[0], ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+    assert np.array_equal(outs[0][:, 40:43], -0.5 * B0[:, 40:43])                 # empty columns: beta * B only
+    ctx.lib.rlhip_saso_destroy(ctx.h, h)
+
+
+def test_cqrrt_linops_sparse_sketch_fallback_path(ctx, orc, monkeypatch):
+    d = _d()
+    op, op_np, A = _ops("sparse", 31)
+    fast = d.drv_qr_linops(ctx, "cqrrt", op, d_factor=2.0, key=(1, 0), want_sketch=True)
+    monkeypatch.setenv("RLHIP_SPARSE_SKETCH_DENSIFY", "1")
+    slow = d.drv_qr_linops(ctx, "cqrrt", op, d_factor=2.0, key=(1, 0), want_sketch=True)
+    a, b = d.cm_to_numpy(fast["sketch"]), d.cm_to_numpy(slow["sketch"])
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * np.abs(b).max())
+    assert fast["next_ctr"] == slow["next_ctr"]
+
+
 @pytest.mark.parametrize("kind", ["dense", "sparse", "dense*sparse", "sparse*dense", "sparse*sparse"])
 def test_linop_apply_all_sides(ctx, kind):
     d = _d()
