@@ -155,6 +155,7 @@ private:
 template <typename T>
 struct SparseLinOp {
     using scalar_t = T;
+    static constexpr bool prefers_row_major = true;     // the SpMM kernels are row-major inside (rl_qr_linops.hh exploits it)
     const int64_t n_rows;
     const int64_t n_cols;
     const int64_t nnz;

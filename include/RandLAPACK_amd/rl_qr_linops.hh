@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <type_traits>
 #include <vector>
 #include "rl_exceptions.hh"
 #include "rl_blaspp.hh"
@@ -28,10 +29,41 @@ namespace RandLAPACK {
 
 namespace detail {
 
+/// operators whose kernels want the tall intermediate in row-major order advertise it (SparseLinOp: the SpMM gathers whole rows)
+template <typename GLO, typename = void>
+struct prefers_row_major : std::false_type {};
+template <typename GLO>
+struct prefers_row_major<GLO, std::void_t<decltype(GLO::prefers_row_major)>> : std::bool_constant<GLO::prefers_row_major> {};
+
+inline void transpose(int64_t m, int64_t n, const double* A, int64_t lda, double* AT, int64_t ldat, blas::Queue& q) {
+    blas::check(rlhip_transpose_f64(q.ctx(), m, n, A, lda, AT, ldat, 0), "transpose");
+}
+inline void transpose(int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat, blas::Queue& q) {
+    blas::check(rlhip_transpose_f32(q.ctx(), m, n, A, lda, AT, ldat, 0), "transpose");
+}
+
 /// G (n x n, ldg) = A^T * (A * M) in column blocks of width b_eff; `buf` holds m x b_eff.  With `post` != nullptr every block is
 /// first formed in Z (n x b_eff) and G[:, blk] = post^T * Z (the M^T (A^T A M) step of rl_scholqr3_linops.hh:300-312).
+/// `row_major_ok`: the caller does not look at `buf` afterwards, so an operator that prefers it may be driven with
+/// Layout::RowMajor operands -- buf and Z are then row-major and only n x n objects are ever transposed.
 template <typename T, typename GLO>
-void gram_through_operator(GLO& A, int64_t m, int64_t n, int64_t b_eff, const T* M, T* buf, const T* post, T* Z, T* G, int64_t ldg, blas::Queue& q) {
+void gram_through_operator(GLO& A, int64_t m, int64_t n, int64_t b_eff, const T* M, T* buf, const T* post, T* Z, T* G, int64_t ldg, blas::Queue& q,
+                           bool row_major_ok = false) {
+    if (row_major_ok && prefers_row_major<GLO>::value) {
+        blas::Scratch ws(q);
+        T* Mt = ws.alloc<T>(n * n);                 // M^T column-major == M row-major
+        T* Zr = ws.alloc<T>(n * b_eff);             // n x bj row-major, ld bj
+        transpose(n, n, M, n, Mt, n, q);
+        for (int64_t j = 0; j < n; j += b_eff) {
+            const int64_t bj = std::min(b_eff, n - j);
+            A(Side::Left, Layout::RowMajor, Op::NoTrans, Op::NoTrans, m, bj, n, (T)1, Mt + j, n, (T)0, buf, bj);
+            A(Side::Left, Layout::RowMajor, Op::Trans, Op::NoTrans, n, bj, m, (T)1, buf, bj, (T)0, Zr, bj);
+            // Zr read as column-major is Z^T (bj x n, ld bj)
+            if (post) blas::gemm(Layout::ColMajor, Op::Trans, Op::Trans, n, bj, n, (T)1, post, n, Zr, bj, (T)0, G + j * ldg, ldg, q);
+            else transpose(bj, n, Zr, bj, G + j * ldg, ldg, q);
+        }
+        return;
+    }
     for (int64_t j = 0; j < n; j += b_eff) {
         const int64_t bj = std::min(b_eff, n - j);
         A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, bj, n, (T)1, M + j * n, n, (T)0, buf, m);
@@ -98,7 +130,7 @@ public:
         T* buf = nullptr;
         if (test_mode) { qh.reset(q, m, n); buf = qh.Q; }       // the full-width buffer doubles as Q (rl_cholqr_linops.hh:236)
         else buf = ws.alloc<T>(m * b_eff);
-        detail::gram_through_operator<T>(A, m, n, b_eff, I_mat, buf, (const T*)nullptr, (T*)nullptr, R, ldr, q);
+        detail::gram_through_operator<T>(A, m, n, b_eff, I_mat, buf, (const T*)nullptr, (T*)nullptr, R, ldr, q, !test_mode);
         if (detail::chol_upper_clean(n, R, ldr, q)) { publish_q(false); return 1; }
         if (test_mode) {
             if (b_eff < n) A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, n, n, (T)1, I_mat, n, (T)0, buf, m);
@@ -189,7 +221,7 @@ public:
         this->publish_q(false);
 
         // iteration 1: shifted Gram matrix of A itself (M = I)                                        (:224-270)
-        detail::gram_through_operator<T>(A, m, n, b_eff, M, A_temp, (const T*)nullptr, (T*)nullptr, G, n, q);
+        detail::gram_through_operator<T>(A, m, n, b_eff, M, A_temp, (const T*)nullptr, (T*)nullptr, G, n, q, true);
         this->shift_gram(n, G, q);
         if (detail::chol_upper_clean(n, G, n, q)) return 1;
         this->keep_factor(this->G1_factor, n, G, q);
@@ -198,7 +230,7 @@ public:
 
         // iterations 2 and 3: G = M^T A^T A M, R <- chol(G) R, M <- M chol(G)^-1                       (:290-420)
         for (int it = 2; it <= 3; ++it) {
-            detail::gram_through_operator<T>(A, m, n, b_eff, M, A_temp, M, Z_buf, G, n, q);
+            detail::gram_through_operator<T>(A, m, n, b_eff, M, A_temp, M, Z_buf, G, n, q, true);
             if (detail::chol_upper_clean(n, G, n, q)) return it;
             this->keep_factor(it == 2 ? this->G2_factor : this->G3_factor, n, G, q);
             this->accumulate_R(n, G, R, ldr, R_temp, q);
@@ -329,7 +361,7 @@ public:
         T* A_pre = nullptr;
         if (test_mode) { qh.reset(q, m, n); A_pre = qh.Q; }
         else A_pre = ws.alloc<T>(m * b_eff);
-        detail::gram_through_operator<T>(A, m, n, b_eff, R_sk_inv, A_pre, (const T*)nullptr, (T*)nullptr, R, ldr, q);   // :264-318
+        detail::gram_through_operator<T>(A, m, n, b_eff, R_sk_inv, A_pre, (const T*)nullptr, (T*)nullptr, R, ldr, q, !test_mode);   // :264-318
         blas::trmm(Layout::ColMajor, Side::Left, Uplo::Upper, Op::Trans, Diag::NonUnit, n, n, (T)1, R_sk_inv, n, R, ldr, q);   // :322
         if (lapack::potrf(Uplo::Upper, n, R, ldr, q)) { publish_q(false); return 1; }                              // :330
 

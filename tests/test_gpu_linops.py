@@ -208,6 +208,9 @@ def test_cholqr_family_vs_oracle(ctx, orc, alg, kind, block):
     # the Cholesky factor is unique: entrywise agreement with the oracle up to cond^2 * eps
     np.testing.assert_allclose(R, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())
     np.testing.assert_allclose(Q, ref["Q"], rtol=0, atol=1e-9)
+    # the Q-less mode (the classes' default; sparse operators then run with row-major intermediates) returns the same R
+    R2 = np.triu(d.cm_to_numpy(d.drv_qr_linops(ctx, alg, op, block_size=block)["R"]))
+    np.testing.assert_allclose(R2, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())
 
 
 @pytest.mark.parametrize("kind", KINDS + ["sparse*sparse"])
@@ -227,6 +230,8 @@ def test_cqrrt_linops_vs_oracle_shared_sketch(ctx, orc, kind, block, dense_sketc
     assert fact <= TOL and orth <= TOL
     np.testing.assert_allclose(R, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())
     np.testing.assert_allclose(Q, ref["Q"], rtol=0, atol=1e-9)
+    R2 = np.triu(d.cm_to_numpy(d.drv_qr_linops(ctx, "cqrrt", op, block_size=block, d_factor=2.0, use_dense_sketch=dense_sketch, key=(1, 0))["R"]))
+    np.testing.assert_allclose(R2, ref["R"], rtol=0, atol=1e-10 * np.abs(ref["R"]).max())      # Q-less mode
     # the sketch of an operator equals the sketch of the matrix it represents, and the state advances as in CQRRT (same SkOp)
     if not dense_sketch:
         o2 = d.drv_cqrrt(ctx, d.cm_from_numpy(A), m, n, d_factor=2.0, nnz=2, key=(1, 0), want_sketch=True)
