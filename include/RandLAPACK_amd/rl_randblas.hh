@@ -6,6 +6,8 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <unordered_map>
+#include <vector>
 #include "rl_blaspp.hh"
 
 namespace r123 {
@@ -65,6 +67,41 @@ RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_rows_f32(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
                                           loc_rows, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
+    return next;
+}
+
+// k distinct indices from {0..n-1}, r independent repetitions (RandBLAS::repeated_fisher_yates as used at testing/rl_gen.hh:269).
+// idxs: HOST buffer of k * r.  Own stream: repetition i draws its k swap targets from Philox words ctr + i*ceil(k/4) ...;
+// swap j picks uniformly from [j, n) by 32x32 -> 64-bit multiply-shift.  Returns the advanced state.
+template <typename RNG>
+RNGState<RNG> repeated_fisher_yates(int64_t k, int64_t n, int64_t r, int64_t* idxs, RNGState<RNG> const& st, blas::Queue& q) {
+    if (k > n) throw blas::Error("repeated_fisher_yates: k > n");
+    RNGState<RNG> next = st;
+    if (k <= 0 || r <= 0) return next;
+    const int64_t blocks_per_rep = (k + 3) / 4, nblk = blocks_per_rep * r;
+    std::vector<uint32_t> words((size_t)(4 * nblk));
+    {
+        blas::Scratch ws(q);
+        uint32_t* dev = ws.alloc<uint32_t>(4 * nblk);
+        blas::check(rlhip_philox4x32_10(q.ctx(), nblk, dev, st.counter.data(), st.key.data()), "philox");
+        blas::copy_to_host(4 * nblk, dev, words.data(), q);
+    }
+    for (int64_t rep = 0; rep < r; ++rep) {
+        std::unordered_map<int64_t, int64_t> moved;            // sparse view of the partially shuffled identity
+        auto at = [&](int64_t i) { auto it = moved.find(i); return it == moved.end() ? i : it->second; };
+        for (int64_t j = 0; j < k; ++j) {
+            const uint64_t w = words[(size_t)(4 * rep * blocks_per_rep + j)];
+            const int64_t t = j + (int64_t)((w * (uint64_t)(n - j)) >> 32);
+            const int64_t vj = at(j), vt = at(t);
+            moved[t] = vj;
+            moved[j] = vt;
+            idxs[rep * k + j] = vt;
+        }
+    }
+    uint64_t lo = ((uint64_t)st.counter[1] << 32) | st.counter[0], hi = ((uint64_t)st.counter[3] << 32) | st.counter[2];
+    const uint64_t nlo = lo + (uint64_t)nblk;
+    if (nlo < lo) hi += 1;
+    next.counter = {(uint32_t)nlo, (uint32_t)(nlo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
     return next;
 }
 

@@ -252,6 +252,17 @@ int rlhip_tau_from_t_f32(rlhip_ctx* ctx, int64_t k, int64_t nb, const float* T, 
 int rlhip_any_abs_gt_f64(rlhip_ctx* ctx, int64_t n, const double* x, double thr, int* any_host);
 int rlhip_any_abs_gt_f32(rlhip_ctx* ctx, int64_t n, const float* x, float thr, int* any_host);
 
+/* ---- test-matrix generator pieces (RandLAPACK/testing/rl_gen.hh; host-side logic in include/RandLAPACK_amd/rl_gen.hh) ----
+ * scal_cols: A[:, j] *= s[j] (s DEVICE, n entries) -- the S factor of gen_singvec (rl_gen.hh:79).
+ * scal_rows_idx: A[idx[r], :] *= alpha for the cnt listed rows (idx DEVICE, each row once) -- gen_spiked_mat rl_gen.hh:286-291.
+ * gen_kahan: the Kahan matrix of gen_kahan_mat (rl_gen.hh:408-434), m x n leading block. */
+int rlhip_scal_cols_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, const double* s_dev);
+int rlhip_scal_cols_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, const float* s_dev);
+int rlhip_scal_rows_idx_f64(rlhip_ctx* ctx, int64_t cnt, const int64_t* idx_dev, int64_t n, double* A, int64_t lda, double alpha);
+int rlhip_scal_rows_idx_f32(rlhip_ctx* ctx, int64_t cnt, const int64_t* idx_dev, int64_t n, float* A, int64_t lda, float alpha);
+int rlhip_gen_kahan_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double theta, double perturb);
+int rlhip_gen_kahan_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float theta, float perturb);
+
 /* ---- sparse linear operator kernels (linops::SparseLinOp; reference RandLAPACK/linops/rl_sparse_linop.hh:125-330 forwards to
  *      RandBLAS left_spmm/right_spmm).  CSR with int64 indices, all arrays DEVICE pointers.
  *      csr_spmm: C (m x n) = alpha * A (m x k, CSR) * B (k x n) + beta * C; layout 'C' (column-major B, C) or 'R' (row-major).

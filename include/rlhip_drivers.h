@@ -128,6 +128,16 @@ int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, cons
 int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,
                           int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
 
+/* gen::mat_gen (RandLAPACK/testing/rl_gen.hh:712-772) in HBM.  type: 0 polynomial, 1 exponential, 2 gaussian, 3 step, 4 spiked,
+ * 5 adverserial, 6 bad_cholqr, 7 kahan (the enum order of rl_gen.hh:22-31).  A: m x n DEVICE (rank x rank, ld rank, when diag != 0).
+ * Fields as mat_gen_info; rank_out (may be NULL) receives info.rank after the call (changed only by check_true_rank). */
+int rlhip_drv_mat_gen_f64(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, double cond_num, double scaling, double exponent,
+                          int diag, double theta, double perturb, double frac_spectrum_one, int check_true_rank, double* A,
+                          uint32_t state[6], int64_t* rank_out);
+int rlhip_drv_mat_gen_f32(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, float cond_num, float scaling, float exponent,
+                          int diag, float theta, float perturb, float frac_spectrum_one, int check_true_rank, float* A,
+                          uint32_t state[6], int64_t* rank_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -460,3 +460,105 @@ def cqrrt_linops(A, A_hat, block_size=0, test_mode=True):
         A_pre = _op_mul(A, R_sk_inv)
         out["Q"] = sla.solve_triangular(R_chol, A_pre.T, trans="T", lower=False).T
     return out
+
+
+# ---- test-matrix generators (numpy restatement of RandLAPACK/testing/rl_gen.hh; shares the library's random stream through
+#      fill_dense / philox so that the device generators can be compared entrywise) -----------------------------------------------
+def _ctr_add(ctr, inc):
+    v = sum(int(c) << (32 * i) for i, c in enumerate(ctr)) + int(inc)
+    return tuple((v >> (32 * i)) & 0xFFFFFFFF for i in range(4))
+
+
+def gen_poly_singvals(k, frac_spectrum_one, cond, p):
+    """rl_gen.hh:105-132"""
+    s = np.ones(k)
+    offset = int(np.floor(k * frac_spectrum_one))
+    first, last, neg_invp = 1.0, 1.0 / cond, -1.0 / p
+    a = ((last ** neg_invp - first ** neg_invp) / (k - offset)) ** p
+    b = (a * first) ** neg_invp - offset
+    for i in range(offset, k):
+        s[i] = 1.0 / (a * (i + b) ** p)
+    return s
+
+
+def gen_exp_singvals(k, cond):
+    """rl_gen.hh:168-180"""
+    s = np.ones(k)
+    offset = int(np.floor(k * 0.1))
+    t = -np.log(1.0 / cond) / (k - offset)
+    for c, i in enumerate(range(offset, k), start=1):
+        s[i] = np.exp(c * -t)
+    return s
+
+
+def gen_step_singvals(k, cond):
+    """rl_gen.hh:215-225"""
+    s = np.empty(k)
+    o = k // 4
+    s[:o], s[o:2 * o], s[2 * o:3 * o], s[3 * o:] = 1.0, 8.0 / cond, 4.0 / cond, 1.0 / cond
+    return s
+
+
+def repeated_fisher_yates(k, n, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """one repetition of the library's sampler (include/RandLAPACK_amd/rl_randblas.hh): returns (k indices, next_ctr)"""
+    nblk = (k + 3) // 4
+    words = []
+    for b in range(nblk):
+        words.extend(int(w) for w in philox(_ctr_add(ctr, b), key))
+    moved = {}
+    out = []
+    for j in range(k):
+        t = j + ((words[j] * (n - j)) >> 32)
+        vj, vt = moved.get(j, j), moved.get(t, t)
+        moved[t], moved[j] = vj, vt
+        out.append(vt)
+    return np.array(out, dtype=np.int64), _ctr_add(ctr, nblk)
+
+
+def _gauss_orth(rows, k, ctr, key):
+    G, ctr = fill_dense(rows, k, ctr, key)
+    return np.linalg.qr(G, mode="reduced")[0], ctr            # geqrf + ungqr (rl_gen.hh:81-85: the implicit Q, leading k columns)
+
+
+def mat_gen(m_type, m, n, rank=None, cond_num=1.0, scaling=1.0, exponent=1.0, diag=False, theta=1.0, perturb=1.0, frac_spectrum_one=0.1,
+            ctr=(0, 0, 0, 0), key=(0, 0)):
+    """gen::mat_gen (rl_gen.hh:712-772).  returns (A, next_ctr)"""
+    k = n if rank is None else rank
+    spectra = {"polynomial": lambda: gen_poly_singvals(k, frac_spectrum_one, cond_num, exponent), "exponential": lambda: gen_exp_singvals(k, cond_num),
+               "step": lambda: gen_step_singvals(k, cond_num), "bad_cholqr": lambda: np.ones(k)}
+    if m_type in spectra:
+        s = spectra[m_type]()
+        if diag:
+            return np.diag(s), ctr
+        U, ctr = _gauss_orth(m, k, ctr, key)                   # gen_singvec, rl_gen.hh:62-101
+        V, ctr = _gauss_orth(n, k, ctr, key)
+        return (U * s) @ V.T, ctr
+    if m_type == "gaussian":
+        return fill_dense(m, n, ctr, key)
+    if m_type == "spiked":                                      # rl_gen.hh:257-305
+        rows, ctr = repeated_fisher_yates(n // 2, m, ctr, key)
+        V, ctr = _gauss_orth(n, n, ctr, key)
+        A = np.vstack([V] * (m // n + 1))[:m].copy()
+        A[rows, :] *= scaling
+        return A, ctr
+    if m_type == "adverserial":                                 # rl_gen.hh:310-365
+        U, ctr = fill_dense(m, n, ctr, key)
+        V, ctr = fill_dense(n, n, ctr, key)
+        U[:10, :] *= scaling
+        U = np.linalg.qr(U, mode="reduced")[0]
+        V = np.triu(np.linalg.qr(V, mode="reduced")[0])
+        idx = np.arange(11, n)
+        V[idx, idx] *= 10e-3
+        return U @ V, ctr
+    if m_type == "kahan":                                       # rl_gen.hh:408-434
+        sn, cs = np.sin(theta), np.cos(theta)
+        S = np.zeros((m, m))
+        Cm = np.zeros((m, m))
+        A = np.zeros((m, m))
+        for i in range(n):
+            A[i, i] = perturb * np.finfo(np.float64).eps * (m - i)
+            S[i, i] = sn ** i
+            Cm[:i, i] = -cs
+            Cm[i, i] = 1.0
+        return (S @ Cm + A)[:, :n], ctr
+    raise ValueError(m_type)

@@ -52,6 +52,9 @@ def _blas3(T):
         "ungqr": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "laswp": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
         "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "scal_cols": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "scal_rows_idx": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, T],
+        "gen_kahan": [c_vp, c_i64, c_i64, c_vp, c_i64, T, T],
         "csr_spmm": [c_vp, c_char, c_i64, c_i64, c_i64, T, c_vp, c_vp, c_vp, c_vp, c_i64, T, c_vp, c_i64],
         "csr_transpose": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
         "csr_densify_cols": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64],
@@ -142,7 +145,9 @@ SIGNATURES.update({
                                           C.POINTER(c_i64), C.POINTER(c_dbl), c_int]),
     "rlhip_linop_apply_f64": (c_int, [c_vp, _ldp, _ldp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
 })
-for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp", "qr_linops"):      # fp32 instantiations: same shapes, float scalars
+SIGNATURES["rlhip_drv_mat_gen_f64"] = (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp, u32p,
+                                                 C.POINTER(c_i64)])
+for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp", "qr_linops", "mat_gen"):      # fp32 instantiations: same shapes, float scalars
     _rt, _args = SIGNATURES[f"rlhip_drv_{_name}_f64"]
     SIGNATURES[f"rlhip_drv_{_name}_f32"] = (_rt, [c_flt if a is c_dbl else a for a in _args])
 for _suf, _T in (("f64", c_dbl), ("f32", c_flt)):

@@ -152,6 +152,24 @@ int drv_qr_linops(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* left, const r
     });
 }
 
+
+template <typename T>
+int drv_mat_gen(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, T cond_num, T scaling, T exponent, int diag, T theta, T perturb,
+                T frac_spectrum_one, int check_true_rank, T* A, uint32_t state[6], int64_t* rank_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if (type < 0 || type > 7) throw RandLAPACK::Error("mat_gen: type must be 0..7 (rl_gen.hh mat_type order, custom_input excluded)");
+        RandLAPACK::gen::mat_gen_info<T> info(m, n, (RandLAPACK::gen::mat_type)type);
+        info.rank = rank;
+        info.cond_num = cond_num; info.scaling = scaling; info.exponent = exponent; info.diag = diag != 0;
+        info.theta = theta; info.perturb = perturb; info.frac_spectrum_one = frac_spectrum_one; info.check_true_rank = check_true_rank != 0;
+        State st = load_state(state);
+        RandLAPACK::gen::mat_gen(info, A, st, q);
+        store_state(st, state);
+        if (rank_out) *rank_out = info.rank;
+        return 0;
+    });
+}
 }  // namespace
 
 extern "C" {
@@ -486,6 +504,18 @@ int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rl
             return 0;
         });
     });
+}
+
+
+int rlhip_drv_mat_gen_f64(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, double cond_num, double scaling, double exponent,
+                          int diag, double theta, double perturb, double frac_spectrum_one, int check_true_rank, double* A,
+                          uint32_t state[6], int64_t* rank_out) {
+    return drv_mat_gen<double>(ctx, type, m, n, rank, cond_num, scaling, exponent, diag, theta, perturb, frac_spectrum_one, check_true_rank, A, state, rank_out);
+}
+int rlhip_drv_mat_gen_f32(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, float cond_num, float scaling, float exponent,
+                          int diag, float theta, float perturb, float frac_spectrum_one, int check_true_rank, float* A,
+                          uint32_t state[6], int64_t* rank_out) {
+    return drv_mat_gen<float>(ctx, type, m, n, rank, cond_num, scaling, exponent, diag, theta, perturb, frac_spectrum_one, check_true_rank, A, state, rank_out);
 }
 
 }  // extern "C"

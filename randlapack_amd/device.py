@@ -304,6 +304,27 @@ def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0
                 next_ctr=tuple(int(x) for x in st[:4]))
 
 
+MAT_TYPES = {"polynomial": 0, "exponential": 1, "gaussian": 2, "step": 3, "spiked": 4, "adverserial": 5, "bad_cholqr": 6, "kahan": 7}
+
+
+def drv_mat_gen(ctx: Context, m_type, m, n, rank=None, cond_num=1.0, scaling=1.0, exponent=1.0, diag=False, theta=1.0, perturb=1.0,
+                frac_spectrum_one=0.1, check_true_rank=False, ctr=(0, 0, 0, 0), key=(0, 0), dtype=None):
+    """gen::mat_gen into HBM.  Returns dict(A, rank, next_ctr); A is a column-major tensor (n, m) ((rank, rank) when diag)."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    dtype = dtype or torch.float64
+    rank = n if rank is None else rank
+    A = cm_zeros(rank, rank, dtype=dtype, device=dev) if diag else cm_zeros(m, n, dtype=dtype, device=dev)
+    st = _state_arr(ctr, key)
+    r_out = C.c_int64(rank)
+    suf = "f64" if dtype == torch.float64 else "f32"
+    rc = getattr(ctx.lib, f"rlhip_drv_mat_gen_{suf}")(ctx.h, MAT_TYPES[m_type] if isinstance(m_type, str) else m_type, m, n, rank, cond_num,
+                                                      scaling, exponent, 1 if diag else 0, theta, perturb, frac_spectrum_one,
+                                                      1 if check_true_rank else 0, A.data_ptr(), st, C.byref(r_out))
+    _drv_check(ctx, rc, "mat_gen")
+    return dict(A=A, rank=int(r_out.value), next_ctr=tuple(int(x) for x in st[:4]))
+
+
 class DenseOperator:
     """linops::DenseLinOp over a column-major device tensor (n, m) (rows m, cols n)."""
 

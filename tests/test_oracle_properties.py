@@ -347,3 +347,40 @@ def test_qr_linops_oracle_failure_and_conditioning(orc):
     o3 = orc.scholqr3_linops(A)
     assert o3["rc"] == 0 and np.linalg.norm(o3["Q"].T @ o3["Q"] - np.eye(40)) < 1e-5
     assert orc.cholqr_linops(A)["rc"] == 1
+
+
+# ---- generators (test/misc/test_gen.cc: spectrum of the generated matrix equals the requested one)
+@pytest.mark.parametrize("m_type,cond", [("polynomial", 1e6), ("exponential", 1e5), ("step", 1e4), ("bad_cholqr", 1e3)])
+def test_mat_gen_oracle_spectra(orc, m_type, cond):
+    m, n, k = 120, 60, 40
+    A, nxt = orc.mat_gen(m_type, m, n, rank=k, cond_num=cond, exponent=2.0, key=(2, 0))
+    want = {"polynomial": lambda: orc.gen_poly_singvals(k, 0.1, cond, 2.0), "exponential": lambda: orc.gen_exp_singvals(k, cond),
+            "step": lambda: orc.gen_step_singvals(k, cond), "bad_cholqr": lambda: np.ones(k)}[m_type]()
+    s = np.linalg.svd(A, compute_uv=False)
+    np.testing.assert_allclose(s[:k], np.sort(want)[::-1], rtol=0, atol=1e-13)
+    assert s[k:].max() < 1e-13                                             # exactly rank k
+    if m_type in ("exponential", "step"):
+        assert abs(want[0] / want[-1] - cond) < 1e-8 * cond                # condition number as requested
+    if m_type == "polynomial":                                              # the reference's formula reaches 1/cond one index PAST the end
+        assert 0.8 * cond < want[0] / want[-1] < cond
+    assert nxt == ((m * k + 3) // 4 + (n * k + 3) // 4, 0, 0, 0)             # two fill_dense calls: U then V
+    D, nxt_d = orc.mat_gen(m_type, m, n, rank=k, cond_num=cond, exponent=2.0, diag=True, key=(2, 0))
+    assert D.shape == (k, k) and np.array_equal(np.diag(D), want) and nxt_d == (0, 0, 0, 0)
+
+
+def test_mat_gen_oracle_spiked_adversarial_kahan(orc):
+    m, n = 70, 12
+    A, _ = orc.mat_gen("spiked", m, n, scaling=7.0, key=(1, 0))
+    rows, _ = orc.repeated_fisher_yates(n // 2, m, key=(1, 0))
+    assert len(set(rows.tolist())) == n // 2 and rows.min() >= 0 and rows.max() < m
+    nr = np.linalg.norm(A, axis=1)
+    mask = np.zeros(m, bool)
+    mask[rows] = True
+    np.testing.assert_allclose(nr[mask], 7.0, atol=1e-12)                  # rows of an orthogonal matrix, scaled
+    np.testing.assert_allclose(nr[~mask], 1.0, atol=1e-12)
+    B, _ = orc.mat_gen("adverserial", m, n + 8, scaling=1e-5, key=(1, 0))
+    sb = np.linalg.svd(B, compute_uv=False)
+    assert B.shape == (m, n + 8) and sb[0] <= 1.0 + 1e-12 and np.sum(sb > 0.2) <= 12       # columns past the 11th are damped by 10e-3
+    K, _ = orc.mat_gen("kahan", 9, 9, theta=1.2, perturb=1e3)
+    c, s = np.cos(1.2), np.sin(1.2)
+    assert np.allclose(K, np.triu(K)) and abs(K[2, 5] + c * s**2) < 1e-15 and abs(K[3, 3] - (s**3 + 1e3 * np.finfo(float).eps * 6)) < 1e-15
