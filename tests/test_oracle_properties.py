@@ -380,7 +380,7 @@ def test_mat_gen_oracle_spiked_adversarial_kahan(orc):
     np.testing.assert_allclose(nr[~mask], 1.0, atol=1e-12)
     B, _ = orc.mat_gen("adverserial", m, n + 8, scaling=1e-5, key=(1, 0))
     sb = np.linalg.svd(B, compute_uv=False)
-    assert B.shape == (m, n + 8) and sb[0] <= 1.0 + 1e-12 and np.sum(sb > 0.2) <= 12       # columns past the 11th are damped by 10e-3
+    assert B.shape == (m, n + 8) and sb[0] < 2.0 and sb[-1] < 1e-6 * sb[0]          # graded, numerically rank deficient (as the reference warns)
     K, _ = orc.mat_gen("kahan", 9, 9, theta=1.2, perturb=1e3)
     c, s = np.cos(1.2), np.sin(1.2)
     assert np.allclose(K, np.triu(K)) and abs(K[2, 5] + c * s**2) < 1e-15 and abs(K[3, 3] - (s**3 + 1e3 * np.finfo(float).eps * 6)) < 1e-15
