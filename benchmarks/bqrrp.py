@@ -1,0 +1,130 @@
+"""BQRRP benchmark mains on the device library, writing the reference's file formats.
+
+  python -m benchmarks.bqrrp speed_mat_size   <dir> <num_runs> <row/col ratio> <cols/block ratio> <m1> [m2 ...]
+        (benchmark/bench_BQRRP/BQRRP_speed_comparisons_mat_size.cc) -> _BQRRP_speed_comparisons_mat_size_num_info_lines_7.txt
+  python -m benchmarks.bqrrp runtime_breakdown <dir> <qr_tall: cholqr|geqrf> <num_runs> <m> <n> <b1> [b2 ...]
+        (BQRRP_runtime_breakdown.cc) -> _BQRRP_runtime_breakdown_num_info_lines_7.txt
+  python -m benchmarks.bqrrp pivot_quality     <dir> <m> <n> <block_size> [mat_type]
+        (BQRRP_pivot_quality.cc) -> _BQRRP_pivot_quality_metric_{1,2}_num_info_lines_6.txt
+"""
+from __future__ import annotations
+
+import sys
+import time
+
+import numpy as np
+
+from randlapack_amd import device as d
+
+from . import _common as c
+
+QR_TALL = {"geqrt": 0, "cholqr": 1, "geqrf": 2}
+
+
+def speed_mat_size(argv):
+    directory, numruns, ratio, blk_ratio = argv[0], int(argv[1]), float(argv[2]), float(argv[3])
+    m_sz = [int(x) for x in argv[4:]]
+    ctx = d.Context(0)
+    d_factor = 1.0
+    path = c.out_path(directory, "_BQRRP_speed_comparisons_mat_size_num_info_lines_7.txt")
+    with open(path, "a") as f:
+        f.write("Description: Results from the BQRRP speed comparison benchmark, recording the time it takes to perform BQRRP and alternative QR and QRCP factorizations."
+                "\nFile format: 7 columns, containing time for each algorithm: BQRRP+CholQR, BQRRP+QRF, HQRRP, HQRRP+QRF, HQRRP+CholQR, QRF, QP3;"
+                "               rows correspond to BQRRP runs with varying mat sizes, with numruns repititions of each mat size."
+                "\nNum OMP threads:0 (device: MI355X)"
+                f"\nInput type:{c.MAT_TYPE_IDS['gaussian']}"
+                f"\nInput row sizes:{', '.join(map(str, m_sz))}, , input row/column ratio: {ratio}"
+                f"\nAdditional parameters: BQRRP columns/block size ratio: {blk_ratio} num runs per size {numruns} BQRRP d factor: {d_factor:f}\n")
+    t_all = time.perf_counter()
+    for m in m_sz:
+        n = int(m / ratio)
+        b = max(1, int(n / blk_ratio))
+        for _ in range(numruns):
+            row = []
+            for what in ("bqrrp_cholqr", "bqrrp_qrf", "hqrrp", "hqrrp_qrf", "hqrrp_cholqr", "qrf", "qp3"):
+                A = c.regen(ctx, "gaussian", m, n)
+                fn = {"bqrrp_cholqr": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=1),
+                      "bqrrp_qrf": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=2),
+                      "hqrrp": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int(d_factor * b) - b + 10 if d_factor > 1 else 10, qr_type=0),
+                      "hqrrp_qrf": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=1),
+                      "hqrrp_cholqr": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=2),
+                      "qrf": lambda: c.geqrf(ctx, A, m, n), "qp3": lambda: c.geqp3(ctx, A, m, n)}[what]
+                row.append(c.timed_us(fn))
+                del A
+            with open(path, "a") as f:
+                f.write(",  ".join(map(str, row)) + ",\n")
+    with open(path, "a") as f:
+        f.write(f"Total benchmark execution time:{int((time.perf_counter() - t_all) * 1e6)}\n")
+    return path
+
+
+def runtime_breakdown(argv):
+    directory, qr_tall, numruns, m, n = argv[0], argv[1], int(argv[2]), int(argv[3]), int(argv[4])
+    b_sz = [int(x) for x in argv[5:]]
+    ctx = d.Context(0)
+    d_factor = 1.0
+    path = c.out_path(directory, "_BQRRP_runtime_breakdown_num_info_lines_7.txt")
+    with open(path, "a") as f:
+        f.write("Description: Results from the BQRRP runtime breakdown benchmark, recording the time it takes to perform every subroutine in BQRRP."
+                "\nFile format: 10 data columns, each corresponding to a given BQRRP subroutine: skop_t_dur, preallocation_t_dur, qrcp_wide_t_dur, panel_preprocessing_t_dur, qr_tall_t_dur, q_reconstruction_t_dur, apply_transq_t_dur, sample_update_t_dur, t_other, total_t_dur"
+                "               rows correspond to BQRRP runs with block sizes varying as specified, with numruns repititions of each block size"
+                "\nNum OMP threads:0 (device: MI355X)"
+                f"\nInput type:{c.MAT_TYPE_IDS['gaussian']}"
+                f"\nInput size:{m} by {n}"
+                f"\nAdditional parameters: Tall QR subroutine {qr_tall} BQRRP block sizes: {', '.join(map(str, b_sz))}, num runs per size {numruns} BQRRP d factor: {d_factor:f}\n")
+    t_all = time.perf_counter()
+    for b in b_sz:
+        for _ in range(numruns):
+            A = c.regen(ctx, "gaussian", m, n)
+            t = d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=QR_TALL[qr_tall], timing=True)["times_us"]
+            # the device driver draws its workspace from the context's arena: the reference's preallocation column is 0
+            cols = [t[0], 0] + list(t[1:])
+            with open(path, "a") as f:
+                f.write(", ".join(map(str, cols)) + ", \n")
+            del A
+    with open(path, "a") as f:
+        f.write(f"Total benchmark execution time:{int((time.perf_counter() - t_all) * 1e6)}\n")
+    return path
+
+
+def pivot_quality(argv):
+    directory, m, n, b = argv[0], int(argv[1]), int(argv[2]), int(argv[3])
+    m_type = argv[4] if len(argv) > 4 else "polynomial"
+    kw = dict(cond_num=1e10, exponent=2.0) if m_type in ("polynomial", "exponential", "step") else {}
+    ctx = d.Context(0)
+    d_factor = 1.0
+    hdr = (f"\nNum OMP threads:0 (device: MI355X)\nInput type:{c.MAT_TYPE_IDS[m_type]}\nInput size:{m} by {n}"
+           f"\nAdditional parameters: BQRRP block size: {b} BQRRP d factor: {d_factor:f}\n")
+    # metric 1: trailing-block norm ratios ||R_qp3[i:, i:]|| / ||R_bqrrp[i:, i:]||  (BQRRP_pivot_quality.cc:116-176)
+    A = c.regen(ctx, m_type, m, n, **kw)
+    c.geqp3(ctx, A, m, n)
+    R_qp3 = c.upper_factor(A, m, n)
+    A = c.regen(ctx, m_type, m, n, **kw)
+    d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=1)
+    R_bq = c.upper_factor(A, m, n)
+    p1 = c.out_path(directory, "_BQRRP_pivot_quality_metric_1_num_info_lines_6.txt")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratios = c.trailing_norms(R_qp3) / c.trailing_norms(R_bq)
+    with open(p1, "a") as f:
+        f.write("Description: Results of the BQRRP pivot quality benchmark for the metric of ratios of the norms of R factors output by QP3 and BQRRP."
+                "\nFile format: File output is one-line." + hdr)
+        f.write("".join(f"{x:g},  " for x in ratios) + "\n")
+    # metric 2: |R_ii| / sigma_i, line one GEQP3, line two BQRRP (the order the reference writes them, :268-283)
+    A = c.regen(ctx, m_type, m, n, **kw)
+    S = c.singular_values(ctx, A, m, n)
+    p2 = c.out_path(directory, "_BQRRP_pivot_quality_metric_2_num_info_lines_6.txt")
+    with open(p2, "a") as f, np.errstate(divide="ignore", invalid="ignore"):
+        f.write("Description: Results of the BQRRP pivot quality benchmark for the metric of ratios of the diagonal R entries to true singular values."
+                "\nFile format: Line one contains BQRRP retults, line 2 contains GEQP3 retults." + hdr)
+        f.write("".join(f"{x:g},  " for x in np.abs(np.diag(R_qp3)) / S) + "\n")
+        f.write("".join(f"{x:g},  " for x in np.abs(np.diag(R_bq)) / S) + "\n")
+    return p1, p2
+
+
+MAINS = {"speed_mat_size": speed_mat_size, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality}
+
+if __name__ == "__main__":
+    if len(sys.argv) < 3 or sys.argv[1] not in MAINS:
+        print(__doc__)
+        sys.exit(1)
+    print(MAINS[sys.argv[1]](sys.argv[2:]))

@@ -1,0 +1,60 @@
+"""-m gpu: the benchmark mains (benchmarks/*.py) run at toy sizes and write the reference's file formats
+(benchmark/bench_BQRRP/*.cc, bench_CQRRPT/*.cc): `num_info_lines` header lines, then comma-separated rows."""
+import re
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(path):
+    lines = open(path).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:")
+    # the header is the reference's, verbatim in structure: it ends with the "Additional parameters" line (6 lines; the
+    # "num_info_lines_7" in two of the file names counts one more than the reference itself writes)
+    last = max(i for i, ln in enumerate(lines) if ln.startswith("Additional parameters"))
+    assert last == 5
+    body = lines[last + 1:]
+    return [[x for x in re.split(r",\s*", ln.strip()) if x] for ln in body]
+
+
+def test_bqrrp_mains(tmp_path):
+    from benchmarks import bqrrp
+
+    p = bqrrp.speed_mat_size([str(tmp_path), "2", "1", "8", "512", "768"])
+    rows = _rows(p)
+    assert rows[-1][0].startswith("Total benchmark execution time:")
+    data = rows[:-1]
+    assert len(data) == 4 and all(len(r) == 7 and all(int(x) > 0 for x in r) for r in data)      # 2 sizes x 2 runs, 7 algorithms
+    p = bqrrp.runtime_breakdown([str(tmp_path), "cholqr", "2", "1024", "512", "64", "128"])
+    data = _rows(p)[:-1]
+    assert len(data) == 4 and all(len(r) == 10 for r in data)
+    for r in data:
+        t = [int(x) for x in r]
+        assert t[9] > 0 and abs(sum(t[:9]) - t[9]) <= 2                      # the columns add up to the total
+    p1, p2 = bqrrp.pivot_quality([str(tmp_path), "600", "256", "32", "polynomial"])
+    r1 = _rows(p1)
+    assert len(r1) == 1 and len(r1[0]) == 256
+    ratios = np.array([float(x) for x in r1[0]])
+    assert abs(ratios[0] - 1.0) < 1e-12 and np.all((ratios[:200] > 0.2) & (ratios[:200] < 5))   # BQRRP's R tracks QP3's
+    r2 = _rows(p2)
+    assert len(r2) == 2 and all(len(r) == 256 for r in r2)
+    q = np.array([[float(x) for x in r] for r in r2])
+    assert np.all((q[:, :200] > 0.05) & (q[:, :200] < 20))                   # |R_ii| within a modest factor of sigma_i
+
+
+def test_cqrrpt_mains(tmp_path):
+    from benchmarks import cqrrpt
+
+    p = cqrrpt.speed([str(tmp_path), "1", "4096", "64", "128"])
+    data = _rows(p)[:-1]
+    assert len(data) == 2 and all(len(r) == 8 and all(int(x) > 0 for x in r) for r in data)
+    p = cqrrpt.runtime_breakdown([str(tmp_path), "2", "4096", "128"])
+    data = _rows(p)[:-1]
+    assert len(data) == 2 and all(len(r) == 8 for r in data)
+    p1, p2 = cqrrpt.pivot_quality([str(tmp_path), "2000", "128", "polynomial"])
+    r1, r2 = _rows(p1), _rows(p2)
+    assert len(r1) == 1 and len(r1[0]) == 128 and len(r2) == 2
+    ratios = np.array([float(x) for x in r1[0]])
+    assert abs(ratios[0] - 1.0) < 1e-10
