@@ -36,6 +36,7 @@ struct QrcpArgs {
     int pivot;                // 0: plain Householder QR (geqr2 order), jpvt untouched
     int64_t max_steps;        // number of columns to factor (< min(m,n): partial factorization, HQRRP's sketch step)
     int hq_formula;           // 1: norm down-date written as (1+t)(1-t) (rl_hqrrp.hh:373), 0: dlaqp2's 1 - t^2
+    int v_in_lds;             // the step's reflector is staged in LDS (m fits) or read from its published slot (tall inputs)
 };
 
 // ---- cross-workgroup traffic uses agent-scope relaxed atomics on 8-byte granules (sc1 write-through stores /
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     T* l_vn1 = reinterpret_cast<T*>(qr_smem);            // partial norms of the owned positions (local to the owner)
     T* l_vn2 = l_vn1 + cpw;
     T* l_v = l_vn2 + cpw;                                // the step's finished pivot column (m)
-    T* lds_cols = l_v + m;
+    T* lds_cols = l_v + (g.v_in_lds ? m : 0);
     __shared__ T s_cval[256];
     __shared__ int64_t s_cpos[256];
     __shared__ int s_cw[256];
@@ -187,11 +188,14 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
         const T tauk = g.cand_tau[par * G + wstar];
         const T* vcol = g.slot + ((int64_t)par * G + wstar) * m;    // finished column: R above k, beta at k, v below
         // ---- C. install the moved columns, swap bookkeeping
-        for (int64_t i = tid; i < m; i += 256) l_v[i] = vcol[i];
-        __syncthreads();
+        if (g.v_in_lds) {
+            for (int64_t i = tid; i < m; i += 256) l_v[i] = vcol[i];
+            __syncthreads();
+        }
+        const T* vv = g.v_in_lds ? l_v : vcol;       // tall inputs: straight from the published slot (L2)
         if (me == own_k) {
             T* col = colptr(k);
-            for (int64_t i = tid; i < m; i += 256) col[i] = l_v[i];
+            for (int64_t i = tid; i < m; i += 256) col[i] = vv[i];
             if (tid == 0) g.tau[k] = tauk;
         }
         if (p != k && me == own_p) {
@@ -213,9 +217,9 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
             T* col = colptr(j);
             if (tauk != T(0)) {
                 T w = 0;
-                for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : l_v[i]) * col[i];
+                for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : vv[i]) * col[i];
                 w = wave_sum(w) * tauk;
-                for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : l_v[i]);
+                for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : vv[i]);
             }
             if (!g.pivot) continue;
             // dlaqp2: vn1(j) *= sqrt(max(0, 1 - (|A(k,j)|/vn1(j))^2)), recomputed when cancellation is detected
@@ -635,8 +639,9 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     }
     hipLaunchKernelGGL(zero_u32, dim3(1), dim3(1), 0, c->stream, g.bar);
     const size_t cpw_final = (size_t)((n + G - 1) / G);
-    const size_t dyn = (2 * cpw_final + (size_t)m) * sizeof(T) + (use_lds ? cpw_final * (size_t)m * sizeof(T) : 0);
-    if (dyn > 150 * 1024) { rlhip_ws_release(c, mark); return -2; }   // pivoted / partial factorizations keep the reflector in LDS: m <= ~18000 rows
+    g.v_in_lds = use_lds || ((2 * cpw_final + (size_t)m) * sizeof(T) <= 140 * 1024);
+    const size_t dyn = (2 * cpw_final + (g.v_in_lds ? (size_t)m : 0)) * sizeof(T) + (use_lds ? cpw_final * (size_t)m * sizeof(T) : 0);
+    if (dyn > 150 * 1024) { rlhip_ws_release(c, mark); return -2; }   // only the per-column norms left: n / G > ~9000 columns per workgroup
     hipLaunchKernelGGL(qrcp_kernel<T>, dim3((unsigned)G), dim3(256), dyn, c->stream, g);
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);

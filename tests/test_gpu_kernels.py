@@ -310,7 +310,8 @@ def test_col_swap_gather_contract_device(ctx, orc, m, n, k, seed):
 
 
 @pytest.mark.parametrize("m,n,kind", [(50, 20, "scaled"), (300, 200, "scaled"), (1280, 1024, "gauss"), (200, 300, "scaled"),
-                                      (640, 512, "lowrank"), (33, 33, "gauss")])
+                                      (640, 512, "lowrank"), (33, 33, "gauss"),
+                                      (40000, 24, "scaled"), (70000, 96, "gauss")])     # tall: reflector read from its published slot, not LDS
 def test_geqp3_pivots_match_lapack(ctx, orc, m, n, kind):
     import torch
 
