@@ -263,6 +263,14 @@ int rlhip_scal_rows_idx_f32(rlhip_ctx* ctx, int64_t cnt, const int64_t* idx_dev,
 int rlhip_gen_kahan_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double theta, double perturb);
 int rlhip_gen_kahan_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float theta, float perturb);
 
+/* symmetrize: F (n x n, ldf) = the symmetric matrix whose `uplo` triangle is stored in A; the other triangle of A is not read
+ * (linops::ExplicitSymLinOp, RandLAPACK/linops/rl_sym_linops.hh:55-98).  axpby: y = alpha * x + beta * y on n-vectors (beta == 0
+ * overwrites without reading y) -- the scal / axpy / copy steps of REVD2's power_error_est (drivers/rl_revd2.hh:34-63). */
+int rlhip_symmetrize_f64(rlhip_ctx* ctx, char uplo, int64_t n, const double* A, int64_t lda, double* F, int64_t ldf);
+int rlhip_symmetrize_f32(rlhip_ctx* ctx, char uplo, int64_t n, const float* A, int64_t lda, float* F, int64_t ldf);
+int rlhip_axpby_f64(rlhip_ctx* ctx, int64_t n, double alpha, const double* x, double beta, double* y);
+int rlhip_axpby_f32(rlhip_ctx* ctx, int64_t n, float alpha, const float* x, float beta, float* y);
+
 /* ---- sparse linear operator kernels (linops::SparseLinOp; reference RandLAPACK/linops/rl_sparse_linop.hh:125-330 forwards to
  *      RandBLAS left_spmm/right_spmm).  CSR with int64 indices, all arrays DEVICE pointers.
  *      csr_spmm: C (m x n) = alpha * A (m x k, CSR) * B (k x n) + beta * C; layout 'C' (column-major B, C) or 'R' (row-major).

@@ -138,6 +138,17 @@ int rlhip_drv_mat_gen_f32(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_
                           int diag, float theta, float perturb, float frac_spectrum_one, int check_true_rank, float* A,
                           uint32_t state[6], int64_t* rank_out);
 
+/* REVD2<SYRF<SYPS, Stabilization>>::call (drivers/rl_revd2.hh:96-243; comps/rl_syrf.hh, rl_syps.hh): A ~ V diag(eigvals) V^T for a
+ * symmetric PSD A given by its `uplo` triangle (m x m, ld m, DEVICE; the other triangle is never read).  *k: in = starting rank,
+ * out = rank used.  *V (m x k) and *eigvals (k) are library-allocated DEVICE buffers (rlhip_free).  orth_kind: 0 CholQRQ, 1 HQRQ,
+ * 2 PLUL (the reference's tests use HQRQ).  err_out (may be NULL): the final power-method error estimate. */
+int rlhip_drv_revd2_f64(rlhip_ctx* ctx, char uplo, int64_t m, const double* A, int64_t* k, double tol, int64_t syps_passes,
+                        int64_t passes_per_stab, int error_est_p, int orth_kind, double** V, double** eigvals, uint32_t state[6],
+                        double* err_out);
+/* SYRF::call alone (comps/rl_syrf.hh:44-92): Q (m x k, DEVICE, caller-allocated) <- orth(A * SYPS sketch). */
+int rlhip_drv_syrf_f64(rlhip_ctx* ctx, char uplo, int64_t m, const double* A, int64_t k, int64_t syps_passes, int64_t passes_per_stab,
+                       int orth_kind, double* Q, uint32_t state[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -562,3 +562,67 @@ def mat_gen(m_type, m, n, rank=None, cond_num=1.0, scaling=1.0, exponent=1.0, di
             Cm[i, i] = 1.0
         return (S @ Cm + A)[:, :n], ctr
     raise ValueError(m_type)
+
+
+# ---- symmetric (Nystrom) path: SYPS / SYRF / REVD2 (numpy restatement; shares the random stream through fill_dense) ---------
+def _sym_from_triangle(A, uplo):
+    """the matrix linops::ExplicitSymLinOp represents: only the `uplo` triangle of A is read (rl_sym_linops.hh:77-97)"""
+    T = np.triu(np.nan_to_num(A, nan=0.0)) if uplo == "U" else np.tril(np.nan_to_num(A, nan=0.0))
+    if uplo == "U":
+        assert not np.isnan(np.triu(A)).any()
+    else:
+        assert not np.isnan(np.tril(A)).any()
+    return T + T.T - np.diag(np.diag(T))
+
+
+def syps(A, k, p, q, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """SYPS::call (comps/rl_syps.hh:81-140) on a full symmetric matrix.  returns (sketch m x k, next_ctr)"""
+    m = A.shape[0]
+    S, ctr = fill_dense(m, k, ctr, key)
+    for done in range(1, p + 1):
+        S = A @ S
+        if done % q == 0:
+            S = np.linalg.qr(S, mode="reduced")[0]            # geqrf + ungqr
+    return S, ctr
+
+
+def syrf(A, k, p, q, orth_kind=1, uplo="U", ctr=(0, 0, 0, 0), key=(0, 0)):
+    """SYRF::call (comps/rl_syrf.hh:54-92).  returns (rc, Q, next_ctr)"""
+    Af = _sym_from_triangle(A, uplo)
+    S, ctr = syps(Af, k, p, q, ctr, key)
+    rc, Q = stab(orth_kind, Af @ S)
+    return rc, Q, ctr
+
+
+def revd2(A, k, tol, p=2, q=1, error_est_p=10, orth_kind=1, uplo="U", ctr=(0, 0, 0, 0), key=(0, 0)):
+    """REVD2::call (drivers/rl_revd2.hh:120-243).  returns dict(k, V, eigvals, err, next_ctr)"""
+    import scipy.linalg as sla
+    Af = _sym_from_triangle(A, uplo)
+    m = Af.shape[0]
+    est_ctr, est_key = tuple(ctr), ((key[0] + 1) & 0xFFFFFFFF, key[1] + (1 if key[0] == 0xFFFFFFFF else 0))     # key.incr(1), :135
+    eps = np.finfo(np.float64).eps
+    while True:
+        S, ctr = syps(Af, k, p, q, ctr, key)
+        rc, Om = stab(orth_kind, Af @ S)                       # SYRF, :147
+        assert rc == 0
+        Y = Af @ Om                                            # :150
+        nu = eps * np.linalg.norm(Y)                           # :153
+        R = sla.cholesky(nu * (Om.T @ Om) + Om.T @ Y, lower=False)      # :159-170 (potrf reads the upper triangle)
+        B = sla.solve_triangular(R, Y.T, trans="T", lower=False).T      # Y R^-1, :173
+        V, s, _ = np.linalg.svd(B, full_matrices=False)        # gesdd SomeVec, :176
+        ev = s ** 2
+        r = int(np.sum(ev > nu))
+        ev[:r] = np.where(ev[:r] - nu < 0, ev[:r], ev[:r] - nu)
+        V[:, r:] = 0.0
+        g, est_ctr = fill_dense(m, 1, est_ctr, est_key)        # :198-199
+        g = g[:, 0]
+        err = 0.0
+        for _ in range(error_est_p):                           # power_error_est, :34-63
+            g = g / np.linalg.norm(g)
+            w = Af @ g - (V * ev) @ (V.T @ g)
+            err = float(g @ w)
+            g = w
+        if err <= 5 * max(tol, nu) or k == m:
+            break
+        k = m if 2 * k > m else 2 * k
+    return dict(k=k, V=V, eigvals=ev, err=err, next_ctr=ctr)

@@ -55,6 +55,8 @@ def _blas3(T):
         "scal_cols": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "scal_rows_idx": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, T],
         "gen_kahan": [c_vp, c_i64, c_i64, c_vp, c_i64, T, T],
+        "symmetrize": [c_vp, c_char, c_i64, c_vp, c_i64, c_vp, c_i64],
+        "axpby": [c_vp, c_i64, T, c_vp, T, c_vp],
         "csr_spmm": [c_vp, c_char, c_i64, c_i64, c_i64, T, c_vp, c_vp, c_vp, c_vp, c_i64, T, c_vp, c_i64],
         "csr_transpose": [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
         "csr_densify_cols": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64],
@@ -145,6 +147,9 @@ SIGNATURES.update({
                                           C.POINTER(c_i64), C.POINTER(c_dbl), c_int]),
     "rlhip_linop_apply_f64": (c_int, [c_vp, _ldp, _ldp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
 })
+SIGNATURES["rlhip_drv_revd2_f64"] = (c_int, [c_vp, c_char, c_i64, c_vp, C.POINTER(c_i64), c_dbl, c_i64, c_i64, c_int, c_int, dpp, dpp, u32p,
+                                               C.POINTER(c_dbl)])
+SIGNATURES["rlhip_drv_syrf_f64"] = (c_int, [c_vp, c_char, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, u32p])
 SIGNATURES["rlhip_drv_mat_gen_f64"] = (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_dbl, c_int, c_vp, u32p,
                                                  C.POINTER(c_i64)])
 for _name in ("stab", "rsvd", "cqrrpt", "hqrrp", "bqrrp", "qr_linops", "mat_gen"):      # fp32 instantiations: same shapes, float scalars

@@ -518,4 +518,44 @@ int rlhip_drv_mat_gen_f32(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_
     return drv_mat_gen<float>(ctx, type, m, n, rank, cond_num, scaling, exponent, diag, theta, perturb, frac_spectrum_one, check_true_rank, A, state, rank_out);
 }
 
+
+int rlhip_drv_revd2_f64(rlhip_ctx* ctx, char uplo, int64_t m, const double* A, int64_t* k, double tol, int64_t syps_passes,
+                        int64_t passes_per_stab, int error_est_p, int orth_kind, double** V, double** eigvals, uint32_t state[6],
+                        double* err_out) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if (uplo != 'U' && uplo != 'L') throw RandLAPACK::Error("uplo must be U or L");
+        using SYPS_t = RandLAPACK::SYPS<double, RNG>;
+        using Orth_t = RandLAPACK::Stabilization<double>;
+        using SYRF_t = RandLAPACK::SYRF<SYPS_t, Orth_t>;
+        SYPS_t syps(q, syps_passes, passes_per_stab, false, false);
+        auto orth = make_stab<double>(q, orth_kind, false);
+        SYRF_t syrf(syps, *orth, false, false);
+        RandLAPACK::REVD2<SYRF_t> revd2(syrf, error_est_p, false);
+        State st = load_state(state);
+        *V = nullptr; *eigvals = nullptr;
+        int rc = revd2.call(uplo == 'U' ? RandLAPACK::Uplo::Upper : RandLAPACK::Uplo::Lower, m, A, *k, tol, *V, *eigvals, st);
+        store_state(st, state);
+        if (err_out) *err_out = revd2.last_err;
+        return rc;
+    });
+}
+
+int rlhip_drv_syrf_f64(rlhip_ctx* ctx, char uplo, int64_t m, const double* A, int64_t k, int64_t syps_passes, int64_t passes_per_stab,
+                       int orth_kind, double* Q, uint32_t state[6]) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if (uplo != 'U' && uplo != 'L') throw RandLAPACK::Error("uplo must be U or L");
+        using SYPS_t = RandLAPACK::SYPS<double, RNG>;
+        using Orth_t = RandLAPACK::Stabilization<double>;
+        SYPS_t syps(q, syps_passes, passes_per_stab, false, false);
+        auto orth = make_stab<double>(q, orth_kind, false);
+        RandLAPACK::SYRF<SYPS_t, Orth_t> syrf(syps, *orth, false, false);
+        State st = load_state(state);
+        int rc = syrf.call(uplo == 'U' ? RandLAPACK::Uplo::Upper : RandLAPACK::Uplo::Lower, m, A, k, Q, st, nullptr);
+        store_state(st, state);
+        return rc;
+    });
+}
+
 }  // extern "C"

@@ -67,3 +67,41 @@ inline unsigned grid_for(int64_t total) { return (unsigned)std::min<int64_t>((to
     }
 CAPI(double, f64)
 CAPI(float, f32)
+
+// ---- pieces of the symmetric (Nystrom) path: linops::ExplicitSymLinOp, REVD2's error estimator (drivers/rl_revd2.hh:34-63)
+namespace {
+// F (n x n, full) from the `uplo` triangle of A; the other triangle of A is never read (it may hold NaNs, test_revd2.cc:123-128)
+template <typename T>
+__global__ void symmetrize_kernel(int upper, int64_t n, const T* __restrict__ A, int64_t lda, T* __restrict__ F, int64_t ldf) {
+    const int64_t total = n * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % n, j = e / n;
+        const bool stored = upper ? (i <= j) : (i >= j);
+        F[i + j * ldf] = stored ? A[i + j * lda] : A[j + i * lda];
+    }
+}
+template <typename T>
+__global__ void axpby_kernel(int64_t n, T alpha, const T* __restrict__ x, T beta, T* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        y[e] = (beta == (T)0) ? alpha * x[e] : alpha * x[e] + beta * y[e];
+}
+}  // namespace
+
+#define CAPI2(T, SUF)                                                                                                             \
+    extern "C" int rlhip_symmetrize_##SUF(rlhip_ctx* c, char uplo, int64_t n, const T* A, int64_t lda, T* F, int64_t ldf) {       \
+        const int up = (uplo == 'U' || uplo == 'u') ? 1 : (uplo == 'L' || uplo == 'l') ? 0 : -1;                                  \
+        if (!c || up < 0 || n < 0 || lda < (n > 1 ? n : 1) || ldf < (n > 1 ? n : 1)) return -2;                                   \
+        if (n == 0) return 0;                                                                                                     \
+        hipLaunchKernelGGL(symmetrize_kernel<T>, dim3(grid_for(n * n)), dim3(256), 0, c->stream, up, n, A, lda, F, ldf);          \
+        RLHIP_LAUNCH_CHECK();                                                                                                     \
+        return 0;                                                                                                                 \
+    }                                                                                                                             \
+    extern "C" int rlhip_axpby_##SUF(rlhip_ctx* c, int64_t n, T alpha, const T* x, T beta, T* y) {                                \
+        if (!c || n < 0) return -2;                                                                                               \
+        if (n == 0) return 0;                                                                                                     \
+        hipLaunchKernelGGL(axpby_kernel<T>, dim3(grid_for(n)), dim3(256), 0, c->stream, n, alpha, x, beta, y);                    \
+        RLHIP_LAUNCH_CHECK();                                                                                                     \
+        return 0;                                                                                                                 \
+    }
+CAPI2(double, f64)
+CAPI2(float, f32)

@@ -304,6 +304,31 @@ def drv_abrik(ctx: Context, A, m, n, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0
                 next_ctr=tuple(int(x) for x in st[:4]))
 
 
+def drv_revd2(ctx: Context, A, m, k, tol, uplo="U", syps_passes=2, passes_per_stab=1, error_est_p=10, orth_kind=1, ctr=(0, 0, 0, 0),
+              key=(0, 0)):
+    """REVD2::call on the symmetric matrix whose `uplo` triangle is stored in A (column-major tensor (m, m)).
+    Returns dict(rc, k, V, eigvals, err, next_ctr); V is a column-major tensor (k, m)."""
+    Vp, Ep = C.c_void_p(), C.c_void_p()
+    kk = C.c_int64(k)
+    err = C.c_double(0)
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_revd2_f64(ctx.h, uplo.encode(), m, A.data_ptr(), C.byref(kk), tol, syps_passes, passes_per_stab, error_est_p,
+                                     orth_kind, C.byref(Vp), C.byref(Ep), st, C.byref(err))
+    _drv_check(ctx, rc, "revd2")
+    kf = int(kk.value)
+    return dict(rc=rc, k=kf, V=_adopt(ctx, Vp, m, kf), eigvals=_adopt(ctx, Ep, kf, 1).reshape(-1), err=float(err.value),
+                next_ctr=tuple(int(x) for x in st[:4]))
+
+
+def drv_syrf(ctx: Context, A, m, k, uplo="U", syps_passes=2, passes_per_stab=1, orth_kind=1, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """SYRF::call.  Returns dict(rc, Q, next_ctr) with Q a column-major tensor (k, m)."""
+    Q = cm_zeros(m, k, device=f"cuda:{ctx.device}")
+    st = _state_arr(ctr, key)
+    rc = ctx.lib.rlhip_drv_syrf_f64(ctx.h, uplo.encode(), m, A.data_ptr(), k, syps_passes, passes_per_stab, orth_kind, Q.data_ptr(), st)
+    _drv_check(ctx, rc, "syrf")
+    return dict(rc=rc, Q=Q, next_ctr=tuple(int(x) for x in st[:4]))
+
+
 MAT_TYPES = {"polynomial": 0, "exponential": 1, "gaussian": 2, "step": 3, "spiked": 4, "adverserial": 5, "bad_cholqr": 6, "kahan": 7}
 
 

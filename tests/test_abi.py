@@ -75,6 +75,12 @@ using RNG = r123::Philox4x32;
   template void RandLAPACK::util::get_L<T>(int64_t, int64_t, T*, int, blas::Queue&); \\
   template void RandLAPACK::util::get_U<T>(int64_t, int64_t, T*, int64_t, blas::Queue&); \\
   template bool RandLAPACK::util::diag_is_nonzero<T>(int64_t, const T*, int64_t, blas::Queue&);
+using SYPS_d = RandLAPACK::SYPS<double, RNG>; using SYRF_d = RandLAPACK::SYRF<SYPS_d, RandLAPACK::HQRQ<double>>;
+template class RandLAPACK::REVD2<SYRF_d>;
+template int RandLAPACK::REVD2<SYRF_d>::call(RandLAPACK::linops::ExplicitSymLinOp<double>&, int64_t&, double, double*&, double*&, RandBLAS::RNGState<RNG>&);
+template int RandLAPACK::CQRRT_linops<double, RNG>::call(RandLAPACK::linops::SparseLinOp<double>&, double*, int64_t, double, RandBLAS::RNGState<RNG>&);
+template int RandLAPACK::sCholQR3_linops<float>::call(RandLAPACK::linops::CompositeOperator<RandLAPACK::linops::DenseLinOp<float>, RandLAPACK::linops::SparseLinOp<float>>&, float*, int64_t);
+template void RandLAPACK::gen::mat_gen<double, RNG>(RandLAPACK::gen::mat_gen_info<double>&, double*, RandBLAS::RNGState<RNG>&, blas::Queue&);
 INST(double)
 INST(float)
 int main(){return 0;}

@@ -384,3 +384,47 @@ def test_mat_gen_oracle_spiked_adversarial_kahan(orc):
     K, _ = orc.mat_gen("kahan", 9, 9, theta=1.2, perturb=1e3)
     c, s = np.cos(1.2), np.sin(1.2)
     assert np.allclose(K, np.triu(K)) and abs(K[2, 5] + c * s**2) < 1e-15 and abs(K[3, 3] - (s**3 + 1e3 * np.finfo(float).eps * 6)) < 1e-15
+
+
+# ---- REVD2 / SYRF (test/drivers/test_revd2.cc: rank-deficient PSD input, rank doubling, uplo with NaNs in the unused triangle)
+def _psd(m, rank, rng, decay=None):
+    B = rng.standard_normal((m, rank))
+    if decay is not None:
+        B = B * decay
+    return B @ B.T
+
+
+def test_revd2_oracle_exact_rank_and_doubling(orc):
+    rng = np.random.default_rng(0)
+    m, rank = 200, 40
+    A = _psd(m, rank, rng)
+    out = orc.revd2(A, rank, 1e-8, key=(1, 0))
+    assert out["k"] == rank                                                   # exact-rank input: one pass, no doubling
+    rel = np.linalg.norm(A - (out["V"] * out["eigvals"]) @ out["V"].T) / np.linalg.norm(A)
+    assert rel < 1e-12
+    np.testing.assert_allclose(np.sort(out["eigvals"])[::-1], np.sort(np.linalg.eigvalsh(A))[::-1][:rank], rtol=1e-10)
+    out2 = orc.revd2(A, 5, 1e-8, key=(1, 0))                                  # start too small: k doubles 5 -> 10 -> 20 -> 40
+    assert out2["k"] == 40
+    assert np.linalg.norm(A - (out2["V"] * out2["eigvals"]) @ out2["V"].T) / np.linalg.norm(A) < 1e-12
+
+
+def test_revd2_oracle_uplo_with_nans(orc):
+    rng = np.random.default_rng(1)
+    m, rank = 120, 20
+    A = _psd(m, rank, rng)
+    Au, Al = np.triu(A), np.tril(A)
+    Au[np.tril_indices(m, -1)] = np.nan
+    Al[np.triu_indices(m, 1)] = np.nan
+    ou = orc.revd2(Au, rank, 1e-8, uplo="U", key=(2, 0))
+    ol = orc.revd2(Al, rank, 1e-8, uplo="L", key=(2, 0))
+    Ru, Rl = (ou["V"] * ou["eigvals"]) @ ou["V"].T, (ol["V"] * ol["eigvals"]) @ ol["V"].T
+    assert not np.isnan(Ru).any() and np.linalg.norm(Ru - Rl) < 1e-10 * np.linalg.norm(A)
+
+
+def test_syrf_oracle_captures_range(orc):
+    rng = np.random.default_rng(2)
+    m, rank = 150, 30
+    A = _psd(m, rank, rng)
+    rc, Q, _ = orc.syrf(A, rank, 2, 1)
+    assert rc == 0 and np.linalg.norm(Q.T @ Q - np.eye(rank)) < 1e-12
+    assert np.linalg.norm(A - Q @ (Q.T @ A)) < 1e-10 * np.linalg.norm(A)
