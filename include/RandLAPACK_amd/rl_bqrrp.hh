@@ -108,7 +108,7 @@ public:
                 lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                       // :336
             } else {                                                                                        // :337-357
                 blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
-                lapack::getrf(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);
+                lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
                 lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
                 util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
                 lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
@@ -246,7 +246,7 @@ public:
                 lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);
             } else {
                 blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
-                lapack::getrf(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);
+                lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
                 lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
                 util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
                 lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);

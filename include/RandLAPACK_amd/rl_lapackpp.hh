@@ -78,6 +78,9 @@ inline void ungqr(int64_t m, int64_t n, int64_t k, float* A, int64_t lda, float 
 // returns info (> 0: exactly singular U, factorization still complete)
 inline int64_t getrf(int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_f64(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf"); return rc; }
 inline int64_t getrf(int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_f32(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf"); return rc; }
+/// getrf whose caller only reads ipiv (same pivots, factors left as scratch)
+inline int64_t getrf_pivots(int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_piv_f64(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf_piv"); return rc; }
+inline int64_t getrf_pivots(int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv, Queue& q) { int rc = rlhip_getrf_piv_f32(q.ctx(), m, n, A, lda, ipiv); blas::check(rc, "getrf_piv"); return rc; }
 inline void laswp(int64_t n, double* A, int64_t lda, int64_t k1, int64_t k2, int64_t const* ipiv, int64_t incx, Queue& q) {
     if (incx != 1) throw blas::Error("laswp: only incx = 1 is on the path");
     blas::check(rlhip_laswp_f64(q.ctx(), n, A, lda, k1, k2, ipiv), "laswp");

@@ -199,6 +199,10 @@ int rlhip_get_diag_f32(rlhip_ctx* ctx, int64_t n, const float* A, int64_t lda, f
 /* lapack::getrf (rl_bqrrp.hh:343, rl_orth.hh:219): row-pivoted LU of an m x n (m up to ~1e5, tall) device matrix;
  * ipiv: DEVICE int64, 1-based, min(m,n) entries.  Returns LAPACK info (first exactly-zero pivot) or 0. */
 int rlhip_getrf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv);
+/* the same factorization when only the PIVOTS are wanted (BQRRP's LU-based qrcp_wide reads J_buffer_lu and discards the factors,
+ * rl_bqrrp.hh:343-352): ipiv is identical; A is left as scratch (U is valid, L misses the interchanges of later panels). */
+int rlhip_getrf_piv_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* ipiv);
+int rlhip_getrf_piv_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv);
 int rlhip_getrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv);
 /* lapack::geqrf (rl_orth.hh:157, rl_bqrrp.hh:356,515): Householder QR, reflectors below the diagonal, tau: DEVICE.
  * lapack::ungqr(m, n, k = n) (rl_orth.hh:162): overwrite the reflectors with the first n columns of Q (k must equal n).

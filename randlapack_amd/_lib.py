@@ -52,6 +52,7 @@ def _blas3(T):
         "ungqr": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "laswp": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
         "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "getrf_piv": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "scal_cols": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "scal_rows_idx": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, T],
         "gen_kahan": [c_vp, c_i64, c_i64, c_vp, c_i64, T, T],

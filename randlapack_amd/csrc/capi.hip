@@ -25,7 +25,7 @@ template <typename T> int larft_gram(rlhip_ctx*, int64_t, int64_t, const T*, int
 template <typename T> int row_sign(rlhip_ctx*, int64_t, T*, int64_t, const T*);
 template <typename T> int tau_from_t(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, T*);
 template <typename T> int any_abs_gt(rlhip_ctx*, int64_t, const T*, T, int*);
-template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*);
+template <typename T> int getrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, int64_t*, int*, int pivots_only);
 int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
 template <typename T> int vrows_explicit(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, T*, int64_t);
@@ -422,7 +422,12 @@ static inline int op_flag(char t, int* out) {
     }                                                                                                           \
     int rlhip_getrf_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv) {               \
         int info = 0;                                                                                           \
-        int rc = rlhip::getrf<T>(c, m, n, A, lda, ipiv, &info);                                                  \
+        int rc = rlhip::getrf<T>(c, m, n, A, lda, ipiv, &info, 0);                                               \
+        return rc ? rc : info;                                                                                  \
+    }                                                                                                           \
+    int rlhip_getrf_piv_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv) {           \
+        int info = 0;                                                                                           \
+        int rc = rlhip::getrf<T>(c, m, n, A, lda, ipiv, &info, 1);                                               \
         return rc ? rc : info;                                                                                  \
     }                                                                                                           \
     int rlhip_geqrf_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau) {                       \

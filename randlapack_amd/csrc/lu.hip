@@ -163,17 +163,236 @@ __global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
     }
 }
 
-// dlaswp on column range [c_lo, c_hi): for j in [j0, j0+pb): swap rows j and ipiv[j]-1; one thread per column
+// ---- register-resident variant.  A thread owns RPT rows of the panel (rows lo + tid + 256 q) as RPT x 32 values in VGPRs, so the
+// elimination is pure register FMAs against the broadcast pivot row, the local pivot search is a wave shuffle reduction, and a
+// workgroup covers 256 * RPT rows: the per-column rendezvous has 4x fewer participants than the LDS version above (the atomic
+// arrivals at the barrier word serialise in L2, ~15 ns each).  Same decisions, same arithmetic order per row -> same pivots and
+// factors bit for bit.
 template <typename T>
-__global__ void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* __restrict__ A, int64_t lda,
-                             const int64_t* __restrict__ ipiv) {
-    int64_t c = c_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= c_hi) return;
-    T* col = A + c * lda;
-    for (int q = 0; q < pb; ++q) {
-        const int64_t j = j0 + q, p = ipiv[j] - 1;
-        if (p != j) { T t = col[j]; col[j] = col[p]; col[p] = t; }
+__device__ __forceinline__ void argmax_take(T& v, int64_t& r, T v2, int64_t r2, int64_t m) {
+    if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; }
+}
+// one column step with the column index as a template parameter: every x[q][c] index is a compile-time constant, so the panel
+// really stays in registers (a runtime-indexed loop put it in scratch)
+template <typename T, int RPT>
+struct LuRegState {
+    T x[RPT][PB];
+    int64_t gr[RPT];
+};
+template <typename T, int RPT, int C>
+__device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww, T* s_piv,
+                                            T* s_drow) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t G = gridDim.x, me = blockIdx.x, m = g.m;
+    const int64_t j = g.j0 + C;
+    constexpr int par = C & 1;
+    // ---- local candidate: first maximum of |x[.][C]| over owned rows >= j (rows increase with q, then with tid)
+    T bv = T(-1); int64_t br = m;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const T v = fabs(st.x[q][C]);
+        if (st.gr[q] >= j && st.gr[q] < m && v > bv) { bv = v; br = st.gr[q]; }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T v2 = __shfl_xor(bv, off); const int64_t r2 = __shfl_xor(br, off);
+        argmax_take(bv, br, v2, r2, m);
+    }
+    if (lane == 0) { s_wv[wid] = bv; s_wr[wid] = br; }
+    __syncthreads();
+    T lbest = s_wv[0]; int64_t lrow = s_wr[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) argmax_take(lbest, lrow, s_wv[w], s_wr[w], m);
+    if (tid == 0) {
+        pstore(g.cand_val + par * G + me, lbest);
+        __hip_atomic_store(g.cand_row + par * G + me, lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the owners of the candidate row and of the diagonal row publish those rows' 32 values
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        if (st.gr[q] == lrow && lrow < m) {
+            T* dst = g.cand_data + ((int64_t)par * G + me) * PB;
+#pragma unroll
+            for (int c2 = 0; c2 < PB; ++c2) pstore(dst + c2, st.x[q][c2]);
+        }
+        if (st.gr[q] == j) {
+            T* dst = g.diag_data + par * PB;
+#pragma unroll
+            for (int c2 = 0; c2 < PB; ++c2) pstore(dst + c2, st.x[q][c2]);
+        }
+    }
+    lu_barrier(g.bar, (unsigned)(G * (++epoch)));
+    // ---- winner (every workgroup, redundantly): thread w looks at workgroup w's candidate.  The winner's row is needed right
+    //      after the decision; instead of a dependent second round trip every thread prefetches, together with the candidates,
+    //      element (tid % 32) of the candidate rows of workgroups tid / 32, tid / 32 + 8, ... (G <= 64 covers 32768+ rows) and the
+    //      decision then picks the winner's copy out of registers.
+    constexpr int PF = 8;                                        // 8 x 8 = 64 workgroups prefetched
+    T pf[PF];
+    const bool pf_ok = G <= 8 * PF;
+    if (pf_ok) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int64_t ww = (tid >> 5) + 8 * u;
+            pf[u] = g.cand_data[((int64_t)par * G + (ww < G ? ww : G - 1)) * PB + (tid & 31)];
+        }
+    }
+    const T dv_pref = g.diag_data[par * PB + (tid & 31)];
+    {
+        T v = T(-1); int64_t r = m; int w = 0;
+        for (int64_t ww = tid; ww < G; ww += 256) {
+            const T v2 = g.cand_val[par * G + ww]; const int64_t r2 = g.cand_row[par * G + ww];
+            if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = (int)ww; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const T v2 = __shfl_xor(v, off); const int64_t r2 = __shfl_xor(r, off); const int w2 = __shfl_xor(w, off);
+            if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = w2; }
+        }
+        if (lane == 0) { s_wv[wid] = v; s_wr[wid] = r; s_ww[wid] = w; }
+    }
+    __syncthreads();
+    T gv = s_wv[0]; int64_t p = s_wr[0]; int wstar = s_ww[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_wr[w] < m && (s_wv[w] > gv || (s_wv[w] == gv && s_wr[w] < p))) { gv = s_wv[w]; p = s_wr[w]; wstar = s_ww[w]; }
+    if (p >= m) p = j;                                           // empty / NaN column: no exchange
+    if (pf_ok) {
+        // the thread group (tid / 32) == wstar % 8 holds the winner's row in pf[wstar / 8]
+        if ((tid >> 5) == (wstar & 7)) {
+            T pv = pf[0];
+#pragma unroll
+            for (int u = 1; u < PF; ++u) pv = ((wstar >> 3) == u) ? pf[u] : pv;
+            s_piv[tid & 31] = (p != j) ? pv : dv_pref;
+        }
+        if (tid < PB) s_drow[tid] = dv_pref;
+    } else if (tid < PB) {
+        const T* prow = g.cand_data + ((int64_t)par * G + wstar) * PB;   // contents of row p (becomes row j)
+        s_drow[tid] = dv_pref;
+        s_piv[tid] = (p != j) ? prow[tid] : dv_pref;
+    }
+    if (me == 0 && tid == 0) g.ipiv[j] = p + 1;
+    __syncthreads();
+    // ---- exchange rows j <-> p in the owners' registers, then eliminate
+    const T piv = s_piv[C];
+    const T rp = T(1) / piv;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        if (p != j) {
+            if (st.gr[q] == j) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_piv[c2];
+            } else if (st.gr[q] == p) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_drow[c2];
+            }
+        }
+        if (piv != T(0) && st.gr[q] > j && st.gr[q] < m) {
+            const T l = st.x[q][C] * rp;
+            st.x[q][C] = l;
+#pragma unroll
+            for (int c2 = C + 1; c2 < PB; ++c2) st.x[q][c2] -= l * s_piv[c2];
+        }
+    }
+    if (piv == T(0) && me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
+    __syncthreads();                                              // s_piv / s_drow / s_w* are rewritten next column
+}
+template <typename T, int RPT, int C>
+__device__ __forceinline__ void lu_reg_steps(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww,
+                                             T* s_piv, T* s_drow) {
+    if constexpr (C < PB) {
+        if (C < g.pb) {                                           // uniform: pb is a kernel argument
+            lu_reg_step<T, RPT, C>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+            lu_reg_steps<T, RPT, C + 1>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+        }
+    }
+}
+template <typename T, int RPT>
+__global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
+    __shared__ T s_wv[4];
+    __shared__ int64_t s_wr[4];
+    __shared__ int s_ww[4];
+    __shared__ T s_piv[PB], s_drow[PB];
+    const int tid = threadIdx.x;
+    const int64_t me = blockIdx.x;
+    const int pb = g.pb;
+    const int64_t j0 = g.j0, m = g.m;
+    const int64_t lo = j0 + me * (256 * RPT);
+    LuRegState<T, RPT> st;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        st.gr[q] = lo + tid + 256 * q;
+        const int64_t rr = st.gr[q] < m ? st.gr[q] : m - 1;           // clamped row: unconditional coalesced loads
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const T t = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];
+            st.x[q][c] = (st.gr[q] < m && c < pb) ? t : T(0);
+        }
+    }
+    unsigned epoch = 0;
+    lu_reg_steps<T, RPT, 0>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        if (st.gr[q] < m) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (c < pb) g.A[st.gr[q] + (j0 + c) * g.lda] = st.x[q][c];
+        }
+    }
+}
+
+// dlaswp on column range [c_lo, c_hi): for j in [j0, j0+pb): swap rows j and ipiv[j]-1.
+// Walking the pb swaps in order costs pb dependent load/store round trips per column (34 us per launch at pb = 32).  The swaps of a
+// panel touch at most 2 pb rows, so every workgroup first composes them into ONE net permutation "row dst receives the old row
+// src" (wave 0, in LDS, ~1 us), and each thread then gathers its column's <= 2 pb source values with independent loads and
+// scatters them: two memory round trips per column instead of pb.
+template <typename T>
+__global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* __restrict__ A, int64_t lda,
+                                                   const int64_t* __restrict__ ipiv) {
+    __shared__ int64_t s_pos[2 * PB], s_src[2 * PB];
+    __shared__ int s_act[2 * PB];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    if (tid < 64) {                                    // one wave: wave-synchronous, no barriers inside
+        const int e = tid;
+        int64_t pos = -1;
+        if (e < pb) pos = j0 + e;
+        else if (e < 2 * pb) pos = ipiv[j0 + (e - pb)] - 1;
+        s_pos[e < 2 * PB ? e : 0] = pos;
+        __builtin_amdgcn_wave_barrier();
+        int act = (e < 2 * pb) ? 1 : 0;
+        for (int l = 0; l < e && act; ++l)
+            if (l < 2 * pb && s_pos[l] == pos) act = 0;          // a later duplicate of a row already listed
+        int64_t content = pos;                                     // which ORIGINAL row's value currently sits at `pos`
+        for (int q = 0; q < pb; ++q) {
+            const int64_t a = j0 + q, b = s_pos[pb + q];
+            if (a == b) continue;                                  // uniform branch (LDS value)
+            // the two holders exchange contents through the wave
+            const int is_a = act && pos == a, is_b = act && pos == b;
+            const unsigned long long ma = __ballot(is_a), mb = __ballot(is_b);
+            const int la = __ffsll((long long)ma) - 1, lb = __ffsll((long long)mb) - 1;
+            const int64_t ca = __shfl(content, la), cb = __shfl(content, lb);
+            if (is_a) content = cb;
+            if (is_b) content = ca;
+        }
+        const int moved = act && content != pos;
+        const unsigned long long mm = __ballot(moved);
+        const int slot = __popcll(mm & ((1ull << e) - 1ull));
+        if (moved) { s_pos[slot] = pos; s_src[slot] = content; }   // compaction: slot <= e, and every lane has read s_pos already
+        if (e == 0) s_n = __popcll(mm);
+        (void)s_act;
+    }
+    __syncthreads();
+    const int64_t c = c_lo + (int64_t)blockIdx.x * 256 + tid;
+    if (c >= c_hi) return;
+    const int nmv = s_n;
+    if (nmv == 0) return;
+    T* col = A + c * lda;
+    T v[2 * PB];
+#pragma unroll
+    for (int e = 0; e < 2 * PB; ++e) v[e] = col[s_src[e < nmv ? e : 0]];      // clamped index: loads stay unconditional and pipelined
+#pragma unroll
+    for (int e = 0; e < 2 * PB; ++e)
+        if (e < nmv) col[s_pos[e]] = v[e];
 }
 
 // U12 = L11^-1 A12 (unit lower, jb x jb at A[j0,j0]); one column per thread
@@ -228,7 +447,7 @@ __global__ void lu_zero_kernel(unsigned* bar, int* info, int zero_info) { *bar =
 namespace rlhip {
 
 template <typename T>
-int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_dev, int* info_host) {
+int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_dev, int* info_host, int pivots_only) {
     if (info_host) *info_host = 0;
     if (m < 0) return -2;
     if (n < 0) return -3;
@@ -261,14 +480,24 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         int64_t rpw = (rows + Gmax - 1) / Gmax;
         if (rpw < 256) rpw = 256;   // fewer, fatter workgroups: the per-column rendezvous and winner search shrink with G
         const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
-        if (rpw > rpw_max) { rlhip_ws_release(c, mark); return -2; }   // > num_cu * 384 rows (fp64): not needed on the path
-        const int64_t G = (rows + rpw - 1) / rpw;
+        if (rpw > rpw_max && getenv("RLHIP_LU_REG_PANEL") && atoi(getenv("RLHIP_LU_REG_PANEL")) == 0) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
+        int64_t G = (rows + rpw - 1) / rpw;
         g.j0 = j0; g.pb = pb; g.rpw = rpw;
         hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
-        hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
+        static int reg_panel = -1;
+        if (reg_panel < 0) { const char* e = getenv("RLHIP_LU_REG_PANEL"); reg_panel = (e && atoi(e) == 0) ? 0 : 1; }
+        constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
+        if (reg_panel && rows >= 1024) {
+            G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
+            hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+        } else if (reg_panel) {
+            G = (rows + 255) / 256;
+            hipLaunchKernelGGL((getrf_panel_reg_kernel<T, 1>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+        } else
+            hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
         RLHIP_LAUNCH_CHECK();
         // row interchanges outside the panel
-        if (j0 > 0)
+        if (j0 > 0 && !pivots_only)   // the interchanges left of the panel only keep L consistent; they never feed a later pivot decision
             hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((j0 + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, j0, j0, pb, A, lda, ipiv_dev);
         const int64_t rest = n - j0 - pb;
         if (rest > 0) {
@@ -296,8 +525,10 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
 template <typename T>
 int laswp(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int64_t k1, int64_t k2, const int64_t* ipiv_dev) {
     if (n <= 0 || k2 < k1) return 0;
-    hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, k1 - 1, (int)(k2 - k1 + 1), A,
-                       lda, ipiv_dev);
+    for (int64_t q0 = k1 - 1; q0 < k2; q0 += PB) {           // the kernel composes up to PB interchanges at a time, in order
+        const int cnt = (int)((k2 - q0 < PB) ? (k2 - q0) : PB);
+        hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, q0, cnt, A, lda, ipiv_dev);
+    }
     RLHIP_LAUNCH_CHECK();
     return 0;
 }
@@ -311,7 +542,7 @@ int luqrcp_piv(rlhip_ctx* c, int64_t sd, int64_t cols, const int64_t* ipiv_dev, 
     return 0;
 }
 
-template int getrf<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, int64_t*, int*);
-template int getrf<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, int64_t*, int*);
+template int getrf<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, int64_t*, int*, int);
+template int getrf<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, int64_t*, int*, int);
 
 }  // namespace rlhip

@@ -17,6 +17,7 @@
 // (coalesced reads, A is streamed exactly once), each thread owns up to 8 sketch rows x 8 columns of
 // accumulators in registers and gathers its nnz source rows per block from LDS with ds_read_b128; partial
 // sketches of the row-block groups are summed in fixed order.  HBM-bound: 8*m*n bytes.
+#include <vector>
 #include "rlhip_internal.h"
 
 namespace {
@@ -440,7 +441,36 @@ int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, c
     int64_t* nmoves = ws_alloc<int64_t>(c, 1);
     unsigned char* seen = ws_alloc<unsigned char>(c, (size_t)n);
     if (!moves || !nmoves || !seen) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    hipLaunchKernelGGL(perm_moves_kernel, dim3(1), dim3(1), 0, c->stream, n, idx_dev, moves, nmoves, seen);
+    if (n >= 4096) {
+        // The cycle decomposition is a serial pointer chase (3-6 ms for one device thread at n = 32768, more than the data movement
+        // it steers): for long index vectors it runs on the host instead -- 8n bytes down, the move list up, one stream sync.
+        std::vector<int64_t> h_idx((size_t)n), h_moves((size_t)(2 * n + 2));
+        std::vector<unsigned char> h_seen((size_t)n, 0);
+        RLHIP_CHECK(hipMemcpyAsync(h_idx.data(), idx_dev, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        int64_t w = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (h_seen[(size_t)i]) continue;
+            h_seen[(size_t)i] = 1;
+            int64_t s_ = h_idx[(size_t)i] - 1;
+            if (s_ < 0 || s_ >= n) { rlhip_ws_release(c, mark); return -7; }
+            if (s_ == i) continue;
+            h_moves[(size_t)w++] = -(i + 1);
+            int64_t j = i;
+            while (s_ != i) {
+                h_moves[(size_t)w++] = s_;
+                h_seen[(size_t)s_] = 1;
+                j = s_;
+                s_ = h_idx[(size_t)j] - 1;
+                if (s_ < 0 || s_ >= n || (s_ != i && h_seen[(size_t)s_])) { rlhip_ws_release(c, mark); return -7; }   // not a permutation
+            }
+        }
+        h_moves[(size_t)(2 * n + 1)] = w;                       // nmoves travels in the same copy when adjacent
+        RLHIP_CHECK(hipMemcpyAsync(moves, h_moves.data(), sizeof(int64_t) * (size_t)std::max<int64_t>(w, 1), hipMemcpyHostToDevice, c->stream));
+        RLHIP_CHECK(hipMemcpyAsync(nmoves, &h_moves[(size_t)(2 * n + 1)], sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));           // the host vectors die at the end of this scope
+    } else
+        hipLaunchKernelGGL(perm_moves_kernel, dim3(1), dim3(1), 0, c->stream, n, idx_dev, moves, nmoves, seen);
     hipLaunchKernelGGL(perm_apply_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, A, lda, moves,
                        nmoves);
     RLHIP_LAUNCH_CHECK();

@@ -296,7 +296,7 @@ def test_col_swap_golden_kats_device(ctx):
 
 
 @pytest.mark.parametrize("m,n,k,seed", [(10, 7, 7, 0), (10, 7, 4, 1), (1000, 200, 200, 2), (8, 12, 5, 3), (5, 1, 1, 5),
-                                        (6, 9, 1, 6), (513, 64, 64, 7)])
+                                        (6, 9, 1, 6), (513, 64, 64, 7), (70, 5000, 5000, 8), (33, 4096, 2000, 9)])   # n >= 4096: host-side cycle decomposition
 def test_col_swap_gather_contract_device(ctx, orc, m, n, k, seed):
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((m, n))
@@ -398,6 +398,31 @@ def test_getrf_pivots_and_factors_match_lapack(ctx, m, n):
     assert info == info_ref == 0
     np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)                     # pivot rows: bit-exact
     np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=5e-13 * np.abs(lu_ref).max(), rtol=0)
+    # pivots-only variant (BQRRP's qrcp_wide reads nothing else): identical ipiv, U part still the LAPACK U
+    Ad2 = d.cm_from_numpy(A)
+    ip2 = torch.zeros(min(m, n), dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_getrf_piv_f64(ctx.h, m, n, Ad2.data_ptr(), m, ip2.data_ptr()) == 0
+    assert torch.equal(ip, ip2)
+    k = min(m, n)
+    np.testing.assert_allclose(np.triu(d.cm_to_numpy(Ad2)[:k]), np.triu(lu_ref[:k]), atol=5e-13 * np.abs(lu_ref).max(), rtol=0)
+
+
+@pytest.mark.parametrize("m,n", [(70000, 96), (33000, 40)])
+def test_getrf_tall_f32_pivots_match_lapack(ctx, m, n):
+    """the 4-rows-per-thread register panel (fp32, > 1024 rows) and the prefetch of candidate rows with many workgroups"""
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m)
+    A = (rng.standard_normal((m, n)) * np.logspace(0, -2, n)).astype(np.float32)
+    Ad = d.cm_from_numpy(A)
+    ip = torch.zeros(n, dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_getrf_f32(ctx.h, m, n, Ad.data_ptr(), m, ip.data_ptr()) == 0
+    lu_ref, piv_ref, info_ref = ll.sgetrf(A)
+    assert info_ref == 0
+    np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)
+    np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=2e-4 * np.abs(lu_ref).max(), rtol=0)
 
 
 def test_getrf_singular_reports_info_and_luqrcp_piv(ctx):
