@@ -205,6 +205,36 @@ public:
         randlapack_require(qr_tall == Subroutines::QRTall::cholqr) << "row-sharded BQRRP needs qr_tall = cholqr (Householder panels do not shard)";
         int64_t m_glob = m, row0 = 0;
         q.shard_extent(m, m_glob, row0);
+        // Row layout of this rank: segments (first global row, count) in increasing global order, stacked in A.
+        //   contiguous (default): one segment [row0, row0 + m).
+        //   rows_block_cyclic: global row blocks of block_size rows dealt round-robin (block g lives on rank g % P), the layout
+        //   SURVEY.md 8e asks for -- the active rows shrink from the top by one block per iteration, so contiguous row blocks idle
+        //   the low ranks early while cyclic blocks keep every rank within one block of the same load.
+        std::vector<int64_t> seg_g0, seg_cnt, seg_l0;
+        if (rows_block_cyclic) {
+            const int64_t P = q.world(), me = q.rank(), nblk = (m_glob + block_size - 1) / block_size;
+            int64_t l0 = 0;
+            for (int64_t g = me; g < nblk; g += P) {
+                const int64_t cnt = std::min(block_size, m_glob - g * block_size);
+                seg_g0.push_back(g * block_size); seg_cnt.push_back(cnt); seg_l0.push_back(l0);
+                l0 += cnt;
+            }
+            randlapack_require(l0 == m) << "block-cyclic layout: this rank should hold " << l0 << " rows of the " << m_glob << ", got m=" << m;
+        } else if (m > 0) {
+            seg_g0.push_back(row0); seg_cnt.push_back(m); seg_l0.push_back(0);
+        }
+        // local index of my first row with global index >= g (m when there is none)
+        auto local_from = [&](int64_t g) {
+            for (size_t i = 0; i < seg_g0.size(); ++i)
+                if (seg_g0[i] + seg_cnt[i] > g) return seg_l0[i] + std::max<int64_t>(0, g - seg_g0[i]);
+            return m;
+        };
+        // global index of local row l
+        auto global_of = [&](int64_t l) {
+            for (size_t i = 0; i < seg_g0.size(); ++i)
+                if (l < seg_l0[i] + seg_cnt[i]) return seg_g0[i] + (l - seg_l0[i]);
+            return m_glob;
+        };
         const int64_t mn = std::min(m_glob, n);
         if (mn == 0) { rank = 0; return 0; }
         int64_t cols = n, curr_sz = 0, b_sz = block_size;
@@ -231,7 +261,10 @@ public:
             blas::Scratch w2(q);
             T* S = w2.alloc<T>(std::max<int64_t>(d * m, 1));
             RandBLAS::DenseDist Dall(d * m_glob, 1);
-            state = RandBLAS::fill_dense_rows(Dall, d * row0, d * m, S, state, q);
+            auto st_in = state;
+            state = RandBLAS::fill_dense_rows(Dall, 0, 0, S, st_in, q);                       // the state after the full fill
+            for (size_t i = 0; i < seg_g0.size(); ++i)                                         // S[:, my rows], segment by segment
+                RandBLAS::fill_dense_rows(Dall, d * seg_g0[i], d * seg_cnt[i], S + d * seg_l0[i], st_in, q);
             if (m > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, d, n, m, (T)1.0, S, d, A, lda, (T)0.0, A_sk, d, q);
             else lapack::laset(MatrixType::General, d, n, (T)0, (T)0, A_sk, d, q);
             q.allreduce_sum(A_sk, d * n);
@@ -253,9 +286,9 @@ public:
             }
             if (m > 0) util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);
             // local row bookkeeping for this iteration (global rows [curr_sz, m_glob) are active)
-            const int64_t act_lo = std::max(curr_sz, row0), act_hi = row0 + m;              // my active global rows [act_lo, act_hi)
-            const int64_t loc_rows = std::max<int64_t>(0, act_hi - act_lo);
-            T* A_work = (loc_rows > 0) ? &A[(act_lo - row0) + lda * curr_sz] : nullptr;       // my active rows of the panel / trailing matrix
+            const int64_t act_loc = local_from(curr_sz);                                      // my active rows are the local suffix [act_loc, m)
+            const int64_t loc_rows = m - act_loc;
+            T* A_work = (loc_rows > 0) ? &A[act_loc + lda * curr_sz] : nullptr;               // my active rows of the panel / trailing matrix
             double nz = 0;                                                                      // zero test on the panel's first column
             if (loc_rows > 0) nz = lapack::any_abs_gt(loc_rows, A_work, std::numeric_limits<T>::epsilon(), q) ? 1.0 : 0.0;
             q.allreduce_sum_host(&nz, 1);
@@ -278,12 +311,14 @@ public:
             if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
             // ---- Householder reconstruction on [top block (gathered); my rows below it]
             const int64_t top_hi = curr_sz + br;                                             // global rows [curr_sz, top_hi) form the top block
-            const int64_t t_lo = std::max(curr_sz, row0), t_hi = std::min(top_hi, row0 + m);
-            const int64_t tcnt = std::max<int64_t>(0, t_hi - t_lo), toff = t_lo - curr_sz;   // my rows of the top block, and where they sit in it
-            const int64_t b_lo = std::max(top_hi, row0);                                      // my rows strictly below the top block
-            const int64_t below = std::max<int64_t>(0, row0 + m - b_lo);
+            // my rows of the top block are the first tcnt rows of my active suffix (both layouts keep local rows in global order,
+            // and a cyclic block never straddles a panel); toff = where they sit inside the block
+            const int64_t tcnt = local_from(top_hi) - act_loc;
+            const int64_t toff = (tcnt > 0) ? global_of(act_loc) - curr_sz : 0;
+            const int64_t t_loc = act_loc, b_loc = act_loc + tcnt;                            // local starts: my top rows / my rows below the block
+            const int64_t below = m - b_loc;
             lapack::laset(MatrixType::General, br, br, (T)0, (T)0, Q1buf, br, q);
-            if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, &A[(t_lo - row0) + lda * curr_sz], lda, Q1buf + toff, br, q);
+            if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, &A[t_loc + lda * curr_sz], lda, Q1buf + toff, br, q);
             q.allreduce_sum(Q1buf, br * br);
             {
                 blas::Scratch w3(q);
@@ -291,17 +326,17 @@ public:
                 T* Pst = w3.alloc<T>(ldp * br);
                 T* Dv = w3.alloc<T>(br);
                 lapack::lacpy(MatrixType::General, br, br, Q1buf, br, Pst, ldp, q);
-                if (below > 0) lapack::lacpy(MatrixType::General, below, br, &A[(b_lo - row0) + lda * curr_sz], lda, Pst + br, ldp, q);
+                if (below > 0) lapack::lacpy(MatrixType::General, below, br, &A[b_loc + lda * curr_sz], lda, Pst + br, ldp, q);
                 lapack::orhr_col(ldp, br, br, Pst, ldp, T_dat, b_sz_const, Dv, q);            // one br x br T block (internal_nb = b)
                 lapack::row_sign(br, R_tall_qr, b_sz_const, Dv, q);
                 lapack::tau_from_t(br, br, T_dat, b_sz_const, tau_sub, q);
                 blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 (replicated)
                 // my rows of V back into A (strictly lower part of the top block is V1, the rest of my rows V2) ...
-                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, Pst + toff, ldp, &A[(t_lo - row0) + lda * curr_sz], lda, q);
-                if (below > 0) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, &A[(b_lo - row0) + lda * curr_sz], lda, q);
+                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, Pst + toff, ldp, &A[t_loc + lda * curr_sz], lda, q);
+                if (below > 0) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, &A[b_loc + lda * curr_sz], lda, q);
                 // ... and my rows of R11 on and above the diagonal of the top block
                 if (tcnt > 0) lapack::lacpy(MatrixType::Upper, tcnt, b_sz - toff, R_tall_qr + toff + toff * b_sz_const, b_sz_const,
-                                            &A[(t_lo - row0) + lda * (curr_sz + toff)], lda, q);
+                                            &A[t_loc + lda * (curr_sz + toff)], lda, q);
                 // ---- compact-WY apply to the trailing columns: W = sum over ranks of V_g^T C_g, C_g -= V_g (T^T W)
                 const int64_t rest = cols - b_sz;
                 const int64_t vrows = (br != b_sz_const) ? tcnt : (tcnt + below);             // reference: a deficient block acts on the top rows only
@@ -312,7 +347,7 @@ public:
                     const int64_t ldvx = std::max<int64_t>(vrows, 1);
                     if (tcnt > 0) lapack::vrows_explicit(br, toff, tcnt, Pst, ldp, Vexp, ldvx, q);
                     if (vrows > tcnt) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, Vexp + tcnt, ldvx, q);
-                    T* Cg = (vrows > 0) ? &A[(act_lo - row0) + lda * (curr_sz + b_sz)] : nullptr;
+                    T* Cg = (vrows > 0) ? &A[act_loc + lda * (curr_sz + b_sz)] : nullptr;
                     if (vrows > 0) blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, vrows, (T)1.0, Vexp, ldvx, Cg, lda, (T)0.0, W, br, q);
                     else lapack::laset(MatrixType::General, br, rest, (T)0, (T)0, W, br, q);
                     q.allreduce_sum(W, br * rest);
@@ -328,7 +363,7 @@ public:
                 const int64_t rest = cols - b_sz;
                 T* R12 = w4.alloc<T>(b_sz * rest);
                 lapack::laset(MatrixType::General, b_sz, rest, (T)0, (T)0, R12, b_sz, q);
-                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, &A[(t_lo - row0) + lda * curr_sz], lda, R12 + toff, b_sz, q);
+                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, &A[t_loc + lda * curr_sz], lda, R12 + toff, b_sz, q);
                 q.allreduce_sum(R12, b_sz * rest);
                 if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);
                 blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R_tall_qr, b_sz_const, R_sk, d, q);
@@ -359,6 +394,7 @@ public:
     Subroutines::QRCPWide qrcp_wide;
     Subroutines::QRTall qr_tall;
     Subroutines::ApplyTransQ apply_trans_q;
+    bool rows_block_cyclic = false;   // sharded queue only: rows are dealt to the ranks in blocks of block_size (see call_sharded)
     // testing hooks (not in the reference): the d x n sketch to use instead of S*A, and a buffer receiving the sketch
     const T* sketch_override = nullptr;
     T* sketch_export = nullptr;

@@ -59,14 +59,14 @@ template <typename RNG>
 RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, double* buf, RNGState<RNG> const& st, blas::Queue& q) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_rows_f64(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
-                                          loc_rows, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
+                                          loc_rows > 0 ? loc_rows : 1, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
     return next;
 }
 template <typename RNG>
 RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, float* buf, RNGState<RNG> const& st, blas::Queue& q) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_rows_f32(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
-                                          loc_rows, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
+                                          loc_rows > 0 ? loc_rows : 1, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
     return next;
 }
 

@@ -57,7 +57,9 @@ int rlhip_drv_hqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
 
 /* BQRRP<double>::call.  qrcp_wide {0 luqr, 1 geqp3}, qr_tall {0 geqrt, 1 cholqr, 2 geqrf}, apply_trans_q {0 ormqr, 1 gemqrt}
  * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default {luqr, cholqr, gemqrt}.
- * Row-sharded context (rlhip_comm_*): m and A are this rank's row block, tau needs min(global rows, n) entries, qr_tall must be cholqr.  A (m x n, lda) -> GEQP3
+ * Row-sharded context (rlhip_comm_*): m and A are this rank's rows, tau needs min(global rows, n) entries, qr_tall must be cholqr;
+ * qr_tall = 1 + 16 selects the BLOCK-CYCLIC layout (global row blocks of b_sz rows dealt round-robin, block g on rank g % P, stacked in
+ * increasing order in A) instead of one contiguous row block per rank.  A (m x n, lda) -> GEQP3
  * format, tau (min(m,n)), J (n) all on the device.  A_sk_in / A_sk_out: shared-sketch hooks as for CQRRPT (d x n,
  * ld d, d = (int64)(d_factor * b_sz)).  times_us[9] may be NULL.              drivers/rl_bqrrp.hh:155-665 */
 int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,

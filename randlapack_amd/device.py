@@ -495,7 +495,7 @@ def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0,
 
 
 def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
-              want_sketch=False, timing=False, qrcp_wide=-1, qr_tall=-1, apply_trans_q=-1, m_global=None):
+              want_sketch=False, timing=False, qrcp_wide=-1, qr_tall=-1, apply_trans_q=-1, m_global=None, block_cyclic=False):
     """BQRRP::call; options as in the reference's enums (qrcp_wide 0 luqr | 1 geqp3; qr_tall 0 geqrt | 1 cholqr | 2 geqrf;
     apply_trans_q 0 ormqr | 1 gemqrt; -1 = object default).  A (column-major tensor (n, m)) is overwritten in GEQP3 format.
     Returns dict(rc, rank, tau, J, next_ctr[, sketch][, times_us])."""
@@ -512,7 +512,7 @@ def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0,
     rc = getattr(ctx.lib, f"rlhip_drv_bqrrp_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), m, d_factor, b_sz, internal_nb, tol, tau.data_ptr(), J.data_ptr(),
                                      st, sketch_in.data_ptr() if sketch_in is not None else None,
                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times,
-                                     qrcp_wide, qr_tall, apply_trans_q)
+                                     qrcp_wide, (1 + 16) if block_cyclic else qr_tall, apply_trans_q)
     _drv_check(ctx, rc, "bqrrp")
     out = dict(rc=rc, rank=int(rank.value), tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
     if want_sketch:

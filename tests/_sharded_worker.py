@@ -47,12 +47,17 @@ def main():
     Ab = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
     rb = d.drv_bqrrp(ctx, Ab, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m)
     Ab_loc, tau_b, J_b = d.cm_to_numpy(Ab), rb["tau"].cpu().numpy(), rb["J"].cpu().numpy()
+    # the same factorization with the rows dealt block-cyclically (blocks of bb rows, block g on rank g % world)
+    crows = np.concatenate([np.arange(g * bb, min((g + 1) * bb, m)) for g in range(rank, (m + bb - 1) // bb, world)] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+    Ac = d.cm_from_numpy(np.ascontiguousarray(Abq[crows]))
+    rc_ = d.drv_bqrrp(ctx, Ac, len(crows), nbq, bb, 1.0, key=(8, 0), m_global=m, block_cyclic=True)
+    Ac_loc, tau_c, J_c = d.cm_to_numpy(Ac), rc_["tau"].cpu().numpy(), rc_["J"].cpu().numpy()
     # ABRIK on the row-sharded operator (CQRRT panels)
     ka, ita = 8, 8
     ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
     Ua_loc = d.cm_to_numpy(ra["U"])
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
@@ -61,8 +66,9 @@ def main():
         Qc = np.zeros((m, ncq))
         Ua = np.zeros((m, ra["triplets"]))
         Abq_out = np.zeros((m, nbq))
-        for rr, u, u2, qq, ua, ab in gathered:
-            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab
+        Acq_out = np.zeros((m, nbq))
+        for rr, u, u2, qq, ua, ab, cr, ac in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
@@ -84,6 +90,8 @@ def main():
         out = dict(
             bq_rank=rb["rank"], bq_rank1=rb1["rank"], bq_J_equal=bool(np.array_equal(J_b, rb1["J"].cpu().numpy())),
             bq_A=float(np.linalg.norm(Abq_out - Ab1n) / np.linalg.norm(Ab1n)), bq_tau=float(np.max(np.abs(tau_b - rb1["tau"].cpu().numpy()))),
+            bqc_rank=rc_["rank"], bqc_J_equal=bool(np.array_equal(J_c, rb1["J"].cpu().numpy())),
+            bqc_A=float(np.linalg.norm(Acq_out - Ab1n) / np.linalg.norm(Ab1n)), bqc_tau=float(np.max(np.abs(tau_c - rb1["tau"].cpu().numpy()))),
             bq_resid=float(np.linalg.norm(Abq[:, J_b - 1] - Qb @ Rb) / np.linalg.norm(Abq)), bq_orth=float(np.linalg.norm(Qb.T @ Qb - np.eye(nbq))),
             ab_iters=ra["iters"], ab_iters1=ra1["iters"], ab_trip=ra["triplets"], ab_trip1=ra1["triplets"],
             ab_S_vs_single=float(np.max(np.abs(Sa[:ka] - Sa1[:ka]) / Sa1[:ka])),

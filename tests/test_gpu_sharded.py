@@ -44,6 +44,9 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded BQRRP == single-device BQRRP: same pivots, GEQP3-format output (V, R, tau) equal to rounding, valid factorization
     assert out["bq_rank"] == out["bq_rank1"] and out["bq_J_equal"]
     assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
+    # block-cyclic row layout: same pivots, reflectors and R as the single-device run
+    assert out["bqc_rank"] == out["bq_rank1"] and out["bqc_J_equal"]
+    assert out["bqc_A"] <= 1e-10 and out["bqc_tau"] <= 1e-10
     assert out["bq_resid"] <= 1e-12 and out["bq_orth"] <= 1e-11
     # row-sharded ABRIK (CQRRT panels): same iteration count, same leading Ritz values as on one device
     assert (out["ab_iters"], out["ab_trip"]) == (out["ab_iters1"], out["ab_trip1"])
