@@ -474,7 +474,11 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     // have trailing columns beyond the last reflector.
     constexpr int64_t NBQ = 256;       // a BLAS-3 panel costs ~1.3 ms of launch latency whatever its width: few, wide panels
     const int64_t kmax = m < n ? m : n;
-    if (kmax <= 1280 && m < 16 * kmax) {  // sketch-sized problems: the pipelined kernel alone beats blocking (1280 x 1024: 11.0 vs 12.2 ms)
+    static int64_t pipe_max = -1;
+    if (pipe_max < 0) { const char* e = getenv("RLHIP_GEQRF_PIPE_MAX"); pipe_max = e ? atoll(e) : 1280; }
+    // sketch-sized, nearly square problems: the pipelined kernel alone beats blocking (1280 x 1024: 11.2 vs 12.3 ms); from about twice
+    // as tall as wide the CholQR-panel route wins (2000 x 1000: 13.0 vs 14.3 ms, 2560 x 1024: 12.2 vs 17.4 ms)
+    if (kmax <= pipe_max && (m < 16 * kmax && (10 * m < 19 * kmax || kmax < 600))) {
         int rc0 = qr_core<T>(c, 0, m, kmax, A, lda, nullptr, tau_dev);
         if (rc0 || n <= kmax) return rc0;
         size_t mark0 = rlhip_ws_mark(c);
