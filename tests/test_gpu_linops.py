@@ -299,3 +299,35 @@ def test_abrik_on_sparse_operator_matches_dense(ctx, orc):
     lead = 4
     res = np.sqrt(np.linalg.norm(A @ V[:, :lead] - U[:, :lead] * Sg[:lead])**2 + np.linalg.norm(A.T @ U[:, :lead] - V[:, :lead] * Sg[:lead])**2)
     assert res / sv[0] < 1e-3
+
+
+def test_linops_degenerate_shapes(ctx, orc):
+    d = _d()
+    import torch
+
+    # an all-zero sparse operator (nnz = 0): products are beta * C, CholQR reports the breakdown, the transpose builds
+    Z = sp.csr_matrix((50, 7))
+    opz = d.CsrOperator.from_scipy(Z)
+    B = np.arange(21.0).reshape(7, 3)
+    C0 = np.ones((50, 3))
+    got = d.linop_apply(ctx, opz, "L", "N", d.cm_from_numpy(B), 50, 3, 7, alpha=2.0, beta=-3.0, C_in=d.cm_from_numpy(C0))
+    np.testing.assert_array_equal(d.cm_to_numpy(got), -3.0 * C0)
+    assert d.drv_qr_linops(ctx, "cholqr", opz)["rc"] == 1
+    # one column, one row per nonzero; n = 1 through every driver
+    S1 = sp.csr_matrix(np.arange(1.0, 41.0).reshape(40, 1))
+    op1 = d.CsrOperator.from_scipy(S1)
+    for alg in ("cholqr", "scholqr3", "scholqr3_basic", "cqrrt"):
+        out = d.drv_qr_linops(ctx, alg, op1, want_Q=True, d_factor=3.0, nnz=1)
+        R, Q = d.cm_to_numpy(out["R"]), d.cm_to_numpy(out["Q"])
+        assert out["rc"] == 0 and abs(abs(R[0, 0]) - np.linalg.norm(S1.toarray())) < 1e-12 * np.linalg.norm(S1.toarray())
+        np.testing.assert_allclose(Q @ R, S1.toarray(), rtol=0, atol=1e-12 * 40)
+    # a single dense column block wider than the operator is tall (m < n): the Gram matrix is singular -> breakdown code, no crash
+    W = np.random.default_rng(0).standard_normal((5, 9))
+    assert d.drv_qr_linops(ctx, "cholqr", d.DenseOperator(d.cm_from_numpy(W), 5, 9))["rc"] == 1
+    # SpMM with a single dense column and with 257 (crosses the 256-column grid chunk)
+    S = _sparse(300, 40, 0.1, 2)
+    op = d.CsrOperator.from_scipy(S)
+    for nc in (1, 257):
+        X = np.random.default_rng(nc).standard_normal((40, nc))
+        got = d.linop_apply(ctx, op, "L", "N", d.cm_from_numpy(X), 300, nc, 40)
+        np.testing.assert_allclose(d.cm_to_numpy(got), S @ X, rtol=0, atol=1e-12)
