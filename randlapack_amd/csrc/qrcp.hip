@@ -273,6 +273,7 @@ struct QrPipeArgs {
     int use_lds;
     int v_in_lds;             // the current reflector fits in LDS (m doubles); otherwise it is read from its column of A
     int wg_per_col;           // tall-skinny: few columns per workgroup -> the whole workgroup updates one column at a time
+    int chunk;                // columns are dealt to the workgroups in chunks of this many consecutive columns (block-cyclic)
 };
 
 template <typename T>
@@ -286,10 +287,20 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
     T* lds_cols = l_v + (g.v_in_lds ? m : 0);
     __shared__ T s_val[4];
     __shared__ T s_tau;
-    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + (j / G) * m) : (g.A + j * g.lda); };
+    // Block-cyclic column ownership: chunks of CH consecutive columns go round the workgroups.  Inside a chunk consecutive steps
+    // stay in ONE workgroup (the look-ahead below makes H_{k+1} right after applying H_k to column k+1, no flag round trip);
+    // only every CH-th step crosses workgroups.  CH = 1 is the plain cyclic layout.
+    const int64_t CH = g.chunk;
+    const int64_t cpw = (((n + CH - 1) / CH + G - 1) / G) * CH;                 // local column slots per workgroup
+    auto owner = [&](int64_t j) -> int64_t { return (j / CH) % G; };
+    auto slot = [&](int64_t j) -> int64_t { return (j / (CH * G)) * CH + (j % CH); };
+    auto col_of = [&](int64_t c) -> int64_t { return ((c / CH) * G + me) * CH + (c % CH); };   // increasing in c
+    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + slot(j) * m) : (g.A + j * g.lda); };
     if (g.use_lds) {
-        for (int64_t j = me; j < n; j += G) {
-            T* dst = lds_cols + (j / G) * m;
+        for (int64_t c = 0; c < cpw; ++c) {
+            const int64_t j = col_of(c);
+            if (j >= n) break;
+            T* dst = lds_cols + c * m;
             const T* src = g.A + j * g.lda;
             for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
         }
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
     };
     bool have_next = false;                               // reflector k already made by the look-ahead of step k-1
     for (int64_t k = 0; k < kmax; ++k) {
-        const int64_t own_k = k % G;
+        const int64_t own_k = owner(k);
         T tk;
         if (me == own_k) {
             if (!have_next) make_reflector(k);            // (k = 0, or G == 1 handled by the look-ahead below)
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
         if (tk != T(0)) {
             // look-ahead: the owner of column k+1 brings that column up to date first and publishes H_{k+1} right away
             const int64_t kn = k + 1;
-            const bool own_next = (kn < kmax) && (me == kn % G);
+            const bool own_next = (kn < kmax) && (me == owner(kn));
             if (own_next) {
                 if (g.wg_per_col) apply_wg(k, tk, colptr(kn));
                 else if (wid == 0) apply_one(k, tk, colptr(kn));
@@ -389,12 +400,16 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
             // H_k for the remaining owned columns (still from l_v: make_reflector(k+1) overwrites it afterwards)
             const T saved_tau = tk;
             if (g.wg_per_col) {
-                for (int64_t j = me; j < n; j += G) {
+                for (int64_t c = 0; c < cpw; ++c) {
+                    const int64_t j = col_of(c);
+                    if (j >= n) break;
                     if (j <= k || (own_next && j == kn)) continue;
                     apply_wg(k, saved_tau, colptr(j));
                 }
             } else {
-                for (int64_t j = me + G * wid; j < n; j += 4 * G) {
+                for (int64_t c = wid; c < cpw; c += 4) {
+                    const int64_t j = col_of(c);
+                    if (j >= n) break;
                     if (j <= k || (own_next && j == kn)) continue;
                     apply_one(k, saved_tau, colptr(j));
                 }
@@ -403,15 +418,17 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
             if (own_next) { make_reflector(kn); have_next = true; }
         } else {
             const int64_t kn = k + 1;
-            if ((kn < kmax) && (me == kn % G)) { make_reflector(kn); have_next = true; }
+            if ((kn < kmax) && (me == owner(kn))) { make_reflector(kn); have_next = true; }
         }
     }
     // columns that never became a pivot (n > m) or global-path bookkeeping: write back what lives only in LDS
     if (g.use_lds) {
         __syncthreads();
-        for (int64_t j = me; j < n; j += G) {
+        for (int64_t c = 0; c < cpw; ++c) {
+            const int64_t j = col_of(c);
+            if (j >= n) break;
             if (j < kmax) continue;                       // pivot columns were published in place
-            const T* src = lds_cols + (j / G) * m;
+            const T* src = lds_cols + c * m;
             T* dst = g.A + j * g.lda;
             for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
         }
@@ -614,6 +631,9 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         pa.m = m; pa.n = n; pa.A = A; pa.lda = lda; pa.tau = tau_dev; pa.use_lds = use_lds;
         pa.v_in_lds = use_lds || ((size_t)m * sizeof(T) <= 64 * 1024);
         pa.wg_per_col = 0;
+        static int chunk_env = -1;
+        if (chunk_env < 0) { const char* e = getenv("RLHIP_QR_CHUNK"); chunk_env = e ? atoi(e) : 8; if (chunk_env < 1) chunk_env = 1; }
+        pa.chunk = chunk_env;
         int64_t Gp = G;
         if (!use_lds && m > 8 * n) {          // tall-skinny: spread the columns over as many workgroups as there are CUs
             Gp = n < num_cu ? n : num_cu;
@@ -622,7 +642,11 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         pa.flag = ws_alloc<unsigned>(c, (size_t)kmax + 4);
         if (!pa.flag) { rlhip_ws_release(c, mark2); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         hipLaunchKernelGGL(zero_u32_n, dim3((unsigned)((kmax + 255) / 256)), dim3(256), 0, c->stream, pa.flag, kmax);
-        const size_t cpw2 = (size_t)((n + Gp - 1) / Gp);
+        // local column slots under the chunked layout; if the rounding up to whole chunks no longer fits LDS, fall back to chunk = 1
+        auto slots = [&](int64_t ch) { return (size_t)((((n + ch - 1) / ch + Gp - 1) / Gp) * ch); };
+        if (pa.wg_per_col) pa.chunk = 1;
+        if (use_lds && (slots(pa.chunk) + 1) * (size_t)m * sizeof(T) > 150 * 1024) pa.chunk = 1;
+        const size_t cpw2 = slots(pa.chunk);
         const size_t dyn2 = (pa.v_in_lds ? (size_t)m * sizeof(T) : 0) + (use_lds ? cpw2 * (size_t)m * sizeof(T) : 0);
         hipLaunchKernelGGL(qr_pipe_kernel<T>, dim3((unsigned)Gp), dim3(256), dyn2, c->stream, pa);
         RLHIP_LAUNCH_CHECK();
