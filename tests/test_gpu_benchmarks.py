@@ -58,3 +58,27 @@ def test_cqrrpt_mains(tmp_path):
     assert len(r1) == 1 and len(r1[0]) == 128 and len(r2) == 2
     ratios = np.array([float(x) for x in r1[0]])
     assert abs(ratios[0] - 1.0) < 1e-10
+
+
+def test_abrik_and_cqrrt_linops_mains(tmp_path):
+    from benchmarks import abrik, cqrrt_linops
+
+    p = abrik.speed([str(tmp_path), "polynomial", "1", "1500", "400", "10", "2", "2", "8", "16", "4", "8"])
+    rows = _rows(p)
+    data = rows[:-1]
+    assert len(data) == 4 and all(len(r) == 15 for r in data)
+    for r in data:
+        v = [float(x) for x in r]
+        assert v[5] > 0 and v[8] > 0 and v[14] > 0                       # times
+        assert v[12] < 1e-8                                               # the full SVD has no residual
+    best = min(float(r[4]) for r in data)
+    assert best < 1e-3                                                    # with 8 matmuls of block 16 ABRIK nails the leading 10 triplets
+    p = cqrrt_linops.basic([str(tmp_path), "2", "1", "20000", "40000", "100", "8", "2.0", "2", "0"])
+    lines = [ln for ln in open(p).read().splitlines() if not ln.startswith("#")]
+    assert lines[0].startswith("m,n,run,aspect_ratio") and len(lines) == 3
+    for ln in lines[1:]:
+        f = ln.split(",")
+        assert len(f) == len(lines[0].split(","))
+        assert float(f[6]) < 1e-10 and int(f[8]) == 1                    # CQRRT_linops: orthonormal Q
+        assert float(f[14]) < 1e-10 and float(f[18]) < 1e-10              # sCholQR3 and dense CQRRT too
+        assert int(f[7]) == int(f[1])                                     # every column of the prefix test passes
