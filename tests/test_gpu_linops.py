@@ -331,3 +331,29 @@ def test_linops_degenerate_shapes(ctx, orc):
         X = np.random.default_rng(nc).standard_normal((40, nc))
         got = d.linop_apply(ctx, op, "L", "N", d.cm_from_numpy(X), 300, nc, 40)
         np.testing.assert_allclose(d.cm_to_numpy(got), S @ X, rtol=0, atol=1e-12)
+
+
+def test_cqrrt_linops_at_scale_sparse_vs_dense_cqrrt(ctx):
+    """bench_CQRRT_linops scale (10^6 x 512 sparse, 8 nonzeros per row): R from the operator route equals R from the dense CQRRT
+    driver on the materialised matrix (same sketching operator, so the same sketch), and reproduces A^T A."""
+    d = _d()
+    import torch
+
+    m, n, r = 1_000_000, 512, 8
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.integers(0, n, size=(m, r)), axis=1).astype(np.int64).ravel()
+    vals = rng.standard_normal(m * r)
+    op = d.CsrOperator(m, n, torch.as_tensor(np.arange(m + 1, dtype=np.int64) * r, device="cuda:0"), torch.as_tensor(cols, device="cuda:0"),
+                       torch.as_tensor(vals, device="cuda:0"))
+    out = d.drv_qr_linops(ctx, "cqrrt", op, d_factor=2.0, nnz=4, key=(1, 0))
+    assert out["rc"] == 0
+    R = torch.triu(out["R"].T)                                       # (n, n) upper triangular, row-major view of the column-major buffer
+    Ad = torch.zeros((n, m), dtype=torch.float64, device="cuda:0")   # column-major m x n
+    Ad.index_put_((torch.as_tensor(cols, device="cuda:0"), torch.arange(m, device="cuda:0").repeat_interleave(r)), op.vals, accumulate=True)
+    G = Ad @ Ad.T                                                    # A^T A
+    err = torch.linalg.norm(R.T @ R - G) / torch.linalg.norm(G)
+    assert float(err) < 1e-13
+    o2 = d.drv_cqrrt(ctx, Ad, m, n, d_factor=2.0, nnz=4, key=(1, 0))
+    R2 = torch.triu(o2["R"].T)
+    assert float(torch.linalg.norm(R - R2) / torch.linalg.norm(R2)) < 1e-11
+    assert out["next_ctr"] == o2["next_ctr"]

@@ -102,3 +102,22 @@ def test_revd2_bad_arguments(ctx):
         d.drv_revd2(ctx, A, 10, 2, -1.0)
     with pytest.raises(RlhipError):
         d.drv_revd2(ctx, A, 10, 2, 1e-8, uplo="X")
+
+
+def test_revd2_at_scale(ctx):
+    """m = 12000 PSD matrix of rank 300 generated on the device; REVD2 from k = 64 doubles to 512 and reconstructs it"""
+    d = _d()
+    import torch
+
+    m, rank = 12000, 300
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    B = torch.randn((rank, m), dtype=torch.float64, device="cuda:0", generator=g)          # column-major m x rank
+    A = B.T @ B                                                                             # symmetric: its own column-major image
+    out = d.drv_revd2(ctx, A, m, 64, 1e-6 * float(torch.linalg.norm(A)), key=(1, 0))
+    assert out["rc"] == 0 and out["k"] == 512
+    V, ev = out["V"], out["eigvals"]                                                        # V: (k, m)
+    R = (V.T * ev) @ V
+    assert float(torch.linalg.norm(A - R) / torch.linalg.norm(A)) < 1e-10
+    top = torch.linalg.eigvalsh(B @ B.T).flip(0)                                            # the 300 nonzero eigenvalues
+    assert float(torch.max(torch.abs(ev[:rank] - top) / top)) < 1e-9
+    assert float(ev[rank:].abs().max()) < 1e-8 * float(top[0])
