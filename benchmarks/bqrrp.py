@@ -6,6 +6,9 @@
         (BQRRP_runtime_breakdown.cc) -> _BQRRP_runtime_breakdown_num_info_lines_7.txt
   python -m benchmarks.bqrrp pivot_quality     <dir> <m> <n> <block_size> [mat_type]
         (BQRRP_pivot_quality.cc) -> _BQRRP_pivot_quality_metric_{1,2}_num_info_lines_6.txt
+  python -m benchmarks.bqrrp error_analysis    <dir> <bqrrp|geqp3> <num_runs> <m> <n> <b1> [b2 ...]
+        (BQRRP_error_analysis.cc) -> _BQRRP_error_analysis_num_info_lines_5.txt: per block size, one row per matrix type
+        (polynomial, staircase, spiked, Kahan): avg ||AP - QR|| / ||A||, max - avg, avg ||Q'Q - I|| / sqrt(n), max - avg
 """
 from __future__ import annotations
 
@@ -121,7 +124,51 @@ def pivot_quality(argv):
     return p1, p2
 
 
-MAINS = {"speed_mat_size": speed_mat_size, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality}
+def error_analysis(argv):
+    import torch
+
+    directory, alg, num_runs, m, n = argv[0], argv[1], int(argv[2]), int(argv[3]), int(argv[4])
+    b_sz = [int(x) for x in argv[5:]]
+    ctx = d.Context(0)
+    tests = [("polynomial", dict(cond_num=1e10, exponent=2.0)), ("step", dict(cond_num=1e10)), ("spiked", dict(scaling=1e10)),
+             ("kahan", dict(theta=1.2, perturb=1e3))]
+    path = c.out_path(directory, "_BQRRP_error_analysis_num_info_lines_5.txt")
+    with open(path, "a") as f:
+        f.write(f"Description: Results from the {alg} error analysis; putput rows capture results per given matrix type, columns capture results per error type."
+                "\nAt the moment, i test polynomial, staircase and spiked matrices with reconstructiuon error, max column norm error and orthogonality loss."
+                "\nNum OMP threads:0 (device: MI355X)"
+                f"\nInput size:{m} by {n}"
+                f"\nAdditional parameters: BQRRP block sizes: {', '.join(map(str, b_sz))}, \n")
+    for b in (b_sz if alg == "bqrrp" else b_sz[:1]):
+        for m_type, kw in tests:
+            if m_type == "kahan" and m != n:
+                continue                                               # the Kahan matrix is square (rl_gen.hh:408-434)
+            rec, orth = [], []
+            for run in range(num_runs):
+                A0 = c.regen(ctx, m_type, m, n, key=(run, 0), **kw)
+                A = A0.clone()
+                if alg == "bqrrp":
+                    out = d.drv_bqrrp(ctx, A, m, n, b, 1.0, qr_tall=1, tol=float(np.finfo(np.float64).eps ** 0.75))
+                    J, tau, k = out["J"], out["tau"], out["rank"]
+                else:
+                    J, tau = c.geqp3(ctx, A, m, n)
+                    k = min(m, n)
+                # Q (m x k) from the reflectors, R (k x n) upper-trapezoidal (error_check(), BQRRP_error_analysis.cc:60-103)
+                Q = A[:k].clone()                                       # first k columns (column-major m x k as a (k, m) tensor)
+                getattr(ctx.lib, "rlhip_ungqr_f64")(ctx.h, m, k, k, Q.data_ptr(), m, tau.data_ptr())
+                R = torch.triu(A[:, :k].T)                              # (k, n)
+                AP = A0[(J - 1).long()]                                 # permuted columns, (n, m)
+                resid = AP - R.T @ Q                                    # (n, m) == (A P - Q R)^T
+                rec.append(float(torch.linalg.norm(resid) / torch.linalg.norm(A0)))
+                G = Q @ Q.T
+                orth.append(float(torch.linalg.norm(G - torch.eye(k, dtype=G.dtype, device=G.device)) / np.sqrt(n)))
+            ar, ao = float(np.mean(rec)), float(np.mean(orth))
+            with open(path, "a") as f:
+                f.write(f"{ar:.14e},  {max(rec) - ar:.14e},  {ao:.14e},  {max(orth) - ao:.14e},\n")
+    return path
+
+
+MAINS = {"speed_mat_size": speed_mat_size, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality, "error_analysis": error_analysis}
 
 if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in MAINS:

@@ -67,6 +67,7 @@ public:
         auto t_begin = stamp();
 
         int64_t rows = m, cols = n, curr_sz = 0, b_sz = block_size;
+        cholqr_fallbacks = 0;
         const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);                                         // :220
         const int64_t b_sz_const = b_sz;
         const int64_t d = (int64_t)(d_factor * b_sz);                                                       // :224
@@ -135,7 +136,19 @@ public:
                 ta = stamp();
                 lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
                 blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
-                lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);   // failure handled "gracefully" as in the reference (:461)
+                const int64_t chol_info = lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);
+                if (chol_info != 0 && cholqr_fallback) {
+                    // The reference carries on with the partially factored Gram matrix (:461 "handles potrf failure gracefully");
+                    // what the panel then holds depends on where the host potrf happened to stop, and on the device it can blow
+                    // up (Kahan matrix, 512 x 512: tau up to 115, ||Q'Q - I|| ~ 1e46).  A Cholesky breakdown means the
+                    // preconditioned panel is numerically rank deficient: undo the preconditioning and factor THIS panel with
+                    // Householder reflectors instead (the qr_tall = geqrf branch), which needs no positive definiteness.
+                    ++cholqr_fallbacks;
+                    blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
+                    lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
+                    have_T = false;
+                    t_tall += us(ta, stamp());
+                } else {
                 blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
                 t_tall += us(ta, stamp());
                 ta = stamp();
@@ -145,6 +158,7 @@ public:
                 blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, block_rank, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // :497
                 lapack::lacpy(MatrixType::Upper, block_rank, b_sz, R_tall_qr, b_sz_const, A_work, lda, q); // :504
                 t_rec += us(ta, stamp());
+                }
             } else if (qr_tall == Subroutines::QRTall::geqrt) {                                             // :438-453
                 t_pre += us(ta, stamp());
                 ta = stamp();
@@ -394,6 +408,8 @@ public:
     Subroutines::QRCPWide qrcp_wide;
     Subroutines::QRTall qr_tall;
     Subroutines::ApplyTransQ apply_trans_q;
+    bool cholqr_fallback = true;      // qr_tall = cholqr: a panel whose Cholesky factorization breaks down is factored by geqrf instead
+    int64_t cholqr_fallbacks = 0;     // number of panels of the last call that took that route
     bool rows_block_cyclic = false;   // sharded queue only: rows are dealt to the ranks in blocks of block_size (see call_sharded)
     // testing hooks (not in the reference): the d x n sketch to use instead of S*A, and a buffer receiving the sketch
     const T* sketch_override = nullptr;

@@ -44,6 +44,20 @@ def test_bqrrp_mains(tmp_path):
     assert np.all((q[:, :200] > 0.05) & (q[:, :200] < 20))                   # |R_ii| within a modest factor of sigma_i
 
 
+def test_bqrrp_error_analysis_main(tmp_path):
+    from benchmarks import bqrrp
+
+    p = bqrrp.error_analysis([str(tmp_path), "bqrrp", "2", "512", "512", "64"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:") and len(lines) == 5 + 4       # 5 info lines, 4 matrix types
+    for ln in lines[5:]:
+        v = [float(x) for x in ln.rstrip(", ").split(",")]
+        assert len(v) == 4 and v[0] < 1e-12 and v[2] < 1e-11 and v[1] >= 0 and v[3] >= 0      # backward stable on every matrix type
+    p2 = bqrrp.error_analysis([str(tmp_path / "g"), "geqp3", "1", "400", "300", "32"]) if (tmp_path / "g").mkdir() is None else None
+    rows = open(p2).read().rstrip("\n").split("\n")[5:]
+    assert len(rows) == 3 and all(float(r.split(",")[0]) < 1e-13 for r in rows)               # no Kahan row for a non-square input
+
+
 def test_cqrrpt_mains(tmp_path):
     from benchmarks import cqrrpt
 

@@ -782,3 +782,24 @@ def test_cqrrpt_orthogonalization_mode(ctx, orc):
     J = r["J"].cpu().numpy()
     AP = A[:, J - 1]
     assert np.linalg.norm(AP - Q[:, :k] @ (Q[:, :k].T @ AP)) <= 1e-9 * np.linalg.norm(A)     # the leading columns carry the range
+
+
+def test_bqrrp_cholqr_panel_breakdown_falls_back_to_householder(ctx, orc):
+    """Kahan matrix (test matrix of BQRRP_error_analysis.cc): the preconditioned panels reach the noise floor and a panel's Gram
+    matrix stops being positive definite.  The reference carries on with the half-factored Gram matrix (its CPU run returns a Q
+    with ||Q'Q - I|| = 1); the device driver refactors that panel with Householder reflectors.  Same pivots as the oracle, and a
+    valid QR."""
+    d = _d()
+    m = n = 512
+    A0 = d.drv_mat_gen(ctx, "kahan", m, n, theta=1.2, perturb=1e3)["A"]
+    A0n = d.cm_to_numpy(A0)
+    A = A0.clone()
+    out = d.drv_bqrrp(ctx, A, m, n, 64, 1.0, qr_tall=1, want_sketch=True)
+    tau, J = out["tau"].cpu().numpy(), out["J"].cpu().numpy()
+    ref = orc.bqrrp(A0n, 64, 1.0, qr_tall=1, sketch=d.cm_to_numpy(out["sketch"]))
+    np.testing.assert_array_equal(J, ref["J"])
+    assert out["rank"] == ref["rank"] == n
+    Q = orc.ungqr(d.cm_to_numpy(A), tau)
+    R = np.triu(d.cm_to_numpy(A))
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-11 and 0 < tau.min() and tau.max() <= 2.0 + 1e-12
+    assert np.linalg.norm(A0n[:, J - 1] - Q @ R) / np.linalg.norm(A0n) < 1e-13
