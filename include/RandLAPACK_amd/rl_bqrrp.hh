@@ -131,20 +131,37 @@ public:
             T* R11 = A_work;
             bool have_T = true;
             if (qr_tall == Subroutines::QRTall::cholqr) {                                                   // :454-505
+                blas::Scratch ws_panel(q);
+                T* panel_copy = nullptr;                    // the unpreconditioned panel, kept for the Householder fallback below
+                if (cholqr_fallback) {
+                    panel_copy = ws_panel.alloc<T>(rows * block_rank);
+                    lapack::lacpy(MatrixType::General, rows, block_rank, A_work, lda, panel_copy, rows, q);
+                }
                 blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
                 t_pre += us(ta, stamp());
                 ta = stamp();
                 lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
                 blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
                 const int64_t chol_info = lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);
-                if (chol_info != 0 && cholqr_fallback) {
-                    // The reference carries on with the partially factored Gram matrix (:461 "handles potrf failure gracefully");
+                bool chol_bad = chol_info != 0;
+                if (cholqr_fallback && !chol_bad && block_rank > 0) {
+                    // Cholesky QR is only as orthogonal as eps * cond(A_pre)^2.  The preconditioner should leave cond(A_pre) = O(1); a
+                    // graded diagonal of R_chol (a lower bound on cond(A_pre)) says it did not -- the panel sits on the noise floor of
+                    // a numerically rank-deficient matrix -- and the panel goes to Householder as well.
+                    std::vector<T> dg((size_t)block_rank);
+                    lapack::get_diag(block_rank, R_tall_qr, b_sz_const, dg.data(), q);
+                    T dmin = std::abs(dg[0]), dmax = std::abs(dg[0]);
+                    for (int64_t i = 1; i < block_rank; ++i) { dmin = std::min(dmin, std::abs(dg[(size_t)i])); dmax = std::max(dmax, std::abs(dg[(size_t)i])); }
+                    chol_bad = !(dmin > cholqr_cond_limit_inv * dmax);          // also catches NaN
+                }
+                if (chol_bad && cholqr_fallback) {
+                    // On a Cholesky breakdown the reference carries on with the partially factored Gram matrix (:461 "handles potrf failure gracefully");
                     // what the panel then holds depends on where the host potrf happened to stop, and on the device it can blow
                     // up (Kahan matrix, 512 x 512: tau up to 115, ||Q'Q - I|| ~ 1e46).  A Cholesky breakdown means the
-                    // preconditioned panel is numerically rank deficient: undo the preconditioning and factor THIS panel with
+                    // preconditioned panel is numerically rank deficient: restore the panel and factor THIS panel with
                     // Householder reflectors instead (the qr_tall = geqrf branch), which needs no positive definiteness.
                     ++cholqr_fallbacks;
-                    blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
+                    lapack::lacpy(MatrixType::General, rows, block_rank, panel_copy, rows, A_work, lda, q);   // (multiplying R_sk back would lose cond(R_sk) * eps)
                     lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
                     have_T = false;
                     t_tall += us(ta, stamp());
@@ -410,6 +427,7 @@ public:
     Subroutines::ApplyTransQ apply_trans_q;
     bool cholqr_fallback = true;      // qr_tall = cholqr: a panel whose Cholesky factorization breaks down is factored by geqrf instead
     int64_t cholqr_fallbacks = 0;     // number of panels of the last call that took that route
+    T cholqr_cond_limit_inv = std::pow(std::numeric_limits<T>::epsilon(), (T)0.25);   // min/max of diag(R_chol) below this (1.2e-4 in double) = ill-conditioned panel
     bool rows_block_cyclic = false;   // sharded queue only: rows are dealt to the ranks in blocks of block_size (see call_sharded)
     // testing hooks (not in the reference): the d x n sketch to use instead of S*A, and a buffer receiving the sketch
     const T* sketch_override = nullptr;

@@ -797,9 +797,11 @@ def test_bqrrp_cholqr_panel_breakdown_falls_back_to_householder(ctx, orc):
     out = d.drv_bqrrp(ctx, A, m, n, 64, 1.0, qr_tall=1, want_sketch=True)
     tau, J = out["tau"].cpu().numpy(), out["J"].cpu().numpy()
     ref = orc.bqrrp(A0n, 64, 1.0, qr_tall=1, sketch=d.cm_to_numpy(out["sketch"]))
+    Qr = orc.ungqr(ref["A"], ref["tau"])
+    assert np.linalg.norm(Qr.T @ Qr - np.eye(n)) > 0.5           # what the reference's "graceful" handling produces here
     np.testing.assert_array_equal(J, ref["J"])
     assert out["rank"] == ref["rank"] == n
     Q = orc.ungqr(d.cm_to_numpy(A), tau)
     R = np.triu(d.cm_to_numpy(A))
-    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-11 and 0 < tau.min() and tau.max() <= 2.0 + 1e-12
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-11 and 0 <= tau.min() and tau.max() <= 2.0 + 1e-12
     assert np.linalg.norm(A0n[:, J - 1] - Q @ R) / np.linalg.norm(A0n) < 1e-13
