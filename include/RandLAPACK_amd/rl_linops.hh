@@ -48,12 +48,12 @@ inline void csr_densify_cols(int64_t m, const int64_t* rpt, const int64_t* cit, 
     blas::check(rlhip_csr_densify_cols_f32(q.ctx(), m, rpt, cit, vt, c0, b, out, ldo), "csr_densify_cols");
 }
 inline void saso_apply_csr(rlhip_saso* S, int64_t n, double alpha, const int64_t* rpt, const int64_t* cit, const double* vt, double beta, double* C,
-                           int64_t ldc, blas::Queue& q) {
-    blas::check(rlhip_saso_apply_csr_f64(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc), "saso_apply_csr");
+                           int64_t ldc, int64_t row0, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_csr_f64(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc, row0), "saso_apply_csr");
 }
 inline void saso_apply_csr(rlhip_saso* S, int64_t n, float alpha, const int64_t* rpt, const int64_t* cit, const float* vt, float beta, float* C,
-                           int64_t ldc, blas::Queue& q) {
-    blas::check(rlhip_saso_apply_csr_f32(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc), "saso_apply_csr");
+                           int64_t ldc, int64_t row0, blas::Queue& q) {
+    blas::check(rlhip_saso_apply_csr_f32(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc, row0), "saso_apply_csr");
 }
 }  // namespace detail
 
@@ -151,7 +151,9 @@ private:
 // ------------------------------------------------------------------------------------------------ sparse
 /// Device CSR operator.  rowptr (n_rows + 1), colidx (nnz), vals (nnz) are DEVICE arrays with int64 indices, borrowed for the
 /// lifetime of the operator; entries of a row need not be sorted; duplicates are summed.  The constructor builds the CSR of the
-/// transpose (one host-staged pass), so that op(A) X is always a gather.
+/// transpose (stable counting sort on the device), so that op(A) X is always a gather.
+/// `row_sharded`: this rank holds a block of ROWS of the operator (n_rows = local rows, indices local); A^T X, S A and the norm
+/// are then summed over the ranks, exactly as for DenseLinOp.
 template <typename T>
 struct SparseLinOp {
     using scalar_t = T;
@@ -183,7 +185,15 @@ struct SparseLinOp {
         if (vals_t) blas::device_free(vals_t, q);
     }
 
-    T fro_nrm() { return nnz > 0 ? lapack::lange(Norm::Fro, nnz, 1, vals, nnz, q) : (T)0; }
+    bool row_sharded = false;
+
+    T fro_nrm() {
+        const T loc = nnz > 0 ? lapack::lange(Norm::Fro, nnz, 1, vals, nnz, q) : (T)0;
+        if (!(row_sharded && q.world() > 1)) return loc;
+        double ss = (double)loc * (double)loc;
+        q.allreduce_sum_host(&ss, 1);
+        return (T)std::sqrt(ss);
+    }
 
     /// dense operand (rl_sparse_linop.hh:125-197); op(B) = B only
     void operator()(Side side, Layout layout, Op trans_A, Op trans_B, int64_t m, int64_t n, int64_t k, T alpha, const T* B, int64_t ldb,
@@ -194,8 +204,15 @@ struct SparseLinOp {
             const int64_t rows_A = nt ? m : k, cols_A = nt ? k : m;
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
             if (nt) detail::csr_spmm((char)layout, m, n, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q);
-            else detail::csr_spmm((char)layout, m, n, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q);
+            else {
+                detail::csr_spmm((char)layout, m, n, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q);
+                if (row_sharded && q.world() > 1) {                       // A^T X sums over the row blocks
+                    randlapack_require(beta == (T)0 && ldc == ((layout == Layout::ColMajor) ? m : n)) << "sharded A^T X needs beta = 0 and a contiguous result";
+                    q.allreduce_sum(C, m * n);
+                }
+            }
         } else {
+            randlapack_require(!(row_sharded && q.world() > 1)) << "Side::Right with a dense operand is not defined for a row-sharded operator";
             // C (m x n) = B (m x k) * op(A) (k x n)  <=>  C^T = op(A)^T * B^T, and a column-major matrix IS its transpose in row-major
             const int64_t rows_A = nt ? k : n, cols_A = nt ? n : k;
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
@@ -216,10 +233,20 @@ struct SparseLinOp {
     template <typename RNG>
     void operator()(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, T alpha, RandBLAS::SparseSkOp<T, RNG>& S,
                     T beta, T* C, int64_t ldc) {
-        check_sketch_call(side, layout, trans_A, trans_S, d, n, m, S.dist.n_rows, S.dist.n_cols, ldc);
+        const bool sharded = row_sharded && q.world() > 1;
+        check_sketch_call(side, layout, trans_A, trans_S, d, n, m, S.dist.n_rows, sharded ? m : S.dist.n_cols, ldc);
         if (n == 0 || d == 0) return;
+        if (sharded) {                                                    // S was built for the GLOBAL row count: my rows start at row0
+            randlapack_require(beta == (T)0 && ldc == d && d <= 19200) << "sharded S A needs beta = 0, a contiguous result and d <= 19200";
+            int64_t m_glob, row0;
+            q.shard_extent(n_rows, m_glob, row0);
+            randlapack_require(S.dist.n_cols == m_glob) << "sketching operator has " << S.dist.n_cols << " columns, the sharded operator " << m_glob << " rows";
+            detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, (T)0, C, ldc, row0, q);
+            q.allreduce_sum(C, d * n);
+            return;
+        }
         if (d <= 19200 && !force_densified_sketch) {
-            detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, beta, C, ldc, q);
+            detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, beta, C, ldc, 0, q);
             return;
         }
         const int64_t b = std::max<int64_t>(1, std::min<int64_t>(n, densify_budget / std::max<int64_t>(m, 1)));
@@ -235,6 +262,7 @@ struct SparseLinOp {
     template <typename RNG>
     void operator()(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, T alpha, RandBLAS::DenseSkOp<T, RNG>& S,
                     T beta, T* C, int64_t ldc) {
+        randlapack_require(!(row_sharded && q.world() > 1)) << "dense sketching operators are not sharded: use the sparse one";
         check_sketch_call(side, layout, trans_A, trans_S, d, n, m, S.dist.n_rows, S.dist.n_cols, ldc);
         RandBLAS::fill_dense(S);
         detail::csr_spmm('R', n, d, m, alpha, rowptr_t, colidx_t, vals_t, S.buff, d, beta, C, ldc, q);

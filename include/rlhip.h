@@ -174,11 +174,12 @@ int rlhip_saso_apply_rows_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, do
 int rlhip_saso_apply_rows_f32(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, float alpha, const float* A_loc, int64_t lda,
                               int64_t row0, int64_t mloc, float beta, float* B, int64_t ldb);
 /* B (d x n, ldb) = alpha * S * A + beta * B for a SPARSE A (m x n) given by the CSR of its transpose (n rows; colidxT = source
- * row).  Scatter with 64-bit fixed-point integer LDS atomics: bitwise reproducible (sketch.hip).  d <= 19200. */
+ * row).  Scatter with 64-bit fixed-point integer LDS atomics: bitwise reproducible (sketch.hip).  d <= 19200.
+ * row0: global index of the operand's first row (0 unless the operator is a row shard of the matrix S was built for). */
 int rlhip_saso_apply_csr_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, double alpha, const int64_t* rowptrT, const int64_t* colidxT,
-                             const double* valsT, double beta, double* B, int64_t ldb);
+                             const double* valsT, double beta, double* B, int64_t ldb, int64_t row0);
 int rlhip_saso_apply_csr_f32(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, float alpha, const int64_t* rowptrT, const int64_t* colidxT,
-                             const float* valsT, float beta, float* B, int64_t ldb);
+                             const float* valsT, float beta, float* B, int64_t ldb, int64_t row0);
 int rlhip_saso_dense_f64(rlhip_ctx* ctx, const rlhip_saso* S, double* dense_d_by_m);   /* tests / debugging */
 int rlhip_saso_dense_f32(rlhip_ctx* ctx, const rlhip_saso* S, float* dense_d_by_m);
 /* util::col_swap (misc/rl_util.hh:151-164 == lapmt forward): on exit column i holds former column idx[i]-1.

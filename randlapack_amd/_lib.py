@@ -36,7 +36,7 @@ def _blas3(T):
         "saso_apply": [c_vp, c_vp, c_i64, T, c_vp, c_i64, T, c_vp, c_i64],
         "saso_apply_rows": [c_vp, c_vp, c_i64, T, c_vp, c_i64, c_i64, c_i64, T, c_vp, c_i64],
         "saso_dense": [c_vp, c_vp, c_vp],
-        "saso_apply_csr": [c_vp, c_vp, c_i64, T, c_vp, c_vp, c_vp, T, c_vp, c_i64],
+        "saso_apply_csr": [c_vp, c_vp, c_i64, T, c_vp, c_vp, c_vp, T, c_vp, c_i64, c_i64],
         "col_swap": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "geqp3": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
         "get_diag": [c_vp, c_i64, c_vp, c_i64, C.POINTER(T)],

@@ -15,7 +15,7 @@ template <typename T> int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_
 template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta,
                                      T* B, int64_t ldb);
 template <typename T> int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int64_t* rowptrT, const int64_t* colidxT,
-                                         const T* valsT, T beta, T* B, int64_t ldb);
+                                         const T* valsT, T beta, T* B, int64_t ldb, int64_t row0);
 template <typename T> int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx);
 int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev);
 template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
@@ -370,8 +370,8 @@ static inline int op_flag(char t, int* out) {
         return rlhip::saso_apply<T>(c, (const rlhip::SasoOp*)S, n, alpha, A, lda, beta, B, ldb);                 \
     }                                                                                                           \
     int rlhip_saso_apply_csr_##SUF(rlhip_ctx* c, const rlhip_saso* S, int64_t n, T alpha, const int64_t* rowptrT, const int64_t* colidxT, \
-                                   const T* valsT, T beta, T* B, int64_t ldb) {                                 \
-        return rlhip::saso_apply_csr<T>(c, (const rlhip::SasoOp*)S, n, alpha, rowptrT, colidxT, valsT, beta, B, ldb); \
+                                   const T* valsT, T beta, T* B, int64_t ldb, int64_t row0) {                   \
+        return rlhip::saso_apply_csr<T>(c, (const rlhip::SasoOp*)S, n, alpha, rowptrT, colidxT, valsT, beta, B, ldb, row0); \
     }                                                                                                           \
     int rlhip_saso_dense_##SUF(rlhip_ctx* c, const rlhip_saso* S, T* dense) {                                   \
         return rlhip::saso_dense<T>(c, (const rlhip::SasoOp*)S, dense);                                          \

@@ -63,6 +63,7 @@ template <typename T>
 std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_linop_desc& d) {
     auto op = std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
     if (const char* e = std::getenv("RLHIP_SPARSE_SKETCH_DENSIFY")) op->force_densified_sketch = (e[0] == '1');   // test knob: fallback path
+    op->row_sharded = q.world() > 1;
     return op;
 }
 template <typename T, typename F>
@@ -82,7 +83,7 @@ int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_lino
         return f(A);
     }
     if (left->kind == 0 && right->kind == 1) {
-        auto L = make_dense<T>(q, *left); auto Rr = make_sparse<T>(q, *right);
+        auto L = make_dense<T>(q, *left); auto Rr = make_sparse<T>(q, *right); Rr->row_sharded = false;
         lo::CompositeOperator<lo::DenseLinOp<T>, lo::SparseLinOp<T>> A(m, n, *L, *Rr);
         return f(A);
     }
@@ -91,7 +92,7 @@ int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_lino
         lo::CompositeOperator<lo::SparseLinOp<T>, lo::DenseLinOp<T>> A(m, n, *L, *Rr);
         return f(A);
     }
-    auto L = make_sparse<T>(q, *left); auto Rr = make_sparse<T>(q, *right);
+    auto L = make_sparse<T>(q, *left); auto Rr = make_sparse<T>(q, *right); Rr->row_sharded = false;
     lo::CompositeOperator<lo::SparseLinOp<T>, lo::SparseLinOp<T>> A(m, n, *L, *Rr);
     return f(A);
 }

@@ -116,7 +116,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, SasoState st,
                                                              const int64_t* __restrict__ afwd, const int64_t* __restrict__ b,
                                                              const int64_t* __restrict__ rowptrT, const int64_t* __restrict__ colidxT,
-                                                             const T* __restrict__ valsT, T alpha, T beta, T* __restrict__ B, int64_t ldb) {
+                                                             const T* __restrict__ valsT, T alpha, T beta, T* __restrict__ B, int64_t ldb, int64_t row0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);       // [d]
     __shared__ double s_red[4];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t 
         while (((int64_t)1 << lg) < len) ++lg;             // len <= 2^lg
         e = 61 - lg - ex;
         for (int64_t p = p0 + tid; p < p1; p += 256) {
-            const int64_t j = colidxT[p];
+            const int64_t j = colidxT[p] + row0;               // global row of the operand (row-sharded operators pass their offset)
             const long long q = llrint(ldexp((double)valsT[p], e));
             const int64_t t = j / d, u = j - t * d;
             uint32_t ctr[4], w[4];
@@ -413,7 +413,8 @@ int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, i
 // B (d x n, ldb) = alpha * S * A + beta * B for a sparse A (m x n) given by the CSR of its transpose
 template <typename T>
 int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int64_t* rowptrT, const int64_t* colidxT, const T* valsT, T beta,
-                   T* B, int64_t ldb) {
+                   T* B, int64_t ldb, int64_t row0) {
+    if (row0 < 0 || row0 > op->m) return -6;
     if (n <= 0) return 0;
     if (ldb < op->d) return -9;
     const size_t smem = sizeof(unsigned long long) * (size_t)op->d;
@@ -424,12 +425,12 @@ int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int
         attr_set = true;
     }
     hipLaunchKernelGGL(saso_apply_csr_kernel<T>, dim3((unsigned)n), dim3(256), smem, c->stream, op->d, op->m, op->T, op->nnz, op->st, op->afwd,
-                       op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb);
+                       op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb, row0);
     RLHIP_LAUNCH_CHECK();
     return 0;
 }
-template int saso_apply_csr<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const int64_t*, const int64_t*, const double*, double, double*, int64_t);
-template int saso_apply_csr<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const int64_t*, const int64_t*, const float*, float, float*, int64_t);
+template int saso_apply_csr<double>(rlhip_ctx*, const SasoOp*, int64_t, double, const int64_t*, const int64_t*, const double*, double, double*, int64_t, int64_t);
+template int saso_apply_csr<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const int64_t*, const int64_t*, const float*, float, float*, int64_t, int64_t);
 
 // in-place forward column permutation; idx is a DEVICE array of n 1-based indices (left untouched)
 template <typename T>

@@ -56,6 +56,14 @@ def main():
     ka, ita = 8, 8
     ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
     Ua_loc = d.cm_to_numpy(ra["U"])
+    # linop QR drivers and ABRIK on a ROW-SHARDED sparse operator (each rank holds a row block of the CSR matrix)
+    import scipy.sparse as sp
+    nsp = min(n, 60)
+    Ssp = (sp.random(m, nsp, 0.15, random_state=np.random.default_rng(11), format="csr", data_rvs=np.random.default_rng(12).standard_normal)
+           @ sp.diags(0.9 ** np.arange(nsp))).tocsr()
+    op_loc = d.CsrOperator.from_scipy(Ssp[rows], device="cuda:0")
+    lin = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx, alg, op_loc, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
+    rsa = d.drv_abrik_linop(ctx, op_loc, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
     gathered = [None] * world
     dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
@@ -87,7 +95,13 @@ def main():
         rq1 = d.drv_cqrrpt(ctx1, Aq1, m, ncq, 1.25, 4, key=(5, 0))
         kq = rq["rank"]
         nA = np.linalg.norm(A)
+        op1 = d.CsrOperator.from_scipy(Ssp, device="cuda:0")
+        lin1 = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx1, alg, op1, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
+        rsa1 = d.drv_abrik_linop(ctx1, op1, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
+        Ssa, Ssa1 = rsa["S"].cpu().numpy(), rsa1["S"].cpu().numpy()
         out = dict(
+            lin_R={alg: float(np.linalg.norm(np.triu(lin[alg]) - np.triu(lin1[alg])) / np.linalg.norm(np.triu(lin1[alg]))) for alg in lin},
+            sp_abrik_trip=[rsa["triplets"], rsa1["triplets"]], sp_abrik_S=float(np.max(np.abs(Ssa[:6] - Ssa1[:6]) / Ssa1[:6])),
             bq_rank=rb["rank"], bq_rank1=rb1["rank"], bq_J_equal=bool(np.array_equal(J_b, rb1["J"].cpu().numpy())),
             bq_A=float(np.linalg.norm(Abq_out - Ab1n) / np.linalg.norm(Ab1n)), bq_tau=float(np.max(np.abs(tau_b - rb1["tau"].cpu().numpy()))),
             bqc_rank=rc_["rank"], bqc_J_equal=bool(np.array_equal(J_c, rb1["J"].cpu().numpy())),

@@ -133,7 +133,7 @@ def test_saso_apply_csr_matches_dense_path_and_is_reproducible(ctx, d_sk, nnz):
     outs = []
     for rep in range(2):
         Bd = d.cm_from_numpy(B0)
-        assert ctx.lib.rlhip_saso_apply_csr_f64(ctx.h, h, n, 1.5, rpt.data_ptr(), cit.data_ptr(), vt.data_ptr(), -0.5, Bd.data_ptr(), d_sk) == 0
+        assert ctx.lib.rlhip_saso_apply_csr_f64(ctx.h, h, n, 1.5, rpt.data_ptr(), cit.data_ptr(), vt.data_ptr(), -0.5, Bd.data_ptr(), d_sk, 0) == 0
         outs.append(d.cm_to_numpy(Bd))
     assert np.array_equal(outs[0], outs[1])                                       # integer accumulation: bitwise reproducible
     Bref = d.cm_from_numpy(B0)

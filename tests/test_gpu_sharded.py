@@ -44,6 +44,9 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded BQRRP == single-device BQRRP: same pivots, GEQP3-format output (V, R, tau) equal to rounding, valid factorization
     assert out["bq_rank"] == out["bq_rank1"] and out["bq_J_equal"]
     assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
+    # linop QR drivers and ABRIK on a row-sharded CSR operator: same R / Ritz values as on one device
+    assert all(v <= 1e-10 for v in out["lin_R"].values()), out["lin_R"]
+    assert out["sp_abrik_trip"][0] == out["sp_abrik_trip"][1] and out["sp_abrik_S"] <= 1e-9
     # block-cyclic row layout: same pivots, reflectors and R as the single-device run
     assert out["bqc_rank"] == out["bq_rank1"] and out["bqc_J_equal"]
     assert out["bqc_A"] <= 1e-10 and out["bqc_tau"] <= 1e-10
