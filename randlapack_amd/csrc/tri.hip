@@ -221,57 +221,72 @@ __global__ __launch_bounds__(256) void trsm_blk_pack_kernel(int64_t n, int unit,
     }
 }
 
-template <typename T>
+template <typename T, int RT>
 __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alpha, const T* __restrict__ Upk, const T* __restrict__ Dinv,
                                                        T* __restrict__ B, int64_t ldb) {
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int fr = lane & 15, fk = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * (16 * RT);      // a wave owns RT row tiles of 16 rows: every U fragment feeds RT MFMAs
     if (row0 >= m) return;
-    const int64_t row = (row0 + fr < m) ? row0 + fr : m - 1;       // clamped: loads unconditional, stores masked
-    const bool live = row0 + fr < m;
+    T* Brow[RT];
+    bool live[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const int64_t r = row0 + 16 * q + fr;
+        live[q] = r < m;
+        Brow[q] = B + (live[q] ? r : m - 1);                               // clamped: loads unconditional, stores masked
+    }
     const int nsub = (nb + 31) >> 5;
-    T* Brow = B + row;
     for (int s = 0; s < nsub; ++s) {
-        acc_t acc[2] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+        acc_t acc[RT][2];
+#pragma unroll
+        for (int q = 0; q < RT; ++q) { acc[q][0] = acc_t{0, 0, 0, 0}; acc[q][1] = acc_t{0, 0, 0, 0}; }
         // ---- contribution of the columns already solved
         const T* up = Upk + 32 * s + fr;
         for (int c = 0; c < 32 * s; c += 4) {
-            const T y = Brow[(int64_t)(c + fk) * ldb];                                  // X[row][c + fk]
             const T x0 = up[(int64_t)(c + fk) * BW], x1 = up[(int64_t)(c + fk) * BW + 16];
-            acc[0] = M::mma(x0, y, acc[0]);
-            acc[1] = M::mma(x1, y, acc[1]);
-        }
-        // ---- T = alpha * B_s - acc   (lane holds row fr, columns 32 s + 16 u + drow(lane, r))
-        acc_t t[2];
+            T y[RT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int q = 0; q < RT; ++q) y[q] = Brow[q][(int64_t)(c + fk) * ldb];         // X[row][c + fk]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = 32 * s + 16 * u + M::drow(lane, r);
-                const T b = Brow[(int64_t)(col < nb ? col : nb - 1) * ldb];
-                t[u][r] = (col < nb) ? alpha * b - acc[u][r] : T(0);
+            for (int q = 0; q < RT; ++q) {
+                acc[q][0] = M::mma(x0, y[q], acc[q][0]);
+                acc[q][1] = M::mma(x1, y[q], acc[q][1]);
             }
-        // ---- X_s = T * inv(U_ss)
-        acc_t xs[2] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+        }
         const T* dv = Dinv + (int64_t)s * 1024 + fr;
 #pragma unroll
-        for (int c = 0; c < 32; c += 4) {
-            const T y = M::operand(t[c >> 4], c & 15, lane);                             // T[row][c + fk]
-            const T d0 = dv[(c + fk) * 32], d1 = dv[(c + fk) * 32 + 16];
-            if (c < 16) xs[0] = M::mma(d0, y, xs[0]);                                    // inverse is upper triangular: rows >= 16 do not reach columns < 16
-            xs[1] = M::mma(d1, y, xs[1]);
-        }
-        if (live) {
+        for (int q = 0; q < RT; ++q) {
+            // ---- T = alpha * B_s - acc   (lane holds row fr, columns 32 s + 16 u + drow(lane, r))
+            acc_t t[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int col = 32 * s + 16 * u + M::drow(lane, r);
-                    if (col < nb) Brow[(int64_t)col * ldb] = xs[u][r];
+                    const T b = Brow[q][(int64_t)(col < nb ? col : nb - 1) * ldb];
+                    t[u][r] = (col < nb) ? alpha * b - acc[q][u][r] : T(0);
                 }
+            // ---- X_s = T * inv(U_ss)
+            acc_t xs[2] = {acc_t{0, 0, 0, 0}, acc_t{0, 0, 0, 0}};
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const T y = M::operand(t[c >> 4], c & 15, lane);                         // T[row][c + fk]
+                const T d0 = dv[(c + fk) * 32], d1 = dv[(c + fk) * 32 + 16];
+                if (c < 16) xs[0] = M::mma(d0, y, xs[0]);                                // inverse is upper triangular: rows >= 16 do not reach columns < 16
+                xs[1] = M::mma(d1, y, xs[1]);
+            }
+            if (live[q]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = 32 * s + 16 * u + M::drow(lane, r);
+                        if (col < nb) Brow[q][(int64_t)col * ldb] = xs[u][r];
+                    }
+            }
         }
     }
 }
@@ -338,8 +353,12 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             a = T(1);
         }
         if (try_blk && !bad_host[j0 / BW]) {
-            hipLaunchKernelGGL(trsm_blk_kernel<T>, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, c->stream, m, nb, a, Upk_all + (j0 / BW) * (int64_t)BW * BW,
-                               Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024, B + j0 * ldb, ldb);
+            if (m >= 65536)       // enough rows to fill the chip with 128-row workgroups: two row tiles per wave halve the U-fragment traffic (four: slower, 108.6 vs 105.5 ms at C3)
+                hipLaunchKernelGGL((trsm_blk_kernel<T, 2>), dim3((unsigned)((m + 127) / 128)), dim3(256), 0, c->stream, m, nb, a,
+                                   Upk_all + (j0 / BW) * (int64_t)BW * BW, Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024, B + j0 * ldb, ldb);
+            else
+                hipLaunchKernelGGL((trsm_blk_kernel<T, 1>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, c->stream, m, nb, a,
+                                   Upk_all + (j0 / BW) * (int64_t)BW * BW, Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024, B + j0 * ldb, ldb);
             RLHIP_LAUNCH_CHECK();
             continue;
         }
