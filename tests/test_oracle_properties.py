@@ -428,3 +428,23 @@ def test_syrf_oracle_captures_range(orc):
     rc, Q, _ = orc.syrf(A, rank, 2, 1)
     assert rc == 0 and np.linalg.norm(Q.T @ Q - np.eye(rank)) < 1e-12
     assert np.linalg.norm(A - Q @ (Q.T @ A)) < 1e-10 * np.linalg.norm(A)
+
+
+def test_benchmark_metric_helpers_cpu():
+    """benchmarks/_common.trailing_norms == lantr on every trailing block (BQRRP_pivot_quality.cc:102-114), pure numpy"""
+    import importlib.util
+    import pathlib
+    import sys
+    import types
+
+    src = (pathlib.Path(__file__).resolve().parent.parent / "benchmarks" / "_common.py").read_text()
+    # the helper module imports torch / the device package at module scope; only the numpy helper is exercised here
+    mod = types.ModuleType("bench_common_cpu")
+    ns = mod.__dict__
+    start = src.index("def trailing_norms")
+    end = src.index("def singular_values")
+    exec("import numpy as np\n" + src[start:end], ns)
+    rng = np.random.default_rng(0)
+    R = np.triu(rng.standard_normal((37, 37)))
+    want = np.array([np.linalg.norm(R[i:, i:]) for i in range(37)])
+    np.testing.assert_allclose(ns["trailing_norms"](R), want, rtol=1e-13)
