@@ -446,6 +446,12 @@ __global__ void lu_zero_kernel(unsigned* bar, int* info, int zero_info) { *bar =
 
 namespace rlhip {
 
+static int reg_panel_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RLHIP_LU_REG_PANEL"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v;
+}
+
 template <typename T>
 int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_dev, int* info_host, int pivots_only) {
     if (info_host) *info_host = 0;
@@ -480,20 +486,17 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         int64_t rpw = (rows + Gmax - 1) / Gmax;
         if (rpw < 256) rpw = 256;   // fewer, fatter workgroups: the per-column rendezvous and winner search shrink with G
         const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
-        if (rpw > rpw_max && getenv("RLHIP_LU_REG_PANEL") && atoi(getenv("RLHIP_LU_REG_PANEL")) == 0) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
+        if (rpw > rpw_max && !(reg_panel_on() && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
         int64_t G = (rows + rpw - 1) / rpw;
         g.j0 = j0; g.pb = pb; g.rpw = rpw;
         hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
-        static int reg_panel = -1;
-        if (reg_panel < 0) { const char* e = getenv("RLHIP_LU_REG_PANEL"); reg_panel = (e && atoi(e) == 0) ? 0 : 1; }
+        const int reg_panel = reg_panel_on();
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
         if (reg_panel && rows >= 1024) {
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
             hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
-        } else if (reg_panel) {
-            G = (rows + 255) / 256;
-            hipLaunchKernelGGL((getrf_panel_reg_kernel<T, 1>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
-        } else
+        } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the
+                 // build of this file (32 unrolled column steps) within minutes
             hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
         RLHIP_LAUNCH_CHECK();
         // row interchanges outside the panel
