@@ -35,6 +35,8 @@ struct LuArgs {
     unsigned* bar;
     int* info;                // first zero pivot (1-based), 0 if none
     int64_t rpw;              // rows per workgroup
+    unsigned long long* tw;   // tagged 8-byte words of the flag-less exchange (fp32 register kernel): 2 x (2 G + G PB + PB)
+    unsigned tag_base;        // tags of this launch are tag_base + 1 .. tag_base + PB (unique across launches)
 };
 
 template <typename T>
@@ -172,6 +174,19 @@ template <typename T>
 __device__ __forceinline__ void argmax_take(T& v, int64_t& r, T v2, int64_t r2, int64_t m) {
     if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; }
 }
+// spin until the 8-byte word carries `tag` in its upper half (bounded: ~seconds), return the payload.  Kept out of line: it is
+// called from 32 fully unrolled column steps.
+__device__ __attribute__((noinline)) unsigned lu_tag_get(const unsigned long long* q, unsigned tag, int* info) {
+    unsigned long long w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while ((unsigned)(w >> 32) != tag) {
+        if (++spins > (1 << 22)) { atomicExch(info, -7); break; }
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return (unsigned)w;
+}
+
 // one column step with the column index as a template parameter: every x[q][c] index is a compile-time constant, so the panel
 // really stays in registers (a runtime-indexed loop put it in scratch)
 template <typename T, int RPT>
@@ -179,7 +194,7 @@ struct LuRegState {
     T x[RPT][PB];
     int64_t gr[RPT];
 };
-template <typename T, int RPT, int C>
+template <typename T, int RPT, int C, bool TAG>
 __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww, T* s_piv,
                                             T* s_drow) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -203,6 +218,78 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
     T lbest = s_wv[0]; int64_t lrow = s_wr[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) argmax_take(lbest, lrow, s_wv[w], s_wr[w], m);
+    int64_t p; int wstar;
+    if constexpr (TAG) {
+        // ---- flag-less exchange (fp32): every published item is an 8-byte word {tag : payload}; a reader simply re-reads a word
+        //      until it carries this step's tag.  No store drain, no barrier counter, no acquire fence: the chain per column is
+        //      "store lands -> poll sees it" (~2 memory round trips) instead of drain + arrive + poll + read (~4.5).
+        //      Slots alternate by column parity; a workgroup publishes column c + 1 only after it has consumed everybody's column c
+        //      records, so nobody can still be reading the slot a fast workgroup overwrites two columns later.
+        const unsigned tag = g.tag_base + C + 1;
+        unsigned long long* base = g.tw + (size_t)par * (size_t)(2 * G + G * PB + PB);
+        unsigned long long* cw0 = base, *cw1 = base + G, *rw = base + 2 * G, *dw = rw + G * PB;
+        auto put = [&](unsigned long long* q, unsigned payload) {
+            __hip_atomic_store(q, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto get = [&](const unsigned long long* q) { return lu_tag_get(q, tag, g.info); };
+        if (tid == 0) { put(cw0 + me, __float_as_uint((float)lbest)); put(cw1 + me, (unsigned)lrow); }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (st.gr[q] == lrow && lrow < m) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) put(rw + me * PB + c2, __float_as_uint((float)st.x[q][c2]));
+            }
+            if (st.gr[q] == j) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) put(dw + c2, __float_as_uint((float)st.x[q][c2]));
+            }
+        }
+        // speculative fetch of every candidate row (one word per thread and group of 8 workgroups), validated after the decision
+        constexpr int PF = 8;
+        unsigned long long pfw[PF];
+        const bool pf_ok = G <= 8 * PF;
+        if (pf_ok) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t ww = (tid >> 5) + 8 * u;
+                pfw[u] = __hip_atomic_load(rw + (ww < G ? ww : G - 1) * PB + (tid & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        {
+            T v = T(-1); int64_t r = m; int w = 0;
+            for (int64_t ww = tid; ww < G; ww += 256) {
+                const T v2 = (T)__uint_as_float(get(cw0 + ww)); const int64_t r2 = (int64_t)get(cw1 + ww);
+                if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = (int)ww; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const T v2 = __shfl_xor(v, off); const int64_t r2 = __shfl_xor(r, off); const int w2 = __shfl_xor(w, off);
+                if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = w2; }
+            }
+            if (lane == 0) { s_wv[wid] = v; s_wr[wid] = r; s_ww[wid] = w; }
+        }
+        if (tid < PB) s_drow[tid] = (T)__uint_as_float(get(dw + tid));          // the diagonal row (published by its owner)
+        __syncthreads();
+        T gv = s_wv[0]; p = s_wr[0]; wstar = s_ww[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_wr[w] < m && (s_wv[w] > gv || (s_wv[w] == gv && s_wr[w] < p))) { gv = s_wv[w]; p = s_wr[w]; wstar = s_ww[w]; }
+        if (p >= m) p = j;
+        if (p != j) {
+            if (pf_ok) {
+                if ((tid >> 5) == (wstar & 7)) {                  // this group of 32 threads prefetched the winner's row in pfw[wstar / 8]
+                    unsigned long long w = pfw[0];
+#pragma unroll
+                    for (int u = 1; u < PF; ++u) w = ((wstar >> 3) == u) ? pfw[u] : w;
+                    unsigned payload = (unsigned)w;
+                    if ((unsigned)(w >> 32) != tag) payload = get(rw + (int64_t)wstar * PB + (tid & 31));   // the speculative read was early
+                    s_piv[tid & 31] = (T)__uint_as_float(payload);
+                }
+            } else if (tid < PB)
+                s_piv[tid] = (T)__uint_as_float(get(rw + (int64_t)wstar * PB + tid));
+        } else if (tid < PB)
+            s_piv[tid] = s_drow[tid];
+    } else {
     if (tid == 0) {
         pstore(g.cand_val + par * G + me, lbest);
         __hip_atomic_store(g.cand_row + par * G + me, lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,7 +338,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
         if (lane == 0) { s_wv[wid] = v; s_wr[wid] = r; s_ww[wid] = w; }
     }
     __syncthreads();
-    T gv = s_wv[0]; int64_t p = s_wr[0]; int wstar = s_ww[0];
+    T gv = s_wv[0]; p = s_wr[0]; wstar = s_ww[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (s_wr[w] < m && (s_wv[w] > gv || (s_wv[w] == gv && s_wr[w] < p))) { gv = s_wv[w]; p = s_wr[w]; wstar = s_ww[w]; }
@@ -269,6 +356,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
         const T* prow = g.cand_data + ((int64_t)par * G + wstar) * PB;   // contents of row p (becomes row j)
         s_drow[tid] = dv_pref;
         s_piv[tid] = (p != j) ? prow[tid] : dv_pref;
+    }
     }
     if (me == 0 && tid == 0) g.ipiv[j] = p + 1;
     __syncthreads();
@@ -296,17 +384,17 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
     if (piv == T(0) && me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
     __syncthreads();                                              // s_piv / s_drow / s_w* are rewritten next column
 }
-template <typename T, int RPT, int C>
+template <typename T, int RPT, int C, bool TAG>
 __device__ __forceinline__ void lu_reg_steps(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww,
                                              T* s_piv, T* s_drow) {
     if constexpr (C < PB) {
         if (C < g.pb) {                                           // uniform: pb is a kernel argument
-            lu_reg_step<T, RPT, C>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
-            lu_reg_steps<T, RPT, C + 1>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+            lu_reg_step<T, RPT, C, TAG>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+            lu_reg_steps<T, RPT, C + 1, TAG>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
         }
     }
 }
-template <typename T, int RPT>
+template <typename T, int RPT, bool TAG>
 __global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
     __shared__ T s_wv[4];
     __shared__ int64_t s_wr[4];
@@ -329,7 +417,7 @@ __global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
         }
     }
     unsigned epoch = 0;
-    lu_reg_steps<T, RPT, 0>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+    lu_reg_steps<T, RPT, 0, TAG>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         if (st.gr[q] < m) {
@@ -478,6 +566,17 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     g.cand_val = ws_alloc<T>(c, 2 * Gmax); g.cand_row = ws_alloc<int64_t>(c, 2 * Gmax);
     g.cand_data = ws_alloc<T>(c, (size_t)2 * Gmax * PB); g.diag_data = ws_alloc<T>(c, 2 * PB);
     g.bar = ws_alloc<unsigned>(c, 4); g.info = (int*)ws_alloc<int>(c, 4);
+    static int tag_on = -1;
+    if (tag_on < 0) { const char* e = getenv("RLHIP_LU_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool use_tag = tag_on && sizeof(T) == 4 && m < ((int64_t)1 << 31);
+    const size_t tw_words = 2 * (size_t)(2 * Gmax + Gmax * PB + PB);
+    g.tw = use_tag ? ws_alloc<unsigned long long>(c, tw_words) : nullptr;
+    g.tag_base = 0;
+    static unsigned launch_counter = 0;                       // tags never repeat on a buffer that is not cleared in between
+    if (use_tag) {
+        if (!g.tw) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        RLHIP_CHECK(hipMemsetAsync(g.tw, 0, tw_words * sizeof(unsigned long long), c->stream));
+    }
     if (!g.cand_val || !g.cand_row || !g.cand_data || !g.diag_data || !g.bar || !g.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
     for (int64_t j0 = 0; j0 < mn; j0 += PB) {
         const int pb = (int)((mn - j0 < PB) ? (mn - j0) : PB);
@@ -494,7 +593,12 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
         if (reg_panel && rows >= 1024) {
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
-            hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+            g.tag_base = (++launch_counter) * 64u;
+            if constexpr (sizeof(T) == 4) {
+                if (use_tag) hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+                else hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, false>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+            } else
+                hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, false>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
         } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the
                  // build of this file (32 unrolled column steps) within minutes
             hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
@@ -519,6 +623,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, g.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
         *info_host = *(int*)(c->h_mail + 56);
+        if (*info_host < 0) { rlhip_ws_release(c, mark); return -9; }   // the flag-less exchange timed out (bounded so that a lost word cannot hang the device)
     }
     rlhip_ws_release(c, mark);
     return 0;
