@@ -220,45 +220,45 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
     for (int w = 1; w < 4; ++w) argmax_take(lbest, lrow, s_wv[w], s_wr[w], m);
     int64_t p; int wstar;
     if constexpr (TAG) {
-        // ---- flag-less exchange (fp32): every published item is an 8-byte word {tag : payload}; a reader simply re-reads a word
-        //      until it carries this step's tag.  No store drain, no barrier counter, no acquire fence: the chain per column is
-        //      "store lands -> poll sees it" (~2 memory round trips) instead of drain + arrive + poll + read (~4.5).
+        // ---- flag-less exchange: every published item travels as 8-byte words {tag : 32-bit payload} (a double is two words); a
+        //      reader simply re-reads a word until it carries this step's tag.  No store drain, no barrier counter, no acquire fence:
+        //      the chain per column is "store lands -> poll sees it" instead of drain + arrive + poll + read.
         //      Slots alternate by column parity; a workgroup publishes column c + 1 only after it has consumed everybody's column c
         //      records, so nobody can still be reading the slot a fast workgroup overwrites two columns later.
+        constexpr int W = (int)sizeof(T) / 4;                     // tagged words per value
         const unsigned tag = g.tag_base + C + 1;
-        unsigned long long* base = g.tw + (size_t)par * (size_t)(2 * G + G * PB + PB);
-        unsigned long long* cw0 = base, *cw1 = base + G, *rw = base + 2 * G, *dw = rw + G * PB;
-        auto put = [&](unsigned long long* q, unsigned payload) {
+        unsigned long long* base = g.tw + (size_t)par * (size_t)(W * G + G + W * G * PB + W * PB);
+        unsigned long long* cw0 = base, *cw1 = cw0 + W * G, *rw = cw1 + G, *dw = rw + W * G * PB;
+        auto putw = [&](unsigned long long* q, unsigned payload) {
             __hip_atomic_store(q, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        auto get = [&](const unsigned long long* q) { return lu_tag_get(q, tag, g.info); };
-        if (tid == 0) { put(cw0 + me, __float_as_uint((float)lbest)); put(cw1 + me, (unsigned)lrow); }
+        auto putv = [&](unsigned long long* q, int64_t idx, T v) {
+            if constexpr (W == 1) putw(q + idx, __float_as_uint((float)v));
+            else { const unsigned long long bits = (unsigned long long)__double_as_longlong((double)v); putw(q + 2 * idx, (unsigned)bits); putw(q + 2 * idx + 1, (unsigned)(bits >> 32)); }
+        };
+        auto getv = [&](const unsigned long long* q, int64_t idx) -> T {
+            if constexpr (W == 1) return (T)__uint_as_float(lu_tag_get(q + idx, tag, g.info));
+            else {
+                const unsigned lo = lu_tag_get(q + 2 * idx, tag, g.info), hi = lu_tag_get(q + 2 * idx + 1, tag, g.info);
+                return (T)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            }
+        };
+        if (tid == 0) { putv(cw0, me, lbest); putw(cw1 + me, (unsigned)lrow); }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             if (st.gr[q] == lrow && lrow < m) {
 #pragma unroll
-                for (int c2 = 0; c2 < PB; ++c2) put(rw + me * PB + c2, __float_as_uint((float)st.x[q][c2]));
+                for (int c2 = 0; c2 < PB; ++c2) putv(rw, me * PB + c2, st.x[q][c2]);
             }
             if (st.gr[q] == j) {
 #pragma unroll
-                for (int c2 = 0; c2 < PB; ++c2) put(dw + c2, __float_as_uint((float)st.x[q][c2]));
-            }
-        }
-        // speculative fetch of every candidate row (one word per thread and group of 8 workgroups), validated after the decision
-        constexpr int PF = 8;
-        unsigned long long pfw[PF];
-        const bool pf_ok = G <= 8 * PF;
-        if (pf_ok) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int64_t ww = (tid >> 5) + 8 * u;
-                pfw[u] = __hip_atomic_load(rw + (ww < G ? ww : G - 1) * PB + (tid & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int c2 = 0; c2 < PB; ++c2) putv(dw, c2, st.x[q][c2]);
             }
         }
         {
             T v = T(-1); int64_t r = m; int w = 0;
             for (int64_t ww = tid; ww < G; ww += 256) {
-                const T v2 = (T)__uint_as_float(get(cw0 + ww)); const int64_t r2 = (int64_t)get(cw1 + ww);
+                const T v2 = getv(cw0, ww); const int64_t r2 = (int64_t)lu_tag_get(cw1 + ww, tag, g.info);
                 if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = (int)ww; }
             }
 #pragma unroll
@@ -268,27 +268,14 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
             }
             if (lane == 0) { s_wv[wid] = v; s_wr[wid] = r; s_ww[wid] = w; }
         }
-        if (tid < PB) s_drow[tid] = (T)__uint_as_float(get(dw + tid));          // the diagonal row (published by its owner)
+        if (tid < PB) s_drow[tid] = getv(dw, tid);                 // the diagonal row (published by its owner)
         __syncthreads();
         T gv = s_wv[0]; p = s_wr[0]; wstar = s_ww[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (s_wr[w] < m && (s_wv[w] > gv || (s_wv[w] == gv && s_wr[w] < p))) { gv = s_wv[w]; p = s_wr[w]; wstar = s_ww[w]; }
         if (p >= m) p = j;
-        if (p != j) {
-            if (pf_ok) {
-                if ((tid >> 5) == (wstar & 7)) {                  // this group of 32 threads prefetched the winner's row in pfw[wstar / 8]
-                    unsigned long long w = pfw[0];
-#pragma unroll
-                    for (int u = 1; u < PF; ++u) w = ((wstar >> 3) == u) ? pfw[u] : w;
-                    unsigned payload = (unsigned)w;
-                    if ((unsigned)(w >> 32) != tag) payload = get(rw + (int64_t)wstar * PB + (tid & 31));   // the speculative read was early
-                    s_piv[tid & 31] = (T)__uint_as_float(payload);
-                }
-            } else if (tid < PB)
-                s_piv[tid] = (T)__uint_as_float(get(rw + (int64_t)wstar * PB + tid));
-        } else if (tid < PB)
-            s_piv[tid] = s_drow[tid];
+        if (tid < PB) s_piv[tid] = (p != j) ? getv(rw, (int64_t)wstar * PB + tid) : s_drow[tid];
     } else {
     if (tid == 0) {
         pstore(g.cand_val + par * G + me, lbest);
@@ -568,8 +555,9 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     g.bar = ws_alloc<unsigned>(c, 4); g.info = (int*)ws_alloc<int>(c, 4);
     static int tag_on = -1;
     if (tag_on < 0) { const char* e = getenv("RLHIP_LU_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
-    const bool use_tag = tag_on && sizeof(T) == 4 && m < ((int64_t)1 << 31);
-    const size_t tw_words = 2 * (size_t)(2 * Gmax + Gmax * PB + PB);
+    const bool use_tag = tag_on && m < ((int64_t)1 << 31);
+    constexpr size_t TW = sizeof(T) / 4;
+    const size_t tw_words = 2 * (size_t)(TW * Gmax + Gmax + TW * Gmax * PB + TW * PB);
     g.tw = use_tag ? ws_alloc<unsigned long long>(c, tw_words) : nullptr;
     g.tag_base = 0;
     static unsigned launch_counter = 0;                       // tags never repeat on a buffer that is not cleared in between
@@ -585,20 +573,16 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         int64_t rpw = (rows + Gmax - 1) / Gmax;
         if (rpw < 256) rpw = 256;   // fewer, fatter workgroups: the per-column rendezvous and winner search shrink with G
         const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
-        if (rpw > rpw_max && !(reg_panel_on() && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
+        if (rpw > rpw_max && !(reg_panel_on() && use_tag && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
         int64_t G = (rows + rpw - 1) / rpw;
         g.j0 = j0; g.pb = pb; g.rpw = rpw;
         hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
         const int reg_panel = reg_panel_on();
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
-        if (reg_panel && rows >= 1024) {
+        if (reg_panel && use_tag && rows >= 1024) {          // RLHIP_LU_TAG=0 / RLHIP_LU_REG_PANEL=0: the barrier-based LDS kernel (debug knob)
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
             g.tag_base = (++launch_counter) * 64u;
-            if constexpr (sizeof(T) == 4) {
-                if (use_tag) hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
-                else hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, false>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
-            } else
-                hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, false>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
+            hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
         } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the
                  // build of this file (32 unrolled column steps) within minutes
             hipLaunchKernelGGL(getrf_panel_kernel<T>, dim3((unsigned)G), dim3(256), (size_t)pb * rpw * sizeof(T), c->stream, g);
