@@ -4,12 +4,15 @@
 // Partial pivoting is inherently one decision per column, and the decision must equal LAPACK's (first maximum of
 // |a(j:m, j)|) for the pivot order to be bit-identical given the same sketch.  Organisation:
 //   * blocked right-looking, panel width 32: the trailing update and the U12 solve are MFMA / thread-per-column work;
-//   * the panel itself is ONE persistent launch: the rows below the diagonal are dealt out to the workgroups and the
-//     workgroup's piece of the 32-column panel lives in LDS for the whole panel; per column there is a single grid
-//     rendezvous -- before it each workgroup publishes its best local candidate TOGETHER WITH that row's 32 values
-//     (and the owner of the diagonal row publishes that row), after it everybody knows the winner, the two owners
-//     exchange rows inside their LDS pieces and every workgroup eliminates its own rows.  Published data are 8-byte
-//     write-through stores read after one L1 invalidate (no release fences), double-buffered by column parity.
+//   * the panel itself is ONE persistent launch with the rows below the diagonal dealt out to the workgroups.  Two kernels:
+//     - register kernel (panels of >= 1024 rows): a thread owns 2 (fp64) / 4 (fp32) rows of the 32-column panel in VGPRs, so the
+//       elimination is pure register FMAs against the broadcast pivot row and the local pivot search a wave shuffle reduction.
+//       Per column every workgroup publishes its best candidate TOGETHER WITH that row's 32 values (and the owner of the diagonal
+//       row publishes that row) as 8-byte words {column tag : 32-bit payload}; readers re-read a word until it carries the tag of
+//       the column -- no store drain, no barrier counter, no acquire fence ("flag-less" exchange, bounded spins);
+//     - LDS kernel (short panels): the workgroup's piece of the panel lives in LDS and the columns are separated by a grid
+//       rendezvous (8-byte write-through stores read after one L1 invalidate, double-buffered by column parity);
+//     in both, after the exchange everybody knows the winner, the two owners swap rows and every workgroup eliminates its own rows.
 //   * dlaswp on the columns outside the panel is a thread-per-column kernel walking the 32 swaps in order.
 #include "rlhip_internal.h"
 
