@@ -226,6 +226,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
     const int nrounds = intra ? (JB - 1) : JB;
     const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
+    d2_t x[8], y[8];
     for (int round = 0; round < nrounds; ++round) {
         if (tid >= NROT) { __syncthreads(); continue; }     // wave-uniform: whole wavefronts sit the rounds out
         int p, q;
@@ -241,13 +242,16 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
         // rows 2*ql + 32*r, 2*ql + 32*r + 1  (r = 0..7): 16-byte accesses, a quarter wave covers 256 contiguous bytes
         d2_t* xp = reinterpret_cast<d2_t*>(Xs + p * JM) + ql;
         d2_t* xq = reinterpret_cast<d2_t*>(Xs + q * JM) + ql;
-        d2_t x[8], y[8];
+        // Cross rounds keep the quarter's own column p (= its slot) in registers from the first round to the last: only the
+        // partner column q makes the LDS round trip.  The rounds are bound by LDS bandwidth (16 pairs x 2 columns x 2 KiB read and
+        // written = 1024 clocks of the CU's 128 B/clk pipe), so this halves their cost.
         double aa = 0, bb = 0, ab = 0;
+        if (intra || round == 0) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            x[r] = xp[16 * r];
-            y[r] = xq[16 * r];
+            for (int r = 0; r < 8; ++r) x[r] = xp[16 * r];
         }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] = xq[16 * r];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             aa = fma(x[r].x, x[r].x, aa); aa = fma(x[r].y, x[r].y, aa);
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
                 d2_t xn, yn;
                 xn.x = cs * x[r].x - sn * y[r].x; xn.y = cs * x[r].y - sn * y[r].y;
                 yn.x = sn * x[r].x + cs * y[r].x; yn.y = sn * x[r].y + cs * y[r].y;
-                xp[16 * r] = xn;
+                if (intra) xp[16 * r] = xn;
+                x[r] = xn;
                 xq[16 * r] = yn;
             }
             if (V != nullptr) {                // the rotation accumulator is only needed when V is wanted
@@ -291,6 +296,12 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
         my_rot += (rot && ql == 0) ? 1u : 0u;
         __syncthreads();
     }
+    if (!intra && tid < NROT) {                        // the register-resident column goes back once
+        d2_t* xp = reinterpret_cast<d2_t*>(Xs + sl * JM) + ql;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xp[16 * r] = x[r];
+    }
+    __syncthreads();
     // one atomic pair per wavefront
     {
         unsigned r = my_rot;
