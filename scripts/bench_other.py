@@ -59,7 +59,7 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
     apply_us = r["times_us"][5]
     ach = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
     pk = PEAK[dtype]
-    print(json.dumps({"metric": f"GFLOP/s BQRRP {m} x {n} {'fp32' if dtype == torch.float32 else 'fp64'}, b={b} (single-GPU cut of BASELINE configs[3])",
+    print(json.dumps({"metric": f"GFLOP/s BQRRP {m} x {n} {'fp32' if dtype == torch.float32 else 'fp64'}, b={b} ({'BASELINE configs[3] on one GPU' if m == 65536 else 'single-GPU cut of BASELINE configs[3]'})",
                       "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 1), "best_of": steps,
                       "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic iid N(0,1), generated on-device",
                       "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"]},
@@ -69,8 +69,9 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
 
 
 if __name__ == "__main__":
-    ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64"]); ap.add_argument("--steps", type=int, default=3)
+    ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64", "bqrrp_full"]); ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
     if a.what == "cqrrpt": cqrrpt(a.steps)
     elif a.what == "bqrrp": bqrrp(a.steps)
+    elif a.what == "bqrrp_full": bqrrp(a.steps, torch.float32, 65536, 2048)      # BASELINE configs[3] itself (17 GB) on ONE device
     else: bqrrp(a.steps, torch.float64, 16384, 512)
