@@ -1,6 +1,7 @@
 """-m gpu: each HIP kernel family through the C ABI against the CPU oracle / numpy on the same inputs.
 Tolerances are stated per test; integer work (Philox, pivots) is bit-exact."""
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -423,6 +424,36 @@ def test_getrf_tall_f32_pivots_match_lapack(ctx, m, n):
     assert info_ref == 0
     np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)
     np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=2e-4 * np.abs(lu_ref).max(), rtol=0)
+
+
+def test_getrf_outer_blocking_knob_matches_lapack():
+    """RLHIP_LU_OUTER (two-level blocking; read once per process, hence the subprocess): same pivots and factors as LAPACK for a
+    tall, a wide and a ragged shape, with full and pivots-only factorizations"""
+    import subprocess, sys, textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np, torch, scipy.linalg.lapack as ll
+        from randlapack_amd import device as d
+        ctx = d.Context(0)
+        for (m, n) in [(3000, 700), (300, 900), (2051, 333), (1500, 256)]:
+            A = np.random.default_rng(m + n).standard_normal((m, n))
+            lu_ref, piv_ref, info_ref = ll.dgetrf(A)
+            k = min(m, n)
+            for fn in (ctx.lib.rlhip_getrf_f64, ctx.lib.rlhip_getrf_piv_f64):
+                Ad = d.cm_from_numpy(A); ip = torch.zeros(k, dtype=torch.int64, device="cuda")
+                assert fn(ctx.h, m, n, Ad.data_ptr(), m, ip.data_ptr()) == 0
+                ctx.sync()
+                assert np.array_equal(ip.cpu().numpy() - 1, piv_ref), (m, n)
+                got = d.cm_to_numpy(Ad)
+                tol = 5e-12 * np.abs(lu_ref).max()
+                assert np.abs(np.triu(got[:k]) - np.triu(lu_ref[:k])).max() < tol, (m, n)
+                if fn is ctx.lib.rlhip_getrf_f64:
+                    assert np.abs(got - lu_ref).max() < tol, (m, n)
+        print("OK")
+    """)
+    env = dict(os.environ, RLHIP_LU_OUTER="256", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_getrf_singular_reports_info_and_luqrcp_piv(ctx):
