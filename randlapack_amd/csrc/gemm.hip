@@ -361,7 +361,11 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
     if (variant < 0) { const char* e = getenv("RLHIP_GEMM_VARIANT"); variant = e ? atoi(e) : 0; }
     int cfg;
     int64_t bm, bn;
-    if (N > 128 && !tri && (variant & 2)) { cfg = 5; bm = 128; bn = 128; }
+    // 128 x 128 tiles with two workgroups per CU beat one 128 x 256 workgroup per CU on every driver measured (the second workgroup's
+    // MFMAs cover the first one's barrier + fragment-read bubble at each K tile): BQRRP 32768^2 fp32 1397 -> 1366 ms, 65536^2 fp32
+    // 5389 -> 5299 ms, 16384^2 fp64 588 -> 572 ms; RSVD and CQRRPT (stream-K kernel for their big products) unchanged.
+    // RLHIP_GEMM_VARIANT bit 1 selects the 128 x 256 shape again.
+    if (N > 128 && !tri && !(variant & 2)) { cfg = 5; bm = 128; bn = 128; }
     else if (N > 128 && !tri) { cfg = 0; bm = 128; bn = 256; }
     else if (N > 64 || tri) { cfg = 1; bm = 128; bn = 128; }
     else if (N > 32) { cfg = 2; bm = 256; bn = 64; }
