@@ -1,5 +1,9 @@
-"""ABRIK speed-comparison main on the device library (benchmark/bench_ABRIK/ABRIK_speed_comparisons.cc).
+"""ABRIK benchmark mains on the device library (benchmark/bench_ABRIK/ABRIK_speed_comparisons.cc, ABRIK_runtime_breakdown.cc and their
+_sparse twins).
 
+  python -m benchmarks.abrik runtime_breakdown <dir> <mat_type | sparse:<density>> <num_runs> <m> <n> <custom_rank> <num_block_sizes> <num_matmul_sizes> <block sizes...> <matmul counts...>
+        -> _ABRIK_runtime_breakdown_num_info_lines_6.txt: block size, matmuls, then the 13 entries of ABRIK::times (microseconds):
+           allocation, get_factors, ungqr, reorth, qr, gemm_A, main_loop, sketching, r_cpy, s_cpy, norm, rest, total
   python -m benchmarks.abrik speed <dir> <mat_type> <num_runs> <m> <n> <target_rank> <num_block_sizes> <num_matmul_sizes> <block sizes...> <matmul counts...>
 
 The reference reads its input matrix from a file; here it is generated in HBM (gen::mat_gen types: polynomial, exponential, step,
@@ -88,7 +92,46 @@ def speed(argv):
     return path
 
 
-MAINS = {"speed": speed}
+def runtime_breakdown(argv):
+    directory, m_type, num_runs, m, n, custom_rank = argv[0], argv[1], int(argv[2]), int(argv[3]), int(argv[4]), int(argv[5])
+    nb, nm = int(argv[6]), int(argv[7])
+    b_sz = [int(x) for x in argv[8:8 + nb]]
+    matmuls = [int(x) for x in argv[8 + nb:8 + nb + nm]]
+    ctx = d.Context(0)
+    tol = float(np.finfo(np.float64).eps ** 0.85)
+    if m_type.startswith("sparse"):                        # ABRIK_runtime_breakdown_sparse.cc reads a Matrix Market file; here: random CSR
+        import scipy.sparse as sp
+        density = float(m_type.split(":")[1]) if ":" in m_type else 1e-3
+        nnz = int(density * m * n)
+        if nnz > 2 * 10**8:
+            raise SystemExit(f"{nnz} nonzeros requested: host-side generation is capped at 2e8")
+        # positions drawn with replacement (duplicates are summed): scipy.sparse.random permutes all m*n cells for a legacy RandomState
+        rng = np.random.default_rng(0)
+        M = sp.coo_matrix((rng.standard_normal(nnz), (rng.integers(0, m, nnz), rng.integers(0, n, nnz))), shape=(m, n)).tocsr()
+        op = d.CsrOperator.from_scipy(M)
+    else:
+        kw = dict(cond_num=1e8, exponent=2.0) if m_type in ("polynomial", "exponential") else (dict(cond_num=1e8) if m_type == "step" else {})
+        A = c.regen(ctx, m_type, m, n, **kw)
+        op = d.DenseOperator(A, m, n)
+    path = c.out_path(directory, "_ABRIK_runtime_breakdown_num_info_lines_6.txt")
+    with open(path, "a") as f:
+        f.write("Description: Results from the ABRIK runtime breakdown benchmark, recording the time it takes to perform every subroutine in ABRIK."
+                "\nFile format: 13 data columns, each corresponding to a given ABRIK subroutine: allocation_t_dur, get_factors_t_dur, ungqr_t_dur, reorth_t_dur, qr_t_dur, gemm_A_t_dur, main_loop_t_dur, sketching_t_dur, r_cpy_t_dur, s_cpy_t_dur, norm_t_dur, t_rest, total_t_dur"
+                "               rows correspond to ABRIK runs with block sizes varying as specified, with numruns repititions of each block size"
+                f"\nInput type:{m_type} (generated in HBM)"
+                f"\nInput size:{m} by {n}"
+                f"\nAdditional parameters: Krylov block sizes {''.join(str(b) + ', ' for b in b_sz)} matmuls: {''.join(str(x) + ', ' for x in matmuls)}"
+                f" num runs per size {num_runs} num singular values and vectors approximated {custom_rank}\n")
+    for b in b_sz:
+        for mm in matmuls:
+            for _ in range(num_runs):
+                o = d.drv_abrik_linop(ctx, op, b, tol, max_krylov_iters=mm, timing=True)
+                with open(path, "a") as f:
+                    f.write("".join(f"{x}, " for x in [b, mm] + o["times_us"]) + "\n")
+    return path
+
+
+MAINS = {"speed": speed, "runtime_breakdown": runtime_breakdown}
 
 if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in MAINS:

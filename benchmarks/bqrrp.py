@@ -2,6 +2,8 @@
 
   python -m benchmarks.bqrrp speed_mat_size   <dir> <num_runs> <row/col ratio> <cols/block ratio> <m1> [m2 ...]
         (benchmark/bench_BQRRP/BQRRP_speed_comparisons_mat_size.cc) -> _BQRRP_speed_comparisons_mat_size_num_info_lines_7.txt
+  python -m benchmarks.bqrrp speed_block_size <dir> <num_runs> <m> <n> <b1> [b2 ...]
+        (BQRRP_speed_comparisons_block_size.cc) -> _BQRRP_speed_comparisons_block_size_num_info_lines_7.txt
   python -m benchmarks.bqrrp runtime_breakdown <dir> <qr_tall: cholqr|geqrf> <num_runs> <m> <n> <b1> [b2 ...]
         (BQRRP_runtime_breakdown.cc) -> _BQRRP_runtime_breakdown_num_info_lines_7.txt
   python -m benchmarks.bqrrp pivot_quality     <dir> <m> <n> <block_size> [mat_type]
@@ -24,6 +26,23 @@ from . import _common as c
 QR_TALL = {"geqrt": 0, "cholqr": 1, "geqrf": 2}
 
 
+def _speed_row(ctx, m, n, b, d_factor):
+    """the seven timings of one line of the speed-comparison files: BQRRP+CholQR, BQRRP+QRF, HQRRP, HQRRP+QRF, HQRRP+CholQR, QRF, QP3
+    (every algorithm on a freshly generated copy of the same Gaussian matrix)"""
+    row = []
+    for what in ("bqrrp_cholqr", "bqrrp_qrf", "hqrrp", "hqrrp_qrf", "hqrrp_cholqr", "qrf", "qp3"):
+        A = c.regen(ctx, "gaussian", m, n)
+        fn = {"bqrrp_cholqr": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=1),
+              "bqrrp_qrf": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=2),
+              "hqrrp": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int(d_factor * b) - b + 10 if d_factor > 1 else 10, qr_type=0),
+              "hqrrp_qrf": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=1),
+              "hqrrp_cholqr": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=2),
+              "qrf": lambda: c.geqrf(ctx, A, m, n), "qp3": lambda: c.geqp3(ctx, A, m, n)}[what]
+        row.append(c.timed_us(fn))
+        del A
+    return row
+
+
 def speed_mat_size(argv):
     directory, numruns, ratio, blk_ratio = argv[0], int(argv[1]), float(argv[2]), float(argv[3])
     m_sz = [int(x) for x in argv[4:]]
@@ -43,17 +62,32 @@ def speed_mat_size(argv):
         n = int(m / ratio)
         b = max(1, int(n / blk_ratio))
         for _ in range(numruns):
-            row = []
-            for what in ("bqrrp_cholqr", "bqrrp_qrf", "hqrrp", "hqrrp_qrf", "hqrrp_cholqr", "qrf", "qp3"):
-                A = c.regen(ctx, "gaussian", m, n)
-                fn = {"bqrrp_cholqr": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=1),
-                      "bqrrp_qrf": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=2),
-                      "hqrrp": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int(d_factor * b) - b + 10 if d_factor > 1 else 10, qr_type=0),
-                      "hqrrp_qrf": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=1),
-                      "hqrrp_cholqr": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=2),
-                      "qrf": lambda: c.geqrf(ctx, A, m, n), "qp3": lambda: c.geqp3(ctx, A, m, n)}[what]
-                row.append(c.timed_us(fn))
-                del A
+            row = _speed_row(ctx, m, n, b, d_factor)
+            with open(path, "a") as f:
+                f.write(",  ".join(map(str, row)) + ",\n")
+    with open(path, "a") as f:
+        f.write(f"Total benchmark execution time:{int((time.perf_counter() - t_all) * 1e6)}\n")
+    return path
+
+
+def speed_block_size(argv):
+    directory, numruns, m, n = argv[0], int(argv[1]), int(argv[2]), int(argv[3])
+    b_sz = [int(x) for x in argv[4:]]
+    ctx = d.Context(0)
+    d_factor = 1.0
+    path = c.out_path(directory, "_BQRRP_speed_comparisons_block_size_num_info_lines_7.txt")
+    with open(path, "a") as f:
+        f.write("Description: Results from the BQRRP speed comparison benchmark, recording the time it takes to perform BQRRP and alternative QR and QRCP factorizations."
+                "\nFile format: 7 columns, containing time for each algorithm: BQRRP+CholQR, BQRRP+QRF, HQRRP, HQRRP+QRF, HQRRP+CholQR, QRF, QP3;"
+                "               rows correspond to BQRRP runs with block sizes varying as specified, with numruns repititions of each block size."
+                "\nNum OMP threads:0 (device: MI355X)"
+                f"\nInput type:{c.MAT_TYPE_IDS['gaussian']}"
+                f"\nInput size:{m} by {n}"
+                f"\nAdditional parameters: BQRRP block sizes: {''.join(str(b) + ', ' for b in b_sz)}num runs per size {numruns} BQRRP d factor: {d_factor:f}\n")
+    t_all = time.perf_counter()
+    for b in b_sz:
+        for _ in range(numruns):
+            row = _speed_row(ctx, m, n, b, d_factor)
             with open(path, "a") as f:
                 f.write(",  ".join(map(str, row)) + ",\n")
     with open(path, "a") as f:
@@ -168,7 +202,7 @@ def error_analysis(argv):
     return path
 
 
-MAINS = {"speed_mat_size": speed_mat_size, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality, "error_analysis": error_analysis}
+MAINS = {"speed_mat_size": speed_mat_size, "speed_block_size": speed_block_size, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality, "error_analysis": error_analysis}
 
 if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in MAINS:

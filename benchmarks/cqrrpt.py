@@ -5,6 +5,9 @@
         8 columns: GEQP3, GEQRF, CQRRPT default (geqp3), CQRRPT hqrrp, CQRRPT bqrrp, sCholQR3, GEQR, GEQPT
   python -m benchmarks.cqrrpt runtime_breakdown <dir> <num_runs> <m> <n1> [n2 ...]
         (CQRRPT_runtime_breakdown.cc): the 8 CQRRPT.times columns
+  python -m benchmarks.cqrrpt error_analysis    <dir> <cqrrpt|geqp3> <num_runs> <m> <n1> [n2 ...]
+        (CQRRPT_error_analysis.cc) -> _CQRRPT_error_analysis_num_info_lines_4.txt: per column size, one row per matrix type
+        (polynomial, staircase, spiked, Kahan): avg ||AP - QR|| / ||A||, max - avg, avg ||Q'Q - I|| / sqrt(n), max - avg
   python -m benchmarks.cqrrpt pivot_quality     <dir> <m> <n> [mat_type]
         (CQRRPT_pivot_quality.cc): metric 1 = trailing-norm ratios vs GEQP3, metric 2 = |R_ii| / sigma_i (GEQP3 line, CQRRPT line)
 """
@@ -110,6 +113,49 @@ def runtime_breakdown(argv):
     return path
 
 
+def error_analysis(argv):
+    directory, alg, num_runs, m = argv[0], argv[1], int(argv[2]), int(argv[3])
+    col_sz = [int(x) for x in argv[4:]]
+    ctx = d.Context(0)
+    atol = float(np.finfo(np.float64).eps ** 0.75)                     # CQRRPT_error_analysis.cc:206
+    tests = [("polynomial", dict(cond_num=1e10, exponent=2.0)), ("step", dict(cond_num=1e10)), ("spiked", dict(scaling=1e10)),
+             ("kahan", dict(theta=1.2, perturb=1e3))]
+    path = c.out_path(directory, "_CQRRPT_error_analysis_num_info_lines_4.txt")
+    with open(path, "a") as f:
+        f.write(f"Description: Results from the {alg} error analysis; putput rows capture results per given matrix type, columns capture results per error type."
+                "\nAt the moment, i test polynomial, staircase and spiked matrices with reconstructiuon error, max column norm error and orthogonality loss."
+                "\nNum OMP threads:0 (device: MI355X)"
+                f"\nInput size:{m} by {''.join(str(n) + ', ' for n in col_sz)}\n")
+    for n in col_sz:
+        for m_type, kw in tests:
+            if m_type == "kahan" and m != n:
+                continue                                               # the Kahan matrix is square (rl_gen.hh:408-434)
+            rec, orth = [], []
+            for run in range(num_runs):
+                A0 = c.regen(ctx, m_type, m, n, key=(run, 0), **kw)
+                A = A0.clone()
+                if alg == "cqrrpt":
+                    out = d.drv_cqrrpt(ctx, A, m, n, D_FACTOR, NNZ, eps=atol, key=(run, 1))
+                    J, k = out["J"], out["rank"]
+                    Q = A[:k]                                           # (k, m): the first k columns of the column-major m x n buffer
+                    R = torch.triu(out["R"].T[:k])                      # (k, n)
+                else:
+                    J, tau = c.geqp3(ctx, A, m, n)
+                    k = min(m, n)
+                    R = torch.triu(A[:, :k].T)
+                    Q = A[:k].clone()
+                    ctx.lib.rlhip_ungqr_f64(ctx.h, m, k, k, Q.data_ptr(), m, tau.data_ptr())
+                AP = A0[(J - 1).long()]                                 # permuted columns, (n, m)
+                resid = AP - R.T @ Q                                    # (n, m) == (A P - Q R)^T   (error_check(), :83-106)
+                rec.append(float(torch.linalg.norm(resid) / torch.linalg.norm(A0)))
+                G = Q @ Q.T
+                orth.append(float(torch.linalg.norm(G - torch.eye(k, dtype=G.dtype, device=G.device)) / np.sqrt(n)))
+            ar, ao = float(np.mean(rec)), float(np.mean(orth))
+            with open(path, "a") as f:
+                f.write(f"{ar:.14e},  {max(rec) - ar:.14e},  {ao:.14e},  {max(orth) - ao:.14e},\n")
+    return path
+
+
 def pivot_quality(argv):
     directory, m, n = argv[0], int(argv[1]), int(argv[2])
     m_type = argv[3] if len(argv) > 3 else "polynomial"
@@ -141,7 +187,7 @@ def pivot_quality(argv):
     return p1, p2
 
 
-MAINS = {"speed": speed, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality}
+MAINS = {"speed": speed, "runtime_breakdown": runtime_breakdown, "pivot_quality": pivot_quality, "error_analysis": error_analysis}
 
 if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in MAINS:

@@ -8,6 +8,7 @@
 // replicated; exchanges: A^T X (n x k, inside the linop), the two re-orthogonalisation inner products of the X side, and
 // CQRRT's sketch + Gram all-reduces.  Needs qr_exp = cqrrt.
 #pragma once
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <limits>
@@ -87,6 +88,15 @@ public:
             q.allreduce_sum(tmp, rows_ * cols_);
             lapack::lacpy(MatrixType::General, rows_, cols_, tmp, rows_, buf, ld_, q);
         };
+        // subroutine timers of the reference (:176-212): every lap drains the stream first, so they are only armed when `timing` is set
+        using clk = std::chrono::steady_clock;
+        long allocation_t = 0, get_factors_t = 0, ungqr_t = 0, reorth_t = 0, qr_t = 0, gemm_A_t = 0, main_loop_t = 0, sketching_t = 0, r_cpy_t = 0,
+             s_cpy_t = 0, norm_t = 0;
+        clk::time_point lap_t0, total_t0, loop_t0;
+        auto tic = [&]() { if (timing) { q.sync(); lap_t0 = clk::now(); } };
+        auto toc = [&](long& acc) { if (timing) { q.sync(); acc += (long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - lap_t0).count(); } };
+        if (timing) { q.sync(); total_t0 = clk::now(); }
+        tic();
         const int64_t m = A.n_rows, n = A.n_cols;
         int64_t iter = 0, iter_od = 0, iter_ev = 0, end_rows = 0, end_cols = 0;
         T norm_R = 0;
@@ -104,24 +114,41 @@ public:
         const T threshold = std::sqrt(1 - sq_tol) * norm_A;
         const T sqrt_eps = std::sqrt(std::numeric_limits<T>::epsilon());
         auto elem = [&](const T* p) { T v; blas::copy_to_host(1, p, &v, q); return v; };
+        toc(allocation_t);
 
+        tic();
         RandBLAS::DenseDist D(n, k);                                                                            // :298-299
         state = RandBLAS::fill_dense(D, Y_od.p + Y_i, state, q);
+        toc(sketching_t);
+        tic();
         A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, (T)1.0, Y_od.p + Y_i, n, (T)0.0, X_ev.p + X_i, m);   // :311
+        toc(gemm_A_t);
         if (use_cqrrt) {                                                                                        // :318-319
+            tic();
             panel_qr(m, X_ev.p + X_i, R_11_trans, k, true, state);
+            toc(qr_t);
         } else {
+            tic();
             lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                       // :333
+            toc(qr_t);
+            tic();
             lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                    // :342
+            toc(ungqr_t);
         }
         ++iter_od;
         ++iter;
+        if (timing) { q.sync(); loop_t0 = clk::now(); }
         while (1) {
             if (iter % 2 != 0) {
+                tic();
                 A(Side::Left, Layout::ColMajor, Op::Trans, Op::NoTrans, n, k, m, (T)1.0, X_ev.p + X_i, m, (T)0.0, Y_od.p + Y_i, n);   // :364
+                toc(gemm_A_t);
+                tic();
                 curr_X_cols += k;                                                                               // :371-375
                 X_ev.ensure(curr_X_cols);
                 X_i = m * (curr_X_cols - k);
+                toc(allocation_t);
+                tic();
                 if (iter != 1) {                                                                                // :384-394
                     blas::Scratch w2(q);
                     Y_orth_buf = w2.alloc<T>(k * iter_ev * k);
@@ -130,25 +157,43 @@ public:
                     blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, k, iter_ev * k, n, (T)1.0, Y_od.p + Y_i, n, Y_od.p, n, (T)0.0, Y_orth_buf, k, q);
                     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, k, iter_ev * k, (T)-1.0, Y_od.p, n, Y_orth_buf, k, (T)1.0, Y_od.p + Y_i, n, q);
                 }
+                toc(reorth_t);
                 if (use_cqrrt) {                                                                                // :402-410
+                    tic();
                     lapack::laset(MatrixType::General, k, k, (T)0, (T)0, R_11_trans, k, q);
                     panel_qr(n, Y_od.p + Y_i, R_11_trans, k, false, state);
+                    toc(qr_t);
+                    tic();
                     util::transposition(k, k, R_11_trans, k, R.p + R_ii, n, 1, q);
+                    toc(r_cpy_t);
                 } else {
+                    tic();
                     lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                               // :420
+                    toc(qr_t);
+                    tic();
                     util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                            // :432 (upper triangle, transposed)
+                    toc(r_cpy_t);
+                    tic();
                     lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                            // :444
+                    toc(ungqr_t);
                 }
                 if (std::abs(elem(R.p + R_ii + (n + 1) * (k - 1))) < sqrt_eps) break;                           // :455-458
+                tic();
                 R.ensure(curr_X_cols);                                                                          // :461-484
                 R_i = (iter_ev + 1) * k;
                 R_ii = (n * k * (iter_ev + 1)) + k + (k * iter_ev);
+                toc(allocation_t);
                 ++iter_ev;
             } else {
+                tic();
                 A(Side::Left, Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, n, (T)1.0, Y_od.p + Y_i, n, (T)0.0, X_ev.p + X_i, m);   // :494
+                toc(gemm_A_t);
+                tic();
                 curr_Y_cols += k;                                                                               // :501-505
                 Y_od.ensure(curr_Y_cols);
                 Y_i = n * (curr_Y_cols - k);
+                toc(allocation_t);
+                tic();
                 {                                                                                               // :515-522
                     blas::Scratch w2(q);
                     const int64_t ldx = iter_od * k;
@@ -160,19 +205,31 @@ public:
                     reduce_m(X_orth_buf, iter_od * k, k, ldx);
                     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, k, iter_od * k, (T)-1.0, X_ev.p, m, X_orth_buf, ldx, (T)1.0, X_ev.p + X_i, m, q);
                 }
+                toc(reorth_t);
                 if (use_cqrrt) {                                                                                // :530-531
+                    tic();
                     panel_qr(m, X_ev.p + X_i, S.p + S_ii, n + k, true, state);
+                    toc(qr_t);
                 } else {
+                    tic();
                     lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                               // :552
+                    toc(qr_t);
+                    tic();
                     lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);              // :561
+                    toc(s_cpy_t);
+                    tic();
                     lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                            // :570
+                    toc(ungqr_t);
                 }
                 if (std::abs(elem(S.p + S_ii + ((n + k) + 1) * (k - 1))) < sqrt_eps) break;                     // :595-598
+                tic();
                 S.ensure(curr_Y_cols);                                                                          // :604-630
                 S_i = (n + k) * k * iter_od;
                 S_ii = (n + k) * k * iter_od + k + (iter_od * k);
+                toc(allocation_t);
                 ++iter_od;
             }
+            tic();
             if (iter % 2 != 0) {                                                                                // :641-642 lantr(Fro, Upper)
                 blas::Scratch w2(q);
                 const int64_t nn = iter_ev * k;
@@ -181,25 +238,36 @@ public:
                 lapack::lacpy(MatrixType::Upper, nn, nn, R.p, n, Tri, nn, q);
                 norm_R = lapack::lange(Norm::Fro, nn, nn, Tri, nn, q);
             }
+            toc(norm_t);
             if (iter >= max_iters) break;                                                                       // :650-653
             ++iter;
             if (norm_R > threshold) break;                                                                      // :659-662
         }
+        if (timing) { q.sync(); main_loop_t = (long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - loop_t0).count(); }
         norm_R_end = norm_R;
         num_krylov_iters = (int)iter;
         end_cols = num_krylov_iters * k / 2;                                                                    // :668-669
         end_rows = (iter % 2 == 0) ? end_cols + k : end_cols;
+        tic();
         T* U_hat = ws.alloc<T>(end_rows * end_cols);
         T* VT_hat = ws.alloc<T>(end_cols * end_cols);
         Sigma = blas::device_malloc<T>(std::min(end_cols, end_rows), q);                                        // :678-680
         U = blas::device_malloc<T>(m * end_cols, q);
         V = blas::device_malloc<T>(n * end_cols, q);
+        toc(allocation_t);
+        tic();
         if (iter % 2 != 0) lapack::gesdd(Job::SomeVec, end_rows, end_cols, R.p, n, Sigma, U_hat, end_rows, VT_hat, end_cols, q);       // :685
         else lapack::gesdd(Job::SomeVec, end_rows, end_cols, S.p, n + k, Sigma, U_hat, end_rows, VT_hat, end_cols, q);                 // :688
         blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, end_cols, end_rows, (T)1.0, X_ev.p, m, U_hat, end_rows, (T)0.0, U, m, q);   // :696
         blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, n, end_cols, end_cols, (T)1.0, Y_od.p, n, VT_hat, end_cols, (T)0.0, V, n, q);    // :698
         singular_triplets_found = end_cols;
         q.sync();
+        toc(get_factors_t);
+        if (timing) {                                                                                           // :730-734
+            const long total_t = (long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - total_t0).count();
+            const long t_rest = total_t - (allocation_t + get_factors_t + ungqr_t + reorth_t + qr_t + gemm_A_t + sketching_t + r_cpy_t + s_cpy_t + norm_t);
+            times = {allocation_t, get_factors_t, ungqr_t, reorth_t, qr_t, gemm_A_t, main_loop_t, sketching_t, r_cpy_t, s_cpy_t, norm_t, t_rest, total_t};
+        }
         return 0;
     }
 

@@ -125,6 +125,12 @@ int rlhip_drv_qr_linops_f32(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* lef
 int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right /* must be NULL */, int64_t k, double tol,
                               int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
                               int64_t* iters, double* norm_R_end, int qr_exp);
+/* The same call with ABRIK's subroutine timers armed (ABRIK(verbose, time_subroutines = true, tol), rl_abrik.hh:64; the 13 entries of
+ * ABRIK::times, rl_abrik.hh:733-734, in microseconds: allocation, get_factors, ungqr, reorth, qr, gemm_A, main_loop, sketching, r_cpy,
+ * s_cpy, norm, rest, total).  Every lap drains the stream, so a timed call is slower than an untimed one. */
+int rlhip_drv_abrik_linop_timed_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, int64_t k, double tol, int64_t max_krylov_iters, double** U,
+                                    double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end,
+                                    int qr_exp, long times[13]);
 /* C (m x n, ldc) = alpha * op(A) * B + beta * C for an operator given by descriptor(s): the raw operator call, for tests and for
  * callers that only want the SpMM / composite product.  side 'L' or 'R', trans 'N' or 'T', column-major B and C. */
 int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,

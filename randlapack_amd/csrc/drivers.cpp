@@ -469,15 +469,15 @@ int rlhip_drv_qr_linops_f32(rlhip_ctx* ctx, int alg, const rlhip_linop_desc* lef
     return drv_qr_linops<float>(ctx, alg, left, right, R, ldr, block_size, Q_out, d_factor, nnz, use_dense_sketch, state, A_hat_in, A_hat_out);
 }
 
-int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int64_t k, double tol,
-                              int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
-                              int64_t* iters, double* norm_R_end, int qr_exp) {
+static int abrik_linop_impl(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int64_t k, double tol,
+                            int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
+                            int64_t* iters, double* norm_R_end, int qr_exp, long* times13) {
     return guarded([&] {
         blas::Queue q(ctx);
         if (right) throw RandLAPACK::Error("ABRIK needs fro_nrm(): single dense / sparse operators only (composites have none, as in the reference)");
         if (!left || (left->kind != 0 && left->kind != 1)) throw RandLAPACK::Error("operator kind must be 0 (dense) or 1 (CSR)");
         auto run = [&](auto& A) -> int {
-            RandLAPACK::ABRIK<double, RNG> alg(q, false, false, tol);
+            RandLAPACK::ABRIK<double, RNG> alg(q, false, times13 != nullptr, tol);
             if (qr_exp >= 0) {
                 if (qr_exp > 1) throw RandLAPACK::Error("qr_exp must be 0 (geqrf_ungqr) or 1 (cqrrt)");
                 alg.qr_exp = (RandLAPACK::ABRIKSubroutines::QR_explicit)qr_exp;
@@ -490,12 +490,26 @@ int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, cons
             if (triplets) *triplets = alg.singular_triplets_found;
             if (iters) *iters = alg.num_krylov_iters;
             if (norm_R_end) *norm_R_end = alg.norm_R_end;
+            if (times13) for (size_t i = 0; i < 13; ++i) times13[i] = (i < alg.times.size()) ? alg.times[i] : 0;
             return rc;
         };
         if (left->kind == 0) { auto A = make_dense<double>(q, *left); return run(*A); }
         auto A = make_sparse<double>(q, *left);
         return run(*A);
     });
+}
+
+int rlhip_drv_abrik_linop_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int64_t k, double tol,
+                              int64_t max_krylov_iters, double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets,
+                              int64_t* iters, double* norm_R_end, int qr_exp) {
+    return abrik_linop_impl(ctx, left, right, k, tol, max_krylov_iters, U, Sigma, V, state, triplets, iters, norm_R_end, qr_exp, nullptr);
+}
+
+int rlhip_drv_abrik_linop_timed_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, int64_t k, double tol, int64_t max_krylov_iters, double** U,
+                                    double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end,
+                                    int qr_exp, long times[13]) {
+    if (!times) return -14;
+    return abrik_linop_impl(ctx, left, nullptr, k, tol, max_krylov_iters, U, Sigma, V, state, triplets, iters, norm_R_end, qr_exp, times);
 }
 
 int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,

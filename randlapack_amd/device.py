@@ -422,19 +422,33 @@ def drv_qr_linops(ctx: Context, alg, op, block_size=0, want_Q=False, d_factor=2.
     return out
 
 
-def drv_abrik_linop(ctx: Context, op, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0), qr_exp=-1):
-    """ABRIK::call on a DenseOperator / CsrOperator.  Same outputs as drv_abrik."""
+ABRIK_TIMES = ("allocation", "get_factors", "ungqr", "reorth", "qr", "gemm_A", "main_loop", "sketching", "r_cpy", "s_cpy", "norm", "rest", "total")
+
+
+def drv_abrik_linop(ctx: Context, op, k, tol, max_krylov_iters=0, ctr=(0, 0, 0, 0), key=(0, 0), qr_exp=-1, timing=False):
+    """ABRIK::call on a DenseOperator / CsrOperator.  Same outputs as drv_abrik; timing=True arms ABRIK's subroutine timers and adds
+    times_us (the 13 entries of ABRIK::times, rl_abrik.hh:733-734, names in ABRIK_TIMES)."""
     ld, rd, m, n, _ = _op_descs(op)
     Up, Sp, Vp = C.c_void_p(), C.c_void_p(), C.c_void_p()
     trip, iters = C.c_int64(0), C.c_int64(0)
     nre = C.c_double(0)
     st = _state_arr(ctr, key)
-    rc = ctx.lib.rlhip_drv_abrik_linop_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, k, tol, max_krylov_iters,
-                                           C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(trip), C.byref(iters), C.byref(nre), qr_exp)
+    times = (C.c_long * 13)() if timing else None
+    if timing:
+        if rd is not None:
+            raise ValueError("ABRIK runs on single operators only")
+        rc = ctx.lib.rlhip_drv_abrik_linop_timed_f64(ctx.h, C.byref(ld), k, tol, max_krylov_iters, C.byref(Up), C.byref(Sp), C.byref(Vp), st,
+                                                     C.byref(trip), C.byref(iters), C.byref(nre), qr_exp, times)
+    else:
+        rc = ctx.lib.rlhip_drv_abrik_linop_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, k, tol, max_krylov_iters,
+                                               C.byref(Up), C.byref(Sp), C.byref(Vp), st, C.byref(trip), C.byref(iters), C.byref(nre), qr_exp)
     _drv_check(ctx, rc, "abrik_linop")
     t = int(trip.value)
-    return dict(rc=rc, U=_adopt(ctx, Up, m, t), S=_adopt(ctx, Sp, t, 1).reshape(-1), V=_adopt(ctx, Vp, n, t), triplets=t,
-                iters=int(iters.value), norm_R_end=float(nre.value), next_ctr=tuple(int(x) for x in st[:4]))
+    out = dict(rc=rc, U=_adopt(ctx, Up, m, t), S=_adopt(ctx, Sp, t, 1).reshape(-1), V=_adopt(ctx, Vp, n, t), triplets=t,
+               iters=int(iters.value), norm_R_end=float(nre.value), next_ctr=tuple(int(x) for x in st[:4]))
+    if timing:
+        out["times_us"] = [int(x) for x in times]
+    return out
 
 
 def linop_apply(ctx: Context, op, side, trans, B, m, n, k, alpha=1.0, beta=0.0, C_in=None):

@@ -96,3 +96,50 @@ def test_abrik_and_cqrrt_linops_mains(tmp_path):
         assert float(f[6]) < 1e-10 and int(f[8]) == 1                    # CQRRT_linops: orthonormal Q
         assert float(f[14]) < 1e-10 and float(f[18]) < 1e-10              # sCholQR3 and dense CQRRT too
         assert int(f[7]) == int(f[1])                                     # every column of the prefix test passes
+
+
+def test_bqrrp_block_size_main(tmp_path):
+    from benchmarks import bqrrp
+
+    p = bqrrp.speed_block_size([str(tmp_path), "1", "768", "512", "64", "128", "256"])
+    rows = _rows(p)
+    assert rows[-1][0].startswith("Total benchmark execution time:")
+    data = rows[:-1]
+    assert len(data) == 3 and all(len(r) == 7 and all(int(x) > 0 for x in r) for r in data)      # 3 block sizes x 1 run, 7 algorithms
+
+
+def test_cqrrpt_error_analysis_main(tmp_path):
+    from benchmarks import cqrrpt
+
+    p = cqrrpt.error_analysis([str(tmp_path), "cqrrpt", "2", "4096", "64", "128"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:") and lines[3].startswith("Input size:4096 by 64, 128, ")
+    body = lines[4:]
+    assert len(body) == 2 * 3                                         # two column sizes x (polynomial, staircase, spiked); no Kahan row (m != n)
+    for ln in body:
+        v = [float(x) for x in ln.rstrip(", ").split(",")]
+        # CQRRPT's guarantees: reconstruction error at the working precision, Q orthonormal to eps * cond(preconditioned A)
+        assert len(v) == 4 and v[0] < 1e-12 and v[2] < 1e-10 and v[1] >= 0 and v[3] >= 0
+    (tmp_path / "g").mkdir()
+    p2 = cqrrpt.error_analysis([str(tmp_path / "g"), "geqp3", "1", "300", "300"])
+    rows = open(p2).read().rstrip("\n").split("\n")[4:]
+    assert len(rows) == 4 and all(float(r.split(",")[0]) < 1e-13 for r in rows)                   # square input: the Kahan row is there
+
+
+@pytest.mark.parametrize("m_type", ["gaussian", "sparse:0.01"])
+def test_abrik_runtime_breakdown_main(tmp_path, m_type):
+    from benchmarks import abrik
+
+    p = abrik.runtime_breakdown([str(tmp_path), m_type, "2", "1500", "1000", "20", "2", "2", "8", "16", "4", "8"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    # header as the reference writes it: 5 lines (the "File format" and "rows correspond" strings are concatenated without a line break)
+    assert lines[0].startswith("Description:") and lines[4].startswith("Additional parameters")
+    data = [[x for x in re.split(r",\s*", ln.strip()) if x] for ln in lines[5:]]
+    assert len(data) == 2 * 2 * 2 and all(len(r) == 15 for r in data)          # block size, matmuls, 13 timers
+    for r in data:
+        t = [int(x) for x in r]
+        assert t[0] in (8, 16) and t[1] in (4, 8)
+        alloc, factors, ungqr, reorth, qr, gemm_a, main_loop, sketch, r_cpy, s_cpy, norm, rest, total = t[2:]
+        assert total > 0 and gemm_a > 0 and qr > 0 and factors > 0
+        assert alloc + factors + ungqr + reorth + qr + gemm_a + sketch + r_cpy + s_cpy + norm + rest == total   # the reference's identity (:732)
+        assert 0 < main_loop <= total and rest >= 0
