@@ -186,18 +186,19 @@ __device__ __forceinline__ double row16_allsum(double v) {
     return dpp_ror_add(v, 1);
 }
 
-template <typename T, int JB>
-__global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
+// JMT = panel rows held in LDS: 256 (1024 threads) or 512 (512 threads: the rotating lanes then carry 32 rows of two columns = 128 VGPRs)
+template <typename T, int JB, int JMT>
+__global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
                                                                int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
                                                                unsigned* __restrict__ nrot) {
     constexpr int JP = 2 * JB;
-    constexpr int NT = 1024;                           // all 16 waves move data; the first 16*JB threads rotate
+    constexpr int NT = (JMT == 256) ? 1024 : 512;                           // all 16 waves move data; the first 16*JB threads rotate
     constexpr int NW = NT / 64;
     constexpr int NROT = 16 * JB;                      // JB pairs per round, 16 lanes each
     typedef double d2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JM] column-major
-    T* Js = Xs + JP * JM;                              // [JP][JP] column-major
+    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
+    T* Js = Xs + JP * JMT;                              // [JP][JP] column-major
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ql = lane & 15;                          // lane inside the quarter
     // block pair of this workgroup (circle method over NB blocks)
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     }
     auto gcol = [&](int c) { return (c < JB) ? (P * JB + c) : (Q * JB + (c - JB)); };   // panel col -> global col
     // ---- load panel (zero padded), J = I
-    for (int e = tid; e < JP * JM; e += NT) {
-        const int r = e % JM, c = e / JM;
+    for (int e = tid; e < JP * JMT; e += NT) {
+        const int r = e % JMT, c = e / JMT;
         const int gc = gcol(c);
         Xs[e] = (r < m && gc < n) ? A[r + (int64_t)gc * lda] : T(0);
     }
@@ -226,7 +227,8 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
     const int nrounds = intra ? (JB - 1) : JB;
     const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
-    d2_t x[8], y[8];
+    constexpr int RL = JMT / 32;                       // 16-byte row pairs per lane
+    d2_t x[RL], y[RL];
     for (int round = 0; round < nrounds; ++round) {
         if (tid >= NROT) { __syncthreads(); continue; }     // wave-uniform: whole wavefronts sit the rounds out
         int p, q;
@@ -240,20 +242,20 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
             p = sl; q = JB + ((sl + round) & (JB - 1));
         }
         // rows 2*ql + 32*r, 2*ql + 32*r + 1  (r = 0..7): 16-byte accesses, a quarter wave covers 256 contiguous bytes
-        d2_t* xp = reinterpret_cast<d2_t*>(Xs + p * JM) + ql;
-        d2_t* xq = reinterpret_cast<d2_t*>(Xs + q * JM) + ql;
+        d2_t* xp = reinterpret_cast<d2_t*>(Xs + p * JMT) + ql;
+        d2_t* xq = reinterpret_cast<d2_t*>(Xs + q * JMT) + ql;
         // Cross rounds keep the quarter's own column p (= its slot) in registers from the first round to the last: only the
         // partner column q makes the LDS round trip.  The rounds are bound by LDS bandwidth (16 pairs x 2 columns x 2 KiB read and
         // written = 1024 clocks of the CU's 128 B/clk pipe), so this halves their cost.
         double aa = 0, bb = 0, ab = 0;
         if (intra || round == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) x[r] = xp[16 * r];
+            for (int r = 0; r < RL; ++r) x[r] = xp[16 * r];
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] = xq[16 * r];
+        for (int r = 0; r < RL; ++r) y[r] = xq[16 * r];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < RL; ++r) {
             aa = fma(x[r].x, x[r].x, aa); aa = fma(x[r].y, x[r].y, aa);
             bb = fma(y[r].x, y[r].x, bb); bb = fma(y[r].y, y[r].y, bb);
             ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
         const double cs = fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * tt;
         if (__builtin_amdgcn_ballot_w64(rot)) {                             // skip the stores when no quarter rotates
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < RL; ++r) {
                 d2_t xn, yn;
                 xn.x = cs * x[r].x - sn * y[r].x; xn.y = cs * x[r].y - sn * y[r].y;
                 yn.x = sn * x[r].x + cs * y[r].x; yn.y = sn * x[r].y + cs * y[r].y;
@@ -297,9 +299,9 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
         __syncthreads();
     }
     if (!intra && tid < NROT) {                        // the register-resident column goes back once
-        d2_t* xp = reinterpret_cast<d2_t*>(Xs + sl * JM) + ql;
+        d2_t* xp = reinterpret_cast<d2_t*>(Xs + sl * JMT) + ql;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xp[16 * r] = x[r];
+        for (int r = 0; r < RL; ++r) xp[16 * r] = x[r];
     }
     __syncthreads();
     // one atomic pair per wavefront
@@ -316,8 +318,8 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
         }
     }
     // ---- write the rotated panel back
-    for (int e = tid; e < JP * JM; e += NT) {
-        const int r = e % JM, c = e / JM;
+    for (int e = tid; e < JP * JMT; e += NT) {
+        const int r = e % JMT, c = e / JMT;
         const int gc = gcol(c);
         if (r < m && gc < n) A[r + (int64_t)gc * lda] = Xs[e];
     }
@@ -327,22 +329,22 @@ __global__ __launch_bounds__(1024) void jacobi_block_kernel(int m, int n, int NB
     //      lane's results run along rows -> 128-byte store segments.
     typedef double d4_t __attribute__((ext_vector_type(4)));
     const int fr = lane & 15, fk = lane >> 4;
-    for (int r0 = 0; V != nullptr && r0 < n; r0 += JM) {
+    for (int r0 = 0; V != nullptr && r0 < n; r0 += JMT) {
         __syncthreads();
-        for (int e = tid; e < JP * JM; e += NT) {
-            const int r = e % JM, c = e / JM;
+        for (int e = tid; e < JP * JMT; e += NT) {
+            const int r = e % JMT, c = e / JMT;
             const int gc = gcol(c);
             Xs[e] = (r0 + r < n && gc < n) ? V[(r0 + r) + (int64_t)gc * ldv] : T(0);
         }
         __syncthreads();
         constexpr int NU = JP / 16;
-        for (int rg = wid; rg < JM / 16; rg += NW) {
+        for (int rg = wid; rg < JMT / 16; rg += NW) {
             d4_t acc[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) acc[u] = d4_t{0, 0, 0, 0};
 #pragma unroll 4
             for (int st = 0; st < JP / 4; ++st) {
-                const double vf = (double)Xs[(16 * rg + fr) + (4 * st + fk) * JM];
+                const double vf = (double)Xs[(16 * rg + fr) + (4 * st + fk) * JMT];
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const double jf = (double)Js[(4 * st + fk) + (16 * u + fr) * JP];
@@ -424,25 +426,26 @@ __global__ void gram_offdiag_kernel(int n, const T* __restrict__ G, T tol, unsig
     if (gi > 0 && gj > 0 && g * g > (double)tol * (double)tol * gi * gj) atomicOr(flag, 1u);
 }
 
-template <typename T, int JB>
+template <typename T, int JB, int JMT>
 int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
     constexpr int JP = 2 * JB;
     int NBk = (n + JB - 1) / JB;
     if (NBk < 2) NBk = 2;
     if (NBk % 2) ++NBk;
-    constexpr int smem = (JP * JM + JP * JP) * (int)sizeof(T);
+    constexpr int smem = (JP * JMT + JP * JP) * (int)sizeof(T);
+    constexpr int NT = (JMT == 256) ? 1024 : 512;
     static bool attr_set = false;
     if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T, JB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T, JB, JMT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
-        hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
+        hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
                            (int64_t)n, tol, d_nrot);
         for (int oround = 0; oround < NBk - 1; ++oround)
-            hipLaunchKernelGGL((jacobi_block_kernel<T, JB>), dim3(NBk / 2), dim3(1024), smem, c->stream, m, n, NBk, oround, 0, A, lda,
+            hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, oround, 0, A, lda,
                                V, (int64_t)n, tol, d_nrot);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -512,12 +515,15 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     const int max_sweeps = 60;
     int sweep = 0;
     int info = 0;
-    if (n > 1 && m <= JM && sizeof(T) == 8) {
+    static int jm512 = -1;
+    if (jm512 < 0) { const char* e = getenv("RLHIP_JACOBI_512"); jm512 = (e && atoi(e) == 0) ? 0 : 1; }
+    if (n > 1 && m <= (jm512 ? 2 * JM : JM) && sizeof(T) == 8) {
         // LDS-resident block Jacobi (see jacobi_block_kernel)
         static int jb_sel = 0;
         if (!jb_sel) { const char* e = getenv("RLHIP_JACOBI_JB"); jb_sel = (e && atoi(e) == 32) ? 32 : 16; }
-        if (jb_sel == 32 || n <= 32) rc = block_jacobi_sweeps<T, 32>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
-        else rc = block_jacobi_sweeps<T, 16>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
+        if (m > JM) rc = block_jacobi_sweeps<T, 16, 2 * JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);   // 257 .. 512 rows: 32 x 512 panel = 128 KiB
+        else if (jb_sel == 32 || n <= 32) rc = block_jacobi_sweeps<T, 32, JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
+        else rc = block_jacobi_sweeps<T, 16, JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
         if (rc) { rlhip_ws_release(c, mark); return rc; }
         if (sweep >= max_sweeps) info = 1;
     } else if (n > 1) {
