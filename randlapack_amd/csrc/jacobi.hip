@@ -363,6 +363,15 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
     }
 }
 
+// dst (ldd) = (TD) src (lds), m x n
+template <typename TS, typename TD>
+__global__ void convert_kernel(int64_t m, int64_t n, const TS* __restrict__ src, int64_t lds_, TD* __restrict__ dst, int64_t ldd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * n) return;
+    const int64_t i = idx % m, j = idx / m;
+    dst[i + j * ldd] = (TD)src[i + j * lds_];
+}
+
 // column norms -> S (unsorted), one workgroup per column
 template <typename T>
 __global__ __launch_bounds__(256) void colnorm_kernel(int64_t m, const T* __restrict__ A, int64_t lda,
@@ -502,6 +511,32 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     if (n64 == 0) return 0;
     const int n = (int)n64;
     const int N = (n % 2) ? n + 1 : n;
+    if constexpr (sizeof(T) == 4) {
+        // fp32 problems run the fp64 kernels on a widened copy.  Short factors (the k x k matrix of an fp32 RSVD / ABRIK tail) then get the
+        // LDS-resident block Jacobi (3.5 ms at n = 256 against 25 ms for 255 per-round launches x ~11 sweeps), and tall ones lose the
+        // drift of thousands of fp32 rotations (measured at 3000 x 256: ||V^T V - I|| = 7e3 eps32 in fp32 arithmetic, 5 eps32 widened).
+        static int widen = -1;
+        if (widen < 0) { const char* e = getenv("RLHIP_JACOBI_WIDEN_F32"); widen = (e && atoi(e) == 0) ? 0 : 1; }
+        if (widen && n > 1) {
+            size_t mk = rlhip_ws_mark(c);
+            double* Ad = ws_alloc<double>(c, (size_t)m * n);
+            double* Sd = ws_alloc<double>(c, (size_t)n);
+            double* VTd = (VT != nullptr) ? ws_alloc<double>(c, (size_t)n * n) : nullptr;
+            if (!Ad || !Sd || (VT != nullptr && !VTd)) { rlhip_ws_release(c, mk); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            const unsigned gA = (unsigned)((m * n + 255) / 256), gV = (unsigned)(((int64_t)n * n + 255) / 256);
+            hipLaunchKernelGGL((convert_kernel<float, double>), dim3(gA), dim3(256), 0, c->stream, m, (int64_t)n, A, lda, Ad, m);
+            int info = gesvdj<double>(c, m, n64, Ad, m, Sd, VTd, (int64_t)n, sweeps_host);
+            if (info >= 0) {
+                hipLaunchKernelGGL((convert_kernel<double, float>), dim3(gA), dim3(256), 0, c->stream, m, (int64_t)n, Ad, m, A, lda);
+                hipLaunchKernelGGL((convert_kernel<double, float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)n, (int64_t)1, Sd, (int64_t)n, S, (int64_t)n);
+                if (VT != nullptr)
+                    hipLaunchKernelGGL((convert_kernel<double, float>), dim3(gV), dim3(256), 0, c->stream, (int64_t)n, (int64_t)n, VTd, (int64_t)n, VT, ldvt);
+                RLHIP_LAUNCH_CHECK();
+            }
+            rlhip_ws_release(c, mk);
+            return info;
+        }
+    }
     size_t mark = rlhip_ws_mark(c);
     T* V = (VT != nullptr) ? ws_alloc<T>(c, (size_t)n * n) : nullptr;
     T* W = ws_alloc<T>(c, (size_t)m * n);

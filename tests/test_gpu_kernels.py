@@ -236,6 +236,38 @@ def test_gesvdj(ctx, m, n, cond):
     assert np.linalg.norm(vt @ vt.T - np.eye(n)) <= 1e-12 * n
 
 
+@pytest.mark.parametrize("m,n", [(256, 256), (500, 120), (1500, 96), (3000, 256)])
+def test_gesvdj_gesdd_f32(ctx, m, n):
+    """fp32 SVDs run the fp64 Jacobi kernels on a widened copy (block kernel for m <= 512, per-round kernel above; gesdd: CholQR2 in fp32 +
+    the widened k x k problem): singular values, reconstruction and orthogonality at the fp32 rounding level against numpy"""
+    import ctypes as C
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m * 7 + n)
+    A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * np.logspace(0, -2, n) @ np.linalg.qr(rng.standard_normal((n, n)))[0]).astype(np.float32)
+    sref = np.linalg.svd(A.astype(np.float64), compute_uv=False)
+    e32 = float(np.finfo(np.float32).eps)
+    for which in ("gesvdj", "gesdd"):
+        Ad = d.cm_from_numpy(A)
+        S = torch.empty(n, dtype=torch.float32, device="cuda")
+        VT = d.cm_empty(n, n, dtype=torch.float32)
+        sw = C.c_int()
+        if which == "gesvdj":
+            info = ctx.lib.rlhip_gesvdj_f32(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), VT.data_ptr(), n, C.byref(sw))
+            U = Ad
+        else:
+            U = d.cm_empty(m, n, dtype=torch.float32)
+            info = ctx.lib.rlhip_gesdd_f32(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n, C.byref(sw))
+        assert info == 0, which
+        u, s_, vt = d.cm_to_numpy(U).astype(np.float64), S.cpu().numpy().astype(np.float64), d.cm_to_numpy(VT).astype(np.float64)
+        assert np.all(np.diff(s_) <= 0)
+        assert np.max(np.abs(s_ - sref)) <= 5 * e32 * sref[0], which
+        assert np.linalg.norm(u * s_ @ vt - A) <= 20 * e32 * np.linalg.norm(A), which
+        assert np.linalg.norm(u.T @ u - np.eye(n)) <= 10 * np.sqrt(n) * e32, which
+        assert np.linalg.norm(vt @ vt.T - np.eye(n)) <= 10 * np.sqrt(n) * e32, which
+
+
 @pytest.mark.parametrize("m,n,cond", [(2000, 64, 10.0), (5000, 256, 1e5), (300, 40, 1e12), (40, 40, 1e3), (3000, 512, 1e4), (576, 512, 10.0), (1000, 384, 1e9)])
 def test_gesdd_tall_vs_lapack(ctx, orc, m, n, cond):
     import ctypes as C
