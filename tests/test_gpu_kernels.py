@@ -673,3 +673,71 @@ def test_geqrf_tall_skinny_matches_lapack(ctx, m, n, cond):
     Q = d.cm_to_numpy(Ad)
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 1e-12 * np.sqrt(n)
     assert np.linalg.norm(Q @ Rg - A) <= 1e-13 * np.linalg.norm(A)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32 instantiations of the kernel families (BASELINE config 4 computes in fp32): each against a float64 numpy / LAPACK result on the
+# same (fp32-representable) input, tolerances in units of eps32
+# ---------------------------------------------------------------------------------------------------
+def test_f32_kernel_families(ctx):
+    import scipy.linalg as sl
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    f32 = torch.float32
+    e32 = float(np.finfo(np.float32).eps)
+    rng = np.random.default_rng(32)
+    m, n = 70000, 512                                       # tall enough for the MFMA block trsm (m >= 65536: two row tiles per wave)
+    A = rng.standard_normal((m, n)).astype(np.float32)
+    A64 = A.astype(np.float64)
+    Ad = d.cm_from_numpy(A)
+    # syrk (upper) + potrf
+    G = d.cm_zeros(n, n, dtype=f32)
+    ctx.syrk("U", "T", n, m, 1.0, Ad, m, 0.0, G, n)
+    Gref = A64.T @ A64
+    g = d.cm_to_numpy(G).astype(np.float64)
+    assert np.abs(np.triu(g) - np.triu(Gref)).max() <= 4 * e32 * np.sqrt(m) * np.abs(Gref).max() / np.sqrt(m) * 8
+    assert np.all(np.tril(g, -1) == 0)                       # LAPACK uplo contract
+    assert ctx.potrf(n, G, n) == 0
+    R = np.triu(d.cm_to_numpy(G)).astype(np.float64)
+    assert np.linalg.norm(R.T @ R - np.triu(g) - np.triu(g, 1).T) <= 50 * e32 * np.linalg.norm(Gref)
+    # trsm: Q = A R^-1 (MFMA block path at this shape), then trmm back
+    ctx.trsm(m, n, 1.0, G, n, Ad, m)
+    Q = d.cm_to_numpy(Ad).astype(np.float64)
+    assert np.linalg.norm(Q @ R - A64) <= 20 * e32 * np.linalg.norm(A64)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 200 * e32 * np.sqrt(n)          # cond(A)^2 * eps32 for a Gaussian A: a few
+    ctx.trmm(m, n, 1.0, G, n, Ad, m)
+    assert np.linalg.norm(d.cm_to_numpy(Ad).astype(np.float64) - A64) <= 40 * e32 * np.linalg.norm(A64)
+    # geqrf + ungqr (pipelined kernel for this width) against LAPACK's reflectors
+    m2, n2 = 3000, 200
+    B = rng.standard_normal((m2, n2)).astype(np.float32)
+    Bd = d.cm_from_numpy(B)
+    tau = torch.zeros(n2, dtype=f32, device="cuda")
+    assert ctx.lib.rlhip_geqrf_f32(ctx.h, m2, n2, Bd.data_ptr(), m2, tau.data_ptr()) == 0
+    qr_ref, tau_ref, _, _ = ll.dgeqrf(B.astype(np.float64))
+    assert np.abs(d.cm_to_numpy(Bd).astype(np.float64) - qr_ref).max() <= 200 * e32 * np.abs(qr_ref).max()   # same reflectors, same signs
+    assert np.abs(tau.cpu().numpy().astype(np.float64) - tau_ref).max() <= 50 * e32
+    assert ctx.lib.rlhip_ungqr_f32(ctx.h, m2, n2, n2, Bd.data_ptr(), m2, tau.data_ptr()) == 0
+    Q2 = d.cm_to_numpy(Bd).astype(np.float64)
+    assert np.linalg.norm(Q2.T @ Q2 - np.eye(n2)) <= 20 * e32 * np.sqrt(n2)
+    assert np.linalg.norm(Q2 @ np.triu(qr_ref[:n2]) - B) <= 50 * e32 * np.linalg.norm(B)
+    # geqp3: pivot order identical to LAPACK's on well separated column norms
+    m3, n3 = 1200, 96
+    Cm = (rng.standard_normal((m3, n3)) * np.logspace(0, -3, n3)[rng.permutation(n3)]).astype(np.float32)
+    Cd = d.cm_from_numpy(Cm)
+    J = torch.zeros(n3, dtype=torch.int64, device="cuda")
+    tau3 = torch.zeros(n3, dtype=f32, device="cuda")
+    assert ctx.lib.rlhip_geqp3_f32(ctx.h, m3, n3, Cd.data_ptr(), m3, J.data_ptr(), tau3.data_ptr()) == 0
+    jref = ll.sgeqp3(Cm)[1]
+    np.testing.assert_array_equal(J.cpu().numpy(), jref)
+    Rg = np.triu(d.cm_to_numpy(Cd)[:n3]).astype(np.float64)
+    _, rref = sl.qr(Cm.astype(np.float64)[:, jref - 1], mode="economic")
+    assert np.abs(np.abs(np.diag(Rg)) - np.abs(np.diag(rref))).max() <= 50 * e32 * abs(rref[0, 0])
+    # col_swap: exact
+    perm = rng.permutation(n3) + 1
+    Cd = d.cm_from_numpy(Cm)
+    Jp = torch.from_numpy(perm.astype(np.int64)).cuda()
+    assert ctx.lib.rlhip_col_swap_f32(ctx.h, m3, n3, n3, Cd.data_ptr(), m3, Jp.data_ptr()) == 0
+    np.testing.assert_array_equal(d.cm_to_numpy(Cd), Cm[:, perm - 1])
+    np.testing.assert_array_equal(Jp.cpu().numpy(), perm)
