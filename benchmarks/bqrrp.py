@@ -34,9 +34,10 @@ def _speed_row(ctx, m, n, b, d_factor):
         A = c.regen(ctx, "gaussian", m, n)
         fn = {"bqrrp_cholqr": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=1),
               "bqrrp_qrf": lambda: d.drv_bqrrp(ctx, A, m, n, b, d_factor, qr_tall=2),
-              "hqrrp": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int(d_factor * b) - b + 10 if d_factor > 1 else 10, qr_type=0),
-              "hqrrp_qrf": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=1),
-              "hqrrp_cholqr": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, qr_type=2),
+              # as the reference's mains call it: oversampling (d_factor - 1) * b, no pivoting inside the panel (:82,146,160,173)
+              "hqrrp": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int((d_factor - 1) * b), panel_pivoting=0, qr_type=0),
+              "hqrrp_qrf": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int((d_factor - 1) * b), panel_pivoting=0, qr_type=1),
+              "hqrrp_cholqr": lambda: d.drv_hqrrp(ctx, A, m, n, nb_alg=b, pp=int((d_factor - 1) * b), panel_pivoting=0, qr_type=2),
               "qrf": lambda: c.geqrf(ctx, A, m, n), "qp3": lambda: c.geqp3(ctx, A, m, n)}[what]
         row.append(c.timed_us(fn))
         del A
