@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void trsm_blk_pack_kernel(int64_t n, int unit,
 
 template <typename T, int RT>
 __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alpha, const T* __restrict__ Upk, const T* __restrict__ Dinv,
-                                                       T* __restrict__ B, int64_t ldb) {
+                                                       T* __restrict__ B, int64_t ldb, int s_lo, int c_lo) {
+    // solves the sub-blocks s_lo .. of the block's first nb columns; the columns < c_lo have been applied by the caller (one GEMM)
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -239,13 +240,13 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
         Brow[q] = B + (live[q] ? r : m - 1);                               // clamped: loads unconditional, stores masked
     }
     const int nsub = (nb + 31) >> 5;
-    for (int s = 0; s < nsub; ++s) {
+    for (int s = s_lo; s < nsub; ++s) {
         acc_t acc[RT][2];
 #pragma unroll
         for (int q = 0; q < RT; ++q) { acc[q][0] = acc_t{0, 0, 0, 0}; acc[q][1] = acc_t{0, 0, 0, 0}; }
         // ---- contribution of the columns already solved
         const T* up = Upk + 32 * s + fr;
-        for (int c = 0; c < 32 * s; c += 4) {
+        for (int c = c_lo; c < 32 * s; c += 4) {
             const T x0 = up[(int64_t)(c + fk) * BW], x1 = up[(int64_t)(c + fk) * BW + 16];
             T y[RT];
 #pragma unroll
@@ -353,13 +354,31 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             a = T(1);
         }
         if (try_blk && !bad_host[j0 / BW]) {
-            if (m >= 65536)       // enough rows to fill the chip with 128-row workgroups: two row tiles per wave halve the U-fragment traffic (four: slower, 108.6 vs 105.5 ms at C3)
-                hipLaunchKernelGGL((trsm_blk_kernel<T, 2>), dim3((unsigned)((m + 127) / 128)), dim3(256), 0, c->stream, m, nb, a,
-                                   Upk_all + (j0 / BW) * (int64_t)BW * BW, Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024, B + j0 * ldb, ldb);
-            else
-                hipLaunchKernelGGL((trsm_blk_kernel<T, 1>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, c->stream, m, nb, a,
-                                   Upk_all + (j0 / BW) * (int64_t)BW * BW, Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024, B + j0 * ldb, ldb);
-            RLHIP_LAUNCH_CHECK();
+            // RLHIP_TRSM_HALF = 128 / 64 lets the fused kernel solve narrower pieces of the block with a GEMM in between (more of the
+            // flops at GEMM speed).  Measured at C3 (m = 2^20, n = 1024): CQRRPT 105.5 ms whole blocks, 107.8 ms halves, 117.2 ms quarters:
+            // the extra passes over B cost more than the fused kernel's lower rate, so whole blocks stay the default.
+            static int hb_env = -1;
+            if (hb_env < 0) { const char* e = getenv("RLHIP_TRSM_HALF"); hb_env = e ? atoi(e) : BW; if (hb_env < 32 || hb_env > BW || hb_env % 32) hb_env = BW; }
+            const T* Upk_b = Upk_all + (j0 / BW) * (int64_t)BW * BW;
+            const T* Dinv_b = Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024;
+            for (int h0 = 0; h0 < nb; h0 += hb_env) {
+                const int hb = (nb - h0 < hb_env) ? (nb - h0) : hb_env;
+                T ah = a;
+                if (h0 > 0) {
+                    const int64_t jc = j0 + h0;
+                    // columns [j0, jc) of this block (the columns left of j0 went in above, with alpha)
+                    int rc = gemm_impl<T>(c, 0, 0, m, hb, h0, T(-1), B + j0 * ldb, ldb, A + j0 + jc * lda, lda, a, B + jc * ldb, ldb, 0);
+                    if (rc) { rlhip_ws_release(c, mark); return rc; }
+                    ah = T(1);
+                }
+                if (m >= 65536)       // enough rows to fill the chip with 128-row workgroups: two row tiles per wave halve the U-fragment traffic (four: slower, 108.6 vs 105.5 ms at C3)
+                    hipLaunchKernelGGL((trsm_blk_kernel<T, 2>), dim3((unsigned)((m + 127) / 128)), dim3(256), 0, c->stream, m, h0 + hb, ah, Upk_b, Dinv_b,
+                                       B + j0 * ldb, ldb, h0 / 32, h0);
+                else
+                    hipLaunchKernelGGL((trsm_blk_kernel<T, 1>), dim3((unsigned)((m + 63) / 64)), dim3(256), 0, c->stream, m, h0 + hb, ah, Upk_b, Dinv_b,
+                                       B + j0 * ldb, ldb, h0 / 32, h0);
+                RLHIP_LAUNCH_CHECK();
+            }
             continue;
         }
         for (int s0 = 0; s0 < nb; s0 += SB) {
