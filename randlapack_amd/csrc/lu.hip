@@ -563,7 +563,8 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     const size_t tw_words = 2 * (size_t)(TW * Gmax + Gmax + TW * Gmax * PB + TW * PB);
     g.tw = use_tag ? ws_alloc<unsigned long long>(c, tw_words) : nullptr;
     g.tag_base = 0;
-    static unsigned launch_counter = 0;                       // tags never repeat on a buffer that is not cleared in between
+    // tags: (panel index + 1) * 64 + column.  The word buffer is cleared at the start of every call and belongs to this call's workspace, so
+    // a tag is unique where it can be seen and never equals the cleared pattern (m < 2^31 keeps 2 * j0 + 64 inside 32 bits)
     if (use_tag) {
         if (!g.tw) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         RLHIP_CHECK(hipMemsetAsync(g.tw, 0, tw_words * sizeof(unsigned long long), c->stream));
@@ -594,7 +595,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
         if (reg_panel && use_tag && rows >= 1024) {          // RLHIP_LU_TAG=0 / RLHIP_LU_REG_PANEL=0: the barrier-based LDS kernel (debug knob)
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
-            g.tag_base = (++launch_counter) * 64u;
+            g.tag_base = (unsigned)(j0 / PB + 1) * 64u;
             hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
         } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the
                  // build of this file (32 unrolled column steps) within minutes
