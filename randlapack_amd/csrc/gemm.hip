@@ -69,7 +69,11 @@ struct PadK {
 };
 template <>
 struct PadK<float> {
-    static constexpr int v = 4;  // keep 16-byte alignment of 4-float chunks
+    // stride 18 floats: the fragment read of a half wave (rows fr = 0..15, k = 4s + {0, 1}) touches banks (18 fr + k) mod 32 = all 32
+    // banks once.  Stride 20 (16-byte aligned chunks) maps the 16 rows onto 8 bank groups: 2-way conflicts on every fragment read
+    // (PMC: SQ_LDS_BANK_CONFLICT = 8 % of the CU cycles per k-contiguous operand, profiles/round1_pmc_gemm_f32.txt).  The staging
+    // stores of such a tile are therefore two 8-byte stores per 4-float chunk.
+    static constexpr int v = 2;
 };
 
 template <typename T, int ROWS, int BK, bool KC>
@@ -138,10 +142,18 @@ __device__ __forceinline__ void tile_sstore(const T* reg, T* __restrict__ s,
         if (TCH % NT != 0 && c >= TCH) break;
         int line = c / CPL;
         int off = (c % CPL) * V;
-        vec_t v;
+        if constexpr (KC && sizeof(T) == 4) {
+            typedef T half_t __attribute__((ext_vector_type(2)));
+            half_t lo, hi;
+            lo[0] = reg[u * V + 0]; lo[1] = reg[u * V + 1]; hi[0] = reg[u * V + 2]; hi[1] = reg[u * V + 3];
+            *reinterpret_cast<half_t*>(s + line * stride + off) = lo;
+            *reinterpret_cast<half_t*>(s + line * stride + off + 2) = hi;
+        } else {
+            vec_t v;
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = reg[u * V + e];
-        *reinterpret_cast<vec_t*>(s + line * stride + off) = v;
+            for (int e = 0; e < V; ++e) v[e] = reg[u * V + e];
+            *reinterpret_cast<vec_t*>(s + line * stride + off) = v;
+        }
     }
 }
 
