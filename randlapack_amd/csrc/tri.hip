@@ -246,16 +246,23 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
         for (int q = 0; q < RT; ++q) { acc[q][0] = acc_t{0, 0, 0, 0}; acc[q][1] = acc_t{0, 0, 0, 0}; }
         // ---- contribution of the columns already solved
         const T* up = Upk + 32 * s + fr;
-        for (int c = c_lo; c < 32 * s; c += 4) {
-            const T x0 = up[(int64_t)(c + fk) * BW], x1 = up[(int64_t)(c + fk) * BW + 16];
-            T y[RT];
+        // one earlier sub-block (32 columns) at a time with a constant trip count: the eight steps' loads are issued together
+        for (int c0 = c_lo; c0 < 32 * s; c0 += 32) {
+            T x0[8], x1[8], y[8][RT];
 #pragma unroll
-            for (int q = 0; q < RT; ++q) y[q] = Brow[q][(int64_t)(c + fk) * ldb];         // X[row][c + fk]
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 4 * u;
+                x0[u] = up[(int64_t)(c + fk) * BW]; x1[u] = up[(int64_t)(c + fk) * BW + 16];
 #pragma unroll
-            for (int q = 0; q < RT; ++q) {
-                acc[q][0] = M::mma(x0, y[q], acc[q][0]);
-                acc[q][1] = M::mma(x1, y[q], acc[q][1]);
+                for (int q = 0; q < RT; ++q) y[u][q] = Brow[q][(int64_t)(c + fk) * ldb];     // X[row][c + fk]
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    acc[q][0] = M::mma(x0[u], y[u][q], acc[q][0]);
+                    acc[q][1] = M::mma(x1[u], y[u][q], acc[q][1]);
+                }
         }
         const T* dv = Dinv + (int64_t)s * 1024 + fr;
 #pragma unroll
