@@ -362,6 +362,7 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
         RLHIP_LAUNCH_CHECK();
     }
     rlhip_ws_release(c, mark);
+    c->path_count[0]++;
     return 1;
 }
 

@@ -179,6 +179,16 @@ class Context:
         return info, int(sweeps.value)
 
     # ---- diagnostics
+    def path_count(self, which: int) -> int:
+        return int(self.lib.rlhip_path_count(self.h, which))
+
+    def gemm_norma(self, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, Cm, ldc):
+        """gemm + ||A||_F in one pass (rlhip_gemm_norma_f64); returns (norm, fused flag)"""
+        nrm, fused = C.c_double(), C.c_int()
+        _lib.check(self.lib.rlhip_gemm_norma_f64(self.h, ta.encode(), tb.encode(), m, n, k, alpha, A.data_ptr(), lda, B.data_ptr(), ldb,
+                                                 beta, Cm.data_ptr(), ldc, C.byref(nrm), C.byref(fused)), "gemm_norma")
+        return float(nrm.value), int(fused.value)
+
     def mfma_peak(self, is_f64=True, iters=20000) -> float:
         tf = C.c_double()
         _lib.check(self.lib.rlhip_mfma_peak(self.h, 1 if is_f64 else 0, iters, C.byref(tf)), "mfma_peak")

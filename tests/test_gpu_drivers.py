@@ -354,7 +354,7 @@ def test_bqrrp_vs_oracle_shared_sketch(ctx, orc, opts, m, n, b, kind):
         np.testing.assert_allclose(tau, o["tau"], atol=1e-9, rtol=0)
     else:
         # cond 1e10 step: pivots among the 1e-10 half are decided by rounding noise; the large half must agree as a set
-        assert set(J[:n // 2].tolist()) == set(o["J"][:n // 2].tolist()) or True
+        assert set(J[:n // 2].tolist()) == set(o["J"][:n // 2].tolist())
         dR = np.abs(np.diag(Aout))
         assert dR[n // 2 - 1] > 1e6 * dR[n // 2]
 

@@ -1,0 +1,331 @@
+"""-m gpu: the kernels and configurations that carry the headline numbers, checked at the sizes where they engage.
+
+* the persistent stream-K GEMM (gemm_sk.hip; NN, TN and the TN upper-triangle "tri" map) entry-wise against numpy at shapes above its
+  work gate, with the path asserted through rlhip_path_count, the fused ||A||_F and bitwise run-to-run equality
+  (reference precedent for kernel-vs-CPU unit parity: test/comps/test_util_gpu.cu:198-385);
+* BASELINE configs[1] (RSVD 200000 x 20000): Y = A * Omega on row samples and range(U) == range(Y);
+* BASELINE configs[3] (BQRRP 65536 x 65536 fp32) on one device through size-independent properties, plus a 4096^2 fp32 shared-sketch
+  comparison with the fp64 oracle;
+* BASELINE configs[4] (ABRIK, rank 128): the largest single-device cases -- a dense 200000 x 20000 operator and a 200000 x 200000
+  implicit (CSR) operator -- with the residual metric of test/drivers/test_abrik.cc:96-123.
+Tolerances are stated at each assertion."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS = float(np.finfo(np.float64).eps)
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def _d():
+    from randlapack_amd import device
+
+    return device
+
+
+def relerr(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------
+# stream-K GEMM, direct
+# ---------------------------------------------------------------------------------------------------
+# (M, N, K, transA): W = tiles * ktiles >= 256 * 64 so that the persistent kernel takes the problem (gemm_sk.hip gate);
+# 1445 and 645 rows leave a peeled block for the generic kernel
+SK_SHAPES = [(38400, 256, 1024, "N"), (1280, 512, 16384, "N"), (1408 + 37, 256, 32768, "N"), (256, 256, 131072, "T"),
+             (640 + 5, 256, 65536, "T"), (2048, 512, 8192, "T")]
+
+
+@pytest.mark.parametrize("m,n,k,ta", SK_SHAPES)
+def test_streamk_gemm_entrywise(ctx, m, n, k, ta):
+    d = _d()
+    rng = np.random.default_rng(m + n + k)
+    A, B, C0 = rng.standard_normal((m, k)), rng.standard_normal((k, n)), rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A if ta == "N" else A.T.copy())
+    Bd = d.cm_from_numpy(B)
+    lda = m if ta == "N" else k
+    before = ctx.path_count(0)
+    Cd = d.cm_from_numpy(C0)
+    ctx.gemm(ta, "N", m, n, k, 1.5, Ad, lda, Bd, k, -0.5, Cd, m)
+    assert ctx.path_count(0) == before + 1, "the persistent stream-K kernel did not take this shape"
+    r1 = d.cm_to_numpy(Cd)
+    ref = 1.5 * (A @ B) - 0.5 * C0
+    assert relerr(r1, ref) <= 50 * EPS * np.sqrt(k)          # fp64 dot products of length k, entry-wise
+    # bitwise run-to-run equality (fixed share boundaries, fix-up sums partial slabs in k order)
+    Cd2 = d.cm_from_numpy(C0)
+    ctx.gemm(ta, "N", m, n, k, 1.5, Ad, lda, Bd, k, -0.5, Cd2, m)
+    assert np.array_equal(r1, d.cm_to_numpy(Cd2))
+    # beta = 0 must not read C (NaNs in the output buffer stay out of the result)
+    Cd3 = d.cm_from_numpy(np.full((m, n), np.nan))
+    ctx.gemm(ta, "N", m, n, k, 1.0, Ad, lda, Bd, k, 0.0, Cd3, m)
+    assert relerr(d.cm_to_numpy(Cd3), A @ B) <= 50 * EPS * np.sqrt(k)
+
+
+@pytest.mark.parametrize("m,n,k,ta", [(38400, 256, 1024, "N"), (1408 + 37, 256, 32768, "N"), (256, 256, 131072, "T"), (645, 256, 65536, "T")])
+def test_streamk_fused_frobenius_norm(ctx, m, n, k, ta):
+    d = _d()
+    rng = np.random.default_rng(3 * m + k)
+    A, B = rng.standard_normal((m, k)), rng.standard_normal((k, n))
+    Ad = d.cm_from_numpy(A if ta == "N" else A.T.copy())
+    Bd = d.cm_from_numpy(B)
+    Cd = d.cm_zeros(m, n)
+    nrm, fused = ctx.gemm_norma(ta, "N", m, n, k, 1.0, Ad, m if ta == "N" else k, Bd, k, 0.0, Cd, m)
+    assert fused == 1                                        # the norm came out of the GEMM's own pass over A
+    assert abs(nrm - np.linalg.norm(A)) <= 1e-13 * np.linalg.norm(A)
+    assert relerr(d.cm_to_numpy(Cd), A @ B) <= 50 * EPS * np.sqrt(k)
+    nrm2, _ = ctx.gemm_norma(ta, "N", m, n, k, 1.0, Ad, m if ta == "N" else k, Bd, k, 0.0, Cd, m)
+    assert nrm2 == nrm                                       # deterministic reduction tree
+
+
+@pytest.mark.parametrize("n,k", [(1024, 32768), (512, 65536), (256, 131072), (768, 49152)])
+def test_streamk_syrk_upper_tiles(ctx, n, k):
+    """C(upper) = alpha A^T A + beta C through the tri tile map: upper triangle entry-wise, strictly lower part untouched."""
+    d = _d()
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((n, n))
+    Ad = d.cm_from_numpy(A)
+    Cd = d.cm_from_numpy(C0)
+    before = ctx.path_count(0)
+    ctx.syrk("U", "T", n, k, 2.0, Ad, k, 0.25, Cd, n)
+    assert ctx.path_count(0) == before + 1
+    got = d.cm_to_numpy(Cd)
+    ref = 2.0 * (A.T @ A) + 0.25 * C0
+    iu = np.triu_indices(n)
+    assert np.abs(got[iu] - ref[iu]).max() <= 50 * EPS * np.sqrt(k) * np.abs(ref).max()
+    il = np.tril_indices(n, -1)
+    assert np.array_equal(got[il], C0[il])                   # LAPACK syrk contract (CQRRPT's trmm relies on it)
+    Cd2 = d.cm_from_numpy(C0)
+    ctx.syrk("U", "T", n, k, 2.0, Ad, k, 0.25, Cd2, n)
+    assert np.array_equal(got, d.cm_to_numpy(Cd2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[1]: the sketch pass itself
+# ---------------------------------------------------------------------------------------------------
+def test_rsvd_full_size_sketch_pass(ctx):
+    """Y = A * Omega at 200000 x 20000 x 256 (the bench's dominant launch) against torch on row samples, B^T = A^T Y on column
+    samples, and range(U) of the full RSVD == range(Y): a wrong tile anywhere in Y changes the captured subspace."""
+    import torch
+
+    d = _d()
+    m, n, k = 200000, 20000, 256
+    A = d.cm_empty(m, n)
+    ctx.fill_dense(A, m, n, key=(7, 0))
+    Om = d.cm_empty(n, k)
+    ctx.fill_dense(Om, n, k, key=(0, 0))                     # the Omega RSVD draws with the default state (ctr 0, key 0)
+    Y = d.cm_empty(m, k)
+    before = ctx.path_count(0)
+    ctx.gemm("N", "N", m, k, n, 1.0, A, m, Om, n, 0.0, Y, m)
+    assert ctx.path_count(0) == before + 1
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rows = torch.cat([torch.randint(0, m, (400,), generator=g), torch.arange(0, 130), torch.arange(m - 130, m)]).to("cuda")
+    ref = A[:, rows].T @ Om.T                                # (len, n) @ (n, k)
+    got = Y[:, rows].T
+    assert float((ref - got).abs().max() / ref.abs().max()) <= 50 * EPS * np.sqrt(n)
+    # every 128-row tile is touched by at least one checksum: column sums of Y against (1^T A) Omega
+    ones = torch.ones(m, dtype=torch.float64, device="cuda")
+    cs = (A @ ones) @ Om.T                                   # (n,) @ (n, k)
+    assert float((Y @ ones - cs).abs().max() / cs.abs().max()) <= 1e-9
+    # per-tile checksums: sums over each block of 128 rows (1562 whole row tiles + the 64-row remainder)
+    mt = (m // 128) * 128
+    Yp = torch.cat([Y[:, :mt].reshape(k, -1, 128).sum(-1), Y[:, mt:].sum(-1, keepdim=True)], dim=1)      # (k, tiles)
+    Ap = torch.cat([A[:, :mt].reshape(n, -1, 128).sum(-1), A[:, mt:].sum(-1, keepdim=True)], dim=1)      # (n, tiles)
+    reft = Om @ Ap                                           # (k, n) @ (n, tiles)
+    assert float((Yp - reft).abs().max() / reft.abs().max()) <= 1e-9
+    del Yp, Ap, reft
+    # the TN pass on the same data
+    BT = d.cm_empty(n, k)
+    ctx.gemm("T", "N", n, k, m, 1.0, A, m, Y, m, 0.0, BT, n)
+    assert ctx.path_count(0) == before + 2
+    cols = torch.cat([torch.arange(0, n, 211), torch.arange(n - 70, n)]).to("cuda")
+    refb = A[cols] @ Y.T                                     # (len, m) @ (m, k)
+    assert float((refb - BT[:, cols].T).abs().max() / refb.abs().max()) <= 50 * EPS * np.sqrt(m)
+    # the driver's own Y spans the same subspace: U (k, m) from RSVD with p = 0 and the default state
+    r = d.drv_rsvd(ctx, A, m, n, k, k, 1e-12, 0, 1)
+    U = r["U"]
+    P = U @ Y.T                                              # (k, m) @ (m, k) = U^T Y
+    resid = Y - (P.T @ U)                                    # (k, m): Y^T - (U^T Y)^T U
+    assert float(torch.linalg.norm(resid) / torch.linalg.norm(Y)) <= 1e-10
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: BQRRP 65536 x 65536 fp32 on one device
+# ---------------------------------------------------------------------------------------------------
+def _apply_qt_householder(V, tau, X, b):
+    """Q^T X for Q = H_1 ... H_k stored LAPACK-style in V (column-major tensor (n, m): V[j] is column j), in fp64 on the device,
+    panel by panel through the compact-WY form built here from V and tau alone (T^-1 = striu(V^T V) + diag(1 / tau)).
+    Independent of the product's own apply kernels."""
+    import torch
+
+    n, m = V.shape
+    k = tau.numel()
+    for j0 in range(0, k, b):
+        jb = min(b, k - j0)
+        Vp = V[j0:j0 + jb, j0:].to(torch.float64).T.contiguous()        # (rows, jb)
+        Vp = torch.tril(Vp, -1)
+        Vp[torch.arange(jb), torch.arange(jb)] = 1.0
+        t = tau[j0:j0 + jb].to(torch.float64)                           # all nonzero (asserted by the caller)
+        Tinv = torch.triu(Vp.T @ Vp, 1) + torch.diag(1.0 / t)
+        W = Vp.T @ X[j0:]                                               # (jb, cols)
+        W = torch.linalg.solve_triangular(Tinv.T.contiguous(), W, upper=False)   # Q^T = I - V T^T V^T
+        X[j0:] -= Vp @ W
+    return X
+
+
+def test_bqrrp_config4_full_size_f32(ctx):
+    import torch
+
+    d = _d()
+    m = n = 65536
+    b = 2048
+    A = d.cm_empty(m, n, dtype=torch.float32)
+    ctx.fill_dense(A, m, n, key=(4, 0))
+    r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, key=(6, 0))
+    assert r["rc"] == 0 and r["rank"] == n
+    J = r["J"]
+    assert torch.equal(torch.sort(J).values, torch.arange(1, n + 1, device="cuda"))      # a permutation
+    assert r["next_ctr"][0] == (b * m + 3) // 4                                           # one d x m Gaussian sketch operator
+    tau = r["tau"]
+    assert bool(torch.isfinite(tau).all()) and float(tau.min()) > 0.0 and float(tau.max()) <= 2.0 + 1e-5
+    dR = torch.diagonal(A).abs().double()
+    assert float(dR.min()) > 0
+    # QRCP quality, size-independent: block maxima of |r_ii| do not grow from block to block (pivoting acts across blocks), and inside
+    # a block |r_ii| is essentially non-increasing
+    blk = dR.reshape(-1, b)
+    bmax = blk.max(dim=1).values
+    assert bool((bmax[1:] <= bmax[:-1] * 1.05).all())
+    assert float((dR[1:] <= dR[:-1] * 1.5).double().mean()) > 0.95
+    # A[:, J] = Q R on a column sample: Q^T a_j must reproduce column j of R and vanish below the diagonal
+    A0 = d.cm_empty(m, n, dtype=torch.float32)
+    ctx.fill_dense(A0, m, n, key=(4, 0))
+    g = torch.Generator(device="cpu").manual_seed(5)
+    cols = torch.cat([torch.randint(0, n, (20,), generator=g), torch.tensor([0, 1, b - 1, b, n - b - 1, n - 2, n - 1])]).to("cuda")
+    X = A0[(J[cols] - 1)].to(torch.float64).T.contiguous()              # (m, ncols): the sampled columns of A[:, J]
+    del A0
+    nrm = torch.linalg.norm(X, dim=0)
+    X = _apply_qt_householder(A, tau, X, b)
+    Rs = A[cols].to(torch.float64).T.contiguous()                       # (m, ncols): sampled columns of the factored matrix ...
+    Rs[torch.arange(m, device="cuda")[:, None] > cols[None, :]] = 0     # ... with the reflectors below the diagonal masked out = R
+    err = torch.linalg.norm(X - Rs, dim=0) / nrm
+    assert float(err.max()) <= 20 * EPS32**0.75                         # test_bqrrp.cc:105-107's bound, column-wise, fp32
+    # norm preservation alone (independent of the reflector replay): ||R[:, j]|| = ||A[:, J_j]||
+    assert float(((torch.linalg.norm(Rs, dim=0) - nrm).abs() / nrm).max()) <= 1e-4
+
+
+def test_bqrrp_4096_f32_vs_f64_oracle_shared_sketch(ctx, orc):
+    """fp32 device BQRRP against the fp64 oracle on the same (fp32-representable) matrix and the same sketch.  Column scales are
+    mildly graded (a factor 44 over the matrix); the pivot order among the Gaussian columns is decided by 1 %-level fluctuations of
+    the sketched column norms, far above fp32 rounding except for rare near-ties -- hence set-wise comparison per block."""
+    import torch
+
+    d = _d()
+    m = n = 4096
+    b = 256
+    rng = np.random.default_rng(44)
+    scale = 1.03 ** (-rng.permutation(n).astype(np.float64) / 32.0)
+    A = (rng.standard_normal((m, n)) * scale).astype(np.float32).astype(np.float64)
+    Ad = d.cm_from_numpy(A).to(torch.float32)
+    r = d.drv_bqrrp(ctx, Ad, m, n, b, 1.0, want_sketch=True, key=(21, 0), qrcp_wide=0, qr_tall=1, apply_trans_q=1)
+    sk = d.cm_to_numpy(r["sketch"]).astype(np.float64)
+    o = orc.bqrrp(A, b, 1.0, qrcp_wide=0, qr_tall=1, apply_trans_q=1, sketch=sk)
+    assert r["rc"] == o["rc"] == 0 and r["rank"] == o["rank"] == n
+    J, Jo = r["J"].cpu().numpy(), o["J"]
+    assert sorted(J.tolist()) == list(range(1, n + 1))
+    # pivots: (nearly) the same column SET in every block of b (the order inside a block may flip on fp32-level near-ties of the
+    # LU pivots, and a tie across a block boundary moves one column to the next block)
+    overlap = [len(set(J[i:i + b].tolist()) & set(Jo[i:i + b].tolist())) / b for i in range(0, n, b)]
+    np.testing.assert_array_equal(J[:16], Jo[:16])                      # the first pivots of the first block: exact
+    assert np.mean(overlap) >= 0.9, overlap
+    Aout = d.cm_to_numpy(Ad).astype(np.float64)
+    dR, dRo = np.abs(np.diag(Aout)), np.abs(np.diag(o["A"]))
+    # |r_ii| profile: block-wise geometric means agree to 1 % (they are invariant under reordering inside a block to first order)
+    gm = np.exp(np.log(dR).reshape(-1, b).mean(1)) / np.exp(np.log(dRo).reshape(-1, b).mean(1))
+    assert np.abs(gm - 1).max() <= 1e-2
+    tau = r["tau"].cpu().numpy().astype(np.float64)
+    Q = orc.ungqr(Aout, tau)
+    R = np.triu(Aout)
+    assert np.linalg.norm(A[:, J - 1] - Q @ R) <= 4 * EPS32**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 4 * EPS32**0.75 * np.sqrt(n)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: ABRIK, rank 128, the largest single-device operators
+# ---------------------------------------------------------------------------------------------------
+def _abrik_residual(AV, ATU, U, S, V):
+    """test/drivers/test_abrik.cc:96-123: hypot(||A V - U S||_F, ||A^T U - V S||_F) (column-major tensors (t, rows))"""
+    import torch
+
+    n1 = torch.linalg.norm(AV - U * S[:, None])
+    n2 = torch.linalg.norm(ATU - V * S[:, None])
+    return float(torch.hypot(n1, n2))
+
+
+def test_abrik_config5_dense_200000x20000_rank128(ctx):
+    import torch
+
+    d = _d()
+    m, n, rank_true, k = 200000, 20000, 96, 32
+    target = 128
+    L = d.cm_empty(m, rank_true)
+    Rf = d.cm_empty(n, rank_true)
+    ctx.fill_dense(L, m, rank_true, key=(31, 0))
+    ctx.fill_dense(Rf, n, rank_true, key=(32, 0))
+    s = torch.logspace(0, -8, rank_true, dtype=torch.float64, device="cuda") / np.sqrt(float(m) * n)
+    A = d.cm_empty(m, n)
+    Ls = (L * s[:, None]).contiguous()
+    ctx.gemm("N", "T", m, n, rank_true, 1.0, Ls, m, Rf, n, 0.0, A, m)        # A = L diag(s) R^T, numerically rank 96
+    op = d.DenseOperator(A, m, n)
+    iters = 2 * target // k                                                  # test_abrik.cc:139
+    r = d.drv_abrik_linop(ctx, op, k, EPS**0.85, iters, key=(1, 0))
+    assert r["rc"] == 0
+    t = r["triplets"]
+    assert t >= 64
+    U, S, V = r["U"], r["S"], r["V"]
+    I = torch.eye(t, device="cuda", dtype=torch.float64)
+    assert float(torch.linalg.norm(U @ U.T - I)) <= 1e-10 and float(torch.linalg.norm(V @ V.T - I)) <= 1e-10
+    assert bool((S[:-1] >= S[1:]).all())
+    c = 64                                                                   # custom_rank <= target_rank
+    AV = (A.T @ V[:c].T).T.contiguous()                                      # (c, m)
+    ATU = (A @ U[:c].T).T.contiguous()                                       # (c, n)
+    res = _abrik_residual(AV, ATU, U[:c], S[:c], V[:c])
+    assert res <= 10 * EPS**0.825 * float(S[0]) * np.sqrt(c)                 # the reference's bound, relative to sigma_1
+    # leading singular values against the exact ones of L diag(s) R^T (small 96 x 96 problem)
+    Ql, Rl = torch.linalg.qr(L.T)
+    Qr, Rr = torch.linalg.qr(Rf.T)
+    sv = torch.linalg.svdvals(Rl @ torch.diag(s) @ Rr.T)
+    assert float(((S[:32] - sv[:32]).abs() / sv[:32]).max()) <= 1e-9
+
+
+def test_abrik_config5_implicit_200000x200000_rank128(ctx):
+    """A = D1 * G * D2 held as a CSR operator (10 nonzeros per row, never densified): 200000 x 200000, block 32, 8 Krylov
+    iterations (rank 128).  Graded diagonal scalings make the leading triplets converge inside the iteration budget."""
+    import scipy.sparse as sp
+    import torch
+
+    d = _d()
+    m = n = 200000
+    k, target = 32, 128
+    rng = np.random.default_rng(77)
+    nnz_row = 10
+    rows = np.repeat(np.arange(m), nnz_row)
+    colsi = rng.integers(0, n, size=m * nnz_row)
+    vals = rng.standard_normal(m * nnz_row)
+    d1 = np.exp(-np.arange(m) / 40.0) + 1e-12
+    d2 = np.exp(-np.arange(n) / 40.0) + 1e-12
+    G = sp.csr_matrix((vals * d1[rows] * d2[colsi], (rows, colsi)), shape=(m, n))
+    G.sum_duplicates()
+    op = d.CsrOperator.from_scipy(G)
+    iters = 2 * target // k
+    r = d.drv_abrik_linop(ctx, op, k, EPS**0.85, iters, key=(2, 0))
+    assert r["rc"] == 0
+    t = r["triplets"]
+    assert t >= 32
+    U, S, V = d.cm_to_numpy(r["U"]), r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
+    assert np.linalg.norm(U.T @ U - np.eye(t)) <= 1e-10 and np.linalg.norm(V.T @ V - np.eye(t)) <= 1e-10
+    c = 16
+    res = np.hypot(np.linalg.norm(G @ V[:, :c] - U[:, :c] * S[:c]), np.linalg.norm(G.T @ U[:, :c] - V[:, :c] * S[:c]))
+    assert res <= 10 * EPS**0.825 * S[0] * np.sqrt(c)
+    # the dense top-left corner carries the spectrum (entries decay like exp(-(i + j) / 40)): compare with its SVD
+    sv = np.linalg.svd(G[:4000, :4000].toarray(), compute_uv=False)
+    assert np.max(np.abs(S[:8] - sv[:8]) / sv[:8]) <= 1e-8
