@@ -135,6 +135,7 @@ template <> struct BlkMma<double> {
     typedef double acc_t __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ acc_t mma(double x, double y, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
     static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+    static constexpr int CS = 4, CL = 1;      // drow(lane, r) = CL * (lane >> 4) + CS * r
     // value T[m = lane & 15][col = c0 + (lane >> 4)] of a 16 x 16 accumulator tile (c0 multiple of 4): already in this lane
     static __device__ __forceinline__ double operand(const acc_t& t, int c0, int) { return t[c0 >> 2]; }
 };
@@ -142,6 +143,7 @@ template <> struct BlkMma<float> {
     typedef float acc_t __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ acc_t mma(float x, float y, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0); }
     static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
+    static constexpr int CS = 1, CL = 4;
     // fp32 accumulators hold columns 4 (lane/16) + r: column c0 + (lane >> 4) sits in lane group c0 / 4, register (lane >> 4)
     static __device__ __forceinline__ float operand(const acc_t& t, int c0, int lane) {
         const int src = (lane & 15) + 16 * (c0 >> 2);
@@ -299,6 +301,260 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused left-looking solve of a RANGE of 256-column blocks in ONE launch ("fused" path; replaces, per call, the chain
+// GEMM update -> trsm_blk_kernel -> GEMM update -> ... of the blk path).
+//   * a wave owns 16 rows of B for the whole launch and keeps the 16 x 256 tile of the block being solved in its accumulator
+//     registers (16 tiles of 16 x 16; for fp64 the v_mfma_f64_16x16x4 accumulator layout IS the B-operand layout of the next
+//     product, so solved columns feed later products without leaving the register file);
+//   * U is packed once per call as Uneg = -(strictly block-upper part of U), ROW-major, zero inside the 32 x 32 diagonal blocks
+//     (those are applied through their explicit inverses Dinv, as in the blk path and under the same kappa_F <= 1e3 guard);
+//   * the four waves of a workgroup share U through LDS: half panels of 16 rows x 256 columns (row stride 272 elements: the four
+//     row groups of an MFMA operand read land on disjoint banks) are DMA'd (global_load_lds) into a two-deep ring, ONE barrier per
+//     half panel, the next half panel in flight during the 64 MFMAs per wave of the current one;
+//   * block J: T = alpha B_J - sum_{I < J} X_I U_IJ with X_I read back from B (this wave wrote those rows itself), then
+//     right-looking over the eight 32-column sub-blocks: X_s = T_s inv(U_ss); T_t -= X_s U_st for t > s -- all 14 - 2 s tile
+//     updates of a step are independent accumulators, so the matrix pipe is never waiting on a dependent result;
+//   * two workgroups per CU (68 KiB + 8 KiB of LDS, <= 256 VGPRs): one's HBM phases (tile load / store) overlap the other's MFMAs.
+// Per 16 rows and n = 1024: 8320 MFMAs, 32 KiB read + 8 KiB x (1 + 2 + 3 + 4) re-read from L2/MALL + 32 KiB written.
+constexpr int FSTR = 272;          // LDS row stride of a half panel (elements)
+template <typename T> constexpr int fused_lds_bytes() { return 3 * 16 * FSTR * (int)sizeof(T) + 2 * 32 * 32 * (int)sizeof(T); }   // three U panels + two inverses
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_neg_pack_kernel(int64_t n, int64_t n_pad, const T* __restrict__ U, int64_t ldu, T* __restrict__ Uneg) {
+    // Uneg[k * n_pad + c] = -U[k, c] where 32-block(k) < 32-block(c), zero elsewhere; 32 x 32 tiles through LDS (coalesced both ways)
+    __shared__ T tile[32][33];
+    const int64_t k0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool upper = blockIdx.y < blockIdx.x;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t k = k0 + tx, c = c0 + j;
+        tile[j][tx] = (upper && k < n && c < n) ? -U[k + c * ldu] : T(0);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) Uneg[(k0 + i) * n_pad + c0 + tx] = tile[tx][i];
+}
+
+template <int N> struct IntC { static constexpr int value = N; };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NW = wavefronts per workgroup (16 rows each), HPR = rows of U per LDS panel (16), ring of three panels
+template <typename T, int NW, int HPR>
+__global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64_t n, int64_t n_pad, T alpha, const T* __restrict__ Uneg,
+                                                                const T* __restrict__ Dinv, T* __restrict__ B, int64_t ldb, int J0, int J1,
+                                                                int K0blk, T* __restrict__ dump) {
+    static_assert(HPR == 16, "the diagonal phase below is written for 16-row panels (two per 32-column sub-block)");
+    using M = BlkMma<T>;
+    using acc_t = typename M::acc_t;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void glb_void_t;
+    constexpr int RING = 3;
+    constexpr int HPB = HPR * FSTR * (int)sizeof(T);            // bytes per panel (34 KiB fp64, 17 KiB fp32)
+    constexpr int NCH = HPB / 1024;                             // 1 KiB DMA pieces per panel
+    constexpr int EPC = 1024 / (int)sizeof(T);                  // elements per piece
+    constexpr int EPL = 16 / (int)sizeof(T);                    // elements per lane of a piece
+    constexpr int P = (NCH + NW - 1) / NW;                      // pieces per wave and panel -- the SAME for every wave (a wave whose last
+                                                                // slot falls beyond the panel re-fetches an earlier piece), so that the
+                                                                // counted s_waitcnt vmcnt(...) below are compile-time constants
+    constexpr int DCH = 32 * 32 * (int)sizeof(T) / 1024;        // pieces of one 32 x 32 inverse (one per wave, duplicates allowed)
+    constexpr int NQ = HPR / 4;                                 // k-steps (MFMA depth 4) per panel
+    constexpr int PPB = 256 / HPR;                              // panels per 256-block
+    constexpr int NDP = 14;                                     // diagonal-block panels that still have tiles to update
+    constexpr int DBY = 32 * 32 * (int)sizeof(T);               // bytes of one inverse
+    extern __shared__ __attribute__((aligned(1024))) unsigned char tf_smem[];
+    unsigned char* sD = tf_smem + RING * HPB;                   // two stages: the inverse of diagonal sub-block s lives in stage s & 1
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * NW + wid) * 16 + fr;
+    const bool live = row < m;
+    T* __restrict__ Brow = B + (live ? row : m - 1);            // clamped: loads unconditional, dead rows store to a scratch line
+    // tile element (j, r) of this lane sits in column 16 j + CS * r + CL * fk: a wave-uniform column (scalar base address) plus the lane
+    // offset `loff` (32 bits: the host takes this path only while 4 ldb + m < 2^28)
+    constexpr int CS = M::CS, CL = M::CL;
+    const unsigned loff = (unsigned)((live ? row : m - 1) + (int64_t)CL * fk * ldb);
+    // per-lane source offsets (elements, relative to the panel's first element) and LDS byte offsets of this wave's DMA pieces
+    int poff[P], pdst[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        int c = wid + NW * i;
+        if (c >= NCH) c -= NCH;                                 // duplicate of an earlier piece (same bytes to the same place)
+        const int e = c * EPC + lane * EPL;
+        const int pr = e / FSTR;
+        int pc = e - pr * FSTR;
+        if (pc >= 256) pc = 0;                                  // padding columns: any valid address
+        poff[i] = (int)(pr * n_pad + pc);
+        pdst[i] = c * 1024;
+    }
+    const int dsrc = (wid % DCH) * EPC + lane * EPL, ddst = (wid % DCH) * 1024;
+    auto issue_panel = [&](const T* base, int buf) {            // P pieces of the panel whose first element is `base` into ring stage `buf`
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(base + poff[i]), (lds_void_t*)(tf_smem + buf * HPB + pdst[i]), 16, 0, 0);
+    };
+    auto issue_dinv = [&](int64_t sblk) {                       // ONE piece per wave: inverse of global diagonal sub-block sblk -> stage sblk & 1
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(Dinv + sblk * 1024 + dsrc), (lds_void_t*)(sD + (int)(sblk & 1) * DBY + ddst), 16, 0, 0);
+    };
+    // One panel: acc[j] += Uneg-panel(rows 4q + fk, tile j) * y[q] for the tiles j >= JLO, in groups of eight products with the LDS
+    // fragments of the next group fetched before the MFMAs of the current one are queued; `side()` runs behind the first group.
+    auto panel_mma = [&](auto jlo_c, acc_t (&acc)[16], const T* sU, const T (&y)[NQ], auto&& side) {
+        constexpr int JLO = decltype(jlo_c)::value;
+        constexpr int NTL = 16 - JLO, TOT = NQ * NTL, G = 8, NG = (TOT + G - 1) / G;
+        const T* su = sU + fk * FSTR + fr;
+        T fa[G], fb[G];
+#pragma unroll
+        for (int e = 0; e < G; ++e)
+            if (e < TOT) fa[e] = su[4 * (e / NTL) * FSTR + 16 * (JLO + e % NTL)];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int f = (g + 1) * G + e;
+                if (f < TOT) fb[e] = su[4 * (f / NTL) * FSTR + 16 * (JLO + f % NTL)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const int f = g * G + e;
+                if (f < TOT) acc[JLO + f % NTL] = M::mma(fa[e], y[f / NTL], acc[JLO + f % NTL]);
+            }
+            if (g == 0) side();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < G; ++e) fa[e] = fb[e];
+        }
+    };
+    // first element of panel t of block J (t counts from the first fused block row K0blk; the diagonal block follows seamlessly)
+    auto panel_ptr = [&](int J, int t) -> const T* { return Uneg + ((int64_t)K0blk * 256 + (int64_t)t * HPR) * n_pad + (int64_t)J * 256; };
+
+    acc_t acc[16];
+    T xc[NQ], xn[NQ];
+    int ring = 0;                                               // ring stage of the panel the next step consumes
+    // ---- prologue: the first two panels, the first inverse, the first tile, the first X operands
+    issue_panel(panel_ptr(J0, 0), 0);
+    issue_panel(panel_ptr(J0, 1), 1);
+    issue_dinv((int64_t)J0 * 8);
+    {
+        const T* bj = B + (int64_t)J0 * 256 * ldb;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = (bj + (int64_t)(16 * j + CS * r) * ldb)[loff];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { xc[q] = T(0); xn[q] = T(0); }
+    if (J0 > K0blk) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];
+    }
+    for (int J = J0; J < J1; ++J) {
+        const int64_t col0 = (int64_t)J * 256;
+        const int ntoff = PPB * (J - K0blk);                    // panels of the blocks left of the diagonal block
+        const bool has_next = (J + 1 < J1);
+        // the raw tile (loaded in the prologue or behind the previous block's diagonal steps) -> alpha * B_J
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = alpha * acc[j][r];
+        const T* xp = Brow + ((int64_t)K0blk * 256 + fk) * ldb;          // X[row][first column of panel t + fk]
+        const int64_t xstep = (int64_t)HPR * ldb;
+        // ---- blocks left of the diagonal block: X from memory, all 16 tiles
+        for (int t = 0; t < ntoff; ++t) {
+            // panel t and the X operands of this step have landed; the P pieces of panel t + 1 (issued one step ago) may still fly.
+            // (t == 0: the X operands were the LAST thing requested before this block, so everything must have landed)
+            if (t == 0) wait_vm<0>(); else wait_vm<P>();
+            __builtin_amdgcn_s_barrier();
+            const int nring = (ring + 2 >= RING) ? ring + 2 - RING : ring + 2;
+            const T* nbase = panel_ptr(J, t + 2);               // (always inside this block: the diagonal panels follow)
+            xp += xstep;
+            const bool more_x = (t + 1 < ntoff);
+            panel_mma(IntC<0>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), xc, [&]() {
+                if (more_x) {
+#pragma unroll
+                    for (int qq = 0; qq < NQ; ++qq) xn[qq] = xp[4 * qq * ldb];
+                }
+                issue_panel(nbase, nring);
+            });
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) xc[q] = xn[q];
+            ring = (ring + 1 >= RING) ? 0 : ring + 1;
+        }
+        // ---- diagonal block: right-looking over the 32-column sub-blocks, X in registers
+        auto solve_sub = [&](int s) {                           // X_s = T_s * inv(U_ss)   (compile-time s after unrolling)
+            const T* dv = reinterpret_cast<const T*>(sD + (s & 1) * DBY) + fr;
+            acc_t xs0 = acc_t{0, 0, 0, 0}, xs1 = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < 32; c += 4) {
+                const T y = M::operand(acc[2 * s + (c >> 4)], c & 15, lane);
+                const T d0 = dv[(c + fk) * 32], d1 = dv[(c + fk) * 32 + 16];
+                if (c < 16) xs0 = M::mma(d0, y, xs0);           // the inverse is upper triangular: rows >= 16 do not reach columns < 16
+                xs1 = M::mma(d1, y, xs1);
+            }
+            acc[2 * s] = xs0; acc[2 * s + 1] = xs1;
+        };
+        // sub-block s is final: its two tiles go back to B and the registers take the same tiles of the NEXT block (raw, scaled at
+        // that block's start).  ALWAYS 8 stores + 8 loads per wave, so that the counted waits stay exact: rows / columns outside the
+        // matrix store to a scratch line, the last block re-loads its own tile (values unused).
+        auto retire_tiles = [&](int s) {
+            T* bj = B + col0 * ldb;
+            const T* bn = has_next ? bj + 256 * ldb : bj;
+            T* dl = dump + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T* dst = bj + (int64_t)(16 * (2 * s + u) + CS * r) * ldb + loff;
+                    *(live ? dst : dl) = acc[2 * s + u][r];
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[2 * s + u][r] = (bn + (int64_t)(16 * (2 * s + u) + CS * r) * ldb)[loff];
+        };
+        auto diag_step = [&](auto h_c) {
+            constexpr int h = decltype(h_c)::value;
+            constexpr int s = h >> 1, hh = h & 1;
+            // Requests that may still fly when panel h is consumed = everything the previous step issued (every count below is exact):
+            // P panel pieces; at even steps also one piece of the next inverse and, from step 2 on, the 16 loads / stores of the
+            // tiles retired there.  h == 0: P (after an off-diagonal step) or nothing (first step of the launch / after a block end).
+            constexpr int prev = h - 1;
+            constexpr int allowed = (h == 0) ? 0 : (P + ((prev & 1) == 0 ? 1 + (prev >= 2 ? 16 : 0) : 0));
+            if (h == 0) { if (ntoff > 0) wait_vm<P>(); else wait_vm<0>(); }
+            else wait_vm<allowed>();
+            __builtin_amdgcn_s_barrier();
+            const int nring = (ring + 2 >= RING) ? ring + 2 - RING : ring + 2;
+            if (hh == 0) solve_sub(s);
+            T y[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) y[q] = M::operand(acc[2 * s + (hh * HPR + 4 * q) / 16], (hh * HPR + 4 * q) % 16, lane);
+            panel_mma(IntC<2 * s + 2>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), y, [&]() {
+                if (hh == 0 && h >= 2) retire_tiles(s - 1);
+                // two panels ahead: this block's, then the next block's first two (the last block re-fetches its own first panel into
+                // the free stage: nobody reads it, the request count stays uniform)
+                issue_panel((h + 2 < NDP) ? panel_ptr(J, ntoff + h + 2) : (has_next ? panel_ptr(J + 1, h + 2 - NDP) : panel_ptr(J, 0)), nring);
+                if (hh == 0) issue_dinv((int64_t)J * 8 + s + 1);                           // needed two steps from now, other stage
+            });
+            ring = (ring + 1 >= RING) ? 0 : ring + 1;
+        };
+        diag_step(IntC<0>{}); diag_step(IntC<1>{}); diag_step(IntC<2>{}); diag_step(IntC<3>{}); diag_step(IntC<4>{});
+        diag_step(IntC<5>{}); diag_step(IntC<6>{}); diag_step(IntC<7>{}); diag_step(IntC<8>{}); diag_step(IntC<9>{});
+        diag_step(IntC<10>{}); diag_step(IntC<11>{}); diag_step(IntC<12>{}); diag_step(IntC<13>{});
+        // the last inverse (requested at step 12) must have landed; step 13's P pieces may still fly
+        wait_vm<P>();
+        __builtin_amdgcn_s_barrier();
+        solve_sub(7);
+        retire_tiles(6);
+        retire_tiles(7);
+        if (has_next) {
+            issue_dinv((int64_t)(J + 1) * 8);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];     // the next block always has blocks to its left
+        }
+    }
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -352,9 +608,55 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     // of a workgroup substituting (32 rows), the 8 x ~1000 dependent LDS/FMA instructions per slab (2.2 ms per block)
     // and the U fragment loads (1.7 ms) cannot hide behind the 0.7 ms of MFMA work; the unfused kernels spread the same
     // substitution over every wave of every CU.)
+    // fused path: ONE launch solves a whole run of well-conditioned 256-blocks (trsm_fused_kernel); blocks whose diagonal sub-blocks are
+    // ill conditioned still take the substitution kernels below, with a GEMM bringing in everything to their left.
+    static int fused_on = -1, fused_min_rows = 0;
+    if (fused_on < 0) {
+        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
+        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;   // >= one 64-row workgroup per CU
+    }
+    const bool use_fused = try_blk && fused_on && m >= fused_min_rows && n >= BW && (4 * ldb + m) < ((int64_t)1 << 28);   // (32-bit lane offsets in the kernel)
+    const int64_t n_pad = nblk * BW;
+    T* Uneg = nullptr;
+    T* fdump = nullptr;
+    if (use_fused) {
+        bool any_good = false;
+        for (int64_t b = 0; (b + 1) * BW <= n; ++b) any_good |= !bad_host[b];   // (a ragged last block stays on the blk path)
+        if (any_good) {
+            Uneg = ws_alloc<T>(c, (size_t)n_pad * n_pad);
+            if (!Uneg) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, c->stream, n, n_pad, A, lda, Uneg);
+            RLHIP_LAUNCH_CHECK();
+            static bool fattr = false;
+            if (!fattr) {
+                RLHIP_CHECK(hipFuncSetAttribute((const void*)trsm_fused_kernel<T, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T>()));
+                fattr = true;
+            }
+            fdump = ws_alloc<T>(c, 512);
+            if (!fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        }
+    }
     for (int64_t j0 = 0; j0 < n; j0 += DB) {
         const int nb = (int)((n - j0 < DB) ? (n - j0) : DB);
         T a = alpha;
+        if (Uneg && !bad_host[j0 / BW] && j0 + BW <= n) {
+            // run of good blocks [Jb, Je): everything left of Jb comes in through one GEMM, the rest is fused
+            const int Jb = (int)(j0 / BW);
+            int Je = Jb;
+            while (Je < nblk && !bad_host[Je] && (int64_t)(Je + 1) * BW <= n) ++Je;
+            const int64_t jend = (Je * (int64_t)BW < n) ? Je * (int64_t)BW : n;
+            if (j0 > 0) {
+                int rc = gemm_impl<T>(c, 0, 0, m, jend - j0, j0, T(-1), B, ldb, A + j0 * lda, lda, alpha, B + j0 * ldb, ldb, 0);
+                if (rc) { rlhip_ws_release(c, mark); return rc; }
+                a = T(1);
+            }
+            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, a, Uneg,
+                               Dinv_all, B, ldb, Jb, Je, Jb, fdump);
+            RLHIP_LAUNCH_CHECK();
+            c->path_count[2]++;
+            j0 = (int64_t)(Je - 1) * DB;     // the loop increment moves on to block Je
+            continue;
+        }
         if (j0 > 0) {
             int rc = gemm_impl<T>(c, 0, 0, m, nb, j0, T(-1), B, ldb, A + j0 * lda, lda, alpha, B + j0 * ldb, ldb, 0);
             if (rc) { rlhip_ws_release(c, mark); return rc; }
@@ -403,6 +705,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             hipLaunchKernelGGL(trsm_diag_kernel<T>, dim3((unsigned)((m + RW - 1) / RW)), dim3(RW), 0, c->stream, m, sbw, SB, a2,
                                Ut, B + jc * ldb, ldb);
             RLHIP_LAUNCH_CHECK();
+            c->path_count[3]++;
         }
     }
     rlhip_ws_release(c, mark);
