@@ -133,6 +133,9 @@ void fill_dense(DenseSkOp<T, RNG>& S) {
 //      drivers/rl_cqrrpt.hh:214-222.  n_rows = d (sketch dimension), n_cols = m, vec_nnz nonzeros per column.
 struct SparseDist {
     int64_t n_rows, n_cols, vec_nnz;
+    // extension (not in RandBLAS): -1 library default (independent columns, RandBLAS's distribution), 1 independent columns,
+    // 0 block affine (one affine row map per block of n_rows columns: faster apply, see rlhip.h)
+    int structure = -1;
     SparseDist(int64_t r, int64_t c, int64_t nnz) : n_rows(r), n_cols(c), vec_nnz(nnz) {}
 };
 
@@ -143,8 +146,8 @@ struct SparseSkOp {
     rlhip_saso* handle = nullptr;
     blas::Queue& q;
     SparseSkOp(SparseDist const& D, RNGState<RNG> const& st, blas::Queue& queue) : dist(D), seed_state(st), next_state(st), q(queue) {
-        blas::check(rlhip_saso_create(q.ctx(), D.n_rows, D.n_cols, (int)D.vec_nnz, st.counter.data(), st.key.data(),
-                                      next_state.counter.data(), &handle), "saso_create");
+        blas::check(rlhip_saso_create_mode(q.ctx(), D.n_rows, D.n_cols, (int)D.vec_nnz, D.structure, st.counter.data(), st.key.data(),
+                                           next_state.counter.data(), &handle), "saso_create");
     }
     SparseSkOp(SparseSkOp const&) = delete;
     SparseSkOp& operator=(SparseSkOp const&) = delete;

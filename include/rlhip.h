@@ -158,10 +158,17 @@ int rlhip_transpose_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, in
 /* ---- sparse sketching operator (SASO): RandBLAS::SparseDist(d, m, nnz) + SparseSkOp(DS, state) +
  *      sketch_general(ColMajor, NoTrans, NoTrans, d, n, m, alpha, S, 0, 0, A, lda, beta, B, ldb)
  *      (rl_cqrrpt.hh:214-222, rl_cqrrt.hh:174-182).  S is d x m with nnz nonzeros (+-1) per column.
- *      next_ctr_host receives `S.next_state`.  Structure of this library's operator: sketch.hip header. ---- */
+ *      next_ctr_host receives `S.next_state`.  Two structures (sketch.hip header; restated in oracle/__init__.py::saso_dense):
+ *      mode 1 = INDEPENDENT COLUMNS, every column draws its nnz distinct rows by its own Fisher-Yates walk (the distribution of
+ *      RandBLAS::SparseSkOp) -- the default; mode 0 = BLOCK AFFINE (one affine row map per block of d columns: faster,
+ *      every d x d block is a sum of nnz signed permutations).  rlhip_saso_create takes the default (environment RLHIP_SASO_MODE =
+ *      affine switches it), rlhip_saso_create_mode the given one.  Limits: nnz <= min(d, 128); the dense-operand apply stages a
+ *      d-row slab in LDS: d <= 20480 (fp64) / 40960 (fp32), -2 beyond. ---- */
 typedef struct rlhip_saso rlhip_saso;
 int rlhip_saso_create(rlhip_ctx* ctx, int64_t d, int64_t m, int nnz, const uint32_t ctr_host[4],
                       const uint32_t key_host[2], uint32_t next_ctr_host[4], rlhip_saso** S);
+int rlhip_saso_create_mode(rlhip_ctx* ctx, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr_host[4],
+                           const uint32_t key_host[2], uint32_t next_ctr_host[4], rlhip_saso** S);
 int rlhip_saso_destroy(rlhip_ctx* ctx, rlhip_saso* S);
 int rlhip_saso_apply_f64(rlhip_ctx* ctx, const rlhip_saso* S, int64_t n, double alpha, const double* A, int64_t lda,
                          double beta, double* B, int64_t ldb);

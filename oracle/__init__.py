@@ -626,3 +626,88 @@ def revd2(A, k, tol, p=2, q=1, error_est_p=10, orth_kind=1, uplo="U", ctr=(0, 0,
             break
         k = m if 2 * k > m else 2 * k
     return dict(k=k, V=V, eigvals=ev, err=err, next_ctr=ctr)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Sparse sketching operator (SASO): independent numpy restatement of the library's documented stream
+# (include/rlhip.h "sparse sketching operator"; reference call sites RandLAPACK/drivers/rl_cqrrpt.hh:214-222,
+# rl_cqrrt.hh:174-182; RandBLAS itself is absent from the reference tree, so this is the library's OWN stream --
+# "parity unpinned" -- and the device generator is checked against this restatement, not against itself).
+# ------------------------------------------------------------------------------------------------------
+def philox_np(ctrs, key):
+    """Philox4x32-10 on an (N, 4) uint32 array of counters, vectorised; pinned by the Random123 KATs in tests/test_oracle_golden.py"""
+    c = np.array(ctrs, dtype=np.uint64).reshape(-1, 4)
+    c0, c1, c2, c3 = (c[:, i].copy() for i in range(4))
+    k0, k1 = np.uint64(int(key[0])), np.uint64(int(key[1]))
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2                                    # 32 x 32 -> 64 bit products (operands < 2^32)
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & MASK
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack([c0, c1, c2, c3], axis=1).astype(np.uint32)
+
+
+def _ctr_array(ctr, offsets):
+    """(N, 4) uint32 counters ctr + offsets (128-bit little-endian addition)"""
+    base = int(ctr[0]) | (int(ctr[1]) << 32) | (int(ctr[2]) << 64) | (int(ctr[3]) << 96)
+    out = np.empty((len(offsets), 4), dtype=np.uint32)
+    for n, o in enumerate(offsets):
+        v = (base + int(o)) & ((1 << 128) - 1)
+        out[n] = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(4)]
+    return out
+
+
+def saso_dense(d, m, nnz, ctr=(0, 0, 0, 0), key=(0, 0), mode=1):
+    """dense d x m copy of the sketching operator and the state after it.
+    mode 1 (independent columns): column j draws nnz distinct rows by a Fisher-Yates walk; step i uses Philox block
+    ctr + j * NB + i // 2 (NB = ceil(nnz / 2)), word 2 (i % 2) for the position ell = i + ((w * (d - i)) >> 32) and word
+    2 (i % 2) + 1 for the sign (low bit set -> -1); next state = ctr + m * NB.
+    mode 0 (block affine): T = ceil(m / d) row blocks; block t takes (a_t, b_t) from Philox(ctr + t): a_t = first value >= 1 + w0 % (d - 1)
+    coprime with d (wrapping to 1), b_{t,i} = distinct values of a 64-bit LCG walk seeded by (w1, w2) with increment w3 | 1; input row
+    t d + u feeds sketch rows (a_t u + b_{t,i}) mod d with sign bit i of Philox(ctr + T + t d + u); next state = ctr + T + m."""
+    import math
+
+    S = np.zeros((d, m))
+    if mode == 1:
+        NB = (nnz + 1) // 2
+        if m > 0:
+            W = philox_np(_ctr_array(ctr, range(m * NB)), key).reshape(m, NB * 4)
+        for j in range(m):
+            moved = {}
+            for i in range(nnz):
+                wa, wb = int(W[j, 4 * (i // 2) + 2 * (i % 2)]), int(W[j, 4 * (i // 2) + 2 * (i % 2) + 1])
+                ell = i + ((wa * (d - i)) >> 32)
+                a, b = moved.get(i, i), moved.get(ell, ell)
+                moved[ell] = a
+                S[b, j] = -1.0 if (wb & 1) else 1.0
+        return S, _ctr_add(ctr, m * NB)
+    if mode != 0:
+        raise ValueError("mode must be 0 (block affine) or 1 (independent columns)")
+    T = (m + d - 1) // d
+    if m > 0:
+        P = philox_np(_ctr_array(ctr, range(T)), key)
+        Wsig = philox_np(_ctr_array(ctr, range(T, T + m)), key)
+    for t in range(T):
+        r = [int(x) for x in P[t]]
+        a = 1 + r[0] % (d - 1 if d > 1 else 1)
+        while math.gcd(a, d) != 1:
+            a += 1
+            if a >= d:
+                a = 1
+        s = (r[1] << 32) | r[2]
+        b = []
+        while len(b) < nnz:
+            s = (s * 6364136223846793005 + (r[3] | 1)) & ((1 << 64) - 1)
+            cand = (s >> 33) % d
+            if cand not in b:
+                b.append(cand)
+        for u in range(min(d, m - t * d)):
+            j = t * d + u
+            for i in range(nnz):
+                bit = (int(Wsig[j, (i >> 5) & 3]) >> (i & 31)) & 1
+                S[(a * u + b[i]) % d, j] = -1.0 if bit else 1.0
+    return S, _ctr_add(ctr, T + m)

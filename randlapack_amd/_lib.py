@@ -96,6 +96,7 @@ SIGNATURES = {
     "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
     "rlhip_saso_create": (c_int, [c_vp, c_i64, c_i64, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
+    "rlhip_saso_create_mode": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
     "rlhip_saso_destroy": (c_int, [c_vp, c_vp]),
     "rlhip_col_swap_i64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_luqrcp_piv": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),

@@ -6,7 +6,7 @@
 
 namespace rlhip {
 struct SasoOp;
-int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
+int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2],
                uint32_t next_ctr[4], SasoOp** out);
 int saso_destroy(rlhip_ctx* c, SasoOp* op);
 template <typename T> int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S);
@@ -292,7 +292,11 @@ int rlhip_fill_dense_f32(rlhip_ctx* c, int dist, int64_t rows, int64_t cols, flo
 
 int rlhip_saso_create(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
                       uint32_t next_ctr[4], rlhip_saso** out) {
-    return rlhip::saso_build(c, d, m, nnz, ctr, key, next_ctr, (rlhip::SasoOp**)out);
+    return rlhip::saso_build(c, d, m, nnz, -1, ctr, key, next_ctr, (rlhip::SasoOp**)out);
+}
+int rlhip_saso_create_mode(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2],
+                           uint32_t next_ctr[4], rlhip_saso** out) {
+    return rlhip::saso_build(c, d, m, nnz, mode, ctr, key, next_ctr, (rlhip::SasoOp**)out);
 }
 int rlhip_saso_destroy(rlhip_ctx* c, rlhip_saso* S) { return rlhip::saso_destroy(c, (rlhip::SasoOp*)S); }
 int rlhip_col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx) {

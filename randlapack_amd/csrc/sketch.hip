@@ -4,19 +4,26 @@
 // (A_hat = S * A, S is d x m with `nnz` nonzeros of value +-1 in every column) and util::col_swap
 // (misc/rl_util.hh:151-198 == LAPACK lapmt forward) at rl_cqrrpt.hh:288, rl_bqrrp.hh:369.
 //
-// RandBLAS is absent from the reference tree, so the operator's random structure is this library's own
-// ("parity unpinned").  It is chosen so that the INVERSE map (which input rows feed sketch
-// row r) is closed-form: the sketch can then be applied as a deterministic GATHER -- every output element is
-// summed by one thread in a fixed order, bitwise reproducible -- instead of a scatter with floating-point
-// atomics.  Input rows are cut into blocks of d; inside block t, input row u (0 <= u < d) feeds the nnz sketch
-// rows   r_i(u) = (a_t * u + b_{t,i}) mod d,   gcd(a_t, d) = 1, b_{t,0..nnz-1} pairwise distinct
-// (=> nnz DISTINCT rows per column, each row index uniform), with iid signs.  (a_t, b_t) come from
-// Philox(ctr + t), the signs of input row j from Philox(ctr + T + j); next state = ctr + T + m, T = ceil(m/d).
+// RandBLAS is absent from the reference tree, so the operator's random stream is this library's own ("parity
+// unpinned"; restated independently in oracle/__init__.py::saso_dense).  Either way the sketch is
+// applied as a deterministic GATHER over inverse lists (which input rows feed sketch row r): every output element is
+// summed by one thread in a fixed order, bitwise reproducible, no floating-point atomics.  Input rows are cut into
+// blocks of d.  Two structures:
+//   mode 1, INDEPENDENT COLUMNS (default; the distribution SURVEY 8 a8 describes for RandBLAS::SparseSkOp): column j
+//     draws nnz DISTINCT rows by a Fisher-Yates walk over {0..d-1} and nnz iid signs.  Step i of column j uses Philox
+//     block ctr + j * NB + i / 2 (NB = ceil(nnz / 2)), words 2 (i % 2) (position: ell = i + ((w * (d - i)) >> 32)) and
+//     2 (i % 2) + 1 (sign = low bit); next state = ctr + m * NB.  The inverse lists are built once on the device
+//     (count -> per-block scan -> scatter -> per-list sort by source row: a counting sort with a deterministic result).
+//   mode 0, BLOCK AFFINE (faster: closed-form inverse map, exactly nnz sources per sketch row and block): inside block
+//     t, input row u feeds  r_i(u) = (a_t * u + b_{t,i}) mod d,  gcd(a_t, d) = 1, b_{t,0..nnz-1} pairwise distinct,
+//     iid signs.  (a_t, b_t) come from Philox(ctr + t), the signs of input row j from Philox(ctr + T + j); next state =
+//     ctr + T + m, T = ceil(m/d).  Every d x d block of S is then a sum of nnz signed permutation matrices.
 //
 // apply: grid = (column tiles of 8) x (groups of row blocks); a workgroup stages the d x 8 block of A in LDS
 // (coalesced reads, A is streamed exactly once), each thread owns up to 8 sketch rows x 8 columns of
 // accumulators in registers and gathers its nnz source rows per block from LDS with ds_read_b128; partial
 // sketches of the row-block groups are summed in fixed order.  HBM-bound: 8*m*n bytes.
+#include <cstdlib>
 #include <vector>
 #include "rlhip_internal.h"
 
@@ -94,6 +101,107 @@ __global__ void saso_lists_kernel(int64_t d, int64_t m, int64_t T, int nnz, Saso
     src[idx] = (int32_t)((uint32_t)u | (bit << 31));
 }
 
+
+// ---- mode 1 (independent columns): generation and the inverse lists ----------------------------------------------------------
+// rows[j * nnz + i] = r | (sign << 31): the nnz distinct sketch rows of column j (Fisher-Yates over a virtual identity vector:
+// only the touched positions are tracked); cnt[(j / d) * d + r] counts the sources of sketch row r inside row block j / d.
+__global__ void saso_ind_gen_kernel(int64_t d, int64_t m, int nnz, SasoState st, int32_t* __restrict__ rows, int32_t* __restrict__ cnt) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const int64_t NB = (nnz + 1) / 2;
+    const int64_t t = j / d;
+    int32_t mp[128], mv[128];            // touched positions beyond the ones already drawn, and what they hold now
+    int nm = 0;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < nnz; ++i) {
+        if ((i & 1) == 0) {
+            uint32_t c[4];
+            ctr_add_dev(st.ctr, (uint64_t)(j * NB + (i >> 1)), c);
+            philox4x32_10_dev(c, st.key, w);
+        }
+        const uint32_t wa = w[2 * (i & 1)], wb = w[2 * (i & 1) + 1];
+        const int32_t ell = (int32_t)(i + (int64_t)(((uint64_t)wa * (uint64_t)(d - i)) >> 32));
+        int32_t a = i, b = ell;          // current contents of positions i and ell
+        int ia = -1, ib = -1;
+        for (int l = 0; l < nm; ++l) {
+            if (mp[l] == i) { a = mv[l]; ia = l; }
+            if (mp[l] == ell) { b = mv[l]; ib = l; }
+        }
+        (void)ia;
+        if (ell != i) {                  // swap: position i takes b (final), position ell takes a
+            if (ib >= 0) mv[ib] = a; else { mp[nm] = ell; mv[nm] = a; ++nm; }
+        } else {
+            b = a;
+        }
+        rows[j * nnz + i] = (int32_t)((uint32_t)b | ((wb & 1u) << 31));
+        atomicAdd(&cnt[t * d + b], 1);
+    }
+}
+
+// ptr[t * d + r] = first entry of (block t, sketch row r) in ent[]; block t's entries start at t * d * nnz (every column of a
+// block contributes nnz entries to that block), so the scan is local to a block: one workgroup per block.
+__global__ __launch_bounds__(256) void saso_ind_scan_kernel(int64_t d, int nnz, const int32_t* __restrict__ cnt, int32_t* __restrict__ ptr,
+                                                            int64_t Tb) {
+    __shared__ int32_t s_part[256];
+    __shared__ int32_t s_run;
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_run = (int32_t)(t * d * nnz);
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < d; r0 += 256) {
+        const int64_t r = r0 + tid;
+        const int32_t v = (r < d) ? cnt[t * d + r] : 0;
+        s_part[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan
+            const int32_t add = (tid >= off) ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        const int32_t base = s_run;
+        if (r < d) ptr[t * d + r] = base + s_part[tid] - v;
+        __syncthreads();
+        if (tid == 255) s_run = base + s_part[255];
+        __syncthreads();
+    }
+    if (t == Tb - 1 && tid == 0) ptr[Tb * d] = s_run;
+}
+
+// ent[ptr[key] + k] = u | (sign << 31) for the sources u of (block, row) = key, in arrival order (sorted by the next kernel)
+__global__ void saso_ind_scatter_kernel(int64_t d, int64_t m, int nnz, const int32_t* __restrict__ rows, const int32_t* __restrict__ ptr,
+                                        int32_t* __restrict__ cursor, int32_t* __restrict__ ent) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * nnz) return;
+    const int64_t j = idx / nnz;
+    const int64_t t = j / d, u = j - t * d;
+    const uint32_t e = (uint32_t)rows[idx];
+    const int64_t key = t * d + (int64_t)(e & 0x7fffffffu);
+    const int32_t k = atomicAdd(&cursor[key], 1);
+    ent[ptr[key] + k] = (int32_t)((uint32_t)u | (e & 0x80000000u));
+}
+
+// every list sorted by source row: the summation order of the gather no longer depends on the arrival order of the scatter
+__global__ void saso_ind_sort_kernel(int64_t nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ ent) {
+    const int64_t key = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    const int32_t p0 = ptr[key], p1 = ptr[key + 1];
+    for (int32_t p = p0 + 1; p < p1; ++p) {
+        const int32_t e = ent[p];
+        int32_t q = p - 1;
+        while (q >= p0 && (ent[q] & 0x7fffffff) > (e & 0x7fffffff)) { ent[q + 1] = ent[q]; --q; }
+        ent[q + 1] = e;
+    }
+}
+
+template <typename T>
+__global__ void saso_ind_dense_kernel(int64_t d, int64_t m, int nnz, const int32_t* __restrict__ rows, T* __restrict__ S) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * nnz) return;
+    const uint32_t e = (uint32_t)rows[idx];
+    S[(int64_t)(e & 0x7fffffffu) + (idx / nnz) * d] = (e & 0x80000000u) ? T(-1) : T(1);
+}
+
 // dense copy of S (d x m, column-major) for tests: S[r, j] = +-1
 template <typename T>
 __global__ void saso_dense_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, const int32_t* __restrict__ src,
@@ -116,7 +224,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t m, int64_t Tb, int nnz, SasoState st,
                                                              const int64_t* __restrict__ afwd, const int64_t* __restrict__ b,
                                                              const int64_t* __restrict__ rowptrT, const int64_t* __restrict__ colidxT,
-                                                             const T* __restrict__ valsT, T alpha, T beta, T* __restrict__ B, int64_t ldb, int64_t row0) {
+                                                             const T* __restrict__ valsT, T alpha, T beta, T* __restrict__ B, int64_t ldb, int64_t row0,
+                                                             const int32_t* __restrict__ rows /* mode 1: the columns' row lists; nullptr in mode 0 */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);       // [d]
     __shared__ double s_red[4];
@@ -140,6 +249,13 @@ __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t 
         for (int64_t p = p0 + tid; p < p1; p += 256) {
             const int64_t j = colidxT[p] + row0;               // global row of the operand (row-sharded operators pass their offset)
             const long long q = llrint(ldexp((double)valsT[p], e));
+            if (rows) {
+                for (int i = 0; i < nnz; ++i) {
+                    const uint32_t e = (uint32_t)rows[j * nnz + i];
+                    atomicAdd(&acc[e & 0x7fffffffu], (unsigned long long)((e & 0x80000000u) ? -q : q));
+                }
+                continue;
+            }
             const int64_t t = j / d, u = j - t * d;
             uint32_t ctr[4], w[4];
             ctr_add_dev(st.ctr, (uint64_t)(Tb + j), ctr);
@@ -162,16 +278,17 @@ __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t 
     }
 }
 
-constexpr int CT = 4;     // columns per workgroup: 40 KiB slab (d = 1280, fp64) -> several workgroups per CU overlap staging and gathering (C3: 8 -> 6.3 ms, 4 -> 4.6 ms, 2 -> 6.3 ms)
+// CT = columns per workgroup: 4 gives a 40 KiB slab at d = 1280 (fp64), so several workgroups per CU overlap staging and gathering
+// (C3: 8 -> 6.3 ms, 4 -> 4.6 ms, 2 -> 6.3 ms); taller sketches take 2 or 1 columns so that the d x CT slab still fits the CU's LDS
 constexpr int RPT = 8;    // sketch rows per thread (256 threads -> d <= 2048 per pass)
 
 // partial[g][r + c*d] = sum over row blocks t in group g of sum_i sign * A[t*d + u_i(r), c]
-template <typename T>
+template <typename T, int CT, int MODE>
 __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, int64_t m, int64_t Tb, int nnz,
                                                          const int32_t* __restrict__ src, const T* __restrict__ A,
                                                          int64_t lda, int64_t t_per_group, int64_t r_base,
                                                          T* __restrict__ partial, int64_t row0, int64_t mloc, int64_t tb0,
-                                                         int64_t tb1) {
+                                                         int64_t tb1, const int32_t* __restrict__ ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);                     // [d][CT] row-major
     const int tid = threadIdx.x;
@@ -200,6 +317,48 @@ __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, i
             }
         }
         __syncthreads();
+        if (MODE == 1) {
+            // variable-length lists (block t, row r) = src[ptr[t d + r] .. ptr[t d + r + 1]), sorted by source row.  All list bounds of
+            // the thread's RPT rows are requested first, then the first eight entries of every list as two 16-byte loads (a list
+            // is contiguous; reading past its end is harmless -- the array is padded -- and masked by the length), so that no load
+            // waits for another; lists longer than eight entries (2 % of them at nnz = 4) finish in a scalar tail loop.
+            int32_t p0[RPT], len[RPT];
+            int4 ea[RPT], eb[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int64_t r = r_base + tid + 256 * q;
+                p0[q] = 0; len[q] = 0;
+                if (r < d) { p0[q] = ptr[t * d + r]; len[q] = ptr[t * d + r + 1] - p0[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                int tmp[8];
+                __builtin_memcpy(tmp, src + p0[q], 32);          // two unaligned 16-byte loads
+                ea[q] = int4{tmp[0], tmp[1], tmp[2], tmp[3]};
+                eb[q] = int4{tmp[4], tmp[5], tmp[6], tmp[7]};
+            }
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int ev[8] = {ea[q].x, ea[q].y, ea[q].z, ea[q].w, eb[q].x, eb[q].y, eb[q].z, eb[q].w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k < len[q]) {
+                        const int32_t e = ev[k];
+                        const T sg = (e & 0x80000000) ? T(-1) : T(1);
+                        const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                    }
+                }
+                for (int32_t k = 8; k < len[q]; ++k) {
+                    const int32_t e = src[p0[q] + k];
+                    const T sg = (e & 0x80000000) ? T(-1) : T(1);
+                    const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int64_t r = r_base + tid + 256 * q;
@@ -214,6 +373,7 @@ __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, i
                     }
                 }
             }
+        }
         }
     }
     T* out = partial + g * d * n;
@@ -307,37 +467,75 @@ namespace rlhip {
 struct SasoOp {
     int64_t d, m, T;
     int nnz;
-    int32_t* src;       // T * nnz * d
-    int64_t* ainv;      // T
-    int64_t* b;         // T * nnz
-    int64_t* afwd;      // T   (the forward multiplier a_t; the sparse-operand path scatters)
+    int mode;           // 1 independent columns (default), 0 block affine
+    int32_t* src;       // mode 0: T * nnz * d inverse table; mode 1: m * nnz list entries (ent)
+    int64_t* ainv;      // T                                   (mode 0)
+    int64_t* b;         // T * nnz                             (mode 0)
+    int64_t* afwd;      // T   (the forward multiplier a_t; the sparse-operand path scatters)   (mode 0)
+    int32_t* rows;      // m * nnz: the columns' own row lists (mode 1; forward map for the sparse-operand path and the dense copy)
+    int32_t* ptr;       // T * d + 1 list starts               (mode 1)
     SasoState st;
 };
 
-int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4], const uint32_t key[2],
+static int saso_default_mode() {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("RLHIP_SASO_MODE"); mode = (e && (e[0] == '0' || e[0] == 'a')) ? 0 : 1; }   // "0" / "affine": block affine
+    return mode;
+}
+
+int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2],
                uint32_t next_ctr[4], SasoOp** out) {
-    if (d <= 0 || m < 0 || nnz <= 0 || nnz > d || nnz > 128) return -2;
+    if (d <= 0 || m < 0 || nnz <= 0 || nnz > d || nnz > 128 || d >= ((int64_t)1 << 31)) return -2;
+    if (mode < 0) mode = saso_default_mode();
+    if (mode > 1) return -5;
     SasoOp* op = new SasoOp();
-    op->d = d; op->m = m; op->nnz = nnz; op->T = (m + d - 1) / d;
+    op->d = d; op->m = m; op->nnz = nnz; op->T = (m + d - 1) / d; op->mode = mode;
+    op->src = nullptr; op->ainv = nullptr; op->b = nullptr; op->afwd = nullptr; op->rows = nullptr; op->ptr = nullptr;
     const int64_t T = op->T > 0 ? op->T : 1;
-    RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (size_t)(T * nnz * d)));
-    RLHIP_CHECK(hipMalloc((void**)&op->ainv, sizeof(int64_t) * (size_t)T));
-    RLHIP_CHECK(hipMalloc((void**)&op->b, sizeof(int64_t) * (size_t)(T * nnz)));
-    RLHIP_CHECK(hipMalloc((void**)&op->afwd, sizeof(int64_t) * (size_t)T));
     SasoState st;
     for (int i = 0; i < 4; ++i) st.ctr[i] = ctr[i];
     st.key[0] = key[0]; st.key[1] = key[1];
     op->st = st;
-    if (op->T > 0) {
-        hipLaunchKernelGGL(saso_params_kernel, dim3((unsigned)((op->T + 63) / 64)), dim3(64), 0, c->stream, d, op->T, nnz,
-                           st, op->ainv, op->b, op->afwd);
-        int64_t total = op->T * nnz * d;
-        hipLaunchKernelGGL(saso_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d, m, op->T,
-                           nnz, st, op->ainv, op->b, op->src);
-        RLHIP_LAUNCH_CHECK();
+    uint64_t inc;
+    if (mode == 0) {
+        RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (size_t)(T * nnz * d)));
+        RLHIP_CHECK(hipMalloc((void**)&op->ainv, sizeof(int64_t) * (size_t)T));
+        RLHIP_CHECK(hipMalloc((void**)&op->b, sizeof(int64_t) * (size_t)(T * nnz)));
+        RLHIP_CHECK(hipMalloc((void**)&op->afwd, sizeof(int64_t) * (size_t)T));
+        if (op->T > 0) {
+            hipLaunchKernelGGL(saso_params_kernel, dim3((unsigned)((op->T + 63) / 64)), dim3(64), 0, c->stream, d, op->T, nnz,
+                               st, op->ainv, op->b, op->afwd);
+            int64_t total = op->T * nnz * d;
+            hipLaunchKernelGGL(saso_lists_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d, m, op->T,
+                               nnz, st, op->ainv, op->b, op->src);
+            RLHIP_LAUNCH_CHECK();
+        }
+        inc = (uint64_t)op->T + (uint64_t)m;
+    } else {
+        if (m * nnz >= ((int64_t)1 << 31)) { delete op; return -3; }      // 32-bit list positions
+        const size_t nent = (size_t)(m * nnz > 0 ? m * nnz : 1), nkeys = (size_t)(T * d);
+        RLHIP_CHECK(hipMalloc((void**)&op->rows, sizeof(int32_t) * nent));
+        RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (nent + 8)));        // + 8: the apply kernel reads eight entries from any list start
+        RLHIP_CHECK(hipMemsetAsync(op->src + nent, 0, sizeof(int32_t) * 8, c->stream));
+        RLHIP_CHECK(hipMalloc((void**)&op->ptr, sizeof(int32_t) * (nkeys + 1)));
+        if (op->T > 0) {
+            size_t mark = rlhip_ws_mark(c);
+            int32_t* cnt = ws_alloc<int32_t>(c, nkeys);
+            int32_t* cursor = ws_alloc<int32_t>(c, nkeys);
+            if (!cnt || !cursor) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            RLHIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nkeys, c->stream));
+            RLHIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * nkeys, c->stream));
+            hipLaunchKernelGGL(saso_ind_gen_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, st, op->rows, cnt);
+            hipLaunchKernelGGL(saso_ind_scan_kernel, dim3((unsigned)op->T), dim3(256), 0, c->stream, d, nnz, cnt, op->ptr, op->T);
+            hipLaunchKernelGGL(saso_ind_scatter_kernel, dim3((unsigned)((m * nnz + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, op->rows,
+                               op->ptr, cursor, op->src);
+            hipLaunchKernelGGL(saso_ind_sort_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, c->stream, (int64_t)nkeys, op->ptr, op->src);
+            RLHIP_LAUNCH_CHECK();
+            rlhip_ws_release(c, mark);
+        }
+        inc = (uint64_t)m * (uint64_t)((nnz + 1) / 2);
     }
     if (next_ctr) {
-        uint64_t inc = (uint64_t)op->T + (uint64_t)m;
         uint64_t lo = ((uint64_t)ctr[1] << 32) | ctr[0], hi = ((uint64_t)ctr[3] << 32) | ctr[2];
         uint64_t nlo = lo + inc;
         if (nlo < lo) hi += 1;
@@ -351,7 +549,7 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, const uint32_t ctr[4
 int saso_destroy(rlhip_ctx* c, SasoOp* op) {
     if (!op) return 0;
     hipStreamSynchronize(c->stream);
-    hipFree(op->src); hipFree(op->ainv); hipFree(op->b); hipFree(op->afwd);
+    hipFree(op->src); hipFree(op->ainv); hipFree(op->b); hipFree(op->afwd); hipFree(op->rows); hipFree(op->ptr);
     delete op;
     return 0;
 }
@@ -359,6 +557,14 @@ int saso_destroy(rlhip_ctx* c, SasoOp* op) {
 template <typename T>
 int saso_dense(rlhip_ctx* c, const SasoOp* op, T* S /* d x m, zeroed here */) {
     RLHIP_CHECK(hipMemsetAsync(S, 0, sizeof(T) * (size_t)(op->d * op->m), c->stream));
+    if (op->mode == 1) {
+        if (op->m > 0) {
+            hipLaunchKernelGGL(saso_ind_dense_kernel<T>, dim3((unsigned)((op->m * op->nnz + 255) / 256)), dim3(256), 0, c->stream, op->d, op->m, op->nnz,
+                               op->rows, S);
+            RLHIP_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     int64_t total = op->T * op->nnz * op->d;
     if (total > 0) {
         hipLaunchKernelGGL(saso_dense_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, op->d,
@@ -379,13 +585,12 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     if (lda < (mloc > 1 ? mloc : 1)) return -6;
     if (ldb < d) return -9;
     const int64_t tb0 = (mloc > 0) ? row0 / d : 0, tb1 = (mloc > 0) ? (row0 + mloc + d - 1) / d : 0, nTb = tb1 - tb0;
+    // columns per workgroup: the d x CT slab has to fit the CU's LDS (4 columns up to d = 5120 fp64 / 10240 fp32, then 2, then 1:
+    // d <= 20480 fp64 / 40960 fp32; taller sketches are refused with -2, documented in rlhip.h)
+    const size_t lds_cap = 160 * 1024;
+    const int CT = (sizeof(T) * (size_t)d * 4 <= lds_cap) ? 4 : (sizeof(T) * (size_t)d * 2 <= lds_cap) ? 2 : 1;
     const size_t smem = sizeof(T) * (size_t)d * CT;
-    if (smem > 160 * 1024) return -2;   // d up to 2560 (fp64)
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)saso_apply_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (smem > lds_cap) return -2;
     const int64_t ctiles = (n + CT - 1) / CT;
     int64_t G = (1024 + ctiles - 1) / ctiles;                       // ~4 workgroups per CU in flight
     if (G > nTb) G = nTb;
@@ -397,10 +602,18 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     T* partial = ws_alloc<T>(c, (size_t)G * d * n);
     if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     if (nTb == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
-    for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT) {
-        if (nTb > 0)
-            hipLaunchKernelGGL(saso_apply_kernel<T>, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m,
-                               op->T, op->nnz, op->src, A, lda, tpg, r_base, partial, row0, mloc, tb0, tb1);
+    auto launch = [&](auto kern) -> int {
+        RLHIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));   // (per device, cheap: set on every call)
+        for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT)
+            hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, tpg, r_base,
+                               partial, row0, mloc, tb0, tb1, op->ptr);
+        return 0;
+    };
+    if (nTb > 0) {
+        int rc;
+        if (op->mode == 1) rc = (CT == 4) ? launch(saso_apply_kernel<T, 4, 1>) : (CT == 2) ? launch(saso_apply_kernel<T, 2, 1>) : launch(saso_apply_kernel<T, 1, 1>);
+        else rc = (CT == 4) ? launch(saso_apply_kernel<T, 4, 0>) : (CT == 2) ? launch(saso_apply_kernel<T, 2, 0>) : launch(saso_apply_kernel<T, 1, 0>);
+        if (rc) { rlhip_ws_release(c, mark); return rc; }
     }
     RLHIP_LAUNCH_CHECK();
     const int64_t total = d * n;
@@ -431,7 +644,7 @@ int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int
         attr_set = true;
     }
     hipLaunchKernelGGL(saso_apply_csr_kernel<T>, dim3((unsigned)n), dim3(256), smem, c->stream, op->d, op->m, op->T, op->nnz, op->st, op->afwd,
-                       op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb, row0);
+                       op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb, row0, op->rows);
     RLHIP_LAUNCH_CHECK();
     return 0;
 }

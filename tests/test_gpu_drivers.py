@@ -210,7 +210,8 @@ def test_cqrrpt_own_sketch_properties_and_state(ctx):
     Ad = d.cm_from_numpy(A)
     r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, key=(3, 0))
     dsk = int(1.25 * n)
-    assert r["rc"] == 0 and r["next_ctr"] == ((m + dsk - 1) // dsk + m, 0, 0, 0)
+    assert dsk == int(1.25 * n)
+    assert r["rc"] == 0 and r["next_ctr"] == (m * ((4 + 1) // 2), 0, 0, 0)      # S.next_state of the independent-column SASO: m * ceil(nnz / 2) Philox blocks
     k = r["rank"]
     J = r["J"].cpu().numpy()
     Q, R = d.cm_to_numpy(Ad)[:, :k], d.cm_to_numpy(r["R"])[:k]
@@ -636,13 +637,15 @@ def test_abrik_early_termination_and_bad_args(ctx, orc):
 # ---------------------------------------------------------------------------------------------------
 # CQRRT (drivers/rl_cqrrt.hh) and ABRIK with CQRRT panels (qr_exp = cqrrt)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,n,cond", [(5000, 200, 1e2), (2000, 64, 1e8), (300, 300, 1e3)])
-def test_cqrrt_vs_oracle_shared_sketch(ctx, orc, m, n, cond):
+# (square input: d_factor = 2 as in test_cqrrt.cc:153-173; a 2-nonzeros-per-column operator with d = 1.25 n is likely to hold two parallel
+#  columns when m <= d, under RandBLAS's independent-column distribution as well)
+@pytest.mark.parametrize("m,n,cond,d_factor,nnz", [(5000, 200, 1e2, 1.25, 2), (2000, 64, 1e8, 1.25, 2), (300, 300, 1e3, 2.0, 4)])
+def test_cqrrt_vs_oracle_shared_sketch(ctx, orc, m, n, cond, d_factor, nnz):
     d = _d()
     rng = np.random.default_rng(m + n)
     A = poly_mat(m, n, n, rng, cond=cond)
     Ad = d.cm_from_numpy(A)
-    r = d.drv_cqrrt(ctx, Ad, m, n, 1.25, 2, want_sketch=True, key=(4, 0))
+    r = d.drv_cqrrt(ctx, Ad, m, n, d_factor, nnz, want_sketch=True, key=(4, 0))
     o = orc.cqrrt(A, d.cm_to_numpy(r["sketch"]))
     assert r["rc"] == o["rc"] == 0
     Q, R = d.cm_to_numpy(Ad), np.triu(d.cm_to_numpy(r["R"]))

@@ -97,3 +97,36 @@ def test_col_swap_large_single_cycle_is_linear(orc):
     rc, B, _ = orc.col_swap(A, J)
     assert time.time() - t0 < 10.0
     np.testing.assert_array_equal(B[0], (np.arange(n) + 1) % n)
+
+
+def test_numpy_philox_restatement_matches_kats_and_cpp(orc):
+    """the vectorised numpy Philox4x32-10 used by the SASO restatement: Random123 KATs + the C++ restatement on carries"""
+    for v in json.loads((G / "philox_kat.json").read_text()):
+        assert [int(x) for x in orc.philox_np([v["ctr"]], v["key"])[0]] == v["out"]
+    for base in [(0xFFFFFFFD, 7, 0, 0), (0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 3)]:
+        ctrs = orc._ctr_array(base, range(6))
+        out = orc.philox_np(ctrs, (11, 13))
+        for i in range(6):
+            assert list(out[i]) == list(orc.philox(tuple(int(x) for x in ctrs[i]), (11, 13)))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_saso_restatement_structure(orc, mode):
+    """d x m operator with nnz nonzeros per column: distinct rows, +-1 values, documented state advance; the
+    block-affine structure additionally gives every sketch row exactly nnz sources per full block of d input rows"""
+    for (d, m, nnz) in [(40, 1000, 4), (25, 333, 2), (64, 64, 8), (7, 50, 7), (1, 5, 1)]:
+        S, nxt = orc.saso_dense(d, m, nnz, (7, 0, 0, 0), (5, 0), mode)
+        assert S.shape == (d, m) and set(np.unique(S)) <= {-1.0, 0.0, 1.0}
+        assert set((S != 0).sum(0)) == {nnz}
+        T = (m + d - 1) // d
+        assert nxt == ((7 + T + m) if mode == 0 else (7 + m * ((nnz + 1) // 2)), 0, 0, 0)
+        if mode == 0:
+            for t in range(m // d):
+                assert set((S[:, t * d:(t + 1) * d] != 0).sum(1)) == {nnz}
+        if m * nnz >= 2000:
+            assert abs(S.sum()) < 6 * np.sqrt(m * nnz)                              # balanced signs
+    # different keys / counters give different operators; same inputs the same operator
+    a, _ = orc.saso_dense(16, 64, 2, (0, 0, 0, 0), (1, 0), mode)
+    b, _ = orc.saso_dense(16, 64, 2, (0, 0, 0, 0), (2, 0), mode)
+    c, _ = orc.saso_dense(16, 64, 2, (0, 0, 0, 0), (1, 0), mode)
+    assert not np.array_equal(a, b) and np.array_equal(a, c)
