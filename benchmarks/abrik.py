@@ -5,6 +5,8 @@ _sparse twins).
         -> _ABRIK_runtime_breakdown_num_info_lines_6.txt: block size, matmuls, then the 13 entries of ABRIK::times (microseconds):
            allocation, get_factors, ungqr, reorth, qr, gemm_A, main_loop, sketching, r_cpy, s_cpy, norm, rest, total
   python -m benchmarks.abrik speed <dir> <mat_type> <num_runs> <m> <n> <target_rank> <num_block_sizes> <num_matmul_sizes> <block sizes...> <matmul counts...>
+  python -m benchmarks.abrik speed_sparse <dir> <path.mtx | sparse:<density>:<m>:<n>> <num_runs> <target_rank> <num_block_sizes> <num_matmul_sizes> <block sizes...> <matmul counts...>
+        -> _ABRIK_speed_comparisons_sparse_num_info_lines_6.txt (ABRIK on a CSR operator in HBM vs a host SVDS)
 
 The reference reads its input matrix from a file; here it is generated in HBM (gen::mat_gen types: polynomial, exponential, step,
 gaussian).  Output `_ABRIK_speed_comparisons_num_info_lines_6.txt`: 15 columns -- block size, matmuls, target rank, then (residual
@@ -131,7 +133,67 @@ def runtime_breakdown(argv):
     return path
 
 
-MAINS = {"speed": speed, "runtime_breakdown": runtime_breakdown}
+def speed_sparse(argv):
+    """<dir> <input: path.mtx | sparse:<density>:<m>:<n>> <num_runs> <target_rank> <num_block_sizes> <num_matmul_sizes> <block sizes...> <matmuls...>
+    (ABRIK_speed_comparisons_sparse.cc:354-436).  ABRIK (qr_exp = cqrrt, as the reference sets it, :271) on a CSR operator in HBM
+    against SVDS.  The reference's SVDS is Spectra (host, Eigen); here it is scipy.sparse.linalg.svds (host ARPACK) with the
+    reference's triplet count min(b * matmuls / 2, n - 2).  Columns: block size, matmuls, target rank, ABRIK residual, ABRIK time
+    (us), SVDS residual, SVDS time (us); residual = sqrt(||A V - U S||_F^2 + ||A^T U - V S||_F^2) on min(target, found) triplets."""
+    import scipy.io
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    directory, src, num_runs, target_rank = argv[0], argv[1], int(argv[2]), int(argv[3])
+    nb, nm = int(argv[4]), int(argv[5])
+    b_sz = [int(x) for x in argv[6:6 + nb]]
+    matmuls = [int(x) for x in argv[6 + nb:6 + nb + nm]]
+    if src.startswith("sparse:"):
+        _, dens, m, n = src.split(":")
+        m, n, nnz = int(m), int(n), int(float(dens) * int(m) * int(n))
+        rng = np.random.default_rng(0)
+        # graded rows and columns: a spectrum that decays, so that a low-rank SVD is meaningful
+        r_, c_ = rng.integers(0, m, nnz), rng.integers(0, n, nnz)
+        M = sp.coo_matrix((rng.standard_normal(nnz) / ((1.0 + r_) ** 0.5 * (1.0 + c_) ** 0.5), (r_, c_)), shape=(m, n)).tocsr()
+    else:
+        M = sp.csr_matrix(scipy.io.mmread(src))
+        m, n = M.shape
+    M.sum_duplicates()
+    ctx = d.Context(0)
+    op = d.CsrOperator.from_scipy(M)
+    tol = float(np.finfo(np.float64).eps ** 0.85)
+    path = c.out_path(directory, "_ABRIK_speed_comparisons_sparse_num_info_lines_6.txt")
+    with open(path, "a") as f:
+        f.write("Description: Results from the ABRIK speed comparison benchmark, recording the time it takes to perform ABRIK and alternative methods for low-rank SVD, specifically on sparse matrices."
+                "\nFile format: 15 columns, showing krylov block size, nummber of matmuls permitted, and num svals and svecs to approximate, followed by the residual error, standard lowrank error and execution time for all algorithms (ABRIK, SVDS)"
+                "\n Rows correspond to algorithm runs with Krylov block sizes varying as specified, and numbers of matmuls varying as specified per each block size, with num_runs repititions of each number of matmuls."
+                f"\nInput type:{src}"
+                f"\nInput size:{m} by {n}"
+                f"\nAdditional parameters: Krylov block sizes {''.join(str(b) + ', ' for b in b_sz)} matmuls: {''.join(str(x) + ', ' for x in matmuls)}"
+                f" num runs per size {num_runs} num singular values and vectors approximated {target_rank}\n")
+
+    def resid(U, S, V, k):                                   # host: U (m, k'), V (n, k') numpy
+        return float(np.hypot(np.linalg.norm(M @ V[:, :k] - U[:, :k] * S[:k]), np.linalg.norm(M.T @ U[:, :k] - V[:, :k] * S[:k])))
+
+    for b in b_sz:
+        for mm in matmuls:
+            for _ in range(num_runs):
+                hold = {}
+                dur_abrik = c.timed_us(lambda: hold.update(o=d.drv_abrik_linop(ctx, op, b, tol, max_krylov_iters=mm, qr_exp=1)))
+                o = hold["o"]
+                ka = min(target_rank, o["triplets"])
+                res_a = resid(d.cm_to_numpy(o["U"]), o["S"].cpu().numpy(), d.cm_to_numpy(o["V"]), ka)
+                ks = max(1, min(b * mm // 2, n - 2, m - 2))
+                t0 = time.perf_counter()
+                Us, Ss, Vts = spl.svds(M, k=ks, ncv=min(2 * ks, n - 1, m - 1) if 2 * ks > ks + 1 else None)
+                dur_svds = int((time.perf_counter() - t0) * 1e6)
+                order = np.argsort(-Ss)
+                res_s = resid(Us[:, order], Ss[order], Vts[order].T, min(target_rank, ks))
+                with open(path, "a") as f:
+                    f.write(f"{b},  {mm},  {target_rank},  {res_a:.16e},  {dur_abrik},  {res_s:.16e},  {dur_svds},\n")
+    return path
+
+
+MAINS = {"speed_sparse": speed_sparse, "speed": speed, "runtime_breakdown": runtime_breakdown}
 
 if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in MAINS:

@@ -18,6 +18,7 @@
 //                                                                the updated G1, so Y2 -= G1 R12 is one more GEMM.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <vector>
@@ -31,9 +32,21 @@ namespace RandLAPACK {
 
 /// returns 0; 1 if a CholQR panel (qr_type == 2) broke down.  `G_export`, when not null, receives the (nb_alg+pp) x m
 /// sketching matrix before it is updated (tests share it with the CPU path, cf. test_bqrrp_gpu.cu:91-110).
+/// `timing` (the reference's last argument, rl_hqrrp.hh:815,1144-1164): when not null, *timing is (re)allocated to 27 entries
+/// (microseconds; the reference documents 26 and its benchmark prints 27):
+///   [0..8]  preallocation, sketching, downdating, qrcp, qr, updating_A, updating_Sketch, other, total
+///   [9..17] the sketch-QRCP kernel's own breakdown, [18..26] the panel-QR kernel's -- on the device each is ONE kernel, so only
+///   the total slots (17 and 26) are filled, the per-step slots stay 0.
+/// Timing synchronises the queue at every stamp.
 template <typename T, typename RNG>
 int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff_jpvt, T* buff_tau, int64_t nb_alg, int64_t pp,
-              int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, blas::Queue& q, T* G_export = nullptr) {
+              int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, blas::Queue& q, T* G_export = nullptr,
+              T** timing = nullptr) {
+    using hq_clk = std::chrono::steady_clock;
+    long t_prealloc = 0, t_sketch = 0, t_down = 0, t_qrcp = 0, t_qr = 0, t_updA = 0, t_updS = 0;
+    auto stamp = [&]() { if (timing) q.sync(); return hq_clk::now(); };
+    auto us = [](hq_clk::time_point a, hq_clk::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const auto t_begin = stamp();
     randlapack_require(m_A >= 0) << "hqrrp: m_A is < 0";                                                   // :871-877
     randlapack_require(n_A >= 0) << "hqrrp: n_A is < 0";
     randlapack_require(ldim_A >= std::max<int64_t>(1, m_A)) << "hqrrp: ldim_A is < max(1, m_A)";
@@ -56,10 +69,13 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
         for (int64_t i = 0; i < n_A; ++i) iota_[(size_t)i] = i + 1;
         blas::copy_to_device(n_A, iota_.data(), buff_jpvt, q);
     }
+    auto t_a = stamp();
+    t_prealloc = us(t_begin, t_a);
     RandBLAS::DenseDist D(nb_alg + pp, m_A, RandBLAS::ScalarDist::Uniform);                                 // :929-930
     state = RandBLAS::fill_dense(D, buff_G, state, q);
     if (G_export) blas::device_copy_vector(m_G * n_G, buff_G, G_export, q);
     blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n_Y, m_A, (T)1, buff_G, ldim_G, buff_A, ldim_A, (T)0, buff_Y, ldim_Y, q);
+    t_sketch = us(t_a, stamp());
 
     for (int64_t j = 0; j < mn_A; j += nb_alg) {
         const int64_t b = std::min(nb_alg, std::min(n_A - j, m_A - j));
@@ -79,6 +95,7 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
         T* buff_Y2 = &buff_Y[std::min(n_Y - 1, j + b) * ldim_Y];
         T* buff_G1 = &buff_G[j * ldim_G];
 
+        auto t0 = stamp();
         if (!last_iter) {                                                                                   // :1040-1062
             lapack::lacpy(MatrixType::General, m_Y, n_VR, buff_YR, ldim_Y, buff_VR, ldim_V, q);
             lapack::qrp_partial(m_Y, n_VR, b, buff_VR, ldim_V, Jloc, tau_scr, q);
@@ -86,6 +103,8 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
             util::col_swap(m_Y, n_VR, n_VR, buff_YR, ldim_Y, Jloc, q);
             util::col_swap(n_VR, n_VR, buff_pB, Jloc, q);
         }
+        auto t1 = stamp();
+        t_qrcp += us(t0, t1);
         // ---- panel [A11; A21] (m_AB1 x b) and its T                                                       :1084-1094
         if (qr_type == 2 && !panel_pivoting) {                                                              // CHOLQR_mod_WY
             lapack::laset(MatrixType::General, nb_alg, nb_alg, (T)0, (T)0, buff_R, nb_alg, q);
@@ -125,13 +144,31 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
             lapack::larft(m_AB1, std::min(m_AB1, b), buff_AB1, ldim_A, buff_sB, T1, nb_alg, q);
         }
         const int64_t kref = std::min(m_AB1, b);
+        auto t2 = stamp();
+        t_qr += us(t1, t2);
         if (j + b < n_A)                                                                                    // :1108-1118
             lapack::gemqrt(Side::Left, Op::Trans, m_AB1, n_A12, kref, kref, buff_AB1, ldim_A, T1, nb_alg, buff_A12, ldim_A, q);
+        auto t3 = stamp();
+        t_updA += us(t2, t3);
         if (!last_iter) {                                                                                   // :1135-1145
             lapack::gemqrt(Side::Right, Op::NoTrans, m_G, n_G - j, kref, kref, buff_AB1, ldim_A, T1, nb_alg, buff_G1, ldim_G, q);
+            auto t4 = stamp();
+            t_updS += us(t3, t4);
             const int64_t n_Y2 = std::max<int64_t>(0, n_Y - j - b);
             if (n_Y2 > 0)
                 blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n_Y2, b, (T)-1, buff_G1, ldim_G, buff_A12, ldim_A, (T)1, buff_Y2, ldim_Y, q);
+            t_down += us(t4, stamp());
+        }
+    }
+    if (timing) {                                                                                           // :1144-1164
+        const long total = us(t_begin, stamp());
+        T* tt = (T*)std::realloc(*timing, 27 * sizeof(T));
+        if (tt) {
+            for (int i = 0; i < 27; ++i) tt[i] = (T)0;
+            tt[0] = (T)t_prealloc; tt[1] = (T)t_sketch; tt[2] = (T)t_down; tt[3] = (T)t_qrcp; tt[4] = (T)t_qr; tt[5] = (T)t_updA; tt[6] = (T)t_updS;
+            tt[7] = (T)(total - (t_prealloc + t_sketch + t_down + t_qrcp + t_qr + t_updA + t_updS)); tt[8] = (T)total;
+            tt[17] = (T)t_qrcp; tt[26] = (T)t_qr;
+            *timing = tt;
         }
     }
     return 0;

@@ -54,6 +54,10 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
  * Returns 0, or 1 if a CholQR panel broke down. */
 int rlhip_drv_hqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg,
                         int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double* G_out);
+/* the same call with the reference's `T** timing` argument armed (rl_hqrrp.hh:815, :1144-1164): times27 receives the 27 entries the
+ * reference's HQRRP_runtime_breakdown benchmark prints, in microseconds (layout: include/RandLAPACK_amd/rl_hqrrp.hh) */
+int rlhip_drv_hqrrp_timed_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg,
+                              int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double times27[27]);
 
 /* BQRRP<double>::call.  qrcp_wide {0 luqr, 1 geqp3}, qr_tall {0 geqrt, 1 cholqr, 2 geqrf}, apply_trans_q {0 ormqr, 1 gemqrt}
  * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default {luqr, cholqr, gemqrt}.

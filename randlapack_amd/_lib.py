@@ -127,6 +127,7 @@ SIGNATURES.update({
     "rlhip_drv_cqrrpt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_i64, c_dbl, u32p, c_vp,
                                      c_vp, C.POINTER(c_i64), C.POINTER(C.c_long), c_int]),
     "rlhip_drv_hqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, u32p, c_vp]),
+    "rlhip_drv_hqrrp_timed_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, u32p, C.POINTER(c_dbl)]),
     "rlhip_drv_bqrrp_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_dbl, c_i64, c_i64, c_dbl, c_vp, c_vp, u32p, c_vp, c_vp,
                                     C.POINTER(c_i64), C.POINTER(C.c_long), c_int, c_int, c_int]),
     "rlhip_drv_abrik_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_dbl, c_i64, dpp, dpp, dpp, u32p, C.POINTER(c_i64),

@@ -294,6 +294,21 @@ int rlhip_drv_hqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
     });
 }
 
+int rlhip_drv_hqrrp_timed_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, int64_t* jpvt, double* tau, int64_t nb_alg,
+                              int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double times27[27]) {
+    if (!times27) return -13;
+    return guarded([&] {
+        blas::Queue q(ctx);
+        State st = load_state(state);
+        double* tt = nullptr;
+        int rc = (int)RandLAPACK::hqrrp<double, RNG>(m, n, A, lda, jpvt, tau, nb_alg, pp, panel_pivoting, qr_type, st, q, (double*)nullptr, &tt);
+        store_state(st, state);
+        for (int i = 0; i < 27; ++i) times27[i] = tt ? tt[i] : 0.0;
+        std::free(tt);
+        return rc;
+    });
+}
+
 int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,
                         int64_t internal_nb, double tol, double* tau, int64_t* J, uint32_t state[6],
                         const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,

@@ -490,6 +490,19 @@ def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type
     return out
 
 
+def drv_hqrrp_timed(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=0, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0)):
+    """hqrrp with the reference's timing argument armed: dict(rc, tau, J, times_us (27 entries, rl_hqrrp.hh:1144-1164))"""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    tau = torch.zeros(min(m, n), dtype=A.dtype, device=dev)
+    J = torch.zeros(n, dtype=torch.int64, device=dev)
+    st = _state_arr(ctr, key)
+    times = (C.c_double * 27)()
+    rc = ctx.lib.rlhip_drv_hqrrp_timed_f64(ctx.h, m, n, A.data_ptr(), m, J.data_ptr(), tau.data_ptr(), nb_alg, pp, panel_pivoting, qr_type, st, times)
+    _drv_check(ctx, rc, "hqrrp_timed")
+    return dict(rc=rc, tau=tau, J=J, times_us=[float(x) for x in times])
+
+
 def drv_cqrrpt(ctx: Context, A, m, n, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0, 0, 0), key=(0, 0), sketch_in=None,
                want_sketch=False, timing=False, qrcp=-1):
     """CQRRPT::call (qrcp = geqp3).  A (column-major tensor (n, m)) is overwritten by Q.  Returns dict(rc, rank, R, J,

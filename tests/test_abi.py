@@ -68,7 +68,7 @@ using RNG = r123::Philox4x32;
   template class RandLAPACK::RSVD<T, RNG>; template class RandLAPACK::CQRRPT<T, RNG>; template class RandLAPACK::CQRRT<T, RNG>; \\
   template class RandLAPACK::BQRRP<T, RNG>; template class RandLAPACK::BQRRP_GPU<T, RNG>; template class RandLAPACK::CQRRPT_GPU<T, RNG>; \\
   template int64_t RandLAPACK::hqrrp<T, RNG>(int64_t, int64_t, T*, int64_t, int64_t*, T*, int64_t, int64_t, int64_t, int64_t, \\
-                                             RandBLAS::RNGState<RNG>&, blas::Queue&, T*); \\
+                                             RandBLAS::RNGState<RNG>&, blas::Queue&, T*, T**); \\
   template int RandLAPACK::ABRIK<T, RNG>::call(RandLAPACK::linops::DenseLinOp<T>&, int64_t, T*&, T*&, T*&, RandBLAS::RNGState<RNG>&); \\
   template void RandLAPACK::util::eye<T>(int64_t, int64_t, T*, blas::Queue&); \\
   template void RandLAPACK::util::diag<T>(int64_t, int64_t, const T*, int64_t, T*, blas::Queue&); \\

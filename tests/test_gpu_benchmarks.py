@@ -143,3 +143,81 @@ def test_abrik_runtime_breakdown_main(tmp_path, m_type):
         assert total > 0 and gemm_a > 0 and qr > 0 and factors > 0
         assert alloc + factors + ungqr + reorth + qr + gemm_a + sketch + r_cpy + s_cpy + norm + rest == total   # the reference's identity (:732)
         assert 0 < main_loop <= total and rest >= 0
+
+
+def test_bqrrp_subroutines_speed_main(tmp_path):
+    """BQRRP_subroutines_speed.cc: three blocks of rows (wide QRCP, tall QR, apply Q^T) in the reference's order and widths"""
+    from benchmarks import bqrrp
+
+    p = bqrrp.subroutines_speed([str(tmp_path), "2", "2048", "64", "128"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:") and any(ln.startswith("Additional parameters num runs per size 2 nb_start 64") for ln in lines[:10])
+    body = [[x for x in re.split(r",\s*", ln.strip()) if x] for ln in lines if ln and ln[0].isdigit()]
+    wide, rest = body[:4], body[4:]                                   # 2 sizes x 2 runs, (GEQP3, LUQR)
+    assert all(len(r) == 2 and all(int(x) > 0 for x in r) for r in wide)
+    tall, apply_q = rest[:4], rest[4:8]
+    # n = 64: nb = 64 only -> 6 + 1 columns; n = 128: nb = 64, 128 -> 6 + 2 columns
+    assert [len(r) for r in tall] == [7, 7, 8, 8] and all(int(x) > 0 for r in tall for x in r)
+    assert [len(r) for r in apply_q] == [2, 2, 3, 3] and all(int(x) > 0 for r in apply_q for x in r)
+    assert lines[-1].startswith("Total benchmark execution time:")
+
+
+def test_hqrrp_runtime_breakdown_main(tmp_path):
+    """HQRRP_runtime_breakdown.cc: 27 numbers per run; the top-level entries add up to the total (rl_hqrrp.hh:1150-1158)"""
+    from benchmarks import bqrrp
+
+    p = bqrrp.hqrrp_runtime_breakdown([str(tmp_path), "2", "1024", "768", "64", "128"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    # 7 header lines, as the file name says (this main's header has a line break before "rows correspond", HQRRP_runtime_breakdown.cc:147-149)
+    assert lines[0].startswith("Description:") and lines[6].startswith("Additional parameters: HQRRP block sizes: 64, 128, ")
+    rows = [[x for x in re.split(r",\s*", ln.strip()) if x] for ln in lines[7:]]
+    assert rows[-1][0].startswith("Total benchmark execution time:")
+    data = rows[:-1]
+    assert len(data) == 4 and all(len(r) == 27 for r in data)
+    for r in data:
+        t = [float(x) for x in r]
+        assert t[8] > 0 and t[1] > 0 and t[3] > 0 and t[4] > 0 and t[5] > 0
+        assert abs(sum(t[:8]) - t[8]) <= 1e-6 * t[8] + 1                  # preallocation + ... + other == total
+        assert t[17] == t[3] and t[26] == t[4]                            # the kernels' own totals
+
+
+def test_abrik_speed_sparse_main(tmp_path):
+    """ABRIK_speed_comparisons_sparse.cc: 7 columns; ABRIK on the CSR operator reaches the host SVDS's residual level"""
+    from benchmarks import abrik
+
+    p = abrik.speed_sparse([str(tmp_path), "sparse:0.02:1500:1000", "1", "5", "1", "2", "8", "4", "8"])
+    lines = open(p).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:") and lines[3].startswith("Input type:sparse:")
+    data = [[x for x in re.split(r",\s*", ln.strip()) if x] for ln in lines[6:]]
+    assert len(data) == 2 and all(len(r) == 7 for r in data)
+    for r in data:
+        assert int(r[0]) == 8 and int(r[1]) in (4, 8) and int(r[2]) == 5 and int(r[4]) > 0 and int(r[6]) > 0
+    assert float(data[1][3]) < float(data[0][3]) * 1.01                  # more matmuls: residual does not grow
+    # a Matrix Market input takes the same path
+    import scipy.io
+    import scipy.sparse as sp
+
+    M = sp.random(300, 200, density=0.05, random_state=1, format="coo")
+    scipy.io.mmwrite(str(tmp_path / "a.mtx"), M)
+    (tmp_path / "o").mkdir()
+    p2 = abrik.speed_sparse([str(tmp_path / "o"), str(tmp_path / "a.mtx"), "1", "4", "1", "1", "8", "6"])
+    assert "Input size:300 by 200" in open(p2).read()
+
+
+def test_cqrrt_linops_composite_applications_main(tmp_path):
+    """CQRRT_linop_composite_applications.cc: the generalized-LS / generalized-SVD study on L^{-1} V"""
+    from benchmarks import cqrrt_linops
+
+    res, brk = cqrrt_linops.composite_applications(["double", str(tmp_path), "1", "gen:3000", "gen:60:6", "2.0", "4", "0", "0", "0"])
+    lines = [ln for ln in open(res).read().splitlines() if not ln.startswith("#")]
+    hdr = lines[0].split(",")
+    assert hdr[:6] == ["m", "n", "run", "algorithm", "chol_time_us", "qr_time_us"] and len(hdr) == 18
+    rows = [ln.split(",") for ln in lines[1:]]
+    assert [r[3] for r in rows] == ["CQRRT_linop", "CholQR", "sCholQR3", "sCholQR3_basic"]
+    for r in rows:
+        assert len(r) == 18 and int(r[0]) == 3000 and int(r[1]) == 60 and int(r[5]) > 0
+        assert float(r[6]) < 1e-10 and int(r[7]) == 60                   # Q = (L^-1 V) R^-1 is orthonormal: R is the factor of the composite
+        assert float(r[9]) < 1e-9                                         # generalized least squares recovers x_true
+        assert float(r[12]) < 1e-10                                       # right singular vectors of R orthonormal
+    blines = [ln for ln in open(brk).read().splitlines() if not ln.startswith("#")]
+    assert blines[0].startswith("m,n,run,algorithm,t0") and len(blines) == 5 and all(len(ln.split(",")) == 22 for ln in blines)
