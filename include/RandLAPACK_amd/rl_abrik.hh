@@ -48,6 +48,8 @@ class ABRIK {
 public:
     using Subroutines = ABRIKSubroutines;
 
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    ABRIK(bool verb, bool time_subroutines, T ep) : ABRIK(blas::default_queue(), verb, time_subroutines, ep) {}                       // rl_abrik.hh:64
     ABRIK(blas::Queue& queue, bool verb, bool time_subroutines, T ep) : q(queue) {                               // :64-77
         qr_exp = Subroutines::QR_explicit::geqrf_ungqr;
         verbose = verb;

@@ -76,23 +76,39 @@ public:
     rlhip_ctx* ctx() const { return ctx_; }
 };
 
+// The queue the reference's own device drivers construct inside every call (`blas::Queue blas_queue(0)`, rl_bqrrp_gpu.hh:232,
+// rl_cqrrpt_gpu.hh:196): device 0, one stream.  Here it is ONE process-wide object, created on first use; every function and
+// constructor of this layer takes it when the caller passes no queue, so that code written against the reference's signatures
+// (no queue argument) compiles unchanged.
+inline Queue& default_queue() {
+    static Queue q0(0);
+    return q0;
+}
+
 template <typename T>
-T* device_malloc(int64_t n, Queue& q) {
+T* device_malloc(int64_t n, Queue& q = blas::default_queue()) {
     void* p = nullptr;
     check(rlhip_malloc(q.ctx(), &p, (size_t)(n > 0 ? n : 1) * sizeof(T)), "device_malloc");
     return (T*)p;
 }
-inline void device_free(void* p, Queue& q) { check(rlhip_free(q.ctx(), p), "device_free"); }
+inline void device_free(void* p, Queue& q = blas::default_queue()) { check(rlhip_free(q.ctx(), p), "device_free"); }
 template <typename T>
-void device_memset(T* p, int byte, int64_t n, Queue& q) { check(rlhip_memset(q.ctx(), p, byte, (size_t)n * sizeof(T)), "memset"); }
+void device_memset(T* p, int byte, int64_t n, Queue& q = blas::default_queue()) { check(rlhip_memset(q.ctx(), p, byte, (size_t)n * sizeof(T)), "memset"); }
 template <typename T>
-void device_copy_vector(int64_t n, T const* src, T* dst, Queue& q) {
+void device_copy_vector(int64_t n, T const* src, T* dst, Queue& q = blas::default_queue()) {
     check(rlhip_memcpy_d2d(q.ctx(), dst, src, (size_t)n * sizeof(T)), "device_copy_vector");
 }
 template <typename T>
-void copy_to_host(int64_t n, T const* dev, T* host, Queue& q) { check(rlhip_memcpy_d2h(q.ctx(), host, dev, (size_t)n * sizeof(T)), "d2h"); }
+void copy_to_host(int64_t n, T const* dev, T* host, Queue& q = blas::default_queue()) { check(rlhip_memcpy_d2h(q.ctx(), host, dev, (size_t)n * sizeof(T)), "d2h"); }
 template <typename T>
-void copy_to_device(int64_t n, T const* host, T* dev, Queue& q) { check(rlhip_memcpy_h2d(q.ctx(), dev, host, (size_t)n * sizeof(T)), "h2d"); }
+void copy_to_device(int64_t n, T const* host, T* dev, Queue& q = blas::default_queue()) { check(rlhip_memcpy_h2d(q.ctx(), dev, host, (size_t)n * sizeof(T)), "h2d"); }
+
+// blas::copy(n, x, incx, y, incy) for contiguous vectors (test/comps/test_qb.cc:83-85,144)
+template <typename T>
+void copy(int64_t n, T const* x, int64_t incx, T* y, int64_t incy, Queue& q = default_queue()) {
+    if (incx != 1 || incy != 1) throw Error("blas::copy: unit strides only");
+    device_copy_vector(n, x, y, q);
+}
 
 // RAII: declare whether row-reductions issued inside the scope run over the sharded dimension
 class RowsSharded {
@@ -120,7 +136,7 @@ public:
 
 // ---- level 3 (ColMajor only, as on the whole reference path)
 inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, double alpha, double const* A, int64_t lda,
-                 double const* B, int64_t ldb, double beta, double* C, int64_t ldc, Queue& q) {
+                 double const* B, int64_t ldb, double beta, double* C, int64_t ldc, Queue& q = blas::default_queue()) {
     auto& nr = q.norm_req;
     if (nr.ptr == (const void*)A && !nr.done && nr.ld == lda &&
         ((ta == Op::NoTrans && nr.rows == m && nr.cols == k) || (ta != Op::NoTrans && nr.rows == k && nr.cols == m))) {
@@ -134,31 +150,31 @@ inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, double a
     check(rlhip_gemm_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc), "gemm");
 }
 inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, float alpha, float const* A, int64_t lda,
-                 float const* B, int64_t ldb, float beta, float* C, int64_t ldc, Queue& q) {
+                 float const* B, int64_t ldb, float beta, float* C, int64_t ldc, Queue& q = blas::default_queue()) {
     check(rlhip_gemm_f32(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc), "gemm");
 }
 inline void syrk(Layout, Uplo u, Op t, int64_t n, int64_t k, double alpha, double const* A, int64_t lda, double beta,
-                 double* C, int64_t ldc, Queue& q) {
+                 double* C, int64_t ldc, Queue& q = blas::default_queue()) {
     check(rlhip_syrk_f64(q.ctx(), (char)u, (char)t, n, k, alpha, A, lda, beta, C, ldc), "syrk");
 }
 inline void syrk(Layout, Uplo u, Op t, int64_t n, int64_t k, float alpha, float const* A, int64_t lda, float beta,
-                 float* C, int64_t ldc, Queue& q) {
+                 float* C, int64_t ldc, Queue& q = blas::default_queue()) {
     check(rlhip_syrk_f32(q.ctx(), (char)u, (char)t, n, k, alpha, A, lda, beta, C, ldc), "syrk");
 }
 inline void trsm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
-                 double* B, int64_t ldb, Queue& q) {
+                 double* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trsm_f64(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trsm");
 }
 inline void trsm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda,
-                 float* B, int64_t ldb, Queue& q) {
+                 float* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trsm_f32(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trsm");
 }
 inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
-                 double* B, int64_t ldb, Queue& q) {
+                 double* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trmm_f64(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trmm");
 }
 inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda,
-                 float* B, int64_t ldb, Queue& q) {
+                 float* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trmm_f32(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trmm");
 }
 

@@ -41,16 +41,26 @@ class BQRRP : public BQRRPalg<T, RNG> {
 public:
     using Subroutines = BQRRPSubroutines;
 
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    BQRRP(bool time_subroutines, int64_t b_sz) : BQRRP(blas::default_queue(), time_subroutines, b_sz) {}                                 // rl_bqrrp.hh:66-68
     BQRRP(blas::Queue& queue, bool time_subroutines, int64_t b_sz) : q(queue) {
         randlapack_require(b_sz > 0) << "BQRRP block size b_sz=" << b_sz << " must be > 0";
         timing = time_subroutines;
         tol = std::numeric_limits<T>::epsilon();
         block_size = b_sz;
         internal_nb = b_sz;
-        qrcp_wide = Subroutines::QRCPWide::luqr;       // the reference's default (rl_bqrrp.hh:74) and the faster one here
-        qr_tall = Subroutines::QRTall::cholqr;         // reference CPU default: geqrf (:75); cholqr is the BLAS-3 panel on the device
-        apply_trans_q = Subroutines::ApplyTransQ::gemqrt;
+        qrcp_wide = Subroutines::QRCPWide::luqr;       // the reference's defaults (rl_bqrrp.hh:74-76): a default-constructed object
+        qr_tall = Subroutines::QRTall::geqrf;          // takes the same numerical path as the reference's
+        apply_trans_q = Subroutines::ApplyTransQ::ormqr;
         rank = 0;
+    }
+    /// Named preset: the fastest subroutine triple on the device -- LU-QR pivoting, Cholesky-QR panels (BLAS-3: syrk / potrf / trsm +
+    /// Householder reconstruction) and the compact-WY apply that reuses the panel's T factor.  The reference's BQRRP_GPU runs the
+    /// same Cholesky-QR panels (rl_bqrrp_gpu.hh:615-667); benchmarks and the row-sharded call use this preset.
+    void use_fast_subroutines() {
+        qrcp_wide = Subroutines::QRCPWide::luqr;
+        qr_tall = Subroutines::QRTall::cholqr;
+        apply_trans_q = Subroutines::ApplyTransQ::gemqrt;
     }
 
     /// A (m x n, lda), tau (min(m,n)), J (n, int64): DEVICE buffers.  Returns 0.  `rank` as in the reference (an upper
@@ -447,6 +457,8 @@ private:
 template <typename T, typename RNG = RandBLAS::DefaultRNG>
 class BQRRP_GPU {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    BQRRP_GPU(bool time_subroutines, int64_t b_sz) : BQRRP_GPU(blas::default_queue(), time_subroutines, b_sz) {}                         // rl_bqrrp_gpu.hh:63-66
     BQRRP_GPU(blas::Queue& queue, bool time_subroutines, int64_t b_sz) : impl(queue, time_subroutines, b_sz), rank(0), block_size(b_sz) {
         impl.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;                                        // LU-QR only (:354-399)
         impl.qr_tall = BQRRPSubroutines::QRTall::cholqr;

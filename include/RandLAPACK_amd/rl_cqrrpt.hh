@@ -32,6 +32,8 @@ class CQRRPT : public CQRRPTalg<T, RNG> {
 public:
     using Subroutines = CQRRPTSubroutines;
 
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    CQRRPT(bool time_subroutines, T ep) : CQRRPT(blas::default_queue(), time_subroutines, ep) {}                                         // rl_cqrrpt.hh:52-55
     CQRRPT(blas::Queue& queue, bool time_subroutines, T ep) : q(queue) {
         timing = time_subroutines;
         eps = ep;
@@ -217,6 +219,8 @@ public:
 template <typename T, typename RNG = RandBLAS::DefaultRNG>
 class CQRRPT_GPU {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    CQRRPT_GPU(bool verb, bool time_subroutines, T ep) : CQRRPT_GPU(blas::default_queue(), verb, time_subroutines, ep) {}                 // rl_cqrrpt_gpu.hh:56-60
     CQRRPT_GPU(blas::Queue& queue, bool verb, bool time_subroutines, T ep) : impl(queue, time_subroutines, ep), q(queue), rank(0) { (void)verb; }
     int call(int64_t m, int64_t n, T* A_host, int64_t lda, T* R_host, int64_t ldr, int64_t* J_host, T d_factor, RandBLAS::RNGState<RNG>& state) {
         randlapack_require(lda == m && ldr == n) << "CQRRPT_GPU: packed host matrices expected (lda = m, ldr = n)";

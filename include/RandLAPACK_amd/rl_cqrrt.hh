@@ -24,6 +24,8 @@ public:
 template <typename T, typename RNG = RandBLAS::DefaultRNG>
 class CQRRT : public CQRRTalg<T, RNG> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    CQRRT(bool time_subroutines, T ep) : CQRRT(blas::default_queue(), time_subroutines, ep) {}
     CQRRT(blas::Queue& queue, bool time_subroutines, T ep) : q(queue) {                                          // :62-72
         timing = time_subroutines;
         eps = ep;

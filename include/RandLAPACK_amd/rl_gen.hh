@@ -44,16 +44,16 @@ struct mat_gen_info {                                                           
 };
 
 namespace detail {
-inline void scal_cols(int64_t m, int64_t n, double* A, int64_t lda, const double* s, blas::Queue& q) { blas::check(rlhip_scal_cols_f64(q.ctx(), m, n, A, lda, s), "scal_cols"); }
-inline void scal_cols(int64_t m, int64_t n, float* A, int64_t lda, const float* s, blas::Queue& q) { blas::check(rlhip_scal_cols_f32(q.ctx(), m, n, A, lda, s), "scal_cols"); }
-inline void scal_rows_idx(int64_t cnt, const int64_t* idx, int64_t n, double* A, int64_t lda, double a, blas::Queue& q) { blas::check(rlhip_scal_rows_idx_f64(q.ctx(), cnt, idx, n, A, lda, a), "scal_rows_idx"); }
-inline void scal_rows_idx(int64_t cnt, const int64_t* idx, int64_t n, float* A, int64_t lda, float a, blas::Queue& q) { blas::check(rlhip_scal_rows_idx_f32(q.ctx(), cnt, idx, n, A, lda, a), "scal_rows_idx"); }
-inline void kahan(int64_t m, int64_t n, double* A, int64_t lda, double th, double p, blas::Queue& q) { blas::check(rlhip_gen_kahan_f64(q.ctx(), m, n, A, lda, th, p), "gen_kahan"); }
-inline void kahan(int64_t m, int64_t n, float* A, int64_t lda, float th, float p, blas::Queue& q) { blas::check(rlhip_gen_kahan_f32(q.ctx(), m, n, A, lda, th, p), "gen_kahan"); }
+inline void scal_cols(int64_t m, int64_t n, double* A, int64_t lda, const double* s, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_cols_f64(q.ctx(), m, n, A, lda, s), "scal_cols"); }
+inline void scal_cols(int64_t m, int64_t n, float* A, int64_t lda, const float* s, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_cols_f32(q.ctx(), m, n, A, lda, s), "scal_cols"); }
+inline void scal_rows_idx(int64_t cnt, const int64_t* idx, int64_t n, double* A, int64_t lda, double a, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_rows_idx_f64(q.ctx(), cnt, idx, n, A, lda, a), "scal_rows_idx"); }
+inline void scal_rows_idx(int64_t cnt, const int64_t* idx, int64_t n, float* A, int64_t lda, float a, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_rows_idx_f32(q.ctx(), cnt, idx, n, A, lda, a), "scal_rows_idx"); }
+inline void kahan(int64_t m, int64_t n, double* A, int64_t lda, double th, double p, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_gen_kahan_f64(q.ctx(), m, n, A, lda, th, p), "gen_kahan"); }
+inline void kahan(int64_t m, int64_t n, float* A, int64_t lda, float th, float p, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_gen_kahan_f32(q.ctx(), m, n, A, lda, th, p), "gen_kahan"); }
 
 /// Q (rows x k, DEVICE, ld rows) <- orthonormal basis of a Gaussian block: fill_dense, geqrf, ungqr; threads the state
 template <typename T, typename RNG>
-void gaussian_orthonormal(int64_t rows, int64_t k, T* Q, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gaussian_orthonormal(int64_t rows, int64_t k, T* Q, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     RandBLAS::DenseDist D(rows, k);
     state = RandBLAS::fill_dense(D, Q, state, q);
     blas::Scratch ws(q);
@@ -65,7 +65,7 @@ void gaussian_orthonormal(int64_t rows, int64_t k, T* Q, RandBLAS::RNGState<RNG>
 
 /// A (m x n, ld m, DEVICE) = U diag(S) V^T with U (m x k), V (n x k) orthonormalised Gaussians; S: k HOST singular values.   (:62-101)
 template <typename T, typename RNG>
-void gen_singvec(int64_t m, int64_t n, T* A, int64_t k, const T* S, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_singvec(int64_t m, int64_t n, T* A, int64_t k, const T* S, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     if (k > std::min(m, n)) throw std::runtime_error("gen_singvec: rank exceeds min(m, n)");
     if (m == 0 || n == 0) return;
     if (k == 0) { lapack::laset(MatrixType::General, m, n, (T)0, (T)0, A, m, q); return; }
@@ -125,7 +125,7 @@ std::vector<T> gen_bad_cholqr_singvals(int64_t k, int64_t n, T cond) {          
 namespace detail {
 /// the shared tail of gen_{poly,exp,step,bad_cholqr}_mat: diagonal k x k matrix in A (ld k), or the full factored form
 template <typename T, typename RNG>
-void from_singvals(int64_t m, int64_t n, T* A, int64_t k, std::vector<T> const& s, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void from_singvals(int64_t m, int64_t n, T* A, int64_t k, std::vector<T> const& s, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     if (diagon) {                                                                                                             // :155-156
         blas::Scratch ws(q);
         T* s_dev = ws.alloc<T>(k);
@@ -138,25 +138,25 @@ void from_singvals(int64_t m, int64_t n, T* A, int64_t k, std::vector<T> const& 
 }  // namespace detail
 
 template <typename T, typename RNG>
-void gen_poly_mat(int64_t& m, int64_t& n, T* A, int64_t k, T frac_spectrum_one, T cond, T p, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_poly_mat(int64_t& m, int64_t& n, T* A, int64_t k, T frac_spectrum_one, T cond, T p, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     detail::from_singvals(m, n, A, k, gen_poly_singvals(k, frac_spectrum_one, cond, p), diagon, state, q);                    // :134-160
 }
 template <typename T, typename RNG>
-void gen_exp_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_exp_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     detail::from_singvals(m, n, A, k, gen_exp_singvals(k, cond), diagon, state, q);                                           // :184-207
 }
 template <typename T, typename RNG>
-void gen_step_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_step_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     detail::from_singvals(m, n, A, k, gen_step_singvals(k, cond), diagon, state, q);                                          // :229-252
 }
 template <typename T, typename RNG>
-void gen_bad_cholqr_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_bad_cholqr_mat(int64_t& m, int64_t& n, T* A, int64_t k, T cond, bool diagon, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     detail::from_singvals(m, n, A, k, gen_bad_cholqr_singvals(k, n, cond), diagon, state, q);                                 // :383-405
 }
 
 /// Stacked copies of an n x n orthogonal V with floor(n/2) sampled rows (without replacement) scaled by spike_scale.         (:257-305)
 template <typename T, typename RNG>
-void gen_spiked_mat(int64_t& m, int64_t& n, T* A, T spike_scale, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_spiked_mat(int64_t& m, int64_t& n, T* A, T spike_scale, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     const int64_t num_rows_sampled = n / 2;
     std::vector<int64_t> rows((size_t)std::max<int64_t>(num_rows_sampled, 1));
     state = RandBLAS::repeated_fisher_yates(num_rows_sampled, m, 1, rows.data(), state, q);
@@ -177,7 +177,7 @@ void gen_spiked_mat(int64_t& m, int64_t& n, T* A, T spike_scale, RandBLAS::RNGSt
 
 /// A = U V: U = orth(Gaussian with its first 10 rows scaled by sigma), V = triu(orth(Gaussian)) with V_ii *= 10e-3 for i >= 11   (:310-365)
 template <typename T, typename RNG>
-void gen_oleg_adversarial_mat(int64_t& m, int64_t& n, T* A, T sigma, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void gen_oleg_adversarial_mat(int64_t& m, int64_t& n, T* A, T sigma, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     const T scaling_factor_V = (T)10e-3;
     blas::Scratch ws(q);
     T* U = ws.alloc<T>(m * n);
@@ -209,11 +209,11 @@ void gen_oleg_adversarial_mat(int64_t& m, int64_t& n, T* A, T sigma, RandBLAS::R
 }
 
 template <typename T>
-void gen_kahan_mat(int64_t m, int64_t n, T* A, T theta, T perturb, blas::Queue& q) { detail::kahan(m, n, A, m, theta, perturb, q); }   // :408-434
+void gen_kahan_mat(int64_t m, int64_t n, T* A, T theta, T perturb, blas::Queue& q = blas::default_queue()) { detail::kahan(m, n, A, m, theta, perturb, q); }   // :408-434
 
 /// Numerical rank from the singular values (misc/rl_util.hh:426-448; the reference's "return i - 1" on the first small value is kept)
 template <typename T>
-int64_t rank_check(int64_t m, int64_t n, const T* A, blas::Queue& q) {
+int64_t rank_check(int64_t m, int64_t n, const T* A, blas::Queue& q = blas::default_queue()) {
     blas::Scratch ws(q);
     T* cpy = ws.alloc<T>(m * n);
     T* s = ws.alloc<T>(n);
@@ -229,7 +229,7 @@ int64_t rank_check(int64_t m, int64_t n, const T* A, blas::Queue& q) {
 
 /// Dispatcher (:712-772).  A: DEVICE buffer of info.rows x info.cols (info.rank x info.rank when info.diag), ld = rows.
 template <typename T, typename RNG>
-void mat_gen(mat_gen_info<T>& info, T* A, RandBLAS::RNGState<RNG>& state, blas::Queue& q) {
+void mat_gen(mat_gen_info<T>& info, T* A, RandBLAS::RNGState<RNG>& state, blas::Queue& q = blas::default_queue()) {
     switch (info.m_type) {
         case polynomial: gen_poly_mat(info.rows, info.cols, A, info.rank, info.frac_spectrum_one, info.cond_num, info.exponent, info.diag, state, q); break;
         case exponential: gen_exp_mat(info.rows, info.cols, A, info.rank, info.cond_num, info.diag, state, q); break;

@@ -174,4 +174,11 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
     return 0;
 }
 
+/// The reference's exact signature (rl_hqrrp.hh:811-815: no queue, `timing` last): the process-wide default queue.
+template <typename T, typename RNG>
+int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff_jpvt, T* buff_tau, int64_t nb_alg, int64_t pp,
+              int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, T** timing = nullptr) {
+    return hqrrp<T, RNG>(m_A, n_A, buff_A, ldim_A, buff_jpvt, buff_tau, nb_alg, pp, panel_pivoting, qr_type, state, blas::default_queue(), (T*)nullptr, timing);
+}
+
 }  // namespace RandLAPACK

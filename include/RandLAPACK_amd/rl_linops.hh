@@ -24,35 +24,35 @@ namespace RandLAPACK::linops {
 
 namespace detail {
 inline void csr_spmm(char layout, int64_t m, int64_t n, int64_t k, double alpha, const int64_t* rp, const int64_t* ci, const double* v,
-                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, blas::Queue& q) {
+                     const double* B, int64_t ldb, double beta, double* C, int64_t ldc, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_spmm_f64(q.ctx(), layout, m, n, k, alpha, rp, ci, v, B, ldb, beta, C, ldc), "csr_spmm");
 }
 inline void csr_spmm(char layout, int64_t m, int64_t n, int64_t k, float alpha, const int64_t* rp, const int64_t* ci, const float* v,
-                     const float* B, int64_t ldb, float beta, float* C, int64_t ldc, blas::Queue& q) {
+                     const float* B, int64_t ldb, float beta, float* C, int64_t ldc, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_spmm_f32(q.ctx(), layout, m, n, k, alpha, rp, ci, v, B, ldb, beta, C, ldc), "csr_spmm");
 }
 inline void csr_transpose(int64_t m, int64_t k, const int64_t* rp, const int64_t* ci, const double* v, int64_t* rpt, int64_t* cit, double* vt,
-                          blas::Queue& q) {
+                          blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_transpose_f64(q.ctx(), m, k, rp, ci, v, rpt, cit, vt), "csr_transpose");
 }
 inline void csr_transpose(int64_t m, int64_t k, const int64_t* rp, const int64_t* ci, const float* v, int64_t* rpt, int64_t* cit, float* vt,
-                          blas::Queue& q) {
+                          blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_transpose_f32(q.ctx(), m, k, rp, ci, v, rpt, cit, vt), "csr_transpose");
 }
 inline void csr_densify_cols(int64_t m, const int64_t* rpt, const int64_t* cit, const double* vt, int64_t c0, int64_t b, double* out, int64_t ldo,
-                             blas::Queue& q) {
+                             blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_densify_cols_f64(q.ctx(), m, rpt, cit, vt, c0, b, out, ldo), "csr_densify_cols");
 }
 inline void csr_densify_cols(int64_t m, const int64_t* rpt, const int64_t* cit, const float* vt, int64_t c0, int64_t b, float* out, int64_t ldo,
-                             blas::Queue& q) {
+                             blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_csr_densify_cols_f32(q.ctx(), m, rpt, cit, vt, c0, b, out, ldo), "csr_densify_cols");
 }
 inline void saso_apply_csr(rlhip_saso* S, int64_t n, double alpha, const int64_t* rpt, const int64_t* cit, const double* vt, double beta, double* C,
-                           int64_t ldc, int64_t row0, blas::Queue& q) {
+                           int64_t ldc, int64_t row0, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_saso_apply_csr_f64(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc, row0), "saso_apply_csr");
 }
 inline void saso_apply_csr(rlhip_saso* S, int64_t n, float alpha, const int64_t* rpt, const int64_t* cit, const float* vt, float beta, float* C,
-                           int64_t ldc, int64_t row0, blas::Queue& q) {
+                           int64_t ldc, int64_t row0, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_saso_apply_csr_f32(q.ctx(), S, n, alpha, rpt, cit, vt, beta, C, ldc, row0), "saso_apply_csr");
 }
 }  // namespace detail

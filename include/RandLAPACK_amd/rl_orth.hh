@@ -22,6 +22,8 @@ public:
 template <typename T>
 class CholQRQ : public Stabilization<T> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    CholQRQ(bool c_check, bool verb) : CholQRQ(blas::default_queue(), c_check, verb) {}                                                   // rl_orth.hh:35-38
     CholQRQ(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
         cond_check = c_check;
         verbose = verb;
@@ -57,6 +59,8 @@ public:
 template <typename T>
 class HQRQ : public Stabilization<T> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    HQRQ(bool c_check, bool verb) : HQRQ(blas::default_queue(), c_check, verb) {}                                                   // rl_orth.hh:110-113
     HQRQ(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
         cond_check = c_check;
         verbose = verb;
@@ -79,6 +83,8 @@ public:
 template <typename T>
 class PLUL : public Stabilization<T> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    PLUL(bool c_check, bool verb) : PLUL(blas::default_queue(), c_check, verb) {}                                                   // rl_orth.hh:176-179
     PLUL(blas::Queue& queue, bool c_check, bool verb) : q(queue) {
         cond_check = c_check;
         verbose = verb;

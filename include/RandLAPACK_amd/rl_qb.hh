@@ -18,6 +18,8 @@ public:
 template <typename T, typename RNG>
 class QB : public QBalg<T, RNG> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    QB(RangeFinder<T, RNG>& rf_obj, Stabilization<T>& orth_obj, bool verb, bool orth) : QB(blas::default_queue(), rf_obj, orth_obj, verb, orth) {}   // rl_qb.hh:58-63
     QB(blas::Queue& queue, RangeFinder<T, RNG>& rf_obj, Stabilization<T>& orth_obj, bool verb, bool orth)
         : q(queue), rf(rf_obj), orth(orth_obj) {
         verbose = verb;

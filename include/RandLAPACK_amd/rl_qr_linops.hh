@@ -35,10 +35,10 @@ struct prefers_row_major : std::false_type {};
 template <typename GLO>
 struct prefers_row_major<GLO, std::void_t<decltype(GLO::prefers_row_major)>> : std::bool_constant<GLO::prefers_row_major> {};
 
-inline void transpose(int64_t m, int64_t n, const double* A, int64_t lda, double* AT, int64_t ldat, blas::Queue& q) {
+inline void transpose(int64_t m, int64_t n, const double* A, int64_t lda, double* AT, int64_t ldat, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_transpose_f64(q.ctx(), m, n, A, lda, AT, ldat, 0), "transpose");
 }
-inline void transpose(int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat, blas::Queue& q) {
+inline void transpose(int64_t m, int64_t n, const float* A, int64_t lda, float* AT, int64_t ldat, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_transpose_f32(q.ctx(), m, n, A, lda, AT, ldat, 0), "transpose");
 }
 
@@ -77,7 +77,7 @@ void gram_through_operator(GLO& A, int64_t m, int64_t n, int64_t b_eff, const T*
 
 /// zero the strictly lower triangle, then potrf(Upper); returns the LAPACK info
 template <typename T>
-int64_t chol_upper_clean(int64_t n, T* G, int64_t ldg, blas::Queue& q) {
+int64_t chol_upper_clean(int64_t n, T* G, int64_t ldg, blas::Queue& q = blas::default_queue()) {
     if (n > 1) lapack::laset(MatrixType::Lower, n - 1, n - 1, (T)0, (T)0, G + 1, ldg, q);
     return lapack::potrf(Uplo::Upper, n, G, ldg, q);
 }
@@ -170,7 +170,7 @@ protected:
         if (!ok) qh.release();
         Q = qh.Q; Q_rows = qh.Q_rows; Q_cols = qh.Q_cols;
     }
-    void keep_factor(std::vector<T>& dst, int64_t n, const T* G_dev, blas::Queue& q) {
+    void keep_factor(std::vector<T>& dst, int64_t n, const T* G_dev, blas::Queue& q = blas::default_queue()) {
         blas::Scratch ws(q);
         T* U = ws.alloc<T>(n * n);
         lapack::laset(MatrixType::General, n, n, (T)0, (T)0, U, n, q);
@@ -179,7 +179,7 @@ protected:
         blas::copy_to_host(n * n, U, dst.data(), q);
     }
     /// G += 11 eps n trace(G) I  -- the shift of rl_scholqr3_linops.hh:243-251 (||A||_F^2 read off the Gram diagonal)
-    void shift_gram(int64_t n, T* G, blas::Queue& q) {
+    void shift_gram(int64_t n, T* G, blas::Queue& q = blas::default_queue()) {
         std::vector<T> dg((size_t)n);
         lapack::get_diag(n, G, n, dg.data(), q);
         T norm_A_sq = 0;
@@ -187,7 +187,7 @@ protected:
         lapack::add_diag(n, (T)11 * std::numeric_limits<T>::epsilon() * (T)n * norm_A_sq, G, n, q);
     }
     /// R <- G * R on the upper triangles (rl_scholqr3_linops.hh:349-354)
-    void accumulate_R(int64_t n, const T* G, T* R, int64_t ldr, T* R_temp, blas::Queue& q) {
+    void accumulate_R(int64_t n, const T* G, T* R, int64_t ldr, T* R_temp, blas::Queue& q = blas::default_queue()) {
         lapack::lacpy(MatrixType::Upper, n, n, R, ldr, R_temp, n, q);
         blas::trmm(Layout::ColMajor, Side::Left, Uplo::Upper, Op::NoTrans, Diag::NonUnit, n, n, (T)1, G, n, R_temp, n, q);
         lapack::lacpy(MatrixType::Upper, n, n, R_temp, n, R, ldr, q);

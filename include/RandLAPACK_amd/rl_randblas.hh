@@ -39,14 +39,14 @@ struct DenseDist {
 
 // Fills the n_rows x n_cols column-major DEVICE buffer (ld = n_rows) and returns the advanced state.
 template <typename RNG>
-RNGState<RNG> fill_dense(DenseDist const& D, double* buf, RNGState<RNG> const& st, blas::Queue& q) {
+RNGState<RNG> fill_dense(DenseDist const& D, double* buf, RNGState<RNG> const& st, blas::Queue& q = blas::default_queue()) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_f64(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, buf,
                                      st.counter.data(), st.key.data(), next.counter.data()), "fill_dense");
     return next;
 }
 template <typename RNG>
-RNGState<RNG> fill_dense(DenseDist const& D, float* buf, RNGState<RNG> const& st, blas::Queue& q) {
+RNGState<RNG> fill_dense(DenseDist const& D, float* buf, RNGState<RNG> const& st, blas::Queue& q = blas::default_queue()) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_f32(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, buf,
                                      st.counter.data(), st.key.data(), next.counter.data()), "fill_dense");
@@ -56,14 +56,14 @@ RNGState<RNG> fill_dense(DenseDist const& D, float* buf, RNGState<RNG> const& st
 // Rows [row0, row0 + loc_rows) of the D.n_rows x D.n_cols operator fill_dense(D, ...) produces, into buf (ld = loc_rows).
 // The returned state is the one the full fill returns.
 template <typename RNG>
-RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, double* buf, RNGState<RNG> const& st, blas::Queue& q) {
+RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, double* buf, RNGState<RNG> const& st, blas::Queue& q = blas::default_queue()) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_rows_f64(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
                                           loc_rows > 0 ? loc_rows : 1, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
     return next;
 }
 template <typename RNG>
-RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, float* buf, RNGState<RNG> const& st, blas::Queue& q) {
+RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows, float* buf, RNGState<RNG> const& st, blas::Queue& q = blas::default_queue()) {
     RNGState<RNG> next = st;
     blas::check(rlhip_fill_dense_rows_f32(q.ctx(), D.family == ScalarDist::Gaussian ? 0 : 1, D.n_rows, D.n_cols, row0, loc_rows, buf,
                                           loc_rows > 0 ? loc_rows : 1, st.counter.data(), st.key.data(), next.counter.data()), "fill_dense_rows");
@@ -74,7 +74,7 @@ RNGState<RNG> fill_dense_rows(DenseDist const& D, int64_t row0, int64_t loc_rows
 // idxs: HOST buffer of k * r.  Own stream: repetition i draws its k swap targets from Philox words ctr + i*ceil(k/4) ...;
 // swap j picks uniformly from [j, n) by 32x32 -> 64-bit multiply-shift.  Returns the advanced state.
 template <typename RNG>
-RNGState<RNG> repeated_fisher_yates(int64_t k, int64_t n, int64_t r, int64_t* idxs, RNGState<RNG> const& st, blas::Queue& q) {
+RNGState<RNG> repeated_fisher_yates(int64_t k, int64_t n, int64_t r, int64_t* idxs, RNGState<RNG> const& st, blas::Queue& q = blas::default_queue()) {
     if (k > n) throw blas::Error("repeated_fisher_yates: k > n");
     RNGState<RNG> next = st;
     if (k <= 0 || r <= 0) return next;
@@ -158,7 +158,7 @@ struct SparseSkOp {
 template <typename RNG>
 void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t n, int64_t m, double alpha,
                     SparseSkOp<double, RNG>& S, int64_t ro, int64_t co, double const* A, int64_t lda, double beta, double* B,
-                    int64_t ldb, blas::Queue& q) {
+                    int64_t ldb, blas::Queue& q = blas::default_queue()) {
     if (opS != blas::Op::NoTrans || opA != blas::Op::NoTrans || ro != 0 || co != 0 || d != S.dist.n_rows || m != S.dist.n_cols)
         throw blas::Error("sketch_general: only the plain left sketch S*A is on the path");
     blas::check(rlhip_saso_apply_f64(q.ctx(), S.handle, n, alpha, A, lda, beta, B, ldb), "saso_apply");
@@ -166,7 +166,7 @@ void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t
 template <typename RNG>
 void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t n, int64_t m, float alpha,
                     SparseSkOp<float, RNG>& S, int64_t ro, int64_t co, float const* A, int64_t lda, float beta, float* B,
-                    int64_t ldb, blas::Queue& q) {
+                    int64_t ldb, blas::Queue& q = blas::default_queue()) {
     if (opS != blas::Op::NoTrans || opA != blas::Op::NoTrans || ro != 0 || co != 0 || d != S.dist.n_rows || m != S.dist.n_cols)
         throw blas::Error("sketch_general: only the plain left sketch S*A is on the path");
     blas::check(rlhip_saso_apply_f32(q.ctx(), S.handle, n, alpha, A, lda, beta, B, ldb), "saso_apply");
@@ -175,12 +175,12 @@ void sketch_general(blas::Layout, blas::Op opS, blas::Op opA, int64_t d, int64_t
 // one row shard's contribution to S * A: B = alpha * S[:, row0 : row0 + mloc] * A_loc + beta * B  (S built for the global row count)
 template <typename RNG>
 void sketch_rows(SparseSkOp<double, RNG>& S, int64_t n, double alpha, double const* A_loc, int64_t lda, int64_t row0, int64_t mloc,
-                 double beta, double* B, int64_t ldb, blas::Queue& q) {
+                 double beta, double* B, int64_t ldb, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_saso_apply_rows_f64(q.ctx(), S.handle, n, alpha, A_loc, lda, row0, mloc, beta, B, ldb), "saso_apply_rows");
 }
 template <typename RNG>
 void sketch_rows(SparseSkOp<float, RNG>& S, int64_t n, float alpha, float const* A_loc, int64_t lda, int64_t row0, int64_t mloc,
-                 float beta, float* B, int64_t ldb, blas::Queue& q) {
+                 float beta, float* B, int64_t ldb, blas::Queue& q = blas::default_queue()) {
     blas::check(rlhip_saso_apply_rows_f32(q.ctx(), S.handle, n, alpha, A_loc, lda, row0, mloc, beta, B, ldb), "saso_apply_rows");
 }
 

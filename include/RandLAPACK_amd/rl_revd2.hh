@@ -72,10 +72,10 @@ private:
 }  // namespace linops
 
 namespace detail {
-inline void axpby(int64_t n, double a, const double* x, double b, double* y, blas::Queue& q) { blas::check(rlhip_axpby_f64(q.ctx(), n, a, x, b, y), "axpby"); }
-inline void axpby(int64_t n, float a, const float* x, float b, float* y, blas::Queue& q) { blas::check(rlhip_axpby_f32(q.ctx(), n, a, x, b, y), "axpby"); }
-inline void scal_cols_dev(int64_t m, int64_t n, double* A, int64_t lda, const double* s, blas::Queue& q) { blas::check(rlhip_scal_cols_f64(q.ctx(), m, n, A, lda, s), "scal_cols"); }
-inline void scal_cols_dev(int64_t m, int64_t n, float* A, int64_t lda, const float* s, blas::Queue& q) { blas::check(rlhip_scal_cols_f32(q.ctx(), m, n, A, lda, s), "scal_cols"); }
+inline void axpby(int64_t n, double a, const double* x, double b, double* y, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_axpby_f64(q.ctx(), n, a, x, b, y), "axpby"); }
+inline void axpby(int64_t n, float a, const float* x, float b, float* y, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_axpby_f32(q.ctx(), n, a, x, b, y), "axpby"); }
+inline void scal_cols_dev(int64_t m, int64_t n, double* A, int64_t lda, const double* s, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_cols_f64(q.ctx(), m, n, A, lda, s), "scal_cols"); }
+inline void scal_cols_dev(int64_t m, int64_t n, float* A, int64_t lda, const float* s, blas::Queue& q = blas::default_queue()) { blas::check(rlhip_scal_cols_f32(q.ctx(), m, n, A, lda, s), "scal_cols"); }
 }  // namespace detail
 
 // ------------------------------------------------------------------------------------------------ SYPS
@@ -91,6 +91,8 @@ public:
     bool cond_check;
     std::vector<T> cond_nums;
 
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    SYPS(int64_t p, int64_t q_, bool verb, bool cond) : SYPS(blas::default_queue(), p, q_, verb, cond) {}
     SYPS(blas::Queue& queue, int64_t p, int64_t q_, bool verb, bool cond) : q(queue), passes_over_data(p), passes_per_stab(q_), verbose(verb), cond_check(cond) {}
 
     /// skop_buff (m x k, DEVICE; allocated here when null, caller frees) <- the power sketch; work_buff: m x k DEVICE scratch or null.
@@ -163,7 +165,7 @@ public:
 /// p steps of the power method on (A - V diag(eigvals) V^T): returns the Rayleigh-quotient estimate of its dominant eigenvalue.
 /// vector_buf: 4 m DEVICE entries, the first m holding the start vector; Mat_buf: m x k DEVICE scratch; eigvals: k DEVICE.   (:34-63)
 template <typename T, typename SLO>
-T power_error_est(SLO& A, int64_t k, int p, T* vector_buf, T* V, T* Mat_buf, const T* eigvals_dev, blas::Queue& q) {
+T power_error_est(SLO& A, int64_t k, int p, T* vector_buf, T* V, T* Mat_buf, const T* eigvals_dev, blas::Queue& q = blas::default_queue()) {
     const int64_t m = A.dim;
     T err = 0;
     blas::Scratch ws(q);

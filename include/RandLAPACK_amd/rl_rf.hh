@@ -15,6 +15,8 @@ public:
 template <typename T, typename RNG>
 class RF : public RangeFinder<T, RNG> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    RF(RowSketcher<T, RNG>& rs_obj, Stabilization<T>& orth_obj, bool verb, bool cond) : RF(blas::default_queue(), rs_obj, orth_obj, verb, cond) {}   // rl_rf.hh:45-50
     RF(blas::Queue& queue, RowSketcher<T, RNG>& rs_obj, Stabilization<T>& orth_obj, bool verb, bool cond)
         : q(queue), rs(rs_obj), orth(orth_obj) {
         verbose = verb;

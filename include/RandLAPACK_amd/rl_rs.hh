@@ -17,6 +17,8 @@ public:
 template <typename T, typename RNG>
 class RS : public RowSketcher<T, RNG> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    RS(Stabilization<T>& stab_obj, int64_t p, int64_t q_, bool verb, bool cond) : RS(blas::default_queue(), stab_obj, p, q_, verb, cond) {}           // rl_rs.hh:55-62
     RS(blas::Queue& queue, Stabilization<T>& stab_obj, int64_t p, int64_t q_, bool verb, bool cond)
         : q(queue), Stab_Obj(stab_obj) {
         verbose = verb;

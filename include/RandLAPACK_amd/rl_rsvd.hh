@@ -16,6 +16,8 @@ public:
 template <typename T, typename RNG>
 class RSVD : public RSVDalg<T, RNG> {
 public:
+    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
+    RSVD(QBalg<T, RNG>& qb_obj, int64_t b_sz) : RSVD(blas::default_queue(), qb_obj, b_sz) {}                                            // rl_rsvd.hh:49-52
     RSVD(blas::Queue& queue, QBalg<T, RNG>& qb_obj, int64_t b_sz) : q(queue), QB_Obj(qb_obj) { block_sz = b_sz; }
 
     /// A (m x n, device, not modified) ~= U diag(S) V^T with U m x k, S k, V n x k (V is NOT transposed).

@@ -13,7 +13,7 @@ namespace RandLAPACK::util {
 /// s_max / s_min of an m x n (m >= n) device matrix, inf if s_min == 0.      (rl_util.hh:403-424)
 /// The reference takes an SVD of a copy with gesdd(NoVec); here the copy goes through the device Jacobi SVD.
 template <typename T>
-T cond_num_check(int64_t m, int64_t n, T const* A, bool verbose, blas::Queue& q) {
+T cond_num_check(int64_t m, int64_t n, T const* A, bool verbose, blas::Queue& q = blas::default_queue()) {
     (void)verbose;
     if (q.reduce_over_rows())
         throw blas::Error("cond_num_check of a row-sharded matrix is not available (needs a distributed SVD)");
@@ -32,7 +32,7 @@ T cond_num_check(int64_t m, int64_t n, T const* A, bool verbose, blas::Queue& q)
 /// (float).                                                                    (rl_util.hh:468-496)
 /// As in the reference the Gram buffer's strictly lower triangle is left at zero.
 template <typename T>
-bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Queue& q) {
+bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Queue& q = blas::default_queue()) {
     (void)verbose;
     blas::Scratch ws(q);
     T* G = ws.alloc<T>(k * k);
@@ -52,31 +52,31 @@ bool orthogonality_check(int64_t m, int64_t k, T const* A, bool verbose, blas::Q
 /// k > n throws std::runtime_error like the reference.                               (rl_util.hh:151-164)
 /// util::eye (misc/rl_util.hh:60-70): A (m x n, ld m, DEVICE) <- identity pattern
 template <typename T>
-void eye(int64_t m, int64_t n, T* A, blas::Queue& q) { lapack::laset(MatrixType::General, m, n, (T)0, (T)1, A, m, q); }
+void eye(int64_t m, int64_t n, T* A, blas::Queue& q = blas::default_queue()) { lapack::laset(MatrixType::General, m, n, (T)0, (T)1, A, m, q); }
 
 /// util::diag (misc/rl_util.hh:84-96): overwrite the first k diagonal entries of S (m x n, ld m, DEVICE) with s (k, DEVICE)
 template <typename T>
-void diag(int64_t m, int64_t n, const T* s_vec, int64_t k, T* S, blas::Queue& q) {
+void diag(int64_t m, int64_t n, const T* s_vec, int64_t k, T* S, blas::Queue& q = blas::default_queue()) {
     if (k > std::min(m, n)) throw std::runtime_error("Invalid rank parameter.");
     if (k > 0) lapack::lacpy(MatrixType::General, 1, k, s_vec, 1, S, m + 1, q);     // a 1 x k matrix with ld 1 -> stride m + 1
 }
 
 /// util::get_L (misc/rl_util.hh:102-115): zero the strictly upper triangle of A (m x n, ld m), optionally set the diagonal to one
 template <typename T>
-void get_L(int64_t m, int64_t n, T* A, int overwrite_diagonal, blas::Queue& q) {
+void get_L(int64_t m, int64_t n, T* A, int overwrite_diagonal, blas::Queue& q = blas::default_queue()) {
     if (overwrite_diagonal) lapack::laset(MatrixType::Upper, m, n, (T)0, (T)1, A, m, q);
     else if (n > 1) lapack::laset(MatrixType::Upper, m, n - 1, (T)0, (T)0, A + m, m, q);
 }
 
 /// util::get_U (misc/rl_util.hh:119-131): zero the strictly lower triangle of A (m x n, lda)
 template <typename T>
-void get_U(int64_t m, int64_t n, T* A, int64_t lda, blas::Queue& q) {
+void get_U(int64_t m, int64_t n, T* A, int64_t lda, blas::Queue& q = blas::default_queue()) {
     if (m > 1) lapack::laset(MatrixType::Lower, m - 1, n, (T)0, (T)0, A + 1, lda, q);
 }
 
 /// util::diag_is_nonzero (misc/rl_util.hh:138-142) on a DEVICE matrix: exact comparison with zero, as the reference
 template <typename T>
-bool diag_is_nonzero(int64_t n, const T* R, int64_t ldr, blas::Queue& q) {
+bool diag_is_nonzero(int64_t n, const T* R, int64_t ldr, blas::Queue& q = blas::default_queue()) {
     std::vector<T> d((size_t)std::max<int64_t>(n, 1));
     lapack::get_diag(n, R, ldr, d.data(), q);
     for (int64_t i = 0; i < n; ++i)
@@ -87,20 +87,20 @@ bool diag_is_nonzero(int64_t n, const T* R, int64_t ldr, blas::Queue& q) {
 /// util::transposition (misc/rl_util.hh:315-334): AT (ld ldat) = A^T; copy_upper_triangle != 0 moves only the upper triangle of the
 /// leading n x n block (the reference ignores m in that mode).
 template <typename T>
-void transposition(int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat, int copy_upper_triangle, blas::Queue& q) {
+void transposition(int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat, int copy_upper_triangle, blas::Queue& q = blas::default_queue()) {
     const int64_t mm = copy_upper_triangle ? n : m;
     if constexpr (sizeof(T) == 8) blas::check(rlhip_transpose_f64(q.ctx(), mm, n, (const double*)A, lda, (double*)AT, ldat, copy_upper_triangle), "transposition");
     else blas::check(rlhip_transpose_f32(q.ctx(), mm, n, (const float*)A, lda, (float*)AT, ldat, copy_upper_triangle), "transposition");
 }
 
 template <typename T>
-void col_swap(int64_t m, int64_t n, int64_t k, T* A, int64_t lda, int64_t const* idx, blas::Queue& q) {
+void col_swap(int64_t m, int64_t n, int64_t k, T* A, int64_t lda, int64_t const* idx, blas::Queue& q = blas::default_queue()) {
     if (k > n) throw std::runtime_error("Invalid rank parameter.");
     if constexpr (sizeof(T) == 8) blas::check(rlhip_col_swap_f64(q.ctx(), m, n, k, (double*)A, lda, idx), "col_swap");
     else blas::check(rlhip_col_swap_f32(q.ctx(), m, n, k, (float*)A, lda, idx), "col_swap");
 }
 /// Integer-vector overload: the first k entries of A are permuted by the permutation idx of 1..k (rl_util.hh:174-198)
-inline void col_swap(int64_t n, int64_t k, int64_t* A, int64_t const* idx, blas::Queue& q) {
+inline void col_swap(int64_t n, int64_t k, int64_t* A, int64_t const* idx, blas::Queue& q = blas::default_queue()) {
     if (k > n) throw std::runtime_error("Incorrect rank parameter.");
     blas::check(rlhip_col_swap_i64(q.ctx(), n, k, A, idx), "col_swap_i64");
 }

@@ -43,6 +43,11 @@ int rlhip_free(rlhip_ctx* ctx, void* dev_ptr);
 /* rlhip_malloc/rlhip_free recycle blocks by exact size (stream-ordered, no synchronisation on free; at most 1/8 of
  * the device memory idles in the pool).  rlhip_trim returns every idle block to the driver. */
 int rlhip_trim(rlhip_ctx* ctx);
+/* page-locked HOST memory that the device kernels can address directly (slowly, over the host link): lets code written for the
+ * reference's host buffers -- std::fill on an array that is then handed to a driver, test/comps/test_qb.cc:154 -- run unchanged
+ * against this library for small problems.  Production data belongs in HBM (rlhip_malloc). */
+int rlhip_malloc_host(rlhip_ctx* ctx, void** host_ptr, size_t bytes);
+int rlhip_free_host(rlhip_ctx* ctx, void* host_ptr);
 int rlhip_memcpy_h2d(rlhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int rlhip_memcpy_d2h(rlhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int rlhip_memcpy_d2d(rlhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);

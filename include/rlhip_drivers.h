@@ -60,7 +60,13 @@ int rlhip_drv_hqrrp_timed_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, i
                               int64_t pp, int64_t panel_pivoting, int64_t qr_type, uint32_t state[6], double times27[27]);
 
 /* BQRRP<double>::call.  qrcp_wide {0 luqr, 1 geqp3}, qr_tall {0 geqrt, 1 cholqr, 2 geqrf}, apply_trans_q {0 ormqr, 1 gemqrt}
- * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default {luqr, cholqr, gemqrt}.
+ * follow the reference's enum order (rl_bqrrp.hh:45-49); -1 keeps the object's default = the reference's {luqr, geqrf, ormqr}
+ * (rl_bqrrp.hh:74-76).  The fastest triple on the device is {0, 1, 1} = {luqr, cholqr, gemqrt} (BQRRP::use_fast_subroutines()).
+ * DIVERGENCE from the reference, qr_tall = cholqr only: when the panel's Cholesky factorization breaks down, or diag(R_chol) is
+ * graded beyond eps^(1/4) (the preconditioned panel is not well conditioned, so Cholesky QR cannot deliver an orthonormal Q), the
+ * panel is re-factored with Householder reflectors (BQRRP::cholqr_fallback, default on; environment RLHIP_BQRRP_CHOLQR_FALLBACK=0
+ * restores the reference's behaviour, which carries on with the half-factored Gram matrix, rl_bqrrp.hh:461).  Pivots, rank and
+ * well-conditioned panels are unaffected.
  * Row-sharded context (rlhip_comm_*): m and A are this rank's rows, tau needs min(global rows, n) entries, qr_tall must be cholqr;
  * qr_tall = 1 + 16 selects the BLOCK-CYCLIC layout (global row blocks of b_sz rows dealt round-robin, block g on rank g % P, stacked in
  * increasing order in A) instead of one contiguous row block per rank.  A (m x n, lda) -> GEQP3

@@ -83,6 +83,8 @@ SIGNATURES = {
     "rlhip_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
     "rlhip_memcpy_d2h": (c_int, [c_vp, c_vp, c_vp, c_sz]),
     "rlhip_trim": (c_int, [c_vp]),
+    "rlhip_malloc_host": (c_int, [c_vp, C.POINTER(c_vp), c_sz]),
+    "rlhip_free_host": (c_int, [c_vp, c_vp]),
     "rlhip_memcpy_d2d": (c_int, [c_vp, c_vp, c_vp, c_sz]),
     "rlhip_memset": (c_int, [c_vp, c_vp, c_int, c_sz]),
     "rlhip_reserve_workspace": (c_int, [c_vp, c_sz]),

@@ -169,6 +169,17 @@ static void pool_drop(rlhip_ctx* c, int i) {
     c->pool_idle_bytes -= c->pool[i].bytes;
     c->pool[i] = c->pool[--c->npool];
 }
+int rlhip_malloc_host(rlhip_ctx* c, void** p, size_t bytes) {
+    RLHIP_CHECK(hipSetDevice(c->device));
+    RLHIP_CHECK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    return 0;
+}
+int rlhip_free_host(rlhip_ctx* c, void* p) {
+    if (!p) return 0;
+    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(hipHostFree(p));
+    return 0;
+}
 int rlhip_trim(rlhip_ctx* c) {
     RLHIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = c->npool - 1; i >= 0; --i)

@@ -319,6 +319,7 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
+        if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
         if (const char* e = std::getenv("RLHIP_BQRRP_CHOLQR_FALLBACK")) alg.cholqr_fallback = (e[0] != '0');   // test knob: reference behaviour on a Cholesky breakdown
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
@@ -455,6 +456,7 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
+        if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
         if (const char* e = std::getenv("RLHIP_BQRRP_CHOLQR_FALLBACK")) alg.cholqr_fallback = (e[0] != '0');   // test knob: reference behaviour on a Cholesky breakdown
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }

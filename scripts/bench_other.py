@@ -54,7 +54,7 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
     best = None
     for it in range(steps + 1):
         ctx.fill_dense(A, m, n, key=(4, 0)); ctx.sync()
-        t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps)); ctx.sync(); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps), qrcp_wide=0, qr_tall=1, apply_trans_q=1); ctx.sync(); dt = time.perf_counter() - t0
         if it > 0: best = dt if best is None else min(best, dt)
     apply_us = r["times_us"][5]
     ach = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12

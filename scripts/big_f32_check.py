@@ -4,7 +4,7 @@ ctx = d.Context(0)
 for (m, b, dt) in [(16384, 1024, torch.float32), (8192, 512, torch.float64)]:
     A0 = d.drv_mat_gen(ctx, "gaussian", m, m, key=(2, 0), dtype=dt)["A"]
     A = A0.clone()
-    t0 = time.perf_counter(); o = d.drv_bqrrp(ctx, A, m, m, b, 1.0); torch.cuda.synchronize(); dtm = time.perf_counter() - t0
+    t0 = time.perf_counter(); o = d.drv_bqrrp(ctx, A, m, m, b, 1.0, qr_tall=1, apply_trans_q=1); torch.cuda.synchronize(); dtm = time.perf_counter() - t0
     Q = A.clone()
     suf = "f32" if dt == torch.float32 else "f64"
     getattr(ctx.lib, f"rlhip_ungqr_{suf}")(ctx.h, m, m, m, Q.data_ptr(), m, o["tau"].data_ptr())

@@ -7,5 +7,5 @@ ctx = d.Context(0)
 A = d.cm_empty(m, m, dtype=dt)
 for it in range(2):
     ctx.fill_dense(A, m, m, key=(4, 0)); ctx.sync()
-    r = d.drv_bqrrp(ctx, A, m, m, b, 1.0, timing=True)
+    r = d.drv_bqrrp(ctx, A, m, m, b, 1.0, timing=True, qr_tall=1, apply_trans_q=1)
     print(r["times_us"])

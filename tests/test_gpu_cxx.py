@@ -1,0 +1,30 @@
+"""The C++ object layer used the way a caller of the reference uses it (tests/cxx/test_qb_caller.cpp = the reference's QB test body,
+test/comps/test_qb.cc:126-176, with only the include, the allocations and one stream sync changed): built with plain g++ against
+librlhip.so by `make -C tests/cxx` (__graft_entry__.build()), run on the device here."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CXX = Path(__file__).resolve().parent / "cxx"
+
+
+def test_cxx_caller_program_builds_and_links():
+    """no GPU needed: the program compiles against RandLAPACK_amd.hh with the host compiler and links against the C ABI only"""
+    subprocess.run(["make", "-C", str(CXX), "-s"], check=True)
+    exe = CXX / "test_qb_caller"
+    assert exe.exists()
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", str(exe)], text=True)
+    assert "rlhip_drv" not in out                      # the object layer is header-only C++ over the kernel-level C ABI ...
+    assert "rlhip_gemm_f64" in out and "rlhip_malloc_host" in out
+    assert "hip" not in out.replace("rlhip", "")       # ... and needs no HIP runtime symbol of its own
+
+
+@pytest.mark.gpu
+def test_reference_qb_test_body_passes_on_the_device():
+    exe = CXX / "test_qb_caller"
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(CXX), "-s"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
+    assert r.stdout.count("FRO NORM OF A - QB") == 3
