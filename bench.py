@@ -180,15 +180,19 @@ def main():
     achieved = 2.0 * mloc * n * k / (kernel_ms * 1e-3) / 1e12
     # L2<->fabric bytes of this kernel from the PMC passes committed under profiles/ (collected at exactly this shape on one
     # GPU; separate --pmc passes, gfx950 x2 correction on FETCH_SIZE); other shapes / rank counts: not measured -> null
-    traffic = None
+    # (a process cannot read its own PMC counters: the number is the committed measurement, and the line says which file and when)
+    traffic, traffic_source = None, None
     try:
         if world == 1 and (m, n, k) == (M, N, K):
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")) as fh:
-                traffic = float(json.load(fh)["traffic_bytes"])
+            tfile = os.path.join("profiles", "round1_pmc_traffic.json")
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tfile)) as fh:
+                tj = json.load(fh)
+            traffic = float(tj["traffic_bytes"])
+            traffic_source = f"{tfile} (rocprofv3 --pmc passes of this kernel at this shape, {tj.get('date', 'round 1')}; not re-measured by this run)"
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=traffic,
+                    frac=round(achieved / PEAK_F64_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                     kernel="gemm_sk_kernel<NN> stream-K 128x256x16 (Y = A*Omega, ||A||_F fused) + fix-up",
                     launch_ms=round(kernel_ms, 3), flops_per_launch=2.0 * mloc * n * k)
 

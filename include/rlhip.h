@@ -311,6 +311,10 @@ int rlhip_csr_densify_cols_f32(rlhip_ctx* ctx, int64_t m, const int64_t* rowptrT
  *      (bound at run time), or through a host-installed hook.  With no communicator every call is a no-op,
  *      so single-GPU callers never notice. ---- */
 typedef int (*rlhip_allreduce_hook)(void* user, void* dev_buf, int64_t count, int is_f64);
+/* 1 when RCCL can be bound in this process, 0 otherwise.  ncclCommInitRank is collective, so ranks agree on this (MIN over the
+ * ranks) BEFORE any of them calls rlhip_comm_init; a process that already maps an RCCL (PyTorch's) gets that copy, never a second one. */
+int rlhip_comm_can_load(void);
+const char* rlhip_comm_rccl_origin(void);   /* where the bound RCCL came from (diagnostics) */
 int rlhip_comm_unique_id(unsigned char id_out[128]);                 /* rank 0: ncclGetUniqueId */
 int rlhip_comm_init(rlhip_ctx* ctx, int nranks, int rank, const unsigned char id[128]);
 int rlhip_comm_set_hook(rlhip_ctx* ctx, rlhip_allreduce_hook hook, void* user, int nranks, int rank);

@@ -108,6 +108,8 @@ SIGNATURES = {
 }
 HOOK = C.CFUNCTYPE(c_int, c_vp, c_vp, c_i64, c_int)
 SIGNATURES.update({
+    "rlhip_comm_can_load": (c_int, []),
+    "rlhip_comm_rccl_origin": (C.c_char_p, []),
     "rlhip_comm_unique_id": (c_int, [c_vp]),
     "rlhip_comm_init": (c_int, [c_vp, c_int, c_int, c_vp]),
     "rlhip_comm_set_hook": (c_int, [c_vp, HOOK, c_vp, c_int, c_int]),

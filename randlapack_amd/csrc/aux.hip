@@ -1,5 +1,6 @@
 // HBM-bound helper kernels: norms, copies, fills.  Lanes always run along the contiguous (row)
 // direction of the column-major operands so every wavefront touches whole 512-byte segments.
+#include <cstring>
 #include "rlhip_internal.h"
 
 namespace {
@@ -37,6 +38,38 @@ __global__ __launch_bounds__(256) void ssq_partial_kernel(int64_t m, int64_t n, 
         const T* col = A + j * lda;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
             double v = (double)col[i];
+            acc += v * v;
+        }
+    }
+    double s = block_sum<double, 256>(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// scaled variant (dlassq's safeguard, taken only when the plain sum over- or underflowed): partial sums of (x * inv_scale)^2, and the
+// largest |x| of the matrix by an integer max on the bit patterns (non-negative doubles order like unsigned integers)
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(int64_t m, int64_t n, const T* __restrict__ A, int64_t lda,
+                                                     unsigned long long* __restrict__ out) {
+    double mx = 0;
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        const T* col = A + j * lda;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            const double v = fabs((double)col[i]);
+            if (v > mx || v != v) mx = v;                      // NaN propagates
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); if (o > mx || o != o) mx = o; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(mx));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ssq_scaled_partial_kernel(int64_t m, int64_t n, const T* __restrict__ A, int64_t lda,
+                                                                 double scale, double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double acc = 0;
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+        const T* col = A + j * lda;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            const double v = (double)col[i] / scale;
             acc += v * v;
         }
     }
@@ -114,8 +147,30 @@ int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* re
     RLHIP_LAUNCH_CHECK();
     RLHIP_CHECK(hipMemcpyAsync(c->h_mail, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     RLHIP_CHECK(hipStreamSynchronize(c->stream));
-    rlhip_ws_release(c, mark);
     double ssq = *(double*)c->h_mail;
+    if (!(ssq > 0.0) || ssq > 1.7e308) {
+        // all zeros, NaN, or the plain sum of squares over- / underflowed (entries beyond ~1e154 or below ~1e-154): redo it the way
+        // LAPACK's dlassq does, relative to the largest entry -- one more pass, taken only here
+        unsigned long long* d_mx = (unsigned long long*)(c->d_mail + 1);
+        RLHIP_CHECK(hipMemsetAsync(d_mx, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(absmax_kernel<T>, grid, dim3(256), 0, c->stream, m, n, A, lda, d_mx);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 1, d_mx, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        double mx;
+        memcpy(&mx, c->h_mail + 1, sizeof(double));
+        if (mx != mx || mx > 1.7e308) { rlhip_ws_release(c, mark); *result_host = (T)mx; return 0; }     // NaN / inf entries: that is the norm
+        if (mx == 0.0) { rlhip_ws_release(c, mark); *result_host = T(0); return 0; }
+        hipLaunchKernelGGL(ssq_scaled_partial_kernel<T>, grid, dim3(256), 0, c->stream, m, n, A, lda, mx, partial);
+        hipLaunchKernelGGL(ssq_final_kernel, dim3(1), dim3(256), 0, c->stream, np, partial, d_out);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        rlhip_ws_release(c, mark);
+        *result_host = (T)(mx * sqrt(*(double*)c->h_mail));
+        return 0;
+    }
+    rlhip_ws_release(c, mark);
     *result_host = (T)sqrt(ssq);
     return 0;
 }

@@ -121,6 +121,10 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
     RLHIP_CHECK(hipSetDevice(device));
     rlhip_ctx* c = new rlhip_ctx();
     c->device = device;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->num_cu = ncu;
+    }
     if (!own_stream) {
         c->stream = (hipStream_t)hip_stream;
         c->owns_stream = false;

@@ -250,11 +250,7 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
     if (use_small < 0) { const char* e = getenv("RLHIP_POTRF_SMALL"); use_small = (e && atoi(e) == 0) ? 0 : 1; }
     if (use_small && n <= PS_MAXN) {
         const size_t smem = (size_t)(32 * 33 + 64 + (size_t)(n + 16) * PS_LD) * sizeof(T);
-        static bool attr_set = false;
-        if (!attr_set) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)potrf_small_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
+        RLHIP_FUNC_LDS(c, potrf_small_kernel<T>, 150 * 1024);
         hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, d_info);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -33,13 +33,42 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+const char* g_rccl_origin = "";
+
+// Bind RCCL.  A process that already maps an RCCL (PyTorch ships its own librccl.so inside torch/lib) must not get a SECOND copy:
+// two RCCL instances in one process each bring their own bootstrap / proxy state.  So: (1) look for an already-loaded copy by
+// soname (RTLD_NOLOAD finds a library whatever directory it came from), (2) look for a mapped file named librccl* in
+// /proc/self/maps and re-open exactly that path, (3) only then load the system copy.
 int load_rccl() {
     if (g_rccl.h) return 0;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
     for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (h) { g_rccl_origin = "already loaded (soname)"; break; }
+    }
+    if (!h) {
+        if (FILE* f = fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            static char path[1024];
+            while (!h && fgets(line, sizeof line, f)) {
+                char* p = strstr(line, "/");
+                if (!p || !strstr(p, "librccl")) continue;
+                size_t len = strcspn(p, "\n");
+                if (len >= sizeof path) continue;
+                memcpy(path, p, len); path[len] = 0;
+                h = dlopen(path, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+                if (h) g_rccl_origin = path;
+            }
+            fclose(f);
+        }
+    }
+    if (!h) {
+        const char* fresh[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : fresh) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) { g_rccl_origin = n; break; }
+        }
     }
     if (!h) { fprintf(stderr, "[rlhip] cannot load RCCL: %s\n", dlerror()); return -1; }
     g_rccl.get_id = (fn_get_id)dlsym(h, "ncclGetUniqueId");
@@ -65,6 +94,11 @@ struct rlhip_comm {
 static rlhip_comm* comm_of(rlhip_ctx* c) { return (rlhip_comm*)c->comm; }
 
 extern "C" {
+
+/* 1 when RCCL can be bound in this process (ncclCommInitRank is collective: every rank must know that EVERY rank can join before
+ * any of them calls rlhip_comm_init).  rlhip_comm_rccl_origin: where the bound copy came from (diagnostics). */
+int rlhip_comm_can_load(void) { return load_rccl() == 0 ? 1 : 0; }
+const char* rlhip_comm_rccl_origin(void) { return g_rccl_origin; }
 
 int rlhip_comm_unique_id(unsigned char id_out[128]) {
     if (load_rccl()) return -1001;

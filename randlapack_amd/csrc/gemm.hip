@@ -341,11 +341,7 @@ int launch_one(rlhip_ctx* c, GemmArgs<T>& g, int64_t splitk) {
     const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid((unsigned)tiles, 1, (unsigned)splitk);
     auto kern = gemm_kernel<T, A_KC, B_KC, BM, BN, BK, WM, WN, VEC, MINW, EARLY, DBG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    RLHIP_FUNC_LDS(c, kern, smem);
     hipLaunchKernelGGL(kern, grid, dim3(NT), smem, c->stream, g);
     RLHIP_LAUNCH_CHECK();
     return 0;

@@ -310,14 +310,12 @@ namespace rlhip {
 int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
                      const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                      int64_t ldc, double* ssqA_dev, int tri) {
-    static int enabled = -1, num_cu = 0;
+    static int enabled = -1;
     if (enabled < 0) {
         const char* e = getenv("RLHIP_STREAMK");
         enabled = e ? atoi(e) : 1;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) num_cu = prop.multiProcessorCount;
-        if (num_cu <= 0) num_cu = 256;
     }
+    const int num_cu = c->num_cu;
     if (!enabled || transB) return 0;
     if (m % BM || n % BN || k % BK || m <= 0 || n <= 0 || k <= 0) return 0;
     if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % 2 || ldb % 2) return 0;
@@ -340,18 +338,11 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     g.ssq_part = ssqA_dev ? ws_alloc<double>(c, (size_t)P) : nullptr;
     constexpr int smem = NSTAGE * STAGE;
-    static bool attr[2] = {false, false};
     if (transA) {
-        if (!attr[1]) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr[1] = true;
-        }
+        RLHIP_FUNC_LDS(c, gemm_sk_kernel<true>, smem);
         hipLaunchKernelGGL(gemm_sk_kernel<true>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
     } else {
-        if (!attr[0]) {
-            RLHIP_CHECK(hipFuncSetAttribute((const void*)gemm_sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr[0] = true;
-        }
+        RLHIP_FUNC_LDS(c, gemm_sk_kernel<false>, smem);
         hipLaunchKernelGGL(gemm_sk_kernel<false>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
     }
     RLHIP_LAUNCH_CHECK();

@@ -443,11 +443,7 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
     if (NBk % 2) ++NBk;
     constexpr int smem = (JP * JMT + JP * JP) * (int)sizeof(T);
     constexpr int NT = (JMT == 256) ? 1024 : 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)jacobi_block_kernel<T, JB, JMT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    RLHIP_FUNC_LDS(c, (jacobi_block_kernel<T, JB, JMT>), smem);
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);

@@ -538,17 +538,8 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     if (lda < (m > 1 ? m : 1)) return -5;
     const int64_t mn = m < n ? m : n;
     if (mn == 0) return 0;
-    static int num_cu = 0;
-    if (!num_cu) {
-        hipDeviceProp_t prop;
-        num_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-        if (num_cu <= 0) num_cu = 256;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)getrf_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    const int num_cu = c->num_cu;
+    RLHIP_FUNC_LDS(c, getrf_panel_kernel<T>, 128 * 1024);
     size_t mark = rlhip_ws_mark(c);
     const int64_t Gmax = num_cu;
     LuArgs<T> g;

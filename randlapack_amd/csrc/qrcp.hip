@@ -595,12 +595,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
     if (m == 0 || n == 0) return 0;
-    static int num_cu = 0;
-    if (!num_cu) {
-        hipDeviceProp_t prop;
-        num_cu = (hipGetDeviceProperties(&prop, c->device) == hipSuccess) ? prop.multiProcessorCount : 256;
-        if (num_cu <= 0) num_cu = 256;
-    }
+    const int num_cu = c->num_cu;
     // Fewer, fatter workgroups make the two rendezvous per step cheaper; the owned columns are kept in LDS when
     // they fit (<= 150 KiB per workgroup), which also keeps the release fences of the grid barrier clean.
     int64_t G = (n + 7) / 8;           // ~8 columns (two per wave) per workgroup (4 and 16 measured: no better)
@@ -616,12 +611,8 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         if ((size_t)(cpw2 + 1) * m * sizeof(T) <= 140 * 1024) { G = G2; lds_bytes = (size_t)cpw2 * m * sizeof(T); use_lds = 1; }
         else lds_bytes = 0;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)qrcp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)qr_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    RLHIP_FUNC_LDS(c, qrcp_kernel<T>, 150 * 1024);
+    RLHIP_FUNC_LDS(c, qr_pipe_kernel<T>, 150 * 1024);
     static int pipe_on = -1;
     if (pipe_on < 0) { const char* e = getenv("RLHIP_QR_PIPE"); pipe_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (!pivot && max_steps < 0 && pipe_on) {
@@ -648,8 +639,13 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         if (use_lds && (slots(pa.chunk) + 1) * (size_t)m * sizeof(T) > 150 * 1024) pa.chunk = 1;
         const size_t cpw2 = slots(pa.chunk);
         const size_t dyn2 = (pa.v_in_lds ? (size_t)m * sizeof(T) : 0) + (use_lds ? cpw2 * (size_t)m * sizeof(T) : 0);
-        hipLaunchKernelGGL(qr_pipe_kernel<T>, dim3((unsigned)Gp), dim3(256), dyn2, c->stream, pa);
-        RLHIP_LAUNCH_CHECK();
+        // every workgroup spins on flags raised by others: the grid must be co-resident.  A cooperative launch checks the grid against the
+        // device's occupancy and is gang-scheduled (serialised against other processes' cooperative kernels), so a GPU shared between ranks
+        // or with busy CUs cannot strand part of the grid.
+        {
+            void* kargs[] = {(void*)&pa};
+            RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qr_pipe_kernel<T>, dim3((unsigned)Gp), dim3(256), kargs, (unsigned)dyn2, c->stream));
+        }
         rlhip_ws_release(c, mark2);
         return 0;
     }
@@ -670,8 +666,10 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     g.v_in_lds = use_lds || ((2 * cpw_final + (size_t)m) * sizeof(T) <= 140 * 1024);
     const size_t dyn = (2 * cpw_final + (g.v_in_lds ? (size_t)m : 0)) * sizeof(T) + (use_lds ? cpw_final * (size_t)m * sizeof(T) : 0);
     if (dyn > 150 * 1024) { rlhip_ws_release(c, mark); return -2; }   // only the per-column norms left: n / G > ~9000 columns per workgroup
-    hipLaunchKernelGGL(qrcp_kernel<T>, dim3((unsigned)G), dim3(256), dyn, c->stream, g);
-    RLHIP_LAUNCH_CHECK();
+    {   // grid barrier inside: cooperative launch (see qr_pipe_kernel above)
+        void* kargs[] = {(void*)&g};
+        RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qrcp_kernel<T>, dim3((unsigned)G), dim3(256), kargs, (unsigned)dyn, c->stream));
+    }
     rlhip_ws_release(c, mark);
     return 0;
 }

@@ -20,10 +20,24 @@
 
 #define RLHIP_LAUNCH_CHECK() RLHIP_CHECK(hipGetLastError())
 
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (kernel function attributes are per device: a process-wide flag would leave
+// the second device of a process at the 64 KiB default).  `func` must be the kernel's address; the flag array lives at the call site.
+#define RLHIP_FUNC_LDS(c, func, bytes)                                                                                     \
+    do {                                                                                                                   \
+        static bool _rlhip_lds_done[64] = {};                                                                              \
+        const int _d = (c)->device & 63;                                                                                   \
+        if (!_rlhip_lds_done[_d]) {                                                                                        \
+            RLHIP_CHECK(hipSetDevice((c)->device));                                                                        \
+            RLHIP_CHECK(hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            _rlhip_lds_done[_d] = true;                                                                                    \
+        }                                                                                                                  \
+    } while (0)
+
 // Execution context: one HIP stream + a growable device scratch arena + a small
 // pinned host mailbox for info codes / scalars coming back from the device.
 struct rlhip_ctx {
     int device = 0;
+    int num_cu = 256;            // compute units of THIS context's device (persistent kernels size their grids with it)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     // scratch arena: stack-disciplined bump allocator over a short list of device segments.  Marks are virtual

@@ -409,22 +409,25 @@ __global__ void perm_moves_kernel(int64_t n, const int64_t* __restrict__ idx, in
     if (threadIdx.x || blockIdx.x) return;
     for (int64_t i = 0; i < n; ++i) seen[i] = 0;
     int64_t w = 0;
-    for (int64_t i = 0; i < n; ++i) {
+    bool bad = false;
+    for (int64_t i = 0; i < n && !bad; ++i) {
         if (seen[i]) continue;
         seen[i] = 1;
         int64_t s = idx[i] - 1;
+        if (s < 0 || s >= n) { bad = true; break; }
         if (s == i) continue;                 // fixed point
         // cycle: i <- s <- idx[s]-1 <- ... ; encode as (start marker, dst, src ...): -(i+1) opens a cycle
         moves[w++] = -(i + 1);
-        int64_t j = i;
         while (s != i) {
-            moves[w++] = s;                   // column j receives column s
+            if (s < 0 || s >= n || seen[s]) { bad = true; break; }     // out of range or a repeated index: idx is not a permutation
+            moves[w++] = s;                   // the column walked last receives column s
             seen[s] = 1;
-            j = s;
-            s = idx[j] - 1;
+            s = idx[s] - 1;
         }
     }
-    *nmoves = w;
+    // a vector that is not a permutation of 1..n leaves the matrix untouched (the host path for n >= 4096 returns -7 for it; this
+    // device path is asynchronous, so the refusal shows as a no-op instead of an endless walk)
+    *nmoves = bad ? 0 : w;
 }
 
 template <typename T>
@@ -603,7 +606,7 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     if (nTb == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
     auto launch = [&](auto kern) -> int {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));   // (per device, cheap: set on every call)
+        RLHIP_FUNC_LDS(c, kern, lds_cap);
         for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT)
             hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, tpg, r_base,
                                partial, row0, mloc, tb0, tb1, op->ptr);
@@ -638,11 +641,7 @@ int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int
     if (ldb < op->d) return -9;
     const size_t smem = sizeof(unsigned long long) * (size_t)op->d;
     if (smem > 150 * 1024) return -2;            // d up to 19200
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLHIP_CHECK(hipFuncSetAttribute((const void*)saso_apply_csr_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    RLHIP_FUNC_LDS(c, saso_apply_csr_kernel<T>, 150 * 1024);
     hipLaunchKernelGGL(saso_apply_csr_kernel<T>, dim3((unsigned)n), dim3(256), smem, c->stream, op->d, op->m, op->T, op->nnz, op->st, op->afwd,
                        op->b, rowptrT, colidxT, valsT, alpha, beta, B, ldb, row0, op->rows);
     RLHIP_LAUNCH_CHECK();

@@ -627,11 +627,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             if (!Uneg) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, c->stream, n, n_pad, A, lda, Uneg);
             RLHIP_LAUNCH_CHECK();
-            static bool fattr = false;
-            if (!fattr) {
-                RLHIP_CHECK(hipFuncSetAttribute((const void*)trsm_fused_kernel<T, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T>()));
-                fattr = true;
-            }
+            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16>), fused_lds_bytes<T>());
             fdump = ws_alloc<T>(c, 512);
             if (!fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         }

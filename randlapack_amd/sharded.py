@@ -6,15 +6,11 @@ rendezvous: rank 0 creates the RCCL unique id, torch.distributed broadcasts the 
 the communicator bound to its rlhip context.  After that the data-path collectives are issued by librlhip.so
 itself on the context's HIP stream (RCCL over xGMI) -- torch.distributed is not in the data path.
 
-`rowsharded_rsvd_model` is a numpy statement of the same exchange pattern; tests run it under gloo with
-world_size 2 on CPU to pin down WHICH quantities are all-reduced (it is test scaffolding for the host
-logic, it is not a fallback and is never called by the product path).
+(A numpy statement of the same exchange pattern lives in tests/_sharded_model.py: test scaffolding, not product code.)
 """
 from __future__ import annotations
 
 import ctypes as C
-
-import numpy as np
 
 from . import _lib
 
@@ -38,8 +34,14 @@ def init_comm(ctx, dist, force_hook: bool = False) -> str:
         force_hook = True
     pg_dev = "cpu" if host_pg else dev
     idbuf = (C.c_ubyte * 128)()
+    # ncclCommInitRank is collective: a rank that cannot bind RCCL would leave the others blocked inside it, so the ranks first agree
+    # (MIN) that EVERY one of them can; only then does anybody join
+    can = torch.tensor([0 if force_hook else int(ctx.lib.rlhip_comm_can_load())], dtype=torch.int32, device=pg_dev)
+    dist.all_reduce(can, op=dist.ReduceOp.MIN)
+    if int(can.item()) == 0:
+        force_hook = True
     ok = 1
-    if rank == 0:
+    if rank == 0 and not force_hook:
         ok = int(ctx.lib.rlhip_comm_unique_id(idbuf) == 0)
     t = torch.tensor([ok] + list(idbuf), dtype=torch.uint8, device=pg_dev)
     dist.broadcast(t, src=0)
@@ -95,19 +97,3 @@ def rsvd_rowsharded(ctx, dist, A_local, m_local, n, k, key=(0, 0), b_sz=None, to
     if ctx.lib.rlhip_comm_size(ctx.h) != dist.get_world_size():
         ctx.comm_transport = init_comm(ctx, dist)
     return dev.drv_rsvd(ctx, A_local, m_local, n, k, b_sz or k, tol, p, q, key=key)
-
-
-# ------------------------------------------------------------------------------------------------------
-def rowsharded_rsvd_model(A_local, k, Omega, allreduce):
-    """numpy model of the exchange pattern for p = 0, one QB block:
-         Y_g = A_g Omega | G = allreduce(Y_g^T Y_g) | R = chol(G) | Q_g = Y_g R^-1 |
-         B^T = allreduce(A_g^T Q_g) | SVD(B^T) replicated | U_g = Q_g Uhat
-    `allreduce(x)` must return the element-wise sum over ranks."""
-    Y = A_local @ Omega
-    G = allreduce(Y.T @ Y)
-    R = np.linalg.cholesky(G).T
-    Q = np.linalg.solve(R.T, Y.T).T
-    BT = allreduce(A_local.T @ Q)
-    V, S, UT = np.linalg.svd(BT, full_matrices=False)
-    U = Q @ UT.T
-    return U, S, V

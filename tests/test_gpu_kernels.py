@@ -775,3 +775,26 @@ def test_f32_kernel_families(ctx):
     assert ctx.lib.rlhip_col_swap_f32(ctx.h, m3, n3, n3, Cd.data_ptr(), m3, Jp.data_ptr()) == 0
     np.testing.assert_array_equal(d.cm_to_numpy(Cd), Cm[:, perm - 1])
     np.testing.assert_array_equal(Jp.cpu().numpy(), perm)
+
+
+def test_lange_extreme_magnitudes_and_col_swap_rejects_non_permutations(ctx):
+    """lange_fro on entries whose squares over- / underflow (LAPACK's scaled dlassq gives the right norm); col_swap's device path
+    (n < 4096) leaves the matrix untouched for an index vector that is not a permutation instead of walking it forever."""
+    import torch
+
+    d = _dev()
+    for scale in (1e200, 1e-200):
+        A = np.array([[3.0, 0.0], [4.0, 0.0], [0.0, 12.0]]) * scale
+        got = ctx.lange_fro(3, 2, d.cm_from_numpy(A), 3)
+        assert abs(got / scale - 13.0) <= 1e-12
+    assert ctx.lange_fro(3, 2, d.cm_zeros(3, 2), 3) == 0.0
+    assert np.isnan(ctx.lange_fro(2, 2, d.cm_from_numpy(np.array([[1.0, np.nan], [0.0, 2.0]])), 2))
+    A = np.arange(12.0).reshape(3, 4)
+    Ad = d.cm_from_numpy(A)
+    bad = torch.tensor([2, 2, 5, 1], dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_col_swap_f64(ctx.h, 3, 4, 4, Ad.data_ptr(), 3, bad.data_ptr()) == 0
+    ctx.sync()
+    assert np.array_equal(d.cm_to_numpy(Ad), A)
+    good = torch.tensor([4, 1, 3, 2], dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_col_swap_f64(ctx.h, 3, 4, 4, Ad.data_ptr(), 3, good.data_ptr()) == 0
+    assert np.array_equal(d.cm_to_numpy(Ad), A[:, [3, 0, 2, 1]])

@@ -23,7 +23,7 @@ def _worker(rank, world, port, m, n, k, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle
-    from randlapack_amd.sharded import rowsharded_rsvd_model
+    from _sharded_model import rowsharded_rsvd_model
 
     rng = np.random.default_rng(123)
     A = rng.standard_normal((m, n)) @ np.diag(np.linspace(1, 0.01, n))
