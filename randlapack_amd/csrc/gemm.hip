@@ -453,17 +453,14 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
 
 namespace rlhip {
 
-int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
-                     const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc, double* ssqA_dev, int tri);
+template <typename T>
+int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B,
+                 int64_t ldb, T beta, T* C, int64_t ldc, double* ssqA_dev, int tri);
 
 template <typename T>
-static int try_streamk(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T,
-                       T*, int64_t, double*, int) { return 0; }
-template <>
-int try_streamk<double>(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
-                        int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, double* ssq, int tri) {
-    return gemm_streamk_f64(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq, tri);
+static int try_streamk(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb,
+                       T beta, T* C, int64_t ldc, double* ssq, int tri) {
+    return gemm_streamk<T>(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq, tri);
 }
 
 template <typename T>
@@ -489,19 +486,20 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (ldc < (m > 1 ? m : 1)) return -13;
     // contraction lengths that are not a multiple of the k-step (row shards of 200000/8 = 25000 rows): the multiple-of-16
     // part goes down the persistent path, the < 16 leftover is one accumulate pass of the generic kernel
-    if (!transB && k % 16 != 0 && k >= 1024 && n % 256 == 0 && !ssqA_dev && (tri ? (m == n) : (m >= 128))) {
-        const int64_t k_main = (k / 16) * 16;
+    constexpr int64_t SKK = (sizeof(T) == 8) ? 16 : 32;      // K-tile of the persistent kernel (128 bytes per row)
+    if (!transB && k % SKK != 0 && k >= 1024 && n % 256 == 0 && !ssqA_dev && (tri ? (m == n) : (m >= 128))) {
+        const int64_t k_main = (k / SKK) * SKK;
         int rc = gemm_impl<T>(c, transA, transB, m, n, k_main, alpha, A, lda, B, ldb, beta, C, ldc, tri, nullptr, nullptr);
         if (rc) return rc;
         const T* A2 = transA ? (A + k_main) : (A + k_main * lda);
         return gemm_impl<T>(c, transA, transB, m, n, k - k_main, alpha, A2, lda, B + k_main, ldb, T(1), C, ldc, tri, nullptr, nullptr);
     }
-    if (tri && !transB && m == n && n % 256 == 0 && k % 16 == 0) {
+    if (tri && !transB && m == n && n % 256 == 0 && k % SKK == 0) {
         int rc = try_streamk<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 1);
         if (rc < 0) return rc;
         if (rc == 1) return 0;
     }
-    if (!tri && !transB && m >= 128 && n % 256 == 0 && k % 16 == 0) {
+    if (!tri && !transB && m >= 128 && n % 256 == 0 && k % SKK == 0) {
         // big data passes: persistent stream-K kernel on the multiple-of-128 row block, generic kernel on the rest
         const int64_t m_main = (m / 128) * 128;
         int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssqA_dev, 0);

@@ -22,6 +22,11 @@
 //     by permuting the SOURCE addresses:  KC operand (Omega, Q, A of A^T*Q): row r keeps 16-byte piece c at
 //     slot c ^ ((r >> 1) & 7);  MC operand (A of A*Omega): plain (the b128 lane groups already spread).
 //   * v_mfma_f64_16x16x4_f64, 64 x 64 accumulator tile per wave (2 x 4 waves -> 128 x 256 block tile).
+//   * fp32 twin (BQRRP's compact-WY products, rl_bqrrp.hh:535-547): the SAME byte geometry -- a K-tile is 32 floats = 128 bytes per
+//     row, so stages, DMA pieces, swizzle and ring are identical -- with v_mfma_f32_16x16x4_f32 (32-cycle issue, 16 independent
+//     accumulators per wave).  A 16-byte piece now holds four consecutive k, i.e. it feeds FOUR MFMA steps:
+//     step (sigma, h), lane group fk  <->  kk = 16*sigma + 4*fk + h;  MC image: lane fr reads rows 4*fr .. 4*fr+3 of one k-row, i.e.
+//     fragment x, lane fr  <->  row 4*fr + x.  Accumulator layout of the f32 MFMA: lane (fr, fk), register r = C[row(fr)][16u + 4fk + r].
 #include "rlhip_internal.h"
 #include <cstdlib>
 
@@ -29,24 +34,44 @@ namespace {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-constexpr int BM = 128, BN = 256, BK = 16;
-constexpr int STAGE_A = BM * BK * 8;          // 16 KiB
-constexpr int STAGE_B = BN * BK * 8;          // 32 KiB
+constexpr int BM = 128, BN = 256;
+constexpr int STAGE_A = BM * 128;             // 16 KiB: a K-tile is 128 bytes per row (16 doubles / 32 floats)
+constexpr int STAGE_B = BN * 128;             // 32 KiB
 constexpr int STAGE = STAGE_A + STAGE_B;      // 48 KiB
 constexpr int NSTAGE = 3;
 constexpr int SLAB_ELEMS = BM * BN;
 
+template <int N> struct HC { static constexpr int value = N; };
+
+template <typename T> struct SkT;
+template <> struct SkT<double> {
+    static constexpr int BK = 16, EPP = 2, NH = 2;      // k per tile, elements per 16-byte piece, MFMA steps fed by one piece
+    typedef d2_t frag_t;                                 // one 16-byte LDS read
+    typedef d4_t acc_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int ccol(int fk, int r) { return fk + 4 * r; }       // column inside a 16-wide tile of register r
+};
+template <> struct SkT<float> {
+    static constexpr int BK = 32, EPP = 4, NH = 4;
+    typedef f4_t frag_t;
+    typedef f4_t acc_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int ccol(int fk, int r) { return 4 * fk + r; }
+};
+
+template <typename T>
 struct SkArgs {
-    int64_t M, N, K;          // M multiple of 128, N multiple of 256, K multiple of 16 (caller peels the rest)
-    const double* A; int64_t lda;
-    const double* B; int64_t ldb;
-    double* C; int64_t ldc;
-    double alpha, beta;
+    int64_t M, N, K;          // M multiple of 128, N multiple of 256, K multiple of BK (caller peels the rest)
+    const T* A; int64_t lda;
+    const T* B; int64_t ldb;
+    T* C; int64_t ldc;
+    T alpha, beta;
     int64_t tiles_m, tiles_n, ktiles;
-    double* slab;             // 2 * gridDim.x slots of 128 x 256
+    T* slab;                  // 2 * gridDim.x slots of 128 x 256
     double* ssq_part;         // nullptr, or gridDim.x partial sums of squares of op(A) (fused ||A||_F^2)
     int tri;                  // 1: syrk-upper -- only tiles touching i <= j are computed, only i <= j is written
     int64_t ntiles;           // number of active tiles
@@ -54,7 +79,8 @@ struct SkArgs {
 
 // active tile index -> (tile_m, tile_n).  Full: row-major over N.  Tri (128 x 256 tiles, upper): column tn holds the
 // tiles tm < min(tiles_m, 2*tn + 2).
-__device__ __forceinline__ void sk_tile(const SkArgs& g, int64_t a, int64_t& tm, int64_t& tn) {
+template <typename T>
+__device__ __forceinline__ void sk_tile(const SkArgs<T>& g, int64_t a, int64_t& tm, int64_t& tn) {
     if (!g.tri) { tm = a / g.tiles_n; tn = a - tm * g.tiles_n; return; }
     tn = 0;
     for (;;) {
@@ -66,12 +92,17 @@ __device__ __forceinline__ void sk_tile(const SkArgs& g, int64_t a, int64_t& tm,
     tm = a;
 }
 
-__device__ __forceinline__ void glds16(const double* g, unsigned char* lds_wave_base) {
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <bool A_KC>
-__global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
+template <typename T, bool A_KC>
+__global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
+    using S = SkT<T>;
+    using frag_t = typename S::frag_t;
+    using acc_t = typename S::acc_t;
+    constexpr int BK = S::BK, EPP = S::EPP, NH = S::NH;
+    constexpr bool F64 = (sizeof(T) == 8);
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
@@ -85,11 +116,13 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
 
     // ---- per-lane constants of the fragment reads (see header for the index re-enumeration)
     // KC image: 16-byte piece c of row r lives at byte r*128 + ((c ^ ((r>>1)&7)) << 4); with r = 16*x + fr the
-    // key is fr>>1; step pair sigma uses piece c = 4*sigma + fk
+    // key is fr>>1; step group sigma uses piece c = 4*sigma + fk
     const int kc_key = (fr >> 1) & 7;
     const int kc_off0 = ((0 + fk) ^ kc_key) << 4, kc_off1 = ((4 + fk) ^ kc_key) << 4;
-    // MC image: byte(i, kk) = kk*1024 + i*8 ; lane reads rows (32*xi + 2*fr, +1) of k-row kk = 8*sigma + 2*fk + h
-    const int mc_row = (wm0 + 2 * fr) * 8, mc_k = 2 * fk * 1024;
+    // MC image, fp64: byte(i, kk) = kk*1024 + i*8 ; lane reads rows (32*xi + 2*fr, +1) of k-row kk = 8*sigma + 2*fk + h
+    //           fp32: byte(i, kk) = kk*512  + i*4 ; lane reads rows 4*fr .. 4*fr+3       of k-row kk = 16*sigma + 4*fk + h
+    const int mc_row = F64 ? (wm0 + 2 * fr) * 8 : (wm0 + 4 * fr) * 4;
+    const int mc_k = F64 ? 2 * fk * 1024 : 4 * fk * 512;
 
     // ---- per-lane source offsets of this wave's 6 DMA pieces per K-tile (elements, relative to tile origin)
     // A: chunks {wid, wid+8}; B: chunks {wid, wid+8, wid+16, wid+24}
@@ -97,18 +130,20 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = wid + 8 * h;
-        if (A_KC) {
+        if constexpr (A_KC) {
             const int r = 8 * c + (lane >> 3), q = lane & 7;
-            a_src[h] = (int64_t)r * g.lda + 2 * (q ^ ((r >> 1) & 7));
+            a_src[h] = (int64_t)r * g.lda + EPP * (q ^ ((r >> 1) & 7));
+        } else if constexpr (F64) {
+            a_src[h] = (int64_t)c * g.lda + 2 * lane;                                  // chunk = one k-row of 128 doubles
         } else {
-            a_src[h] = (int64_t)c * g.lda + 2 * lane;
+            a_src[h] = (int64_t)(2 * c + (lane >> 5)) * g.lda + 4 * (lane & 31);       // chunk = two k-rows of 128 floats
         }
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int c = wid + 8 * h;
         const int r = 8 * c + (lane >> 3), q = lane & 7;
-        b_src[h] = (int64_t)r * g.ldb + 2 * (q ^ ((r >> 1) & 7));
+        b_src[h] = (int64_t)r * g.ldb + EPP * (q ^ ((r >> 1) & 7));
     }
     const int64_t a_step = A_KC ? (int64_t)BK : (int64_t)BK * g.lda;
 
@@ -122,57 +157,64 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
         sk_tile(g, tile, tile_m, tile_n);
         const int64_t m0 = tile_m * BM, n0 = tile_n * BN, k0 = kt0 * BK;
 
-        const double* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
-        const double* Bg = g.B + k0 + n0 * g.ldb;
+        const T* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
+        const T* Bg = g.B + k0 + n0 * g.ldb;
 
         auto issue = [&](int64_t t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
             unsigned char* st = smem + stage * STAGE;
-            const double* Ap = Ag + t * a_step;
-            const double* Bp = Bg + t * BK;
+            const T* Ap = Ag + t * a_step;
+            const T* Bp = Bg + t * BK;
 #pragma unroll
             for (int h = 0; h < 2; ++h) glds16(Ap + a_src[h], st + (wid + 8 * h) * 1024);
 #pragma unroll
             for (int h = 0; h < 4; ++h) glds16(Bp + b_src[h], st + STAGE_A + (wid + 8 * h) * 1024);
         };
 
-        d4_t acc[4][4];
+        acc_t acc[4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[t][u] = d4_t{0, 0, 0, 0};
-
+            for (int u = 0; u < 4; ++u) acc[t][u] = acc_t{0, 0, 0, 0};
         // ---- software pipeline (one rendezvous per K-tile, placed in the MIDDLE of the tile):
-        //   F0 = fragments of step pair 0, F1 = step pair 1.  While the 32 MFMAs of F0 run, F1 is fetched; at
+        //   F0 = fragments of step group 0, F1 = step group 1.  While the MFMAs of F0 run, F1 is fetched; at
         //   the mid-point the wave retires its own DMA pieces of tile t+1 (the only group outstanding) and
         //   meets the other waves: after that barrier tile t+1 is visible to everybody AND everybody has left
-        //   tile t-1, so tile t+2 may be DMA'd into t-1's stage and F0 of tile t+1 may be fetched while the 32
+        //   tile t-1, so tile t+2 may be DMA'd into t-1's stage and F0 of tile t+1 may be fetched while the
         //   MFMAs of F1 run.  The matrix pipe therefore never waits for a tile boundary.
-        d2_t fa0[4], fb0[4], fa1[4], fb1[4];
+        frag_t fa0[4], fb0[4], fa1[4], fb1[4];
         const bool do_ssq = (g.ssq_part != nullptr) && (tile_n == 0);   // every A element is staged once by tile_n == 0
-        auto fetch = [&](const unsigned char* sA, int sg, d2_t (&a)[4], d2_t (&b)[4]) {
+        auto fetch = [&](const unsigned char* sA, int sg, frag_t (&a)[4], frag_t (&b)[4]) {
             const unsigned char* sB = sA + STAGE_A;
             const int kc = sg ? kc_off1 : kc_off0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) b[x] = *reinterpret_cast<const d2_t*>(sB + (wn0 + 16 * x + fr) * 128 + kc);
-            if (A_KC) {
+            for (int x = 0; x < 4; ++x) b[x] = *reinterpret_cast<const frag_t*>(sB + (wn0 + 16 * x + fr) * 128 + kc);
+            if constexpr (A_KC) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) a[x] = *reinterpret_cast<const d2_t*>(sA + (wm0 + 16 * x + fr) * 128 + kc);
-            } else {
+                for (int x = 0; x < 4; ++x) a[x] = *reinterpret_cast<const frag_t*>(sA + (wm0 + 16 * x + fr) * 128 + kc);
+            } else if constexpr (F64) {
                 // MC image: a[2*h + xi] = rows (32*xi + 2*fr, +1) of k-row 8*sg + 2*fk + h
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int xi = 0; xi < 2; ++xi)
-                        a[2 * h + xi] = *reinterpret_cast<const d2_t*>(sA + (8 * sg + h) * 1024 + mc_k + mc_row + xi * 256);
+                        a[2 * h + xi] = *reinterpret_cast<const frag_t*>(sA + (8 * sg + h) * 1024 + mc_k + mc_row + xi * 256);
+            } else {
+                // MC image: a[h] = rows 4*fr .. 4*fr+3 of k-row 16*sg + 4*fk + h
+#pragma unroll
+                for (int h = 0; h < 4; ++h) a[h] = *reinterpret_cast<const frag_t*>(sA + (16 * sg + h) * 512 + mc_k + mc_row);
             }
         };
-        auto mma16 = [&](d2_t (&a)[4], d2_t (&b)[4], int h) {
+        auto mma16 = [&](frag_t (&a)[4], frag_t (&b)[4], auto hc) {
+            constexpr int h = decltype(hc)::value;     // compile-time element index: a run-time index into a register vector goes through scratch
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double av = A_KC ? a[x][h] : a[2 * h + (x >> 1)][x & 1];
-                    acc[x][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][h], av, acc[x][u], 0, 0, 0);
+                    T av;
+                    if constexpr (A_KC) av = a[x][h];
+                    else if constexpr (F64) av = a[2 * h + (x >> 1)][x & 1];
+                    else av = a[h][x];
+                    acc[x][u] = S::mma(b[u][h], av, acc[x][u]);
                 }
         };
 
@@ -191,30 +233,76 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
             const int st_next = (st_cur == 2) ? 0 : st_cur + 1;
             const int st_prev = (st_cur == 0) ? 2 : st_cur - 1;
             fetch(smem + st_cur * STAGE, 1, fa1, fb1);
-            if (do_ssq) {   // 128 x 16 doubles of the A stage / 512 threads = two b128 reads per thread (layout-agnostic)
-                const d2_t* sa = reinterpret_cast<const d2_t*>(smem + st_cur * STAGE);
-                const d2_t v0 = sa[tid], v1 = sa[tid + 512];
-                ssq_acc = fma(v0[0], v0[0], fma(v0[1], v0[1], fma(v1[0], v1[0], fma(v1[1], v1[1], ssq_acc))));
+            if (do_ssq) {   // the A stage = 16 KiB / 512 threads = two b128 reads per thread (layout-agnostic)
+                const frag_t* sa = reinterpret_cast<const frag_t*>(smem + st_cur * STAGE);
+                const frag_t v0 = sa[tid], v1 = sa[tid + 512];
+                if constexpr (F64) {
+                    ssq_acc = fma(v0[0], v0[0], fma(v0[1], v0[1], fma(v1[0], v1[0], fma(v1[1], v1[1], ssq_acc))));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ssq_acc = fma((double)v0[e], (double)v0[e], fma((double)v1[e], (double)v1[e], ssq_acc));
+                }
             }
-            mma16(fa0, fb0, 0);
-            mma16(fa0, fb0, 1);
+            mma16(fa0, fb0, HC<0>{});
+            mma16(fa0, fb0, HC<1>{});
+            if constexpr (NH == 4) { mma16(fa0, fb0, HC<2>{}); mma16(fa0, fb0, HC<3>{}); }
             if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // unconditional (straight-line code lets hipcc use a counted lgkmcnt for F1 instead of lgkmcnt(0));
             // on the last tile this reads a stale stage and the values are never used
             fetch(smem + st_next * STAGE, 0, fa0, fb0);
-            mma16(fa1, fb1, 0);
+            mma16(fa1, fb1, HC<0>{});
+            if constexpr (NH == 4) mma16(fa1, fb1, HC<1>{});
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nk) issue(t + 2, st_prev);   // DMA issue slots hidden behind the 16 MFMAs just queued
+            if (t + 2 < nk) issue(t + 2, st_prev);   // DMA issue slots hidden behind the MFMAs just queued
             __builtin_amdgcn_sched_barrier(0);
-            mma16(fa1, fb1, 1);
+            mma16(fa1, fb1, HC<NH / 2>{});
+            if constexpr (NH == 4) mma16(fa1, fb1, HC<3>{});
             st_cur = st_next;
         }
 
-        // ---- epilogue: lane owns C[i = 16x + fr][j = 16u + fk + 4r] of its 64 x 64 wave tile
-        // C row of fragment x, lane fr (MC images interleave fragment pairs, see header)
-        auto crow = [&](int x) { return A_KC ? (wm0 + 16 * x + fr) : (wm0 + 32 * (x >> 1) + 2 * fr + (x & 1)); };
+        // ---- epilogue: lane owns C[i = crow(x)][j = 16u + ccol(fk, r)] of its 64 x 64 wave tile
+        // C row of fragment x, lane fr (MC images interleave the fragments' rows, see header)
+        auto crow = [&](int x) {
+            if constexpr (A_KC) return wm0 + 16 * x + fr;
+            else if constexpr (F64) return wm0 + 32 * (x >> 1) + 2 * fr + (x & 1);
+            else return wm0 + 4 * fr + x;
+        };
         const bool whole = (kt0 == 0) && (nk == KT);
+        if constexpr (!A_KC && !F64) {
+            // fp32 MC image: the lane's four fragments are the four CONSECUTIVE rows 4 fr .. 4 fr + 3 -> one 16-byte access per column
+            // (16 lanes cover 256 contiguous bytes of a column of C) instead of four 4-byte accesses 16 bytes apart
+            const int64_t i0 = m0 + wm0 + 4 * fr;
+            if (whole) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t j = n0 + wn0 + 16 * u + S::ccol(fk, r);
+                        f4_t v = f4_t{acc[0][u][r], acc[1][u][r], acc[2][u][r], acc[3][u][r]} * g.alpha;
+                        T* dst = g.C + i0 + j * g.ldc;
+                        if (g.tri) {                      // (the tri map is only used with A_KC operands; kept for completeness)
+#pragma unroll
+                            for (int x = 0; x < 4; ++x)
+                                if (i0 + x <= j) dst[x] = (g.beta != T(0)) ? v[x] + g.beta * dst[x] : v[x];
+                        } else if ((g.ldc & 3) == 0 && (((uintptr_t)g.C) & 15) == 0) {
+                            if (g.beta != T(0)) v += g.beta * *reinterpret_cast<const f4_t*>(dst);
+                            *reinterpret_cast<f4_t*>(dst) = v;
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) dst[x] = (g.beta != T(0)) ? v[x] + g.beta * dst[x] : v[x];
+                        }
+                    }
+            } else {
+                T* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<f4_t*>(out + (wm0 + 4 * fr) + (wn0 + 16 * u + S::ccol(fk, r)) * BM) =
+                            f4_t{acc[0][u][r], acc[1][u][r], acc[2][u][r], acc[3][u][r]};
+            }
+        } else
         if (whole) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -223,21 +311,21 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t i = m0 + crow(x);
-                        const int64_t j = n0 + wn0 + 16 * u + fk + 4 * r;
+                        const int64_t j = n0 + wn0 + 16 * u + S::ccol(fk, r);
                         if (g.tri && i > j) continue;
-                        double v = g.alpha * acc[x][u][r];
-                        if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
+                        T v = g.alpha * acc[x][u][r];
+                        if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
                         g.C[i + j * g.ldc] = v;
                     }
         } else {
-            double* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+            T* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        out[crow(x) + (wn0 + 16 * u + fk + 4 * r) * BM] = acc[x][u][r];
+                        out[crow(x) + (wn0 + 16 * u + S::ccol(fk, r)) * BM] = acc[x][u][r];
         }
         pos += nk;
     }
@@ -258,7 +346,8 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs g) {
 }
 
 // Sums the partial slabs of every tile that was cut by a share boundary, in increasing k order.
-__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P) {
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t P) {
     const int64_t KT = g.ktiles, tile = blockIdx.x;
     const int64_t W = g.ntiles * KT;
     const int64_t lo = tile * KT, hi = lo + KT;
@@ -275,16 +364,16 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs g, int64_t P)
     // blockIdx.y slices the tile so that a tile shared by many workgroups (tall Gram matrices) is not summed by one CU
     const int per = SLAB_ELEMS / (int)gridDim.y;
     for (int e = blockIdx.y * per + threadIdx.x; e < (int)(blockIdx.y + 1) * per; e += 256) {
-        double s = 0;
+        T s = 0;
         for (int64_t w = w0; w <= w1; ++w) {
             const int64_t first_tile_w = ((w * W) / P) / KT;
-            const double* slab = g.slab + (2 * w + (tile != first_tile_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+            const T* slab = g.slab + (2 * w + (tile != first_tile_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
             s += slab[e];
         }
         const int64_t i = m0 + (e % BM), j = n0 + (e / BM);
         if (g.tri && i > j) continue;
-        double v = g.alpha * s;
-        if (g.beta != 0.0) v += g.beta * g.C[i + j * g.ldc];
+        T v = g.alpha * s;
+        if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
         g.C[i + j * g.ldc] = v;
     }
 }
@@ -307,18 +396,26 @@ __global__ __launch_bounds__(256) void ssq_sum_kernel(int np, const double* __re
 namespace rlhip {
 
 // returns 1 if the problem was handled here, 0 if the caller should use the generic kernel, <0 on error
-int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, double alpha,
-                     const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
-                     int64_t ldc, double* ssqA_dev, int tri) {
-    static int enabled = -1;
+template <typename T>
+int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B,
+                 int64_t ldb, T beta, T* C, int64_t ldc, double* ssqA_dev, int tri) {
+    constexpr int BK = SkT<T>::BK, EPP = SkT<T>::EPP;
+    static int enabled = -1, enabled_f32 = -1;
     if (enabled < 0) {
         const char* e = getenv("RLHIP_STREAMK");
         enabled = e ? atoi(e) : 1;
+        const char* f = getenv("RLHIP_STREAMK_F32");
+        enabled_f32 = f ? atoi(f) : 1;
     }
     const int num_cu = c->num_cu;
-    if (!enabled || transB) return 0;
+    if (!enabled || transB || (sizeof(T) == 4 && !enabled_f32)) return 0;
+    // fp32: the kernel carries ONE fma chain per output entry through the whole K of a tile.  Beyond ~16k products the rounding of the
+    // growing partial sum (eps * K / sqrt 2) is 2-3x that of a cache-blocked host sgemm or of the split-K generic kernel (measured on
+    // BQRRP 65536^2: residual per column 4e-5 -> 7.5e-5; a second accumulator level costs more registers than the kernel has: 137 ->
+    // 123 TFLOP/s), so longer contractions stay on the generic kernel.  RLHIP_STREAMK_F32=2 lifts the cap (A/B measurements).
+    if (sizeof(T) == 4 && k > 16384 && enabled_f32 != 2) return 0;
     if (m % BM || n % BN || k % BK || m <= 0 || n <= 0 || k <= 0) return 0;
-    if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % 2 || ldb % 2) return 0;
+    if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % EPP || ldb % EPP) return 0;    // 16-byte aligned DMA pieces
     const int64_t tiles_m = m / BM, tiles_n = n / BN, ktiles = k / BK;
     int64_t ntiles = tiles_m * tiles_n;
     if (tri) {
@@ -328,33 +425,37 @@ int gemm_streamk_f64(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n,
     }
     const int64_t W = ntiles * ktiles;
     if (W < (int64_t)num_cu * 64) return 0;   // too little work to amortise the persistent launch
-    SkArgs g;
+    SkArgs<T> g;
     g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;
     g.tri = tri; g.ntiles = ntiles;
     const int64_t P = num_cu;
     size_t mark = rlhip_ws_mark(c);
-    g.slab = ws_alloc<double>(c, (size_t)2 * P * SLAB_ELEMS);
+    g.slab = ws_alloc<T>(c, (size_t)2 * P * SLAB_ELEMS);
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     g.ssq_part = ssqA_dev ? ws_alloc<double>(c, (size_t)P) : nullptr;
     constexpr int smem = NSTAGE * STAGE;
     if (transA) {
-        RLHIP_FUNC_LDS(c, gemm_sk_kernel<true>, smem);
-        hipLaunchKernelGGL(gemm_sk_kernel<true>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
+        RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, true>), smem);
+        hipLaunchKernelGGL((gemm_sk_kernel<T, true>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
     } else {
-        RLHIP_FUNC_LDS(c, gemm_sk_kernel<false>, smem);
-        hipLaunchKernelGGL(gemm_sk_kernel<false>, dim3((unsigned)P), dim3(512), smem, c->stream, g);
+        RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, false>), smem);
+        hipLaunchKernelGGL((gemm_sk_kernel<T, false>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
     }
     RLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_sk_fixup_kernel, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P);
+    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P);
     RLHIP_LAUNCH_CHECK();
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);
         RLHIP_LAUNCH_CHECK();
     }
     rlhip_ws_release(c, mark);
-    c->path_count[0]++;
+    c->path_count[sizeof(T) == 8 ? 0 : 1]++;
     return 1;
 }
+template int gemm_streamk<double>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, double, double*,
+                                  int64_t, double*, int);
+template int gemm_streamk<float>(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, float, float*, int64_t,
+                                 double*, int);
 
 }  // namespace rlhip

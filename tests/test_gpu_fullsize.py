@@ -397,3 +397,62 @@ def test_trsm_fused_with_an_ill_conditioned_block_in_the_middle(ctx):
     assert ctx.path_count(2) == f0 + 2 and ctx.path_count(3) == s0 + 8      # two fused runs around eight substitution sub-blocks
     X = d.cm_to_numpy(Bd)
     assert np.linalg.norm(X @ U - B) <= 1e-13 * np.linalg.norm(B) * n
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32 twin of the stream-K kernel (BQRRP's compact-WY products at BASELINE configs[3])
+# ---------------------------------------------------------------------------------------------------
+# (the work gate counts K-tiles of 128 bytes per row = 32 floats: twice the K of the fp64 shapes)
+@pytest.mark.parametrize("m,n,k,ta", [(38400, 256, 2048, "N"), (1280, 512, 32768, "N"), (1408 + 40, 256, 65536, "N"), (256, 256, 262144, "T"),
+                                      (640 + 5, 256, 131072, "T"), (2048, 512, 16384, "T"), (4096, 2048, 2048, "N"), (2048, 4096, 4096, "T"),
+                                      (8192, 2048, 16384, "T"), (16384, 1024, 2048, "N"),
+                                      (1408 + 44, 256, 65536, "N")])
+def test_streamk_gemm_f32_entrywise(ctx, m, n, k, ta):
+    import os
+
+    if k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2":
+        pytest.skip("contractions beyond 16384 stay on the split-K kernel in fp32 (rounding of one long fma chain); RLHIP_STREAMK_F32=2 lifts the cap")
+
+    d = _d()
+    rng = np.random.default_rng(m + n + k + 1)
+    A = rng.standard_normal((m, k)).astype(np.float32)
+    B = rng.standard_normal((k, n)).astype(np.float32)
+    C0 = rng.standard_normal((m, n)).astype(np.float32)
+    Ad = d.cm_from_numpy(A if ta == "N" else A.T.copy())
+    Bd = d.cm_from_numpy(B)
+    lda = m if ta == "N" else k
+    before = ctx.path_count(1)
+    Cd = d.cm_from_numpy(C0)
+    ctx.gemm(ta, "N", m, n, k, 1.5, Ad, lda, Bd, k, -0.5, Cd, m)
+    assert ctx.path_count(1) == before + 1, "the fp32 stream-K kernel did not take this shape"
+    r1 = d.cm_to_numpy(Cd)
+    ref = 1.5 * (A.astype(np.float64) @ B.astype(np.float64)) - 0.5 * C0
+    assert relerr(r1, ref) <= 4 * EPS32 * np.sqrt(k)            # fp32 fma chains of length k (measured class: ~1e-7 * sum |a b|)
+    Cd2 = d.cm_from_numpy(C0)
+    ctx.gemm(ta, "N", m, n, k, 1.5, Ad, lda, Bd, k, -0.5, Cd2, m)
+    assert np.array_equal(r1, d.cm_to_numpy(Cd2))                # bitwise run to run
+    Cd3 = d.cm_from_numpy(np.full((m, n), np.nan, dtype=np.float32))
+    ctx.gemm(ta, "N", m, n, k, 1.0, Ad, lda, Bd, k, 0.0, Cd3, m)
+    assert relerr(d.cm_to_numpy(Cd3), A.astype(np.float64) @ B.astype(np.float64)) <= 4 * EPS32 * np.sqrt(k)
+
+
+@pytest.mark.parametrize("n,k", [(1024, 32768), (512, 131072), (768, 49152), (2048, 16384)])
+def test_streamk_syrk_f32_upper_tiles(ctx, n, k):
+    import os
+
+    if k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2":
+        pytest.skip("see test_streamk_gemm_f32_entrywise")
+    d = _d()
+    rng = np.random.default_rng(n + k + 7)
+    A = rng.standard_normal((k, n)).astype(np.float32)
+    C0 = rng.standard_normal((n, n)).astype(np.float32)
+    Cd = d.cm_from_numpy(C0)
+    before = ctx.path_count(1)
+    ctx.syrk("U", "T", n, k, 2.0, d.cm_from_numpy(A), k, 0.25, Cd, n)
+    assert ctx.path_count(1) == before + 1
+    got = d.cm_to_numpy(Cd)
+    ref = 2.0 * (A.astype(np.float64).T @ A.astype(np.float64)) + 0.25 * C0
+    iu = np.triu_indices(n)
+    assert np.abs(got[iu] - ref[iu]).max() <= 4 * EPS32 * np.sqrt(k) * np.abs(ref).max()
+    il = np.tril_indices(n, -1)
+    assert np.array_equal(got[il], C0[il])
