@@ -77,19 +77,45 @@ struct SkArgs {
     int64_t ntiles;           // number of active tiles
 };
 
-// active tile index -> (tile_m, tile_n).  Full: row-major over N.  Tri (128 x 256 tiles, upper): column tn holds the
-// tiles tm < min(tiles_m, 2*tn + 2).
+// active tile index -> tile descriptor: first row m0 of the 128-row operand block, first column of the tile's left 128 columns (nA0)
+// and of its right 128 columns MINUS 128 (nB0: column jl >= 128 of the tile is global column nB0 + jl), and whether the tile is
+// written transposed.
+//   Full map: row-major over N (nA0 == nB0 == 256 tn).
+//   Tri map (syrk, upper triangle of the n x n Gram matrix, T = n / 128 block rows): block row i needs the 128-blocks i .. T-1 of
+//   its row.  They are taken in PAIRS starting at the diagonal block (tiles (i; i + 2p, i + 2p + 1): floor((T - i) / 2) per row);
+//   an odd row is left with the single block (i, T-1).  Those leftovers all share the column block T-1, so two of them are computed
+//   as ONE tile of the TRANSPOSED product  A_{T-1}^T [A_r1 A_r2]  (= [G(r1, T-1)^T  G(r2, T-1)^T]) and written transposed.
+//   n = 1024: 16 + 2 = 18 tiles instead of the 20 of a 256-aligned map (of which four were half below the diagonal).
+struct SkTile { int64_t m0, nA0, nB0; int transposed, single; };
 template <typename T>
-__device__ __forceinline__ void sk_tile(const SkArgs<T>& g, int64_t a, int64_t& tm, int64_t& tn) {
-    if (!g.tri) { tm = a / g.tiles_n; tn = a - tm * g.tiles_n; return; }
-    tn = 0;
-    for (;;) {
-        int64_t cnt = 2 * tn + 2;
-        if (cnt > g.tiles_m) cnt = g.tiles_m;
-        if (a < cnt) break;
-        a -= cnt; ++tn;
+__device__ __forceinline__ SkTile sk_tile(const SkArgs<T>& g, int64_t a) {
+    SkTile t;
+    t.transposed = 0; t.single = 0;
+    if (!g.tri) {
+        const int64_t tm = a / g.tiles_n, tn = a - tm * g.tiles_n;
+        t.m0 = tm * BM; t.nA0 = t.nB0 = tn * BN;
+        return t;
     }
-    tm = a;
+    const int64_t Tb = g.tiles_m;                   // 128-blocks per side
+    for (int64_t i = 0; i < Tb; ++i) {
+        const int64_t cnt = (Tb - i) / 2;
+        if (a < cnt) { t.m0 = i * BM; t.nA0 = t.nB0 = (i + 2 * a) * BM; return t; }
+        a -= cnt;
+    }
+    // leftover halves: odd block rows 1, 3, ..., paired two by two
+    const int64_t r1 = 4 * a + 1;
+    const int64_t r2 = (r1 + 2 < Tb) ? r1 + 2 : r1;     // an unpaired last one: the right half recomputes the left one and is not written
+    t.m0 = (Tb - 1) * BM; t.nA0 = r1 * BM; t.nB0 = r2 * BM - BM; t.transposed = 1; t.single = (r2 == r1);
+    return t;
+}
+
+// element (il, jl) of a tile -> position in C; false when the tri map must not write it
+__device__ __forceinline__ bool sk_cpos(const SkTile& t, int tri, int64_t il, int64_t jl, int64_t& i, int64_t& j) {
+    if (t.single && jl >= BM) return false;
+    const int64_t col = (jl < BM ? t.nA0 : t.nB0) + jl;
+    if (t.transposed) { i = col; j = t.m0 + il; }
+    else { i = t.m0 + il; j = col; }
+    return !(tri && i > j);
 }
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
@@ -153,21 +179,22 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         const int64_t kt0 = pos - tile * KT;
         int64_t nk = KT - kt0;
         if (nk > we - pos) nk = we - pos;
-        int64_t tile_m, tile_n;
-        sk_tile(g, tile, tile_m, tile_n);
-        const int64_t m0 = tile_m * BM, n0 = tile_n * BN, k0 = kt0 * BK;
+        const SkTile td = sk_tile(g, tile);
+        const int64_t m0 = td.m0, n0 = td.nA0, k0 = kt0 * BK;
 
         const T* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
-        const T* Bg = g.B + k0 + n0 * g.ldb;
+        const T* Bg = g.B + k0 + td.nA0 * g.ldb;              // columns 0 .. 127 of the tile
+        const T* Bg1 = g.B + k0 + td.nB0 * g.ldb;             // columns 128 .. 255 (the same block row for ordinary tiles)
 
         auto issue = [&](int64_t t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
             unsigned char* st = smem + stage * STAGE;
             const T* Ap = Ag + t * a_step;
             const T* Bp = Bg + t * BK;
+            const T* Bp1 = Bg1 + t * BK;
 #pragma unroll
             for (int h = 0; h < 2; ++h) glds16(Ap + a_src[h], st + (wid + 8 * h) * 1024);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) glds16(Bp + b_src[h], st + STAGE_A + (wid + 8 * h) * 1024);
+            for (int h = 0; h < 4; ++h) glds16((h < 2 ? Bp : Bp1) + b_src[h], st + STAGE_A + (wid + 8 * h) * 1024);
         };
 
         acc_t acc[4][4];
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         //   tile t-1, so tile t+2 may be DMA'd into t-1's stage and F0 of tile t+1 may be fetched while the
         //   MFMAs of F1 run.  The matrix pipe therefore never waits for a tile boundary.
         frag_t fa0[4], fb0[4], fa1[4], fb1[4];
-        const bool do_ssq = (g.ssq_part != nullptr) && (tile_n == 0);   // every A element is staged once by tile_n == 0
+        const bool do_ssq = (g.ssq_part != nullptr) && (td.nA0 == 0);   // every A element is staged once by tile_n == 0
         auto fetch = [&](const unsigned char* sA, int sg, frag_t (&a)[4], frag_t (&b)[4]) {
             const unsigned char* sB = sA + STAGE_A;
             const int kc = sg ? kc_off1 : kc_off0;
@@ -310,9 +337,8 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int64_t i = m0 + crow(x);
-                        const int64_t j = n0 + wn0 + 16 * u + S::ccol(fk, r);
-                        if (g.tri && i > j) continue;
+                        int64_t i, j;
+                        if (!sk_cpos(td, g.tri, crow(x), wn0 + 16 * u + S::ccol(fk, r), i, j)) continue;
                         T v = g.alpha * acc[x][u][r];
                         if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
                         g.C[i + j * g.ldc] = v;
@@ -358,9 +384,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t
     int64_t w1 = w0;
     while (((w1 + 1) * W) / P < hi) ++w1;
     if (w0 == w1) return;   // one workgroup covered the whole tile and wrote C itself
-    int64_t tile_m, tile_n;
-    sk_tile(g, tile, tile_m, tile_n);
-    const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+    const SkTile td = sk_tile(g, tile);
     // blockIdx.y slices the tile so that a tile shared by many workgroups (tall Gram matrices) is not summed by one CU
     const int per = SLAB_ELEMS / (int)gridDim.y;
     for (int e = blockIdx.y * per + threadIdx.x; e < (int)(blockIdx.y + 1) * per; e += 256) {
@@ -370,8 +394,8 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t
             const T* slab = g.slab + (2 * w + (tile != first_tile_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
             s += slab[e];
         }
-        const int64_t i = m0 + (e % BM), j = n0 + (e / BM);
-        if (g.tri && i > j) continue;
+        int64_t i, j;
+        if (!sk_cpos(td, g.tri, e % BM, e / BM, i, j)) continue;
         T v = g.alpha * s;
         if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
         g.C[i + j * g.ldc] = v;
@@ -421,7 +445,8 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     if (tri) {
         if (m != n) return 0;
         ntiles = 0;
-        for (int64_t tn = 0; tn < tiles_n; ++tn) ntiles += (2 * tn + 2 < tiles_m) ? (2 * tn + 2) : tiles_m;
+        for (int64_t i = 0; i < tiles_m; ++i) ntiles += (tiles_m - i) / 2;      // pairs of 128-blocks from the diagonal block on
+        ntiles += (tiles_m / 2 + 1) / 2;                                       // the leftover halves of the odd rows, two per tile
     }
     const int64_t W = ntiles * ktiles;
     if (W < (int64_t)num_cu * 64) return 0;   // too little work to amortise the persistent launch
