@@ -101,7 +101,7 @@ constexpr int PS_MAXN = 448;
 constexpr int PS_LD = 34;          // column stride (doubles) of the LDS copy of U12: conflict-free MFMA fragment reads
 
 template <typename T>
-__global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict__ A, int64_t lda, int* __restrict__ info) {
+__global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict__ A, int64_t lda, int* __restrict__ info, int info_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
     T* sU11 = reinterpret_cast<T*>(ps_smem);          // [32][33]
     T* sRow = sU11 + 32 * 33;                          // [32] : row k of the diagonal block during its factorization
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
     T* sU12 = sInv + 32;                               // [rest16][PS_LD] : sU12[c*PS_LD + l] = U12[l, c], zero padded to 16 columns
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (info_base > 0 && *info != 0) return;           // a diagonal block of an earlier step of the two-level driver already failed
     if (tid == 0) s_bad = 0;
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += NB) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
         __threadfence_block();
         __syncthreads();
     }
-    if (tid == 0) *info = s_bad;
+    if (tid == 0) *info = s_bad ? info_base + s_bad : 0;
 }
 
 }  // namespace
@@ -238,6 +239,9 @@ template <typename T>
 int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
               int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev = nullptr,
               int* ssq_done = nullptr);
+
+template <typename T>
+int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B, int64_t ldb);
 
 template <typename T>
 int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
@@ -251,11 +255,51 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
     if (use_small && n <= PS_MAXN) {
         const size_t smem = (size_t)(32 * 33 + 64 + (size_t)(n + 16) * PS_LD) * sizeof(T);
         RLHIP_FUNC_LDS(c, potrf_small_kernel<T>, 150 * 1024);
-        hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, d_info);
+        hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, d_info, 0);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
         *info_host = *(int*)(c->h_mail + 8);
+        return 0;
+    }
+    static int two_level = -1;
+    if (two_level < 0) { const char* e = getenv("RLHIP_POTRF_TWO_LEVEL"); two_level = (e && atoi(e) == 0) ? 0 : 1; }
+    if (use_small && two_level) {
+        // Two-level blocking for the n x n Gram matrices of CQRRPT / BQRRP's Cholesky-QR panels (n = 1024 .. 4096): 256-wide block steps,
+        //   diagonal block      : the one-workgroup kernel above (its 32-wide panels never leave the CU),
+        //   block row           : U12 = U11^-T A12 as the RIGHT-side solve of the transposed slab (W = A12^T, W <- W U11^-1, A12 = W^T)
+        //                         on the blocked trsm of tri.hip,
+        //   trailing update     : A22 -= U12^T U12 with K = 256 on the MFMA tri-tile GEMM.
+        // Against the 32-wide right-looking loop below (one panel launch + one K = 32 update per 32 columns: 3.9 ms at n = 1024) this
+        // runs the same flops in a quarter of the launches with 8x deeper updates.
+        constexpr int64_t BS = 256;
+        const size_t mark = rlhip_ws_mark(c);
+        T* W = (n > BS) ? ws_alloc<T>(c, (size_t)(n - BS) * BS) : nullptr;
+        if (n > BS && !W) { rlhip_ws_release(c, mark); return 2; }
+        RLHIP_FUNC_LDS(c, potrf_small_kernel<T>, 150 * 1024);
+        hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, c->stream, d_info);
+        int rc = 0;
+        for (int64_t j0 = 0; j0 < n && !rc; j0 += BS) {
+            const int64_t jb = (n - j0 < BS) ? (n - j0) : BS;
+            const int64_t rest = n - j0 - jb;
+            T* A11 = A + j0 + j0 * lda;
+            const size_t smem = (size_t)(32 * 33 + 64 + (size_t)(jb + 16) * PS_LD) * sizeof(T);
+            hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)jb, A11, lda, d_info, (int)j0 + 1);
+            RLHIP_LAUNCH_CHECK();
+            if (rest <= 0) break;
+            T* A12 = A + j0 + (j0 + jb) * lda;
+            T* A22 = A + (j0 + jb) + (j0 + jb) * lda;
+            rc = transpose<T>(c, jb, rest, A12, lda, W, rest, 0);
+            if (!rc) rc = trsm_right_upper<T>(c, 0, rest, jb, T(1), A11, lda, W, rest);
+            if (!rc) rc = transpose<T>(c, rest, jb, W, rest, A12, lda, 0);
+            if (!rc) rc = gemm_impl<T>(c, 1, 0, rest, rest, jb, T(-1), A12, lda, A12, lda, T(1), A22, lda, 1);
+        }
+        rlhip_ws_release(c, mark);
+        if (rc) return rc;
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        const int v = *(int*)(c->h_mail + 8);
+        *info_host = v ? v - 1 : 0;
         return 0;
     }
     hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, c->stream, d_info);

@@ -552,7 +552,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     const bool use_tag = tag_on && m < ((int64_t)1 << 31);
     constexpr size_t TW = sizeof(T) / 4;
     const size_t tw_words = 2 * (size_t)(TW * Gmax + Gmax + TW * Gmax * PB + TW * PB);
-    g.tw = use_tag ? ws_alloc<unsigned long long>(c, tw_words) : nullptr;
+    g.tw = use_tag ? (unsigned long long*)rlhip_xchg_buffer(c, tw_words * sizeof(unsigned long long)) : nullptr;   // uncached exchange memory of the context
     g.tag_base = 0;
     // tags: (panel index + 1) * 64 + column.  The word buffer is cleared at the start of every call and belongs to this call's workspace, so
     // a tag is unique where it can be seen and never equals the cleared pattern (m < 2^31 keeps 2 * j0 + 64 inside 32 bits)

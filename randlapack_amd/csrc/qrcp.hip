@@ -16,6 +16,7 @@
 // columns 36 ms -> single rendezvous + fence-free publication: see DESIGN.md.
 #include "rlhip_internal.h"
 #include <cstdlib>
+#include <cstdio>
 #include <cmath>
 #include <limits>
 
@@ -251,6 +252,396 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
             T* dst = g.A + j * g.lda;
             for (int64_t i = tid; i < m; i += 256) dst[i] = src[i];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same factorization with a FLAG-LESS exchange (the scheme of the LU panel kernel, lu.hip): everything that crosses workgroups
+// travels as 8-byte words {step tag : 32-bit payload} written with write-through stores and simply re-read until they carry the
+// step's tag.  No store drain, no barrier counter whose arrivals serialise in L2, no acquire fence, no speculative reflectors:
+//   1. every workgroup publishes (best partial norm, position) of its owned columns; the owner of position k publishes that column;
+//      a workgroup whose candidate would have ranked among the first few of the previous step's records finishes it (dlarfg) right
+//      away and publishes the finished column in its own slot while the records travel;
+//   2. every workgroup reads all G records (thread w <- workgroup w) and reduces them: the winner is known;
+//   3. the WINNER forms the reflector of its column and publishes column + tau + jpvt entry -- unless it already has (step 1);
+//   4. everybody else spins on the winner's slot (one batch of loads per thread) and stages the column in LDS;
+//   5. owners install the two moved columns; 6. everybody applies H to the columns it owns and down-dates their norms.
+// One store->load hand-off per step when the guess of step 1 holds (two otherwise) instead of drain + atomic arrival + poll + read.
+// A hand-off through memory costs ~3 us on this part (8 XCDs: agent-scope data has to pass the memory side), which is the floor of
+// any one-decision-per-column scheme; measured 1280 x 1024 fp64: rendezvous kernel 15.9, this one see DESIGN.md.  The statements
+// (candidate order, dlarfg, dlaqp2 down-date) are those of the kernel above; only the dot products of step 6 are summed in four
+// partial sums.  The speculation decides WHEN the winner's dlarfg runs, never what it computes.  jpvt entries live with their
+// columns in LDS (they move with the swaps) and are written out once at the end: no cross-workgroup ordering is needed for them.
+// Words alternate between two buffers by step parity: a workgroup publishes step k + 1 only after it has consumed everybody's step-k
+// records, so the words of step k are dead for all readers before anyone overwrites them at step k + 2.
+template <typename T>
+struct QrcpTagArgs {
+    int64_t m, n;
+    T* A; int64_t lda;
+    int64_t* jpvt; T* tau;
+    unsigned long long* tw;   // 2 x words_per_parity, zeroed by the host before the launch
+    int* info;                // -7: a spin ran out (lost word): the host reports an error instead of hanging the device
+    T tol3z;
+    int64_t max_steps;
+    int hq_formula;
+};
+
+constexpr int QT_NV = 8;      // values fetched per thread per batch of polling loads
+
+__device__ __forceinline__ unsigned qt_get_u32(const unsigned long long* q, unsigned tag, int* info) {
+    for (int spins = 0;; ++spins) {
+        const unsigned long long w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) == tag) return (unsigned)w;
+        if (spins > (1 << 22)) { atomicExch(info, -7); return (unsigned)w; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// fetch `cnt` (<= QT_NV) values idx[0..cnt) of the tagged array q -- and optionally one more 32-bit word xq -- in ONE batch of loads.
+// The first batch is optimistic (data that is already there costs a single round trip); if a word is still missing the thread waits
+// on one word and then takes the whole batch again.
+template <typename T>
+__device__ __forceinline__ void qt_get(const unsigned long long* q, const int64_t (&idx)[QT_NV], int cnt, unsigned tag, T (&out)[QT_NV], int* info,
+                                       const unsigned long long* xq = nullptr, unsigned* xout = nullptr) {
+    constexpr int W = (int)sizeof(T) / 4;
+    if (cnt <= 0 && !xq) return;
+    for (int spins = 0;; ++spins) {
+        unsigned long long w[QT_NV * W];
+        unsigned long long xw = (unsigned long long)tag << 32;
+#pragma unroll
+        for (int r = 0; r < QT_NV; ++r) {
+#pragma unroll
+            for (int h = 0; h < W; ++h) w[r * W + h] = (r < cnt) ? __hip_atomic_load(q + idx[r] * W + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        if (xq) xw = __hip_atomic_load(xq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = (unsigned)(xw >> 32) == tag;
+#pragma unroll
+        for (int r = 0; r < QT_NV * W; ++r) ok = ok && (r / W >= cnt || (unsigned)(w[r] >> 32) == tag);
+        if (ok || spins > 64) {
+            if (!ok) atomicExch(info, -7);
+#pragma unroll
+            for (int r = 0; r < QT_NV; ++r) {
+                if constexpr (W == 1) out[r] = (T)__uint_as_float((unsigned)w[r]);
+                else out[r] = (T)__longlong_as_double((long long)(((unsigned long long)(unsigned)w[2 * r + 1] << 32) | (unsigned)w[2 * r]));
+            }
+            if (xout) *xout = (unsigned)xw;
+            return;
+        }
+        // wait on ONE word (the last one this thread needs: stores tend to land in order), then the whole batch again
+        (void)qt_get_u32(xq ? xq : q + idx[cnt - 1] * W + (W - 1), tag, info);
+    }
+}
+// one value (both halves of a double) plus one 32-bit word, requested together
+template <typename T>
+__device__ __forceinline__ T qt_get1(const unsigned long long* q, int64_t i, unsigned tag, int* info, const unsigned long long* xq, unsigned* xout) {
+    constexpr int W = (int)sizeof(T) / 4;
+    for (int spins = 0;; ++spins) {
+        const unsigned long long lo = __hip_atomic_load(q + W * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = (W == 2) ? __hip_atomic_load(q + W * i + (W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lo;
+        const unsigned long long xw = __hip_atomic_load(xq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag && (unsigned)(xw >> 32) == tag;
+        if (ok || spins > (1 << 22)) {
+            if (!ok) atomicExch(info, -7);
+            *xout = (unsigned)xw;
+            if constexpr (W == 1) return (T)__uint_as_float((unsigned)lo);
+            else return (T)__longlong_as_double((long long)((hi << 32) | (unsigned)lo));
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void qt_put_u32(unsigned long long* q, unsigned tag, unsigned payload) {
+    __hip_atomic_store(q, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void qt_put(unsigned long long* q, int64_t i, unsigned tag, T v) {
+    if constexpr (sizeof(T) == 4) qt_put_u32(q + i, tag, __float_as_uint((float)v));
+    else {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong((double)v);
+        qt_put_u32(q + 2 * i, tag, (unsigned)bits);
+        qt_put_u32(q + 2 * i + 1, tag, (unsigned)(bits >> 32));
+    }
+}
+// words per parity: records (W G + G), one finished-column slot PER workgroup (W (m + 1) + 1 each), position-k column (W (m + 2) + 1)
+template <typename T>
+__host__ __device__ inline size_t qt_words(int64_t m, int64_t G) {
+    constexpr size_t W = sizeof(T) / 4;
+    return W * (size_t)G + (size_t)G + (size_t)G * (W * (size_t)(m + 1) + 1) + W * (size_t)(m + 2) + 1;
+}
+constexpr int QT_SPEC = 6;    // workgroups whose candidate ranked this high among the previous step's records finish it speculatively
+
+template <typename T>
+__global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
+    constexpr int W = (int)sizeof(T) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // 32-bit indices throughout (the host guarantees m, n < 2^31 - 2) and owned columns addressed by SLOT s (position me + G s):
+    // 64-bit divisions by G on every access cost ~1 us per step
+    const int G = (int)gridDim.x, me = (int)blockIdx.x;
+    const int m = (int)g.m, n = (int)g.n;
+    const int kmin = m < n ? m : n;
+    const int kmax = (g.max_steps >= 0 && g.max_steps < kmin) ? (int)g.max_steps : kmin;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qr_smem[];
+    const int cpw = (n + G - 1) / G;                     // owned positions: j = me + G*s, s < cpw
+    int64_t* l_jp = reinterpret_cast<int64_t*>(qr_smem);  // jpvt entries of the owned positions
+    T* l_vn1 = reinterpret_cast<T*>(l_jp + cpw);
+    T* l_vn2 = l_vn1 + cpw;
+    T* l_v = l_vn2 + cpw;                                // the step's finished pivot column (m)
+    T* lds_cols = l_v + m;
+    __shared__ T s_val[4];
+    __shared__ T s_wv[4];
+    __shared__ int64_t s_wp[4];
+    __shared__ int s_ww[4];
+    __shared__ int s_cnt[4];
+    __shared__ T s_tau;
+    __shared__ unsigned s_jp;
+    auto colslot = [&](int sl) -> T* { return lds_cols + (size_t)sl * m; };
+    for (int sl = 0, j = me; j < n; ++sl, j += G) {
+        T* dst = colslot(sl);
+        const T* src = g.A + (int64_t)j * g.lda;
+        for (int i = tid; i < m; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int sl = wid; sl < cpw; sl += 4) {
+        const int j = me + G * sl;
+        if (j >= n) continue;
+        const T* col = colslot(sl);
+        T ss = 0;
+        for (int i = lane; i < m; i += 64) ss += col[i] * col[i];
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            T nr = sqrt(ss);
+            l_vn1[sl] = nr; l_vn2[sl] = nr;
+            l_jp[sl] = j + 1;
+        }
+    }
+    __syncthreads();
+    const size_t PW = qt_words<T>(m, G);
+    const size_t CS = (size_t)W * (m + 1) + 1;           // words of one finished-column slot
+    T hv_prev = std::numeric_limits<T>::infinity();       // record of workgroup `tid` at the previous step (G <= 256); +inf: nobody speculates at step 0
+    // dlarfg on the column at position `pos` (rows k+1.. are scaled, row k becomes beta), staged in l_v and published in this workgroup's slot
+    auto finish_column = [&](int psl, int k, unsigned tag, unsigned long long* cw) {
+        const T* col = colslot(psl);
+        T ss = 0;
+        for (int i = k + 1 + tid; i < m; i += 256) ss += col[i] * col[i];
+        ss = wave_sum(ss);
+        __syncthreads();
+        if (lane == 0) s_val[wid] = ss;
+        __syncthreads();
+        const T xnorm = sqrt(s_val[0] + s_val[1] + s_val[2] + s_val[3]);
+        const T alpha = col[k];
+        T beta = alpha, scale = 0, my_tau = 0;
+        if (xnorm != T(0)) {
+            beta = -copysign(hypot(alpha, xnorm), alpha);
+            my_tau = (beta - alpha) / beta;
+            scale = T(1) / (alpha - beta);
+        }
+        for (int i = tid; i < m; i += 256) {
+            T v = col[i];
+            if (i == k) v = beta; else if (i > k) v *= scale;
+            l_v[i] = v;
+            qt_put<T>(cw, i, tag, v);
+        }
+        if (tid == 0) { qt_put<T>(cw, m, tag, my_tau); qt_put_u32(cw + (size_t)W * (m + 1), tag, (unsigned)l_jp[psl]); s_tau = my_tau; }
+    };
+#ifdef RLHIP_QT_PROF
+    long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt = wall_clock64();
+#define QT_MARK(i) { const long long now_ = wall_clock64(); pf[i] += now_ - pt; pt = now_; }
+#else
+#define QT_MARK(i)
+#endif
+    int own_k = 0, slot_k = 0;                            // k = own_k + G slot_k
+    for (int k = 0; k < kmax; ++k, own_k = (own_k + 1 == G ? 0 : own_k + 1), slot_k += (own_k == 0)) {
+        const unsigned tag = (unsigned)(k + 1);
+        unsigned long long* base = g.tw + (size_t)(k & 1) * PW;
+        unsigned long long* hv = base;                          // [W G]   best partial norm of workgroup w
+        unsigned long long* hp = hv + (size_t)W * G;            // [G]     its position (n: nothing to offer); bit 31: column already finished
+        unsigned long long* cws = hp + G;                       // [G][CS] finished pivot column of workgroup w: m values, tau, jpvt entry
+        unsigned long long* kc = cws + (size_t)G * CS;          // [W (m + 2)] the column at position k, vn1, vn2
+        unsigned long long* kcj = kc + (size_t)W * (m + 2);     // [1]     its jpvt entry
+        unsigned long long* my_cw = cws + (size_t)me * CS;
+        // ---- 1. local candidate over owned positions >= k (first maximum)
+        T best = T(-1); int bpos = n, bsl = 0;
+        for (int sl = 0, j = me; j < n; ++sl, j += G) {
+            if (j < k) continue;
+            T v = l_vn1[sl];
+            if (v > best) { best = v; bpos = j; bsl = sl; }
+        }
+        //      Would this candidate have ranked among the first QT_SPEC of the previous step's records?  Then finish it NOW, while the
+        //      records travel: if it wins, its column is already on its way when the others learn the winner (one hand-off per step
+        //      instead of two).  The guess only decides WHEN the winner's dlarfg runs, never what it computes.
+        int ahead = 0;
+        {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(tid < G && hv_prev > best);
+            if (lane == 0) s_cnt[wid] = __builtin_popcountll(bal);
+            __syncthreads();
+            ahead = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        const bool spec = (bpos < n) && (ahead < QT_SPEC);
+        if (tid == 0) { qt_put<T>(hv, me, tag, best); qt_put_u32(hp + me, tag, (unsigned)bpos | (spec ? 0x80000000u : 0u)); }
+        if (me == own_k) {                                      // the owner of position k publishes that column
+            const T* col = colslot(slot_k);
+            for (int i = tid; i < m; i += 256) qt_put<T>(kc, i, tag, col[i]);
+            if (tid == 0) { qt_put<T>(kc, m, tag, l_vn1[slot_k]); qt_put<T>(kc, m + 1, tag, l_vn2[slot_k]); qt_put_u32(kcj, tag, (unsigned)l_jp[slot_k]); }
+        }
+        QT_MARK(0)
+        // a speculating workgroup is the likely winner, and the winner receives the column that sits at position k: fetch it while the
+        // records travel (registers; unused if somebody else wins)
+        T kpre[QT_NV]; unsigned kpre_jp = 0; bool have_k = false;
+        if (spec) {
+            finish_column(bsl, k, tag, my_cw);
+            if (bpos != k && m + 2 <= 256 * QT_NV) {
+                int64_t ix[QT_NV]; int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < QT_NV; ++r) { ix[r] = tid + 256 * r; if (ix[r] < m + 2) cnt = r + 1; }
+                qt_get<T>(kc, ix, cnt, tag, kpre, g.info, tid == 0 ? kcj : nullptr, &kpre_jp);
+                have_k = true;
+            }
+        }
+        QT_MARK(1)
+        // ---- 2. global pivot (every workgroup, redundantly): max norm, ties -> smallest position
+        {
+            T v = T(-1); int q = n; int w = own_k; unsigned fl = 0;
+            T mine = T(-1);
+            for (int ww = tid; ww < G; ww += 256) {
+                unsigned pw; const T v2 = qt_get1<T>(hv, ww, tag, g.info, hp + ww, &pw);     // value and position words in one batch of loads
+                const int q2 = (int)(pw & 0x7fffffffu);
+                mine = v2;
+                if (q2 < n && (v2 > v || (v2 == v && q2 < q))) { v = v2; q = q2; w = ww; fl = pw >> 31; }
+            }
+            hv_prev = (tid < G) ? mine : T(-1);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const T v2 = __shfl_xor(v, off); const int q2 = __shfl_xor(q, off); const int w2 = __shfl_xor(w, off);
+                const unsigned f2 = __shfl_xor(fl, off);
+                if (q2 < n && (v2 > v || (v2 == v && q2 < q))) { v = v2; q = q2; w = w2; fl = f2; }
+            }
+            if (lane == 0) { s_wv[wid] = v; s_wp[wid] = q; s_ww[wid] = w | (int)(fl << 30); }
+        }
+        __syncthreads();
+        T gv = s_wv[0]; int p = (int)s_wp[0]; int wf = s_ww[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_wp[w] < n && (s_wv[w] > gv || (s_wv[w] == gv && s_wp[w] < p))) { gv = s_wv[w]; p = (int)s_wp[w]; wf = s_ww[w]; }
+        int wstar = wf & 0x3fffffff;
+        bool finished = (wf >> 30) & 1;
+        int psl = bsl;                                         // slot of position p in the winner's LDS (meaningful in the winner only)
+        if (p >= n) { p = k; wstar = own_k; finished = false; psl = slot_k; }   // nothing comparable left (NaNs): natural order
+        if (tid == wstar) hv_prev = T(-1);            // the winner's record is consumed; its next candidate is unknown to the others
+        QT_MARK(2)
+        // ---- 3. / 4. the winner finishes its column unless it already has; the others fetch it from the winner's slot
+        const unsigned long long* cw = cws + (size_t)wstar * CS;
+        if (me == wstar) {
+            if (!finished) finish_column(psl, k, tag, my_cw);
+        } else {
+            for (int i0 = 0; i0 < m + 1; i0 += 256 * QT_NV) {
+                int64_t ix[QT_NV]; T vv[QT_NV];
+                int cnt = 0;
+#pragma unroll
+                for (int r = 0; r < QT_NV; ++r) { ix[r] = i0 + tid + 256 * r; if (ix[r] < m + 1) cnt = r + 1; }
+                const bool want_jp = (me == own_k && tid == 0 && i0 == 0);          // the owner of position k also takes the jpvt entry
+                unsigned xj = 0;
+                qt_get<T>(cw, ix, cnt, tag, vv, g.info, want_jp ? cw + (size_t)W * (m + 1) : nullptr, &xj);
+                if (want_jp) s_jp = xj;
+#pragma unroll
+                for (int r = 0; r < QT_NV; ++r)
+                    if (r < cnt) { if (ix[r] < m) l_v[ix[r]] = vv[r]; else s_tau = vv[r]; }
+            }
+        }
+        __syncthreads();
+        const T tauk = s_tau;
+        QT_MARK(3)
+        // ---- 5. install the moved columns; the jpvt entries move with them
+        int64_t jp_p = 0;
+        if (me == own_k && tid == 0) jp_p = (me == wstar) ? l_jp[psl] : (int64_t)s_jp;
+        if (p != k && me == wstar) {                           // the winner owns position p: it receives the column that was at k
+            T* col = colslot(psl);
+            if (have_k) {
+#pragma unroll
+                for (int r = 0; r < QT_NV; ++r) {
+                    const int i = tid + 256 * r;
+                    if (i < m) col[i] = kpre[r];
+                    else if (i == m) l_vn1[psl] = kpre[r];
+                    else if (i == m + 1) l_vn2[psl] = kpre[r];
+                }
+                if (tid == 0) l_jp[psl] = (int64_t)kpre_jp;
+            } else {
+                for (int i0 = 0; i0 < m + 2; i0 += 256 * QT_NV) {
+                    int64_t ix[QT_NV]; T vv[QT_NV];
+                    int cnt = 0;
+#pragma unroll
+                    for (int r = 0; r < QT_NV; ++r) { ix[r] = i0 + tid + 256 * r; if (ix[r] < m + 2) cnt = r + 1; }
+                    const bool want_jp = (tid == 0 && i0 == 0);
+                    unsigned xj = 0;
+                    qt_get<T>(kc, ix, cnt, tag, vv, g.info, want_jp ? kcj : nullptr, &xj);
+                    if (want_jp) l_jp[psl] = (int64_t)xj;
+#pragma unroll
+                    for (int r = 0; r < QT_NV; ++r)
+                        if (r < cnt) {
+                            if (ix[r] < m) col[ix[r]] = vv[r];
+                            else if (ix[r] == m) l_vn1[psl] = vv[r];
+                            else l_vn2[psl] = vv[r];
+                        }
+                }
+            }
+        }
+        if (me == own_k) {
+            T* col = colslot(slot_k);
+            for (int i = tid; i < m; i += 256) col[i] = l_v[i];
+            if (tid == 0) { g.tau[k] = tauk; l_jp[slot_k] = jp_p; }
+        }
+        __syncthreads();
+        QT_MARK(4)
+        // ---- 6. apply H = I - tau v v^T (v_k = 1) to owned columns j > k, one wave per column; down-date norms.  Rows are walked in
+        //      64-row slabs from the slab holding row k; four slabs per trip keep four independent LDS loads / fma chains in flight.
+        const int r_lo = (k & ~63) + lane;
+        for (int sl = wid; sl < cpw; sl += 4) {
+            const int j = me + G * sl;
+            if (j <= k || j >= n) continue;
+            T* col = colslot(sl);
+            if (tauk != T(0)) {
+                T w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                int i = r_lo;
+                for (; i + 192 < m; i += 256) {
+                    const T v0 = (i > k) ? l_v[i] : (i == k ? T(1) : T(0));
+                    w0 += v0 * col[i]; w1 += l_v[i + 64] * col[i + 64]; w2 += l_v[i + 128] * col[i + 128]; w3 += l_v[i + 192] * col[i + 192];
+                }
+                for (; i < m; i += 64) w0 += ((i > k) ? l_v[i] : (i == k ? T(1) : T(0))) * col[i];
+                const T w = wave_sum((w0 + w1) + (w2 + w3)) * tauk;
+                i = r_lo;
+                for (; i + 192 < m; i += 256) {
+                    const T v0 = (i > k) ? l_v[i] : (i == k ? T(1) : T(0));
+                    col[i] -= w * v0; col[i + 64] -= w * l_v[i + 64]; col[i + 128] -= w * l_v[i + 128]; col[i + 192] -= w * l_v[i + 192];
+                }
+                for (; i < m; i += 64) col[i] -= w * ((i > k) ? l_v[i] : (i == k ? T(1) : T(0)));
+            }
+            T v1 = l_vn1[sl];
+            if (v1 != T(0)) {
+                T akj = fabs(col[k]);
+                T r = akj / v1;
+                T temp = g.hq_formula ? (T(1) + r) * (T(1) - r) : T(1) - r * r;
+                temp = temp > T(0) ? temp : T(0);
+                T q = v1 / l_vn2[sl];
+                T temp2 = temp * q * q;
+                if (temp2 <= g.tol3z) {
+                    T ss = 0;
+                    for (int i = k + 1 + lane; i < m; i += 64) ss += col[i] * col[i];
+                    ss = wave_sum(ss);
+                    v1 = sqrt(ss);
+                    if (lane == 0) { l_vn1[sl] = v1; l_vn2[sl] = v1; }
+                } else {
+                    if (lane == 0) l_vn1[sl] = v1 * sqrt(temp);
+                }
+            }
+        }
+        __syncthreads();
+        QT_MARK(5)
+    }
+#ifdef RLHIP_QT_PROF
+    if (tid == 0 && me == G / 2) for (int i = 0; i < 6; ++i) ((long long*)(g.info + 2))[i] = pf[i];
+#endif
+    for (int sl = 0, j = me; j < n; ++sl, j += G) {
+        const T* src = colslot(sl);
+        T* dst = g.A + (int64_t)j * g.lda;
+        for (int i = tid; i < m; i += 256) dst[i] = src[i];
+        if (tid == 0) g.jpvt[j] = l_jp[sl];
     }
 }
 
@@ -648,6 +1039,48 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         }
         rlhip_ws_release(c, mark2);
         return 0;
+    }
+    static int tag_on = -1;
+    if (tag_on < 0) { const char* e = getenv("RLHIP_QRCP_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (pivot && use_lds && tag_on && m < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) - 2) {
+        static int64_t g_env = -2;
+        if (g_env == -2) { const char* e = getenv("RLHIP_QRCP_TAG_COLS"); g_env = e ? atoll(e) : 4; if (g_env < 1) g_env = 1; }
+        // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: g_env (4) per workgroup
+        int64_t Gt = (n + g_env - 1) / g_env;
+        if (Gt > num_cu) Gt = num_cu;
+        if (Gt < 1) Gt = 1;
+        const size_t cpw_t = (size_t)((n + Gt - 1) / Gt);
+        const size_t dyn = cpw_t * sizeof(int64_t) + (2 * cpw_t + (size_t)m) * sizeof(T) + cpw_t * (size_t)m * sizeof(T);
+        if (dyn <= 150 * 1024) {
+            RLHIP_FUNC_LDS(c, qrcp_tag_kernel<T>, 150 * 1024);
+            size_t mark = rlhip_ws_mark(c);
+            QrcpTagArgs<T> t;
+            t.m = m; t.n = n; t.A = A; t.lda = lda; t.jpvt = jpvt_dev; t.tau = tau_dev;
+            const size_t words = 2 * qt_words<T>(m, Gt);
+            t.tw = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
+            t.info = (int*)ws_alloc<int>(c, 32);
+            if (!t.tw || !t.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            t.tol3z = std::sqrt(std::numeric_limits<T>::epsilon() / 2);
+            t.max_steps = max_steps; t.hq_formula = hq_formula;
+            RLHIP_CHECK(hipMemsetAsync(t.tw, 0, words * sizeof(unsigned long long), c->stream));
+            RLHIP_CHECK(hipMemsetAsync(t.info, 0, sizeof(int), c->stream));
+            const double kq = (double)((max_steps >= 0 && max_steps < (m < n ? m : n)) ? max_steps : (m < n ? m : n)); (void)kq;
+            void* kargs[] = {(void*)&t};
+            RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qrcp_tag_kernel<T>, dim3((unsigned)Gt), dim3(256), kargs, (unsigned)dyn, c->stream));
+            RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, t.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+#ifdef RLHIP_QT_PROF
+            {
+                long long pf[6];
+                RLHIP_CHECK(hipMemcpy(pf, t.info + 2, sizeof(pf), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[qrcp prof %ldx%ld G=%ld] per step (us): cand+put %.2f  spec %.2f  records %.2f  column %.2f  install %.2f  apply %.2f\n", (long)m, (long)n, (long)Gt,
+                        pf[0] / 100.0 / kq, pf[1] / 100.0 / kq, pf[2] / 100.0 / kq, pf[3] / 100.0 / kq, pf[4] / 100.0 / kq, pf[5] / 100.0 / kq);
+            }
+#endif
+            rlhip_ws_release(c, mark);
+            if (*(int*)(c->h_mail + 56) != 0) return -9;     // a published word never arrived (bounded spins): report instead of hanging
+            return 0;
+        }
     }
     size_t mark = rlhip_ws_mark(c);
     QrcpArgs<T> g;

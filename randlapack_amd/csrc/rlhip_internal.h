@@ -53,6 +53,8 @@ struct rlhip_ctx {
     // pinned mailbox
     int64_t* h_mail = nullptr;   // 64 x int64 host-pinned
     int64_t* d_mail = nullptr;   // 64 x int64 device
+    void* xchg = nullptr;        // exchange words of the persistent panel kernels (see rlhip_xchg_buffer)
+    size_t xchg_bytes = 0;
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // row-sharding communicator (comm.hip), nullptr = single GPU
@@ -76,6 +78,9 @@ void rlhip_ws_release(rlhip_ctx* c, size_t mark);
 
 template <typename T>
 static inline T* ws_alloc(rlhip_ctx* c, size_t n) { return (T*)rlhip_ws_alloc(c, n * sizeof(T)); }
+// device buffer for the tagged-word exchanges between workgroups (QRCP / LU panel kernels); grows, lives with the context.
+// RLHIP_XCHG = 0: ordinary device memory, 1: fine-grained, 2: uncached (default)
+void* rlhip_xchg_buffer(rlhip_ctx* c, size_t bytes);
 
 // ---- typed internal entry points (implemented in the .hip files; the extern "C" ABI wraps them) ----
 namespace rlhip {

@@ -129,7 +129,7 @@ def test_syrk_upper(ctx, n, k):
     assert relerr(np.triu(d.cm_to_numpy(Cd)), np.triu(A.T @ A)) < 1e-13
 
 
-@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 256, 700])
+@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 256, 449, 700, 1024, 1100, 2048])
 def test_potrf_upper(ctx, n):
     d = _dev()
     rng = np.random.default_rng(n)
@@ -149,6 +149,17 @@ def test_potrf_reports_first_bad_minor(ctx, orc):
     assert ctx.potrf(40, d.cm_from_numpy(Gm), 40) == 18                    # LAPACK info semantics
     Gm = np.ones((6, 6))                                                     # rank 1 -> fails at minor 2
     assert ctx.potrf(6, d.cm_from_numpy(Gm), 6) == 2
+    for bad in (3, 300, 700):                                                # two-level path: first, second and last 256-block
+        Gm = np.eye(700)
+        Gm[bad - 1, bad - 1] = -2.0
+        assert ctx.potrf(700, d.cm_from_numpy(Gm), 700) == bad
+    rng = np.random.default_rng(5)                                           # numerically rank-deficient Gram matrix: same info as LAPACK
+    X = rng.standard_normal((900, 300))
+    Gm = np.zeros((600, 600))
+    Gm[:300, :300] = X.T @ X
+    Gm[300:, 300:] = Gm[:300, :300]
+    Gm[300, 300] = 0.0
+    assert ctx.potrf(600, d.cm_from_numpy(Gm), 600) == 301
 
 
 @pytest.mark.parametrize("m,n", [(1000, 256), (333, 100), (2000, 600), (70, 5), (1, 1), (513, 257)])
