@@ -280,96 +280,129 @@ __global__ __launch_bounds__(256) void saso_apply_csr_kernel(int64_t d, int64_t 
 
 // CT = columns per workgroup: 4 gives a 40 KiB slab at d = 1280 (fp64), so several workgroups per CU overlap staging and gathering
 // (C3: 8 -> 6.3 ms, 4 -> 4.6 ms, 2 -> 6.3 ms); taller sketches take 2 or 1 columns so that the d x CT slab still fits the CU's LDS
-constexpr int RPT = 8;    // sketch rows per thread (256 threads -> d <= 2048 per pass)
 
 // partial[g][r + c*d] = sum over row blocks t in group g of sum_i sign * A[t*d + u_i(r), c]
-template <typename T, int CT, int MODE>
-__global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, int64_t m, int64_t Tb, int nnz,
+template <typename T, int CT, int MODE, int NR>
+__global__ __launch_bounds__(256, (NR == 5) ? 4 : 1) void saso_apply_kernel(int64_t d, int64_t n, int64_t m, int64_t Tb, int nnz,
                                                          const int32_t* __restrict__ src, const T* __restrict__ A,
                                                          int64_t lda, int64_t t_per_group, int64_t r_base,
                                                          T* __restrict__ partial, int64_t row0, int64_t mloc, int64_t tb0,
                                                          int64_t tb1, const int32_t* __restrict__ ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* sA = reinterpret_cast<T*>(smem_raw);                     // [d][CT] row-major
+    // LDS image of the slab: 16-byte elements (CPE columns of one row), NH planes of d elements: plane h holds columns h CPE .. of
+    // every row.  A gather lane then reads ONE 16-byte element per plane, and rows u, u' collide only if u = u' mod 16 (the 64 banks
+    // hold 16 such elements) -- with the [d][CT] row-major image (32-byte rows for fp64, CT = 4) every row started on one of 8 bank
+    // groups: 2-way conflicts for the affine operator's strided rows, ~4-way for independent columns, and 8-way on the staging stores.
+    constexpr int EB = (CT * (int)sizeof(T) >= 16) ? 16 : CT * (int)sizeof(T);   // element bytes
+    constexpr int CPE = EB / (int)sizeof(T);                                     // columns per element
+    constexpr int NH = CT / CPE;                                                 // planes
+    struct alignas(EB) Elem { T v[CPE]; };
+    Elem* sE = reinterpret_cast<Elem*>(smem_raw);               // [NH][d]
     const int tid = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * CT;
     const int64_t g = blockIdx.y;
     // A holds global rows [row0, row0 + mloc) only (row-block sharding); row blocks tb0 .. tb1-1 intersect that window
     const int64_t t0 = tb0 + g * t_per_group, t1 = (t0 + t_per_group < tb1) ? (t0 + t_per_group) : tb1;
     (void)Tb;
-    T acc[RPT][CT];
+    T acc[NR][CT];
 #pragma unroll
-    for (int q = 0; q < RPT; ++q)
+    for (int q = 0; q < NR; ++q)
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[q][c] = T(0);
     for (int64_t t = t0; t < t1; ++t) {
         __syncthreads();
-        // stage A[t*d : t*d+d, c0:c0+CT] (zero padded) -- threads run along rows: coalesced
-        //    (two nested loops: the flat index form cost two 64-bit divisions per element, 40 elements per thread per row block --
-        //    more ALU time than the slab's HBM time)
+        // stage A[t*d : t*d+d, c0:c0+CT] (zero padded) -- threads run along rows: coalesced global loads; a thread holds all CT values
+        // of its rows and stores them as whole 16-byte elements (see the layout note above): conflict-free
+        for (int ub = 0; ub < (int)d; ub += 256 * NR) {           // (the slab holds all d source rows; 2048 per trip)
+            T stg[NR][CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const bool col_ok = c0 + c < n;
-            const T* colp = A + (c0 + c) * lda - row0 + t * d;
-            for (int u = tid; u < (int)d; u += 256) {
+            for (int i = 0; i < NR; ++i) {
+                const int u = ub + tid + 256 * i;
                 const int64_t j = t * d + u - row0;      // local row
-                sA[u * CT + c] = (col_ok && j >= 0 && j < mloc && t * d + u < m) ? colp[u] : T(0);
+                const bool row_ok = u < (int)d && j >= 0 && j < mloc && t * d + u < m;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) stg[i][c] = (row_ok && c0 + c < n) ? A[(c0 + c) * lda + j] : T(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int u = ub + tid + 256 * i;
+                if (u < (int)d) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        Elem e;
+#pragma unroll
+                        for (int c2 = 0; c2 < CPE; ++c2) e.v[c2] = stg[i][h * CPE + c2];
+                        sE[(int64_t)h * d + u] = e;
+                    }
+                }
             }
         }
         __syncthreads();
         if (MODE == 1) {
             // variable-length lists (block t, row r) = src[ptr[t d + r] .. ptr[t d + r + 1]), sorted by source row.  All list bounds of
-            // the thread's RPT rows are requested first, then the first eight entries of every list as two 16-byte loads (a list
+            // the thread's NR rows are requested first, then the first eight entries of every list as two 16-byte loads (a list
             // is contiguous; reading past its end is harmless -- the array is padded -- and masked by the length), so that no load
             // waits for another; lists longer than eight entries (2 % of them at nnz = 4) finish in a scalar tail loop.
-            int32_t p0[RPT], len[RPT];
-            int4 ea[RPT], eb[RPT];
+            int32_t p0[NR], len[NR];
+            int4 ea[NR], eb[NR];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
+            for (int q = 0; q < NR; ++q) {
                 const int64_t r = r_base + tid + 256 * q;
                 p0[q] = 0; len[q] = 0;
                 if (r < d) { p0[q] = ptr[t * d + r]; len[q] = ptr[t * d + r + 1] - p0[q]; }
             }
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
+            for (int q = 0; q < NR; ++q) {
                 int tmp[8];
                 __builtin_memcpy(tmp, src + p0[q], 32);          // two unaligned 16-byte loads
                 ea[q] = int4{tmp[0], tmp[1], tmp[2], tmp[3]};
                 eb[q] = int4{tmp[4], tmp[5], tmp[6], tmp[7]};
             }
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
+            for (int q = 0; q < NR; ++q) {
                 const int ev[8] = {ea[q].x, ea[q].y, ea[q].z, ea[q].w, eb[q].x, eb[q].y, eb[q].z, eb[q].w};
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (k < len[q]) {
                         const int32_t e = ev[k];
                         const T sg = (e & 0x80000000) ? T(-1) : T(1);
-                        const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+                        const int64_t ur = (int64_t)(e & 0x7fffffff);
 #pragma unroll
-                        for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                        for (int h = 0; h < NH; ++h) {
+                            const Elem el = sE[(int64_t)h * d + ur];
+#pragma unroll
+                            for (int c2 = 0; c2 < CPE; ++c2) acc[q][h * CPE + c2] += sg * el.v[c2];
+                        }
                     }
                 }
                 for (int32_t k = 8; k < len[q]; ++k) {
                     const int32_t e = src[p0[q] + k];
                     const T sg = (e & 0x80000000) ? T(-1) : T(1);
-                    const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+                    const int64_t ur = (int64_t)(e & 0x7fffffff);
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                    for (int h = 0; h < NH; ++h) {
+                        const Elem el = sE[(int64_t)h * d + ur];
+#pragma unroll
+                        for (int c2 = 0; c2 < CPE; ++c2) acc[q][h * CPE + c2] += sg * el.v[c2];
+                    }
                 }
             }
         } else {
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
+        for (int q = 0; q < NR; ++q) {
             const int64_t r = r_base + tid + 256 * q;
             if (r < d) {
                 for (int i = 0; i < nnz; ++i) {
                     const int32_t e = src[(t * nnz + i) * d + r];
                     if ((e & 0x7fffffff) != 0x7fffffff) {
                         const T sg = (e & 0x80000000) ? T(-1) : T(1);
-                        const T* row = sA + (int64_t)(e & 0x7fffffff) * CT;
+                        const int64_t ur = (int64_t)(e & 0x7fffffff);
 #pragma unroll
-                        for (int c = 0; c < CT; ++c) acc[q][c] += sg * row[c];
+                        for (int h = 0; h < NH; ++h) {
+                            const Elem el = sE[(int64_t)h * d + ur];
+#pragma unroll
+                            for (int c2 = 0; c2 < CPE; ++c2) acc[q][h * CPE + c2] += sg * el.v[c2];
+                        }
                     }
                 }
             }
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(256) void saso_apply_kernel(int64_t d, int64_t n, i
     }
     T* out = partial + g * d * n;
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
+    for (int q = 0; q < NR; ++q) {
         const int64_t r = r_base + tid + 256 * q;
         if (r < d)
 #pragma unroll
@@ -605,17 +638,22 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     T* partial = ws_alloc<T>(c, (size_t)G * d * n);
     if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     if (nTb == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
-    auto launch = [&](auto kern) -> int {
+    // sketch rows per thread and pass: 5 (d <= 1280, the CQRRPT sketches of the benchmark configurations: 40 accumulator registers
+    // instead of 64) or 8
+    auto launch = [&](auto kern, int nr) -> int {
         RLHIP_FUNC_LDS(c, kern, lds_cap);
-        for (int64_t r_base = 0; r_base < d; r_base += 256 * RPT)
+        for (int64_t r_base = 0; r_base < d; r_base += 256 * nr)
             hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, tpg, r_base,
                                partial, row0, mloc, tb0, tb1, op->ptr);
         return 0;
     };
     if (nTb > 0) {
         int rc;
-        if (op->mode == 1) rc = (CT == 4) ? launch(saso_apply_kernel<T, 4, 1>) : (CT == 2) ? launch(saso_apply_kernel<T, 2, 1>) : launch(saso_apply_kernel<T, 1, 1>);
-        else rc = (CT == 4) ? launch(saso_apply_kernel<T, 4, 0>) : (CT == 2) ? launch(saso_apply_kernel<T, 2, 0>) : launch(saso_apply_kernel<T, 1, 0>);
+        const bool small = d <= 1280;
+#define RLHIP_SASO_LAUNCH(CTV, MODEV) (small ? launch(saso_apply_kernel<T, CTV, MODEV, 5>, 5) : launch(saso_apply_kernel<T, CTV, MODEV, 8>, 8))
+        if (op->mode == 1) rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 1) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 1) : RLHIP_SASO_LAUNCH(1, 1);
+        else rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 0) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 0) : RLHIP_SASO_LAUNCH(1, 0);
+#undef RLHIP_SASO_LAUNCH
         if (rc) { rlhip_ws_release(c, mark); return rc; }
     }
     RLHIP_LAUNCH_CHECK();
