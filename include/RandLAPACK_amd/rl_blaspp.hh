@@ -169,6 +169,16 @@ inline void trsm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, flo
                  float* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trsm_f32(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trsm");
 }
+// (extension) B = alpha * (Bsrc * P) * inv(A): the out-of-place right-upper solve with the column pivoting of CQRRPT folded in
+// (jpvt: 1-based, device; nullptr = no permutation); see rlhip_trsm_gather_f64
+inline void trsm_gather(Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda, double const* Bsrc, int64_t ldsrc,
+                        int64_t const* jpvt, double* B, int64_t ldb, Queue& q = blas::default_queue()) {
+    check(rlhip_trsm_gather_f64(q.ctx(), (char)d, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb), "trsm_gather");
+}
+inline void trsm_gather(Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda, float const* Bsrc, int64_t ldsrc,
+                        int64_t const* jpvt, float* B, int64_t ldb, Queue& q = blas::default_queue()) {
+    check(rlhip_trsm_gather_f32(q.ctx(), (char)d, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb), "trsm_gather");
+}
 inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
                  double* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trmm_f64(q.ctx(), (char)s, (char)u, (char)t, (char)d, m, n, alpha, A, lda, B, ldb), "trmm");

@@ -113,6 +113,14 @@ int rlhip_trsm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, 
                    double alpha, const double* A, int64_t lda, double* B, int64_t ldb);
 int rlhip_trsm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
                    float alpha, const float* A, int64_t lda, float* B, int64_t ldb);
+/* Out-of-place right-side solve with a column gather:  B <- alpha * (Bsrc * P) * inv(A), where column c of Bsrc * P is column
+ * jpvt_dev[c] - 1 of Bsrc (LAPACK-style 1-based pivot vector in device memory; NULL: P = I).  Bsrc (m x n, ldsrc) is not modified and
+ * must not overlap B unless it IS B with jpvt_dev == NULL (plain rlhip_trsm).  This is CQRRPT's "util::col_swap(A, J) followed by
+ * blas::trsm(A, R_sk)" (rl_cqrrpt.hh:288-300) as ONE pass over A, and its second solve (rl_cqrrpt.hh:329) written straight into A. */
+int rlhip_trsm_gather_f64(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, double alpha, const double* A, int64_t lda,
+                          const double* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, double* B, int64_t ldb);
+int rlhip_trsm_gather_f32(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, float alpha, const float* A, int64_t lda,
+                          const float* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, float* B, int64_t ldb);
 /* side 'R': B <- alpha * B * A, A n x n upper triangular, B m x n (trans 'N' only);
  * side 'L': B <- alpha * op(A) * B, A m x m upper triangular (trans 'N' or 'T').  uplo 'U' only. */
 int rlhip_trmm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,

@@ -29,6 +29,7 @@ def _blas3(T):
         "syrk": [c_vp, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, T, c_vp, c_i64],
         "trsm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
         "trmm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
+        "trsm_gather": [c_vp, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64],
         "potrf": [c_vp, c_char, c_i64, c_vp, c_i64],
         "lange_fro": [c_vp, c_i64, c_i64, c_vp, c_i64, C.POINTER(T)],
         "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],

@@ -370,6 +370,11 @@ static inline int op_flag(char t, int* out) {
         int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
         return rlhip::trsm_right_upper<T>(c, fd, m, n, alpha, A, lda, B, ldb);                                   \
     }                                                                                                           \
+    int rlhip_trsm_gather_##SUF(rlhip_ctx* c, char diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, \
+                                const T* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, T* B, int64_t ldb) {     \
+        int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
+        return rlhip::trsm_right_upper_oop<T>(c, fd, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt_dev, B, ldb);        \
+    }                                                                                                           \
     int rlhip_trmm_##SUF(rlhip_ctx* c, char side, char uplo, char trans, char diag, int64_t m, int64_t n,       \
                          T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {                                 \
         if (uplo != 'U' && uplo != 'u') return -3;                                                              \

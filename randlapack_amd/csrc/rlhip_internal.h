@@ -104,6 +104,9 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host);
 
 // B <- alpha * B * inv(op(A)),  A upper triangular n x n (Side::Right, Uplo::Upper, NoTrans)
 template <typename T>
+int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, const T* Bsrc, int64_t ldsrc,
+                         const int64_t* perm_dev, T* B, int64_t ldb);
+template <typename T>
 int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda,
                      T* B, int64_t ldb);
 

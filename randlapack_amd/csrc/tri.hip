@@ -341,10 +341,15 @@ template <int N> struct IntC { static constexpr int value = N; };
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NW = wavefronts per workgroup (16 rows each), HPR = rows of U per LDS panel (16), ring of three panels
-template <typename T, int NW, int HPR>
+// OOP = out of place: the right-hand side is READ from Bsrc (column c of the solve = column perm[c] - pbase of Bsrc when perm is given:
+// CQRRPT's column pivoting folded into the solve, rl_cqrrpt.hh:288-300) and the solution is WRITTEN to B; the solved tiles needed by
+// later blocks are re-read from B.  The pivot entries of a tile are wave-uniform (scalar loads), only the choice among the lane
+// group's four columns is per lane, so the number of vector-memory requests per step -- which the counted waits rely on -- is unchanged.
+template <typename T, int NW, int HPR, bool OOP>
 __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64_t n, int64_t n_pad, T alpha, const T* __restrict__ Uneg,
                                                                 const T* __restrict__ Dinv, T* __restrict__ B, int64_t ldb, int J0, int J1,
-                                                                int K0blk, T* __restrict__ dump) {
+                                                                int K0blk, T* __restrict__ dump, const T* __restrict__ Bsrc, int64_t ldsrc,
+                                                                const int64_t* __restrict__ perm, int64_t pbase) {
     static_assert(HPR == 16, "the diagonal phase below is written for 16-row panels (two per 32-column sub-block)");
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
@@ -375,6 +380,17 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     // offset `loff` (32 bits: the host takes this path only while 4 ldb + m < 2^28)
     constexpr int CS = M::CS, CL = M::CL;
     const unsigned loff = (unsigned)((live ? row : m - 1) + (int64_t)CL * fk * ldb);
+    // raw right-hand-side element of this lane in tile (jj, r) of the 256-block starting at column cb0
+    auto load_raw = [&](int64_t cb0, int jj, int r) -> T {
+        if constexpr (!OOP) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
+        else {
+            const int64_t cb = cb0 + 16 * jj + CS * r;                  // wave-uniform
+            int64_t p0 = cb, p1 = cb + CL, p2 = cb + 2 * CL, p3 = cb + 3 * CL;
+            if (perm) { p0 = perm[p0] - pbase; p1 = perm[p1] - pbase; p2 = perm[p2] - pbase; p3 = perm[p3] - pbase; }
+            const int64_t mc = (fk == 0) ? p0 : (fk == 1) ? p1 : (fk == 2) ? p2 : p3;
+            return Bsrc[mc * ldsrc + (live ? row : m - 1)];
+        }
+    };
     // per-lane source offsets (elements, relative to the panel's first element) and LDS byte offsets of this wave's DMA pieces
     int poff[P], pdst[P];
 #pragma unroll
@@ -437,11 +453,10 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     issue_panel(panel_ptr(J0, 1), 1);
     issue_dinv((int64_t)J0 * 8);
     {
-        const T* bj = B + (int64_t)J0 * 256 * ldb;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][r] = (bj + (int64_t)(16 * j + CS * r) * ldb)[loff];
+            for (int r = 0; r < 4; ++r) acc[j][r] = load_raw((int64_t)J0 * 256, j, r);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { xc[q] = T(0); xn[q] = T(0); }
@@ -499,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         // matrix store to a scratch line, the last block re-loads its own tile (values unused).
         auto retire_tiles = [&](int s) {
             T* bj = B + col0 * ldb;
-            const T* bn = has_next ? bj + 256 * ldb : bj;
+            const int64_t cbn = has_next ? col0 + 256 : col0;
             T* dl = dump + threadIdx.x;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[2 * s + u][r] = (bn + (int64_t)(16 * (2 * s + u) + CS * r) * ldb)[loff];
+                for (int r = 0; r < 4; ++r) acc[2 * s + u][r] = load_raw(cbn, 2 * s + u, r);
         };
         auto diag_step = [&](auto h_c) {
             constexpr int h = decltype(h_c)::value;
@@ -553,6 +568,15 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
             for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];     // the next block always has blocks to its left
         }
     }
+}
+
+// dst[:, c] = src[:, perm[c] - pbase] (perm == nullptr: plain copy); threads along rows
+template <typename T>
+__global__ __launch_bounds__(256) void gather_cols_kernel(int64_t m, int64_t n, const T* __restrict__ src, int64_t lds_, const int64_t* __restrict__ perm,
+                                                          int64_t pbase, T* __restrict__ dst, int64_t ldd) {
+    const int64_t c = blockIdx.y;
+    const int64_t sc = perm ? perm[c] - pbase : c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) dst[i + c * ldd] = src[i + sc * lds_];
 }
 
 }  // namespace
@@ -627,7 +651,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             if (!Uneg) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, c->stream, n, n_pad, A, lda, Uneg);
             RLHIP_LAUNCH_CHECK();
-            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16>), fused_lds_bytes<T>());
+            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, false>), fused_lds_bytes<T>());
             fdump = ws_alloc<T>(c, 512);
             if (!fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         }
@@ -646,8 +670,8 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
                 if (rc) { rlhip_ws_release(c, mark); return rc; }
                 a = T(1);
             }
-            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, a, Uneg,
-                               Dinv_all, B, ldb, Jb, Je, Jb, fdump);
+            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, false>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, a, Uneg,
+                               Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0);
             RLHIP_LAUNCH_CHECK();
             c->path_count[2]++;
             j0 = (int64_t)(Je - 1) * DB;     // the loop increment moves on to block Je
@@ -708,6 +732,66 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     return 0;
 }
 
+// Out-of-place solve with the column pivoting folded in:  B = alpha * (Bsrc * P) * inv(A),  column c of Bsrc * P = column perm[c] - 1
+// of Bsrc (perm: LAPACK-style 1-based pivot vector on the device, or nullptr for P = I).  CQRRPT's "permute A, then precondition it"
+// (rl_cqrrpt.hh:288-300) is one pass over A this way instead of two, and its second solve writes Q straight back into A.
+// Taken in ONE fused launch when every 256-block passes the conditioning guard and n is a multiple of 256; otherwise the columns are
+// gathered into B by a copy kernel and the in-place solver above runs on B.
+template <typename T>
+int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, const T* Bsrc, int64_t ldsrc,
+                         const int64_t* perm_dev, T* B, int64_t ldb) {
+    if (m < 0) return -6;
+    if (n < 0) return -7;
+    if (lda < (n > 1 ? n : 1)) return -10;
+    if (ldsrc < (m > 1 ? m : 1)) return -12;
+    if (ldb < (m > 1 ? m : 1)) return -15;
+    if (m == 0 || n == 0) return 0;
+    if ((const T*)B == Bsrc) { if (perm_dev) return -14; return trsm_right_upper<T>(c, diag, m, n, alpha, A, lda, B, ldb); }
+    static int fused_on = -1, fused_min_rows = 0, blk_on = -1;
+    if (fused_on < 0) {
+        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
+        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;
+        const char* b = getenv("RLHIP_TRSM_BLK"); blk_on = (b && atoi(b) == 0) ? 0 : 1;
+    }
+    const int64_t nblk = (n + BW - 1) / BW;
+    bool fused = blk_on && fused_on && m >= fused_min_rows && n >= BW && n % BW == 0 && nblk <= 32 && (4 * ldb + m) < ((int64_t)1 << 28);
+    size_t mark = rlhip_ws_mark(c);
+    if (fused) {
+        T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
+        T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
+        int* bad_dev = ws_alloc<int>(c, 32);
+        T* Uneg = ws_alloc<T>(c, (size_t)n * n);
+        T* fdump = ws_alloc<T>(c, 512);
+        if (!Upk_all || !Dinv_all || !bad_dev || !Uneg || !fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        RLHIP_CHECK(hipMemsetAsync(bad_dev, 0, 32 * sizeof(int), c->stream));
+        hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, n, diag, A, lda, Upk_all, Dinv_all, bad_dev,
+                           1.0e6);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        for (int64_t b = 0; b < nblk; ++b) fused = fused && ((int*)(c->h_mail + 16))[b] == 0;
+        if (fused) {
+            hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
+            RLHIP_LAUNCH_CHECK();
+            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, true>), fused_lds_bytes<T>());
+            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, true>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n, alpha, Uneg,
+                               Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1);
+            RLHIP_LAUNCH_CHECK();
+            c->path_count[4]++;
+            rlhip_ws_release(c, mark);
+            return 0;
+        }
+    }
+    rlhip_ws_release(c, mark);
+    {
+        unsigned gx = (unsigned)((m + 256 * 8 - 1) / (256 * 8));
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(gather_cols_kernel<T>, dim3(gx, (unsigned)n), dim3(256), 0, c->stream, m, n, Bsrc, ldsrc, perm_dev, (int64_t)1, B, ldb);
+        RLHIP_LAUNCH_CHECK();
+    }
+    return trsm_right_upper<T>(c, diag, m, n, alpha, A, lda, B, ldb);
+}
+
 template <typename T>
 int trmm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, T* B,
                      int64_t ldb) {
@@ -753,6 +837,8 @@ template int trmm_left_upper<double>(rlhip_ctx*, int, int, int64_t, int64_t, dou
 template int trmm_left_upper<float>(rlhip_ctx*, int, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
 
 template int trsm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
+template int trsm_right_upper_oop<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, const int64_t*, double*, int64_t);
+template int trsm_right_upper_oop<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, const int64_t*, float*, int64_t);
 template int trsm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
 template int trmm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trmm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);

@@ -141,6 +141,14 @@ class Context:
             fn(self.h, b"R", b"U", b"N", diag.encode(), m, n, T(alpha), A.data_ptr(), lda, B.data_ptr(), ldb), "trsm"
         )
 
+    def trsm_gather(self, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb, diag="N"):
+        """B = alpha * Bsrc[:, jpvt - 1] * inv(A), out of place (rlhip_trsm_gather_*); jpvt: device int64 tensor (1-based) or None"""
+        suf, T = _suffix(B)
+        fn = getattr(self.lib, f"rlhip_trsm_gather_{suf}")
+        return _lib.check(
+            fn(self.h, diag.encode(), m, n, T(alpha), A.data_ptr(), lda, Bsrc.data_ptr(), ldsrc, jpvt.data_ptr() if jpvt is not None else None,
+               B.data_ptr(), ldb), "trsm_gather")
+
     def trmm(self, m, n, alpha, A, lda, B, ldb, diag="N"):
         suf, T = _suffix(B)
         fn = getattr(self.lib, f"rlhip_trmm_{suf}")

@@ -376,6 +376,44 @@ def test_trsm_fused_blocks_vs_lapack(ctx, m, n, dtype):
     assert torch.equal(Bd, Bd2)
 
 
+@pytest.mark.parametrize("m,n,dtype,perm,fused", [(20000, 1024, "f64", True, True), (16500, 512, "f64", False, True), (33000, 300, "f64", True, False),
+                                                  (20000, 768, "f32", True, True), (900, 256, "f64", True, False)])
+def test_trsm_gather_out_of_place_vs_lapack(ctx, m, n, dtype, perm, fused):
+    """rlhip_trsm_gather: B = alpha (Bsrc P) inv(U) with the pivot vector read inside the solve (CQRRPT's col_swap + trsm in one pass);
+    the source is left untouched; fused launch where every block qualifies, gather-copy + in-place solver elsewhere -- same numbers."""
+    import torch
+
+    d = _d()
+    rng = np.random.default_rng(m * 3 + n)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2 * np.eye(n)
+    U += np.tril(rng.standard_normal((n, n)), -1)
+    B = rng.standard_normal((m, n))
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    npdt = np.float64 if dtype == "f64" else np.float32
+    U = U.astype(npdt).astype(np.float64)
+    B = B.astype(npdt).astype(np.float64)
+    jp = rng.permutation(n) + 1 if perm else None
+    Jd = torch.from_numpy(jp.astype(np.int64)).cuda() if perm else None
+    Sd = d.cm_from_numpy(B).to(tdt)
+    S0 = Sd.clone()
+    Xd = d.cm_from_numpy(np.full((m, n), np.nan)).to(tdt)
+    before = ctx.path_count(4)
+    ctx.trsm_gather(m, n, 0.75, d.cm_from_numpy(U).to(tdt), n, Sd, m, Jd, Xd, m)
+    assert ctx.path_count(4) == before + (1 if fused else 0)
+    assert torch.equal(Sd, S0)                                   # the source is read only
+    X = d.cm_to_numpy(Xd).astype(np.float64)
+    Bp = B[:, jp - 1] if perm else B
+    ref = _np_trsm_right_upper(Bp, np.triu(U), 0.75)
+    eps = EPS if dtype == "f64" else EPS32
+    assert relerr(X, ref) <= 200 * eps
+    # the same numbers as "permute, then solve in place"
+    Pd = d.cm_from_numpy(Bp).to(tdt)
+    ctx.trsm(m, n, 0.75, d.cm_from_numpy(U).to(tdt), n, Pd, m)
+    assert relerr(X, d.cm_to_numpy(Pd).astype(np.float64)) <= 4 * eps
+    if fused and m >= 16384 and n % 256 == 0:
+        assert torch.equal(Xd, Pd)                               # both take the fused kernel: identical arithmetic per entry
+
+
 def test_trsm_fused_with_an_ill_conditioned_block_in_the_middle(ctx):
     """Blocks 0 and 2 (256 columns each) are well conditioned and go through the fused kernel; block 1 carries a graded diagonal
     (cond 1e12) and must take the substitution path (explicit inverses would lose eps * cond); the residual stays at eps ||B||."""
