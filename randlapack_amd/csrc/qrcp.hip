@@ -217,10 +217,30 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
             if (j <= k) continue;
             T* col = colptr(j);
             if (tauk != T(0)) {
-                T w = 0;
-                for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : vv[i]) * col[i];
-                w = wave_sum(w) * tauk;
-                for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : vv[i]);
+                // eight 64-row slabs per trip: eight independent loads in flight per lane (columns that live in HBM / L2 are latency-bound
+                // otherwise: 1.6 TB/s at 16384^2) and eight partial sums
+                T w8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int64_t i = k + lane;
+                for (; i + 448 < m; i += 512) {
+                    T cv[8], vx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { cv[u] = col[i + 64 * u]; vx[u] = vv[i + 64 * u]; }
+                    if (i == k) vx[0] = T(1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w8[u] += vx[u] * cv[u];
+                }
+                for (; i < m; i += 64) w8[0] += ((i == k) ? T(1) : vv[i]) * col[i];
+                T w = wave_sum(((w8[0] + w8[1]) + (w8[2] + w8[3])) + ((w8[4] + w8[5]) + (w8[6] + w8[7]))) * tauk;
+                i = k + lane;
+                for (; i + 448 < m; i += 512) {
+                    T cv[8], vx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { cv[u] = col[i + 64 * u]; vx[u] = vv[i + 64 * u]; }
+                    if (i == k) vx[0] = T(1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) col[i + 64 * u] = cv[u] - w * vx[u];
+                }
+                for (; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : vv[i]);
             }
             if (!g.pivot) continue;
             // dlaqp2: vn1(j) *= sqrt(max(0, 1 - (|A(k,j)|/vn1(j))^2)), recomputed when cancellation is detected

@@ -15,6 +15,7 @@
 //     registers, earlier x values of the same row in an LDS tile.
 #include <cstdlib>
 #include "rlhip_internal.h"
+#include <cstdio>
 
 namespace rlhip {
 template <typename T>
@@ -445,6 +446,13 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     // first element of panel t of block J (t counts from the first fused block row K0blk; the diagonal block follows seamlessly)
     auto panel_ptr = [&](int J, int t) -> const T* { return Uneg + ((int64_t)K0blk * 256 + (int64_t)t * HPR) * n_pad + (int64_t)J * 256; };
 
+#ifdef RLHIP_TF_PROF
+    long long tfp[20]; for (int i = 0; i < 20; ++i) tfp[i] = 0;
+    long long tft = wall_clock64();
+#define TF_MARK(i) { const long long now_ = wall_clock64(); tfp[i] += now_ - tft; tft = now_; }
+#else
+#define TF_MARK(i)
+#endif
     acc_t acc[16];
     T xc[NQ], xn[NQ];
     int ring = 0;                                               // ring stage of the panel the next step consumes
@@ -496,6 +504,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
             for (int q = 0; q < NQ; ++q) xc[q] = xn[q];
             ring = (ring + 1 >= RING) ? 0 : ring + 1;
         }
+        TF_MARK(0)
         // ---- diagonal block: right-looking over the 32-column sub-blocks, X in registers
         auto solve_sub = [&](int s) {                           // X_s = T_s * inv(U_ss)   (compile-time s after unrolling)
             const T* dv = reinterpret_cast<const T*>(sD + (s & 1) * DBY) + fr;
@@ -552,6 +561,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
                 if (hh == 0) issue_dinv((int64_t)J * 8 + s + 1);                           // needed two steps from now, other stage
             });
             ring = (ring + 1 >= RING) ? 0 : ring + 1;
+            TF_MARK(1 + h)
         };
         diag_step(IntC<0>{}); diag_step(IntC<1>{}); diag_step(IntC<2>{}); diag_step(IntC<3>{}); diag_step(IntC<4>{});
         diag_step(IntC<5>{}); diag_step(IntC<6>{}); diag_step(IntC<7>{}); diag_step(IntC<8>{}); diag_step(IntC<9>{});
@@ -562,12 +572,16 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         solve_sub(7);
         retire_tiles(6);
         retire_tiles(7);
+        TF_MARK(15)
         if (has_next) {
             issue_dinv((int64_t)(J + 1) * 8);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];     // the next block always has blocks to its left
         }
     }
+#ifdef RLHIP_TF_PROF
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) for (int i = 0; i < 16; ++i) ((long long*)(dump + 512))[i] = tfp[i];
+#endif
 }
 
 // dst[:, c] = src[:, perm[c] - pbase] (perm == nullptr: plain copy); threads along rows
@@ -652,7 +666,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, c->stream, n, n_pad, A, lda, Uneg);
             RLHIP_LAUNCH_CHECK();
             RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, false>), fused_lds_bytes<T>());
-            fdump = ws_alloc<T>(c, 512);
+            fdump = ws_alloc<T>(c, 512 + 64);
             if (!fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         }
     }
@@ -673,6 +687,16 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, false>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, a, Uneg,
                                Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0);
             RLHIP_LAUNCH_CHECK();
+#ifdef RLHIP_TF_PROF
+            {
+                long long pf[16];
+                hipStreamSynchronize(c->stream);
+                hipMemcpy(pf, fdump + 512, sizeof(pf), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[trsm prof, one workgroup, us over %d blocks] off-diagonal %.1f | diag steps", Je - Jb, pf[0] / 100.0);
+                for (int i = 1; i <= 14; ++i) fprintf(stderr, " %.1f", pf[i] / 100.0);
+                fprintf(stderr, " | tail %.1f\n", pf[15] / 100.0);
+            }
+#endif
             c->path_count[2]++;
             j0 = (int64_t)(Je - 1) * DB;     // the loop increment moves on to block Je
             continue;
