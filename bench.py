@@ -184,11 +184,14 @@ def main():
     traffic, traffic_source = None, None
     try:
         if world == 1 and (m, n, k) == (M, N, K):
-            tfile = os.path.join("profiles", "round1_pmc_traffic.json")
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), tfile)) as fh:
+            import glob
+            here = os.path.dirname(os.path.abspath(__file__))
+            tfile = sorted(glob.glob(os.path.join(here, "profiles", "round*_pmc_traffic.json")))[-1]      # the latest committed pass
+            with open(tfile) as fh:
                 tj = json.load(fh)
             traffic = float(tj["traffic_bytes"])
-            traffic_source = f"{tfile} (rocprofv3 --pmc passes of this kernel at this shape, {tj.get('date', 'round 1')}; not re-measured by this run)"
+            tfile = os.path.relpath(tfile, here)
+            traffic_source = f"{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape, scripts/pmc_traffic.sh; not re-measured by this run)"
     except Exception:
         traffic, traffic_source = None, None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",
