@@ -494,6 +494,23 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
         const T* A2 = transA ? (A + k_main) : (A + k_main * lda);
         return gemm_impl<T>(c, transA, transB, m, n, k - k_main, alpha, A2, lda, B + k_main, ldb, T(1), C, ldc, tri, nullptr, nullptr);
     }
+    // fp32, long contractions (BQRRP's W = V^T C over up to 63488 rows): the persistent kernel keeps one fp32 fma chain per output through
+    // its whole K, which is only accurate up to ~16k products (gemm_sk.hip) -- so the contraction is cut into chunks of 16384 that
+    // accumulate into C (beta = 1 from the second chunk on): the rounding behaviour of a 4-way split-K at the persistent kernel's rate.
+    if (sizeof(T) == 4 && !tri && !transB && k > 16384 && k % SKK == 0 && m >= 128 && n % 256 == 0 && !ssqA_dev) {
+        static int chunk_on = -1;
+        if (chunk_on < 0) { const char* e = getenv("RLHIP_STREAMK_F32_CHUNK"); chunk_on = (e && atoi(e) == 0) ? 0 : 1; }
+        if (chunk_on) {
+            const int64_t KC = 16384;
+            for (int64_t k0 = 0; k0 < k; k0 += KC) {
+                const int64_t kc = (k - k0 < KC) ? (k - k0) : KC;
+                const T* Ac = transA ? (A + k0) : (A + k0 * lda);
+                int rc = gemm_impl<T>(c, transA, transB, m, n, kc, alpha, Ac, lda, B + k0, ldb, k0 == 0 ? beta : T(1), C, ldc, 0, nullptr, nullptr);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     if (tri && !transB && m == n && n % 256 == 0 && k % SKK == 0) {
         int rc = try_streamk<T>(c, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 1);
         if (rc < 0) return rc;
