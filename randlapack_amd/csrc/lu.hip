@@ -15,6 +15,7 @@
 //     in both, after the exchange everybody knows the winner, the two owners swap rows and every workgroup eliminates its own rows.
 //   * dlaswp on the columns outside the panel is a thread-per-column kernel walking the 32 swaps in order.
 #include "rlhip_internal.h"
+#include <cstdio>
 
 namespace rlhip {
 template <typename T>
@@ -190,13 +191,42 @@ __device__ __attribute__((noinline)) unsigned lu_tag_get(const unsigned long lon
     return (unsigned)w;
 }
 
+// N tagged words in ONE batch of loads (re-read together until every needed word carries the tag): data that is already there costs
+// a single round trip however many words a thread needs
+template <int N>
+__device__ __forceinline__ void lu_tag_get_n(const unsigned long long* const (&ad)[N], const bool (&need)[N], unsigned tag, unsigned (&out)[N], int* info) {
+    for (int spins = 0;; ++spins) {
+        unsigned long long w[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) w[i] = need[i] ? __hip_atomic_load(ad[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && ((unsigned)(w[i] >> 32) == tag);
+        if (ok || spins > (1 << 22)) {
+            if (!ok) atomicExch(info, -7);
+#pragma unroll
+            for (int i = 0; i < N; ++i) out[i] = (unsigned)w[i];
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // one column step with the column index as a template parameter: every x[q][c] index is a compile-time constant, so the panel
 // really stays in registers (a runtime-indexed loop put it in scratch)
 template <typename T, int RPT>
 struct LuRegState {
     T x[RPT][PB];
     int64_t gr[RPT];
+#ifdef RLHIP_LU_PROF
+    long long pf[5], pt;
+#endif
 };
+#ifdef RLHIP_LU_PROF
+#define LU_MARK(i) { const long long now_ = wall_clock64(); st.pf[i] += now_ - st.pt; st.pt = now_; }
+#else
+#define LU_MARK(i)
+#endif
 template <typename T, int RPT, int C, bool TAG>
 __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww, T* s_piv,
                                             T* s_drow) {
@@ -222,6 +252,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
 #pragma unroll
     for (int w = 1; w < 4; ++w) argmax_take(lbest, lrow, s_wv[w], s_wr[w], m);
     int64_t p; int wstar;
+    LU_MARK(0)
     if constexpr (TAG) {
         // ---- flag-less exchange: every published item travels as 8-byte words {tag : 32-bit payload} (a double is two words); a
         //      reader simply re-reads a word until it carries this step's tag.  No store drain, no barrier counter, no acquire fence:
@@ -247,6 +278,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
             }
         };
         if (tid == 0) { putv(cw0, me, lbest); putw(cw1 + me, (unsigned)lrow); }
+        if (lrow >= m && tid < PB) putv(rw, me * PB + tid, T(0));   // nothing to offer: a dummy row, so that readers never wait for one
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             if (st.gr[q] == lrow && lrow < m) {
@@ -258,9 +290,46 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
                 for (int c2 = 0; c2 < PB; ++c2) putv(dw, c2, st.x[q][c2]);
             }
         }
+        // Everything a thread needs from the other workgroups in ONE batch of loads: the record of workgroup `tid` (tid < G), element
+        // tid % 32 of the diagonal row, and -- the winner's row is needed right after the decision -- element tid % 32 of the candidate
+        // rows of workgroups tid / 32 + 8 u, u < 8 (G <= 64 covers 65536 rows in fp32).  Three dependent round trips before (record
+        // value, record row, then the winner's row after the decision) are one now.
+        constexpr int PF = 8;
+        const bool pf_ok = G <= 8 * PF;
+        constexpr int NWD = W + 1 + W + PF * W;
+        const unsigned long long* ad[NWD]; bool need[NWD]; unsigned got[NWD];
+        {
+            const int64_t wme = (tid < G) ? tid : 0;
+#pragma unroll
+            for (int h = 0; h < W; ++h) { ad[h] = cw0 + W * wme + h; need[h] = tid < G; }
+            ad[W] = cw1 + wme; need[W] = tid < G;
+#pragma unroll
+            for (int h = 0; h < W; ++h) { ad[W + 1 + h] = dw + W * (tid & 31) + h; need[W + 1 + h] = true; }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t wu = (tid >> 5) + 8 * u;
+#pragma unroll
+                for (int h = 0; h < W; ++h) {
+                    ad[2 * W + 1 + u * W + h] = rw + W * ((wu < G ? wu : 0) * PB + (tid & 31)) + h;
+                    need[2 * W + 1 + u * W + h] = pf_ok && wu < G;
+                }
+            }
+        }
+        LU_MARK(1)
+        lu_tag_get_n<NWD>(ad, need, tag, got, g.info);
+        LU_MARK(2)
+        auto dec = [&](int i0) -> T {
+            if constexpr (W == 1) return (T)__uint_as_float(got[i0]);
+            else return (T)__longlong_as_double((long long)(((unsigned long long)got[i0 + 1] << 32) | got[i0]));
+        };
+        const T dv_pref = dec(W + 1);
         {
             T v = T(-1); int64_t r = m; int w = 0;
-            for (int64_t ww = tid; ww < G; ww += 256) {
+            if (tid < G) {
+                const T v2 = dec(0); const int64_t r2 = (int64_t)got[W];
+                if (r2 < m) { v = v2; r = r2; w = tid; }
+            }
+            for (int64_t ww = tid + 256; ww < G; ww += 256) {          // (G > 256 never happens: one workgroup per 512+ rows, <= num_cu)
                 const T v2 = getv(cw0, ww); const int64_t r2 = (int64_t)lu_tag_get(cw1 + ww, tag, g.info);
                 if (r2 < m && (v2 > v || (v2 == v && r2 < r))) { v = v2; r = r2; w = (int)ww; }
             }
@@ -271,14 +340,25 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
             }
             if (lane == 0) { s_wv[wid] = v; s_wr[wid] = r; s_ww[wid] = w; }
         }
-        if (tid < PB) s_drow[tid] = getv(dw, tid);                 // the diagonal row (published by its owner)
         __syncthreads();
         T gv = s_wv[0]; p = s_wr[0]; wstar = s_ww[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (s_wr[w] < m && (s_wv[w] > gv || (s_wv[w] == gv && s_wr[w] < p))) { gv = s_wv[w]; p = s_wr[w]; wstar = s_ww[w]; }
         if (p >= m) p = j;
-        if (tid < PB) s_piv[tid] = (p != j) ? getv(rw, (int64_t)wstar * PB + tid) : s_drow[tid];
+        if (pf_ok) {
+            // the thread group (tid / 32) == wstar % 8 holds the winner's row in slot wstar / 8
+            if ((tid >> 5) == (wstar & 7)) {
+                T pv = dec(2 * W + 1);
+#pragma unroll
+                for (int u = 1; u < PF; ++u) pv = ((wstar >> 3) == u) ? dec(2 * W + 1 + u * W) : pv;
+                s_piv[tid & 31] = (p != j) ? pv : dv_pref;
+            }
+            if (tid < PB) s_drow[tid] = dv_pref;
+        } else if (tid < PB) {
+            s_drow[tid] = dv_pref;
+            s_piv[tid] = (p != j) ? getv(rw, (int64_t)wstar * PB + tid) : dv_pref;
+        }
     } else {
     if (tid == 0) {
         pstore(g.cand_val + par * G + me, lbest);
@@ -350,6 +430,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
     }
     if (me == 0 && tid == 0) g.ipiv[j] = p + 1;
     __syncthreads();
+    LU_MARK(3)
     // ---- exchange rows j <-> p in the owners' registers, then eliminate
     const T piv = s_piv[C];
     const T rp = T(1) / piv;
@@ -373,6 +454,7 @@ __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RP
     }
     if (piv == T(0) && me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
     __syncthreads();                                              // s_piv / s_drow / s_w* are rewritten next column
+    LU_MARK(4)
 }
 template <typename T, int RPT, int C, bool TAG>
 __device__ __forceinline__ void lu_reg_steps(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww,
@@ -406,10 +488,222 @@ __global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
             st.x[q][c] = (st.gr[q] < m && c < pb) ? t : T(0);
         }
     }
+#ifdef RLHIP_LU_PROF
+    for (int i = 0; i < 5; ++i) st.pf[i] = 0;
+    st.pt = wall_clock64();
+#endif
     unsigned epoch = 0;
     lu_reg_steps<T, RPT, 0, TAG>(g, st, epoch, s_wv, s_wr, s_ww, s_piv, s_drow);
+#ifdef RLHIP_LU_PROF
+    if (me == (int64_t)gridDim.x / 2 && tid == 0) for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)(g.diag_data + 2 * PB) + i, (unsigned long long)st.pf[i]);
+#endif
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
+        if (st.gr[q] < m) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+                if (c < pb) g.A[st.gr[q] + (j0 + c) * g.lda] = st.x[q][c];
+        }
+    }
+}
+
+// ---- fp32 panels of up to 65536 rows (BQRRP's transposed sketch, rl_bqrrp.hh:341-352): the column step rewritten around what the per-phase
+// profile of the general step showed (us per column at 65536 x 2048: candidate 1.2, publish 1.3, exchange 1.8, decision 1.1, eliminate
+// 1.7 -- the hand-off itself is a quarter; the rest is LOCAL work with one workgroup per CU and nothing to hide latencies behind):
+//   * a row is published by 32 lanes with ONE store instruction (the owner lane hands its 32 registers to its own wave through a
+//     wave-private LDS line; no workgroup barrier) instead of 32 store instructions from one lane;
+//   * (|value|, row) travel as ONE 64-bit key {float bits : 2^32 - 1 - row}: a maximum over keys is LAPACK's first maximum, the wave
+//     reduction is four DPP row rotations + four readlanes instead of six dependent cross-lane shuffles of three values;
+//   * G <= 64 workgroups, so every WAVE reads all records itself (lane l <- workgroup l) and decides without a workgroup barrier;
+//   * two workgroup barriers per column (candidate combine, pivot rows staged) instead of four.
+// Same decisions and the same arithmetic per row as the general step: identical pivots and factors.
+__device__ __forceinline__ unsigned long long lu_dpp_max_step(unsigned long long k, const int which) {
+    int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32), lo2, hi2;
+    switch (which) {   // row_ror:n inside each 16-lane row
+        case 8: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false); break;
+        case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, false); break;
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, false); break;
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false); break;
+    }
+    const unsigned long long o = ((unsigned long long)(unsigned)hi2 << 32) | (unsigned)lo2;
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long lu_wave_max_u64(unsigned long long k) {
+    k = lu_dpp_max_step(k, 8); k = lu_dpp_max_step(k, 4); k = lu_dpp_max_step(k, 2); k = lu_dpp_max_step(k, 1);
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    unsigned long long r = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l += 16) {
+        const unsigned long long v = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, l) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, l);
+        r = v > r ? v : r;
+    }
+    return r;
+}
+// key of a candidate: larger value wins, equal values -> smaller row wins; 0 = nothing to offer (also for NaN, which LAPACK's
+// strict '>' search never selects either)
+__device__ __forceinline__ unsigned long long lu_key(float absval, unsigned row) {
+    return (absval == absval) ? (((unsigned long long)__float_as_uint(absval) << 32) | (0xffffffffu - row)) : 0ull;
+}
+
+constexpr int LF_RPT = 4;                 // rows per thread: 1024 rows per workgroup
+struct LuF32Shared {
+    float rb[4][PB];                      // wave-private hand-over lines (owner lane -> 32 lanes)
+    unsigned long long key[4];
+    float piv[2][PB], drow[2][PB];        // by column parity: no barrier needed before the next column rewrites them
+};
+
+template <int C>
+__device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<float, LF_RPT>& st, LuF32Shared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = (int)gridDim.x, me = (int)blockIdx.x;
+    const unsigned m = (unsigned)g.m;
+    const unsigned j = (unsigned)g.j0 + C;
+    constexpr int par = C & 1;
+    const unsigned tag = g.tag_base + C + 1;
+    unsigned long long* base = g.tw + (size_t)par * (size_t)(2 * G + G * PB + PB);
+    unsigned long long* cw0 = base, *cw1 = cw0 + G, *rw = cw1 + G, *dw = rw + (size_t)G * PB;
+    auto putw = [&](unsigned long long* q, unsigned payload) {
+        __hip_atomic_store(q, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // owner lane (row `want`) -> its wave's 32 low lanes -> one store instruction into dst[0..31]
+    auto publish_row = [&](unsigned want, unsigned long long* dst) {
+#pragma unroll
+        for (int q = 0; q < LF_RPT; ++q) {
+            const bool own = ((unsigned)st.gr[q] == want);
+            if (__builtin_amdgcn_ballot_w64(own)) {                       // wave-uniform
+                if (own) {
+#pragma unroll
+                    for (int c2 = 0; c2 < PB; ++c2) sh.rb[wid][c2] = st.x[q][c2];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the line is written (same wave)
+                __builtin_amdgcn_wave_barrier();
+                if (lane < PB) putw(dst + lane, __float_as_uint(sh.rb[wid][lane]));
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    LU_MARK(0)
+    // ---- the diagonal row leaves first (its owner is known without any search)
+    publish_row(j, dw);
+    // ---- local candidate
+    unsigned long long key = 0;
+#pragma unroll
+    for (int q = 0; q < LF_RPT; ++q) {
+        const unsigned r = (unsigned)st.gr[q];
+        const unsigned long long k2 = (r >= j && r < m) ? lu_key(fabsf(st.x[q][C]), r) : 0ull;
+        key = k2 > key ? k2 : key;
+    }
+    key = lu_wave_max_u64(key);
+    if (lane == 0) sh.key[wid] = key;
+    __syncthreads();
+    {
+        unsigned long long k1 = sh.key[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) k1 = sh.key[w] > k1 ? sh.key[w] : k1;
+        key = k1;
+    }
+    const unsigned lrow = key ? 0xffffffffu - (unsigned)key : m;
+    if (tid == 0) { putw(cw0 + me, (unsigned)(key >> 32)); putw(cw1 + me, lrow); }
+    if (lrow >= m) { if (tid < PB) putw(rw + (size_t)me * PB + tid, 0u); }        // nothing to offer: a dummy row, readers never wait for one
+    else publish_row(lrow, rw + (size_t)me * PB);
+    LU_MARK(1)
+    // ---- one batch of loads: record of workgroup `lane` (every wave reads all G <= 64 records), element tid % 32 of the diagonal row and
+    //      of the candidate rows of workgroups tid / 32 + 8 u
+    constexpr int PF = 8, NWD = 3 + PF;
+    const unsigned long long* ad[NWD]; bool need[NWD]; unsigned got[NWD];
+    {
+        const int wl = lane < G ? lane : 0;
+        ad[0] = cw0 + wl; need[0] = lane < G;
+        ad[1] = cw1 + wl; need[1] = lane < G;
+        ad[2] = dw + (tid & 31); need[2] = true;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int wu = (tid >> 5) + 8 * u;
+            ad[3 + u] = rw + (size_t)(wu < G ? wu : 0) * PB + (tid & 31); need[3 + u] = wu < G;
+        }
+    }
+    lu_tag_get_n<NWD>(ad, need, tag, got, g.info);
+    LU_MARK(2)
+    // ---- decision, per wave
+    unsigned long long gk = (lane < G && got[1] < m) ? (((unsigned long long)got[0] << 32) | (0xffffffffu - got[1])) : 0ull;
+    gk = lu_wave_max_u64(gk);
+    const unsigned p = gk ? 0xffffffffu - (unsigned)gk : j;                 // empty / NaN column: no exchange
+    const int wstar = gk ? (int)((p - (unsigned)g.j0) >> 10) : 0;           // 1024 rows per workgroup
+    const float dv = __uint_as_float(got[2]);
+    if ((tid >> 5) == (wstar & 7)) {
+        unsigned pv = got[3];
+#pragma unroll
+        for (int u = 1; u < PF; ++u) pv = ((wstar >> 3) == u) ? got[3 + u] : pv;
+        sh.piv[par][tid & 31] = (p != j) ? __uint_as_float(pv) : dv;
+    }
+    if (tid < PB) sh.drow[par][tid] = dv;
+    if (me == 0 && tid == 0) g.ipiv[j] = (int64_t)p + 1;
+    __syncthreads();
+    LU_MARK(3)
+    // ---- exchange rows j <-> p in the owners' registers, then eliminate
+    const float* s_piv = sh.piv[par];
+    const float* s_drow = sh.drow[par];
+    const float piv = s_piv[C];
+    const float rp = 1.0f / piv;
+#pragma unroll
+    for (int q = 0; q < LF_RPT; ++q) {
+        const unsigned r = (unsigned)st.gr[q];
+        if (p != j) {
+            if (r == j) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_piv[c2];
+            } else if (r == p) {
+#pragma unroll
+                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_drow[c2];
+            }
+        }
+        if (piv != 0.0f && r > j && r < m) {
+            const float l = st.x[q][C] * rp;
+            st.x[q][C] = l;
+#pragma unroll
+            for (int c2 = C + 1; c2 < PB; ++c2) st.x[q][c2] -= l * s_piv[c2];
+        }
+    }
+    if (piv == 0.0f && me == 0 && tid == 0 && *g.info == 0) *g.info = (int)(j + 1);
+    LU_MARK(4)
+}
+template <int C>
+__device__ __forceinline__ void lu_f32_steps(const LuArgs<float>& g, LuRegState<float, LF_RPT>& st, LuF32Shared& sh) {
+    if constexpr (C < PB) {
+        if (C < g.pb) {
+            lu_f32_step<C>(g, st, sh);
+            lu_f32_steps<C + 1>(g, st, sh);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void getrf_panel_f32_kernel(LuArgs<float> g) {
+    __shared__ LuF32Shared sh;
+    const int tid = threadIdx.x;
+    const int64_t me = blockIdx.x;
+    const int pb = g.pb;
+    const int64_t j0 = g.j0, m = g.m;
+    const int64_t lo = j0 + me * (256 * LF_RPT);
+    LuRegState<float, LF_RPT> st;
+#pragma unroll
+    for (int q = 0; q < LF_RPT; ++q) {
+        st.gr[q] = lo + tid + 256 * q;
+        const int64_t rr = st.gr[q] < m ? st.gr[q] : m - 1;
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const float t = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];
+            st.x[q][c] = (st.gr[q] < m && c < pb) ? t : 0.0f;
+        }
+    }
+#ifdef RLHIP_LU_PROF
+    for (int i = 0; i < 5; ++i) st.pf[i] = 0;
+    st.pt = wall_clock64();
+#endif
+    lu_f32_steps<0>(g, st, sh);
+#ifdef RLHIP_LU_PROF
+    if (me == (int64_t)gridDim.x / 2 && tid == 0) for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)(g.diag_data + 2 * PB) + i, (unsigned long long)st.pf[i]);
+#endif
+#pragma unroll
+    for (int q = 0; q < LF_RPT; ++q) {
         if (st.gr[q] < m) {
 #pragma unroll
             for (int c = 0; c < PB; ++c)
@@ -545,7 +839,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     LuArgs<T> g;
     g.m = m; g.n = n; g.A = A; g.lda = lda; g.ipiv = ipiv_dev;
     g.cand_val = ws_alloc<T>(c, 2 * Gmax); g.cand_row = ws_alloc<int64_t>(c, 2 * Gmax);
-    g.cand_data = ws_alloc<T>(c, (size_t)2 * Gmax * PB); g.diag_data = ws_alloc<T>(c, 2 * PB);
+    g.cand_data = ws_alloc<T>(c, (size_t)2 * Gmax * PB); g.diag_data = ws_alloc<T>(c, 2 * PB + 64);
     g.bar = ws_alloc<unsigned>(c, 4); g.info = (int*)ws_alloc<int>(c, 4);
     static int tag_on = -1;
     if (tag_on < 0) { const char* e = getenv("RLHIP_LU_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
@@ -568,6 +862,9 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     // than the HBM traffic saved at this width, so the default outer block is the panel itself.
     static int64_t nbo = -1;
     if (nbo < 0) { const char* e = getenv("RLHIP_LU_OUTER"); nbo = e ? atoll(e) : PB; if (nbo < PB) nbo = PB; nbo = (nbo / PB) * PB; }
+#ifdef RLHIP_LU_PROF
+    hipMemsetAsync(g.diag_data, 0, (2 * PB + 64) * sizeof(T), c->stream);
+#endif
     for (int64_t J0 = 0; J0 < mn; J0 += nbo) {
     const int64_t Jend = (J0 + nbo < mn) ? J0 + nbo : mn;      // columns factored by this outer block
     const int64_t Cin = (J0 + nbo < n) ? J0 + nbo : n;         // columns the panel steps keep up to date
@@ -587,6 +884,16 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         if (reg_panel && use_tag && rows >= 1024) {          // RLHIP_LU_TAG=0 / RLHIP_LU_REG_PANEL=0: the barrier-based LDS kernel (debug knob)
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
             g.tag_base = (unsigned)(j0 / PB + 1) * 64u;
+            static int f32_fast = -1;
+            if (f32_fast < 0) { const char* e = getenv("RLHIP_LU_F32_FAST"); f32_fast = (e && atoi(e) == 0) ? 0 : 1; }
+            bool launched = false;
+            if constexpr (sizeof(T) == 4) {
+                if (f32_fast && G <= 64 && m < ((int64_t)1 << 31)) {        // up to 65536 rows below the diagonal: the step of lu_f32_step
+                    hipLaunchKernelGGL(getrf_panel_f32_kernel, dim3((unsigned)G), dim3(256), 0, c->stream, g);
+                    launched = true;
+                }
+            }
+            if (!launched)
             hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
         } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the
                  // build of this file (32 unrolled column steps) within minutes
@@ -637,6 +944,16 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         }
     }
     }
+#ifdef RLHIP_LU_PROF
+    {
+        unsigned long long pf[5];
+        hipStreamSynchronize(c->stream);
+        hipMemcpy(pf, (unsigned long long*)(g.diag_data + 2 * PB), sizeof(pf), hipMemcpyDeviceToHost);
+        const double cols = (double)mn;
+        fprintf(stderr, "[lu prof %ld x %ld] us per column: candidate %.2f  publish %.2f  exchange %.2f  decision %.2f  eliminate %.2f\n", (long)m, (long)n,
+                pf[0] / 100.0 / cols, pf[1] / 100.0 / cols, pf[2] / 100.0 / cols, pf[3] / 100.0 / cols, pf[4] / 100.0 / cols);
+    }
+#endif
     if (info_host) {
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, g.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
