@@ -855,13 +855,15 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         RLHIP_CHECK(hipMemsetAsync(g.tw, 0, tw_words * sizeof(unsigned long long), c->stream));
     }
     if (!g.cand_val || !g.cand_row || !g.cand_data || !g.diag_data || !g.bar || !g.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    // Optional two-level blocking (RLHIP_LU_OUTER = 256, 512, ...): the 32-column panel steps then update only the columns of their own
+    // Two-level blocking (RLHIP_LU_OUTER = 64, 128, ...): the 32-column panel steps then update only the columns of their own
     // OUTER block; everything to the right of it gets the block's interchanges, one block forward substitution and ONE rank-nbo GEMM
-    // when the block is finished.  Measured on BQRRP's sketch LU (n = 2048 columns, 32768 .. 2048 rows, fp32): 682 ms (256) and 694 ms
-    // (512) against 650 ms for the plain right-looking order -- the skinny in-block GEMMs and the 23 extra launches per block cost more
-    // than the HBM traffic saved at this width, so the default outer block is the panel itself.
-    static int64_t nbo = -1;
-    if (nbo < 0) { const char* e = getenv("RLHIP_LU_OUTER"); nbo = e ? atoll(e) : PB; if (nbo < PB) nbo = PB; nbo = (nbo / PB) * PB; }
+    // when the block is finished.  Pays for very tall matrices only (numbers below); round 1 measured it slower everywhere because the
+    // panel kernel, not the updates, dominated then.
+    static int64_t nbo_env = -1;
+    if (nbo_env < 0) { const char* e = getenv("RLHIP_LU_OUTER"); nbo_env = e ? atoll(e) : 0; if (nbo_env && nbo_env < PB) nbo_env = PB; nbo_env = (nbo_env / PB) * PB; }
+    // default: with the faster fp32 panel step the HBM-bound K = 32 updates of a very tall matrix are worth saving again -- 65536 x 2048
+    // fp32: 32.1 ms (outer = panel), 27.0 (64), 25.0 (128), 25.1 (256); 32768 rows: 20.7 / 20.4 / 20.5 / 21.5; 8192 rows: 16.4 / 17.1 / 17.9
+    const int64_t nbo = nbo_env ? nbo_env : ((m >= 49152 && n >= 256) ? 128 : PB);
 #ifdef RLHIP_LU_PROF
     hipMemsetAsync(g.diag_data, 0, (2 * PB + 64) * sizeof(T), c->stream);
 #endif
