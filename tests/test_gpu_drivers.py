@@ -202,6 +202,39 @@ def test_cqrrpt_vs_oracle_shared_sketch(ctx, orc, m, n, rank, cond):
     assert abs(k - rank) <= 5                                                              # :178-179
 
 
+@pytest.mark.parametrize("n,cond", [(512, 1.0), (256, 1e8), (300, 1.0)])
+def test_cqrrpt_folded_pivoting_equals_reference_statement_order(ctx, orc, n, cond, monkeypatch):
+    """m >= 16384 with a full-rank sketch takes the folded flow (pivoting read inside the first solve, out-of-place solves through
+    rlhip_trsm_gather; n = 300: its gather-copy route): same rank, pivots, R and Q as the reference's col_swap -> trsm -> syrk -> trsm
+    order (RLHIP_CQRRPT_FOLD_PIVOTING=0), and both against the oracle on the shared sketch."""
+    d = _d()
+    m = 20000
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((m, n)) if cond == 1.0 else poly_mat(m, n, n, rng, cond=cond)
+    eps_user = EPS**0.85
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("RLHIP_CQRRPT_FOLD_PIVOTING", fold)
+        Ad = d.cm_from_numpy(A)
+        before = ctx.path_count(4)
+        r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, eps=eps_user, want_sketch=True, key=(3, 0))
+        took_fused_gather = ctx.path_count(4) - before
+        assert r["rc"] == 0
+        res[fold] = (r["rank"], r["J"].cpu().numpy(), d.cm_to_numpy(r["R"]), d.cm_to_numpy(Ad), d.cm_to_numpy(r["sketch"]), took_fused_gather)
+    (k1, J1, R1, Q1, S1, g1), (k0, J0, R0, Q0, S0, g0) = res["1"], res["0"]
+    # two fused out-of-place solves for a well-conditioned R_sk with whole 256-blocks; a graded R_sk (cond 1e8) fails the conditioning
+    # guard of the first solve and a ragged n every shape test: those take the gather-copy route
+    assert g0 == 0 and (g1 == 2 if (n % 256 == 0 and cond == 1.0) else g1 in (0, 1))
+    assert k1 == k0 == n and np.array_equal(J1, J0) and np.array_equal(S1, S0)
+    assert np.linalg.norm(R1 - R0) <= 1e-12 * np.linalg.norm(R0)
+    assert np.linalg.norm(Q1 - Q0) <= 1e-11 * np.sqrt(n)
+    o = orc.cqrrpt(A, S1, eps_user)
+    assert o["rank"] == n and np.array_equal(o["J"], J1)
+    assert np.linalg.norm(R1 - o["R"]) <= EPS**0.6 * np.linalg.norm(o["R"])
+    assert np.linalg.norm(A[:, J1 - 1] - Q1 @ R1) <= EPS**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q1.T @ Q1 - np.eye(n)) <= EPS**0.75 * np.sqrt(n)
+
+
 def test_cqrrpt_own_sketch_properties_and_state(ctx):
     d = _d()
     rng = np.random.default_rng(5)

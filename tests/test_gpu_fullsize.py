@@ -414,6 +414,35 @@ def test_trsm_gather_out_of_place_vs_lapack(ctx, m, n, dtype, perm, fused):
         assert torch.equal(Xd, Pd)                               # both take the fused kernel: identical arithmetic per entry
 
 
+def test_trsm_gather_with_an_ill_conditioned_block_takes_the_copy_route(ctx):
+    """One 256-block fails the conditioning guard -> no fused out-of-place launch: columns gathered by the copy kernel, then the
+    in-place solver (fused runs around the bad block, substitution inside it).  Same accuracy as the in-place solve of the permuted input."""
+    import torch
+    import scipy.linalg as sl
+
+    d = _d()
+    m, n = 16640, 768
+    rng = np.random.default_rng(8)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2 * np.eye(n)
+    sv = np.array([1.0] * 8 + [1e-9] * 248)
+    Mx = rng.standard_normal((256, 256))
+    Qa, _ = np.linalg.qr(Mx)
+    Qb, _ = np.linalg.qr(rng.standard_normal((256, 256)))
+    _, Rb, _ = sl.qr((Qa * sv) @ Qb.T, pivoting=True)
+    U[256:512, 256:512] = Rb
+    jp = rng.permutation(n) + 1
+    Bp = rng.standard_normal((m, n)) @ np.triu(U)              # the permuted right-hand side has an O(1) solution
+    B = np.empty_like(Bp)
+    B[:, jp - 1] = Bp                                          # ... and the source holds its columns scattered: B[:, jp - 1] = Bp
+    Jd = torch.from_numpy(jp.astype(np.int64)).cuda()
+    Xd = d.cm_zeros(m, n)
+    b4, b2, b3 = ctx.path_count(4), ctx.path_count(2), ctx.path_count(3)
+    ctx.trsm_gather(m, n, 1.0, d.cm_from_numpy(U), n, d.cm_from_numpy(B), m, Jd, Xd, m)
+    assert ctx.path_count(4) == b4 and ctx.path_count(2) == b2 + 2 and ctx.path_count(3) == b3 + 8
+    X = d.cm_to_numpy(Xd)
+    assert np.linalg.norm(X @ np.triu(U) - Bp) <= 1e-13 * n * np.linalg.norm(Bp)
+
+
 def test_trsm_fused_with_an_ill_conditioned_block_in_the_middle(ctx):
     """Blocks 0 and 2 (256 columns each) are well conditioned and go through the fused kernel; block 1 carries a graded diagonal
     (cond 1e12) and must take the substitution path (explicit inverses would lose eps * cond); the residual stays at eps ||B||."""
