@@ -68,6 +68,29 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// the same sum with DPP row rotations (VALU speed) + four readlanes instead of six dependent cross-lane shuffles through the LDS
+// crossbar: the reductions sit on the critical path of every column step of the barrier-free kernel below
+__device__ __forceinline__ double dpp_ror_add_f64(double v, const int n) {
+    int lo = __double2loint(v), hi = __double2hiint(v), lo2, hi2;
+    switch (n) {
+        case 8: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, false); break;
+        case 4: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, false); break;
+        case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xF, 0xF, false); break;
+        default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xF, 0xF, false); break;
+    }
+    return v + __hiloint2double(hi2, lo2);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_fast(T x) {
+    double v = (double)x;                                       // (fp32 inputs: the sum itself in double, rounded once)
+    v = dpp_ror_add_f64(v, 8); v = dpp_ror_add_f64(v, 4); v = dpp_ror_add_f64(v, 2); v = dpp_ror_add_f64(v, 1);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l += 16) r += __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+    return (T)r;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -425,7 +448,7 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
         const T* col = colslot(sl);
         T ss = 0;
         for (int i = lane; i < m; i += 64) ss += col[i] * col[i];
-        ss = wave_sum(ss);
+        ss = wave_sum_fast(ss);
         if (lane == 0) {
             T nr = sqrt(ss);
             l_vn1[sl] = nr; l_vn2[sl] = nr;
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
         const T* col = colslot(psl);
         T ss = 0;
         for (int i = k + 1 + tid; i < m; i += 256) ss += col[i] * col[i];
-        ss = wave_sum(ss);
+        ss = wave_sum_fast(ss);
         __syncthreads();
         if (lane == 0) s_val[wid] = ss;
         __syncthreads();
@@ -551,7 +574,10 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
         if (me == wstar) {
             if (!finished) finish_column(psl, k, tag, my_cw);
         } else {
-            for (int i0 = 0; i0 < m + 1; i0 += 256 * QT_NV) {
+            // only the owner of position k needs the rows above k (the finished R entries of the column it installs); everybody else
+            // applies the reflector to rows >= k and fetches just those (on average half the column)
+            const int first = (me == own_k) ? 0 : k;
+            for (int i0 = first; i0 < m + 1; i0 += 256 * QT_NV) {
                 int64_t ix[QT_NV]; T vv[QT_NV];
                 int cnt = 0;
 #pragma unroll
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
                     w0 += v0 * col[i]; w1 += l_v[i + 64] * col[i + 64]; w2 += l_v[i + 128] * col[i + 128]; w3 += l_v[i + 192] * col[i + 192];
                 }
                 for (; i < m; i += 64) w0 += ((i > k) ? l_v[i] : (i == k ? T(1) : T(0))) * col[i];
-                const T w = wave_sum((w0 + w1) + (w2 + w3)) * tauk;
+                const T w = wave_sum_fast((w0 + w1) + (w2 + w3)) * tauk;
                 i = r_lo;
                 for (; i + 192 < m; i += 256) {
                     const T v0 = (i > k) ? l_v[i] : (i == k ? T(1) : T(0));
@@ -643,7 +669,7 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
                 if (temp2 <= g.tol3z) {
                     T ss = 0;
                     for (int i = k + 1 + lane; i < m; i += 64) ss += col[i] * col[i];
-                    ss = wave_sum(ss);
+                    ss = wave_sum_fast(ss);
                     v1 = sqrt(ss);
                     if (lane == 0) { l_vn1[sl] = v1; l_vn2[sl] = v1; }
                 } else {
