@@ -515,7 +515,11 @@ __global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
 //   * (|value|, row) travel as ONE 64-bit key {float bits : 2^32 - 1 - row}: a maximum over keys is LAPACK's first maximum, the wave
 //     reduction is four DPP row rotations + four readlanes instead of six dependent cross-lane shuffles of three values;
 //   * G <= 64 workgroups, so every WAVE reads all records itself (lane l <- workgroup l) and decides without a workgroup barrier;
-//   * two workgroup barriers per column (candidate combine, pivot rows staged) instead of four.
+//   * two workgroup barriers per column (candidate combine, pivot row staged) instead of four;
+//   * rows are never moved between registers: an interchange j <-> p only swaps the two ROW LABELS (st.gr) -- the slot that held row p
+//     now is row j (final, no longer eliminated), the slot that held row j carries on as row p -- and every slot is written to the row
+//     its label names when the panel is done.  The old diagonal row is therefore never published or fetched, and the 256 conditional
+//     moves + 64 LDS reads per thread and column of the value swap are gone (the step was VALU-issue bound: ~500 instructions per thread).
 // Same decisions and the same arithmetic per row as the general step: identical pivots and factors.
 __device__ __forceinline__ unsigned long long lu_dpp_max_step(unsigned long long k, const int which) {
     int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32), lo2, hi2;
@@ -549,7 +553,7 @@ constexpr int LF_RPT = 4;                 // rows per thread: 1024 rows per work
 struct LuF32Shared {
     float rb[4][PB];                      // wave-private hand-over lines (owner lane -> 32 lanes)
     unsigned long long key[4];
-    float piv[2][PB], drow[2][PB];        // by column parity: no barrier needed before the next column rewrites them
+    float piv[2][PB];                     // by column parity: no barrier needed before the next column rewrites it
 };
 
 template <int C>
@@ -561,7 +565,7 @@ __device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<f
     constexpr int par = C & 1;
     const unsigned tag = g.tag_base + C + 1;
     unsigned long long* base = g.tw + (size_t)par * (size_t)(2 * G + G * PB + PB);
-    unsigned long long* cw0 = base, *cw1 = cw0 + G, *rw = cw1 + G, *dw = rw + (size_t)G * PB;
+    unsigned long long* cw0 = base, *cw1 = cw0 + G, *rw = cw1 + G;
     auto putw = [&](unsigned long long* q, unsigned payload) {
         __hip_atomic_store(q, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -583,8 +587,6 @@ __device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<f
         }
     };
     LU_MARK(0)
-    // ---- the diagonal row leaves first (its owner is known without any search)
-    publish_row(j, dw);
     // ---- local candidate
     unsigned long long key = 0;
 #pragma unroll
@@ -609,17 +611,16 @@ __device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<f
     LU_MARK(1)
     // ---- one batch of loads: record of workgroup `lane` (every wave reads all G <= 64 records), element tid % 32 of the diagonal row and
     //      of the candidate rows of workgroups tid / 32 + 8 u
-    constexpr int PF = 8, NWD = 3 + PF;
+    constexpr int PF = 8, NWD = 2 + PF;
     const unsigned long long* ad[NWD]; bool need[NWD]; unsigned got[NWD];
     {
         const int wl = lane < G ? lane : 0;
         ad[0] = cw0 + wl; need[0] = lane < G;
         ad[1] = cw1 + wl; need[1] = lane < G;
-        ad[2] = dw + (tid & 31); need[2] = true;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int wu = (tid >> 5) + 8 * u;
-            ad[3 + u] = rw + (size_t)(wu < G ? wu : 0) * PB + (tid & 31); need[3 + u] = wu < G;
+            ad[2 + u] = rw + (size_t)(wu < G ? wu : 0) * PB + (tid & 31); need[2 + u] = wu < G;
         }
     }
     lu_tag_get_n<NWD>(ad, need, tag, got, g.info);
@@ -627,36 +628,25 @@ __device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<f
     // ---- decision, per wave
     unsigned long long gk = (lane < G && got[1] < m) ? (((unsigned long long)got[0] << 32) | (0xffffffffu - got[1])) : 0ull;
     gk = lu_wave_max_u64(gk);
-    const unsigned p = gk ? 0xffffffffu - (unsigned)gk : j;                 // empty / NaN column: no exchange
+    const unsigned p = gk ? 0xffffffffu - (unsigned)gk : j;                 // empty / NaN column: no exchange, (dummy) zero pivot row
     const int wstar = gk ? (int)((p - (unsigned)g.j0) >> 10) : 0;           // 1024 rows per workgroup
-    const float dv = __uint_as_float(got[2]);
     if ((tid >> 5) == (wstar & 7)) {
-        unsigned pv = got[3];
+        unsigned pv = got[2];
 #pragma unroll
-        for (int u = 1; u < PF; ++u) pv = ((wstar >> 3) == u) ? got[3 + u] : pv;
-        sh.piv[par][tid & 31] = (p != j) ? __uint_as_float(pv) : dv;
+        for (int u = 1; u < PF; ++u) pv = ((wstar >> 3) == u) ? got[2 + u] : pv;
+        sh.piv[par][tid & 31] = __uint_as_float(pv);                        // (p == j: the winner's candidate row IS row j)
     }
-    if (tid < PB) sh.drow[par][tid] = dv;
     if (me == 0 && tid == 0) g.ipiv[j] = (int64_t)p + 1;
     __syncthreads();
     LU_MARK(3)
-    // ---- exchange rows j <-> p in the owners' registers, then eliminate
+    // ---- interchange j <-> p by LABEL, then eliminate the rows below j
     const float* s_piv = sh.piv[par];
-    const float* s_drow = sh.drow[par];
     const float piv = s_piv[C];
     const float rp = 1.0f / piv;
 #pragma unroll
     for (int q = 0; q < LF_RPT; ++q) {
-        const unsigned r = (unsigned)st.gr[q];
-        if (p != j) {
-            if (r == j) {
-#pragma unroll
-                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_piv[c2];
-            } else if (r == p) {
-#pragma unroll
-                for (int c2 = 0; c2 < PB; ++c2) st.x[q][c2] = s_drow[c2];
-            }
-        }
+        unsigned r = (unsigned)st.gr[q];
+        if (p != j) { r = (r == j) ? p : (r == p) ? j : r; st.gr[q] = (int64_t)r; }
         if (piv != 0.0f && r > j && r < m) {
             const float l = st.x[q][C] * rp;
             st.x[q][C] = l;
