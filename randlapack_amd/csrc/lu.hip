@@ -626,10 +626,13 @@ __device__ __forceinline__ void lu_f32_step(const LuArgs<float>& g, LuRegState<f
     lu_tag_get_n<NWD>(ad, need, tag, got, g.info);
     LU_MARK(2)
     // ---- decision, per wave
-    unsigned long long gk = (lane < G && got[1] < m) ? (((unsigned long long)got[0] << 32) | (0xffffffffu - got[1])) : 0ull;
-    gk = lu_wave_max_u64(gk);
+    const unsigned long long myk = (lane < G && got[1] < m) ? (((unsigned long long)got[0] << 32) | (0xffffffffu - got[1])) : 0ull;
+    const unsigned long long gk = lu_wave_max_u64(myk);
     const unsigned p = gk ? 0xffffffffu - (unsigned)gk : j;                 // empty / NaN column: no exchange, (dummy) zero pivot row
-    const int wstar = gk ? (int)((p - (unsigned)g.j0) >> 10) : 0;           // 1024 rows per workgroup
+    // the winner is the workgroup whose record carries the maximal key (keys are unique: rows are).  NOT (p - j0) / 1024: with
+    // interchanges done by label a row lives wherever the slot that received its label is
+    const unsigned long long whob = __builtin_amdgcn_ballot_w64(gk != 0ull && myk == gk);
+    const int wstar = whob ? (int)__builtin_ctzll(whob) : 0;
     if ((tid >> 5) == (wstar & 7)) {
         unsigned pv = got[2];
 #pragma unroll

@@ -485,9 +485,10 @@ def test_getrf_pivots_and_factors_match_lapack(ctx, m, n):
     np.testing.assert_allclose(np.triu(d.cm_to_numpy(Ad2)[:k]), np.triu(lu_ref[:k]), atol=5e-13 * np.abs(lu_ref).max(), rtol=0)
 
 
-@pytest.mark.parametrize("m,n", [(70000, 96), (33000, 40)])
+@pytest.mark.parametrize("m,n", [(70000, 96), (33000, 40), (65536, 160), (5000, 70), (1030, 33)])
 def test_getrf_tall_f32_pivots_match_lapack(ctx, m, n):
-    """the 4-rows-per-thread register panel (fp32, > 1024 rows) and the prefetch of candidate rows with many workgroups"""
+    """the 4-rows-per-thread register panels (fp32, > 1024 rows): the general step with more than 64 workgroups (70000 rows) and the
+    label-swapping step of lu_f32_step below that, over several panels (repeated interchanges move rows between workgroups)"""
     import scipy.linalg.lapack as ll
     import torch
 
