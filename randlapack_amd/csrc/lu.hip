@@ -642,6 +642,14 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
                     launched = true;
                 }
             }
+            if constexpr (sizeof(T) == 8) {
+                static int f64_fast = -1;
+                if (f64_fast < 0) { const char* e = getenv("RLHIP_LU_F64_FAST"); f64_fast = (e && atoi(e) == 0) ? 0 : 1; }
+                if (f64_fast && G <= 64 && m < ((int64_t)1 << 31)) {        // up to 32768 rows below the diagonal: the step of lu_f64_step
+                    rlhip_lu::launch_getrf_panel_f64(g, (unsigned)G, c->stream);
+                    launched = true;
+                }
+            }
             if (!launched)
             hipLaunchKernelGGL((getrf_panel_reg_kernel<T, RPT_BIG, true>), dim3((unsigned)G), dim3(256), 0, c->stream, g);
         } else   // short panels (< 1024 rows, at most 4 workgroups): the LDS-resident kernel; one register-kernel instantiation per type keeps the

@@ -61,5 +61,7 @@ struct LuRegState {
 
 // launcher of the fp32 panel step (lu_f32.hip): grid G <= 64 workgroups of 256 threads, 1024 rows each
 void launch_getrf_panel_f32(const LuArgs<float>& g, unsigned G, hipStream_t stream);
+// launcher of the fp64 panel step (lu_f64.hip): G <= 64 workgroups of 256 threads, 512 rows each
+void launch_getrf_panel_f64(const LuArgs<double>& g, unsigned G, hipStream_t stream);
 
 }  // namespace rlhip_lu

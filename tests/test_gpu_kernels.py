@@ -504,6 +504,25 @@ def test_getrf_tall_f32_pivots_match_lapack(ctx, m, n):
     np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=2e-4 * np.abs(lu_ref).max(), rtol=0)
 
 
+@pytest.mark.parametrize("m,n", [(16384, 96), (33000, 40), (2000, 65), (1024, 32)])
+def test_getrf_tall_f64_fast_step_pivots_match_lapack(ctx, m, n):
+    """the fp64 panel step of lu_f64.hip (two-stage first-maximum reductions, rows published by the owner's wave, interchanges by label;
+    up to 32768 rows; 33000 rows take the general step) against LAPACK: pivots identical, factors to rounding"""
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, n)) * np.logspace(0, -3, n)
+    A[5] = A[m - 7]                                                         # an exact tie between two rows of different workgroups
+    Ad = d.cm_from_numpy(A)
+    ip = torch.zeros(n, dtype=torch.int64, device="cuda")
+    assert ctx.lib.rlhip_getrf_f64(ctx.h, m, n, Ad.data_ptr(), m, ip.data_ptr()) == 0
+    lu_ref, piv_ref, info_ref = ll.dgetrf(A)
+    np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)
+    np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=1e-12 * np.abs(lu_ref).max(), rtol=0)
+
+
 def test_getrf_outer_blocking_knob_matches_lapack():
     """RLHIP_LU_OUTER (two-level blocking; read once per process, hence the subprocess): same pivots and factors as LAPACK for a
     tall, a wide and a ragged shape, with full and pivots-only factorizations"""
