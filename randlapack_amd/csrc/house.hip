@@ -13,6 +13,10 @@
 //   larft_gram T from (V, tau) in LAPACK geqrf format, via  T^-1 = striu(V^T V) + diag(1/tau)  and one triangular
 //              solve -- lets the same block apply serve lapack::ormqr (rl_bqrrp.hh:545).
 #include "rlhip_internal.h"
+#include <vector>
+#include <limits>
+#include <cmath>
+#include <cstdlib>
 
 namespace rlhip {
 template <typename T>
@@ -356,6 +360,45 @@ __global__ void r2_identity_dev_kernel(int n, const T* __restrict__ R, int64_t l
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// Cholesky-QR twice, in place: on success A = Q (orthonormal columns) and R2 = the upper-triangular R with A_in = Q R2; *good = false
+// (A restored to A_in up to rounding, or untouched) when a Cholesky factorization breaks down or the second R factor is not close to the
+// identity -- the first Q was then too far from orthonormal for the second pass to repair it (cond(A) beyond ~1e7 in fp64).
+template <typename T>
+static int cholqr2_inplace(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R1, T* R2, T* dev1, bool* good) {
+    *good = false;
+    int info = 0;
+    int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
+    if (!rc) rc = potrf_upper<T>(c, n, R1, n, &info);
+    if (rc || info) return rc;                                                       // A untouched so far
+    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
+    if (!rc) rc = laset<T>(c, 2, n, n, T(0), T(0), R2, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R2, n);
+    if (!rc) rc = potrf_upper<T>(c, n, R2, n, &info);
+    bool ok = !rc && !info;
+    if (ok) {
+        hipLaunchKernelGGL(r2_identity_dev_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R2, (int64_t)n, dev1);
+        T dev_h = 0;
+        RLHIP_CHECK(hipMemcpyAsync(&dev_h, dev1, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        ok = (dev_h <= T(1e-2));                                                     // Q1 was orthonormal to ~1e-2: pass 2 is accurate
+    }
+    if (!ok) {                                                                       // restore A = Q1 R1
+        int rc2 = trmm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
+        return rc ? rc : rc2;
+    }
+    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R2, n, A, lda);                 // A = Q
+    if (!rc) rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R1, n, R2, n);         // R2 <- R2 R1 (upper; lower part is zero)
+    if (!rc) *good = true;
+    return rc;
+}
+
+struct SasoOp;
+int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2], uint32_t next_ctr[4], SasoOp** out);
+int saso_destroy(rlhip_ctx* c, SasoOp* op);
+template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb);
+template <typename T> int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev);
+
 template <typename T>
 int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done) {
     *done = 0;
@@ -366,31 +409,56 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
     T* D = ws_alloc<T>(c, (size_t)n);
     T* dev1 = ws_alloc<T>(c, 4);
     if (!R1 || !R2 || !Tm || !D || !dev1) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    int info = 0;
-    int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
-    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
-    if (!rc) rc = potrf_upper<T>(c, n, R1, n, &info);
-    if (rc || info) { rlhip_ws_release(c, mark); return rc; }                       // A untouched so far
-    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
-    if (!rc) rc = laset<T>(c, 2, n, n, T(0), T(0), R2, n);
-    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R2, n);
-    if (!rc) rc = potrf_upper<T>(c, n, R2, n, &info);
-    bool good = !rc && !info;
-    if (good) {
-        hipLaunchKernelGGL(r2_identity_dev_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R2, (int64_t)n, dev1);
-        T dev_h = 0;
-        RLHIP_CHECK(hipMemcpyAsync(&dev_h, dev1, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
-        good = (dev_h <= T(1e-2));                                                  // Q1 was orthonormal to ~1e-2: pass 2 is accurate
+    bool good = false;
+    int rc = cholqr2_inplace<T>(c, m, n, A, lda, R1, R2, dev1, &good);
+    if (rc) { rlhip_ws_release(c, mark); return rc; }
+    // An ill-conditioned tall panel (ABRIK's Krylov blocks on a quickly decaying operator, rl_abrik.hh:333: cond 1e10 and beyond) is
+    // where Cholesky-QR gives up and the column-by-column Householder kernel took over -- 10 ms for a 200000 x 32 panel.  Before that,
+    // one more BLAS-3 attempt in the manner of CQRRT (rl_cqrrt.hh:124-200): a sparse sketch S A (2n rows), its small QR, and
+    // A R_sk^-1 has condition O(1) whatever A's was (short of numerical rank deficiency), so Cholesky-QR twice goes through and
+    // R = R_chol R_sk.  The sketch uses a fixed counter: the factorization stays a deterministic function of A.
+    static int precond_on = -1;
+    if (precond_on < 0) { const char* e = getenv("RLHIP_GEQRF_PRECOND"); precond_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!good && precond_on && m >= 8 * n && n >= 2) {
+        const int64_t d = 2 * n > n + 32 ? 2 * n : n + 32;
+        T* Acopy = ws_alloc<T>(c, (size_t)m * n);
+        T* Ask = ws_alloc<T>(c, (size_t)d * n);
+        T* R0 = ws_alloc<T>(c, (size_t)n * n);
+        T* tsk = ws_alloc<T>(c, (size_t)n);
+        if (Acopy && Ask && R0 && tsk) {
+            rc = lacpy<T>(c, 2, m, n, A, lda, Acopy, m);
+            SasoOp* S = nullptr;
+            const uint32_t ctr[4] = {0x9e3779b9u, 0, 0, 0}, key[2] = {0x51ab17u, 0x2f};
+            uint32_t nxt[4];
+            if (!rc) rc = saso_build(c, d, m, (int)(d < 8 ? d : 8), 1, ctr, key, nxt, &S);
+            if (!rc) rc = saso_apply<T>(c, S, n, T(1), A, lda, T(0), Ask, d);
+            if (S) saso_destroy(c, S);
+            if (!rc) rc = geqrf<T>(c, d, n, Ask, d, tsk);
+            std::vector<T> dg((size_t)n);
+            if (!rc) {
+                RLHIP_CHECK(hipMemcpy2DAsync(dg.data(), sizeof(T), Ask, (size_t)(d + 1) * sizeof(T), sizeof(T), (size_t)n, hipMemcpyDeviceToHost, c->stream));
+                RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            }
+            bool usable = !rc;
+            if (usable) {
+                T dmax = 0, dmin = std::numeric_limits<T>::max();
+                for (int64_t i = 0; i < n; ++i) { const T a = std::abs(dg[i]); dmax = a > dmax ? a : dmax; dmin = a < dmin ? a : dmin; }
+                usable = dmax > T(0) && dmin > T(64) * std::numeric_limits<T>::epsilon() * dmax;      // numerically rank deficient: leave it to Householder
+            }
+            if (usable) {
+                rc = laset<T>(c, 2, n, n, T(0), T(0), R0, n);
+                if (!rc) rc = lacpy<T>(c, 0, n, n, Ask, d, R0, n);
+                if (!rc) rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R0, n, A, lda);        // A <- A R_sk^-1
+                if (!rc) rc = cholqr2_inplace<T>(c, m, n, A, lda, R1, R2, dev1, &good);
+                if (!rc && good) rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R0, n, R2, n); // R <- R_chol R_sk
+                if (rc || !good) { int rc2 = lacpy<T>(c, 2, m, n, Acopy, m, A, lda); if (!rc) rc = rc2; good = false; }   // the input, bit for bit
+                else c->path_count[5]++;
+            }
+        }
+        if (rc) { rlhip_ws_release(c, mark); return rc; }
     }
-    if (!good) {                                                                    // restore A = Q1 R1 and let Householder do it
-        int rc2 = trmm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);
-        rlhip_ws_release(c, mark);
-        return rc ? rc : rc2;
-    }
-    rc = trsm_right_upper<T>(c, NonUnit, m, n, T(1), R2, n, A, lda);                // A = Q
-    if (!rc) rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R1, n, R2, n);        // R2 <- R2 R1 = R (upper; lower part is zero)
-    if (!rc) rc = orhr_col<T>(c, m, n, n, A, lda, Tm, n, D);                        // V below the diagonal, T, sign vector D
+    if (!good) { rlhip_ws_release(c, mark); return 0; }                              // let Householder do it
+    rc = orhr_col<T>(c, m, n, n, A, lda, Tm, n, D);                                  // V below the diagonal, T, sign vector D
     if (!rc) rc = row_sign<T>(c, n, R2, n, D);                                      // R <- D R
     if (!rc) rc = tau_from_t<T>(c, n, n, Tm, n, tau);
     if (!rc) rc = lacpy<T>(c, 0, n, n, R2, n, A, lda);                              // upper triangle incl. diagonal

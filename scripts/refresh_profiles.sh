@@ -11,6 +11,7 @@ timeout 300 python scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/${TA
 RLHIP_SASO_MODE=affine timeout 300 python scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/${TAG}_c3_cqrrpt_affine_saso_line.json 2>> $O/c3.err
 timeout 300 python scripts/bench_other.py bqrrp64 --steps 3 < /dev/null > $O/${TAG}_bqrrp_f64_16k_line.json 2> $O/b64.err
 timeout 300 python scripts/bench_other.py bqrrp_full --steps 2 < /dev/null > $O/${TAG}_c4_bqrrp_f32_65536_line.json 2> $O/c4.err
+timeout 300 python scripts/bench_other.py abrik --steps 2 < /dev/null > $O/${TAG}_c5_abrik_line.json 2> $O/c5.err
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, command...
     local name=$1; shift

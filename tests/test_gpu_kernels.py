@@ -713,8 +713,9 @@ def test_gesdd_clustered_singular_values(ctx, m, n, kind):
 
 @pytest.mark.parametrize("m,n,cond", [(20000, 128, 1e2), (20000, 64, 1e12), (100000, 32, 1.0), (9000, 16, 1e9)])
 def test_geqrf_tall_skinny_matches_lapack(ctx, m, n, cond):
-    """Tall-skinny geqrf: Cholesky-QR twice + Householder reconstruction when it can be trusted, the Householder pipeline
-    otherwise (cond 1e9 / 1e12 force the fallback).  Either way the GEQRF-format output equals LAPACK's to rounding."""
+    """Tall-skinny geqrf: Cholesky-QR twice + Householder reconstruction when it can be trusted; for cond 1e9 / 1e12 plain Cholesky-QR
+    gives up and the sketch-preconditioned retry (S A, its small QR, A R_sk^-1, Cholesky-QR twice) must take the panel -- not the
+    column-by-column Householder kernel.  Either way the GEQRF-format output equals LAPACK's to rounding."""
     import scipy.linalg.lapack as ll
     import torch
 
@@ -724,8 +725,10 @@ def test_geqrf_tall_skinny_matches_lapack(ctx, m, n, cond):
     A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
     Ad = d.cm_from_numpy(A)
     tau = torch.zeros(n, dtype=torch.float64, device="cuda")
+    pre = ctx.path_count(5)
     assert ctx.lib.rlhip_geqrf_f64(ctx.h, m, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
     ctx.sync()
+    assert ctx.path_count(5) - pre == (1 if cond >= 1e9 else 0)
     qr_ref, tau_ref, _, _ = ll.dgeqrf(A)
     out = d.cm_to_numpy(Ad)
     # R rows scale with the singular values: compare relative to each row of R; V and tau absolutely
