@@ -150,8 +150,8 @@ private:
 
 // ------------------------------------------------------------------------------------------------ sparse
 /// Device CSR operator.  rowptr (n_rows + 1), colidx (nnz), vals (nnz) are DEVICE arrays with int64 indices, borrowed for the
-/// lifetime of the operator; entries of a row need not be sorted; duplicates are summed.  The constructor builds the CSR of the
-/// transpose (stable counting sort on the device), so that op(A) X is always a gather.
+/// lifetime of the operator; entries of a row need not be sorted; duplicates are summed.  The CSR of the transpose is built on
+/// first use (stable counting sort on the device), so that op(A) X is always a gather.
 /// `row_sharded`: this rank holds a block of ROWS of the operator (n_rows = local rows, indices local); A^T X, S A and the norm
 /// are then summed over the ranks, exactly as for DenseLinOp.
 template <typename T>
@@ -172,10 +172,15 @@ struct SparseLinOp {
     SparseLinOp(int64_t rows, int64_t cols, int64_t nnz_, const int64_t* rp, const int64_t* ci, const T* v, blas::Queue& queue)
         : n_rows(rows), n_cols(cols), nnz(nnz_), rowptr(rp), colidx(ci), vals(v), q(queue) {
         randlapack_require(rows >= 0 && cols >= 0 && nnz_ >= 0) << "negative dimension";
-        rowptr_t = blas::device_malloc<int64_t>(cols + 1, q);
+    }
+    /// the CSR of the transpose, built on FIRST use (stable counting sort on the device, ~1 ms for 2e6 nonzeros): an operator that is
+    /// only ever applied as A * X (or lives for a single product, as behind rlhip_linop_apply) never pays for it
+    void ensure_transpose() {
+        if (rowptr_t) return;
+        rowptr_t = blas::device_malloc<int64_t>(n_cols + 1, q);
         colidx_t = blas::device_malloc<int64_t>(nnz, q);
         vals_t = blas::device_malloc<T>(nnz, q);
-        detail::csr_transpose(rows, cols, rp, ci, v, rowptr_t, colidx_t, vals_t, q);
+        detail::csr_transpose(n_rows, n_cols, rowptr, colidx, vals, rowptr_t, colidx_t, vals_t, q);
     }
     SparseLinOp(SparseLinOp const&) = delete;
     SparseLinOp& operator=(SparseLinOp const&) = delete;
@@ -205,6 +210,7 @@ struct SparseLinOp {
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
             if (nt) detail::csr_spmm((char)layout, m, n, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q);
             else {
+                ensure_transpose();
                 detail::csr_spmm((char)layout, m, n, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q);
                 if (row_sharded && q.world() > 1) {                       // A^T X sums over the row blocks
                     randlapack_require(beta == (T)0 && ldc == ((layout == Layout::ColMajor) ? m : n)) << "sharded A^T X needs beta = 0 and a contiguous result";
@@ -217,7 +223,7 @@ struct SparseLinOp {
             const int64_t rows_A = nt ? k : n, cols_A = nt ? n : k;
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
             const char flipped = (layout == Layout::ColMajor) ? 'R' : 'C';
-            if (nt) detail::csr_spmm(flipped, n, m, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q);
+            if (nt) { ensure_transpose(); detail::csr_spmm(flipped, n, m, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q); }
             else detail::csr_spmm(flipped, n, m, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q);
         }
     }
@@ -241,11 +247,13 @@ struct SparseLinOp {
             int64_t m_glob, row0;
             q.shard_extent(n_rows, m_glob, row0);
             randlapack_require(S.dist.n_cols == m_glob) << "sketching operator has " << S.dist.n_cols << " columns, the sharded operator " << m_glob << " rows";
+            ensure_transpose();
             detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, (T)0, C, ldc, row0, q);
             q.allreduce_sum(C, d * n);
             return;
         }
         if (d <= 19200 && !force_densified_sketch) {
+            ensure_transpose();
             detail::saso_apply_csr(S.handle, n, alpha, rowptr_t, colidx_t, vals_t, beta, C, ldc, 0, q);
             return;
         }
@@ -254,6 +262,7 @@ struct SparseLinOp {
         T* blk = ws.alloc<T>(m * b);
         for (int64_t j = 0; j < n; j += b) {
             const int64_t bj = std::min(b, n - j);
+            ensure_transpose();
             detail::csr_densify_cols(m, rowptr_t, colidx_t, vals_t, j, bj, blk, m, q);
             RandBLAS::sketch_general(layout, Op::NoTrans, Op::NoTrans, d, bj, m, alpha, S, 0, 0, blk, m, beta, C + j * ldc, ldc, q);
         }
@@ -265,6 +274,7 @@ struct SparseLinOp {
         randlapack_require(!(row_sharded && q.world() > 1)) << "dense sketching operators are not sharded: use the sparse one";
         check_sketch_call(side, layout, trans_A, trans_S, d, n, m, S.dist.n_rows, S.dist.n_cols, ldc);
         RandBLAS::fill_dense(S);
+        ensure_transpose();
         detail::csr_spmm('R', n, d, m, alpha, rowptr_t, colidx_t, vals_t, S.buff, d, beta, C, ldc, q);
     }
 
