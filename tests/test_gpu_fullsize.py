@@ -477,8 +477,10 @@ def test_trsm_fused_with_an_ill_conditioned_block_in_the_middle(ctx):
 def test_streamk_gemm_f32_entrywise(ctx, m, n, k, ta):
     import os
 
-    if k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2":
-        pytest.skip("contractions beyond 16384 stay on the split-K kernel in fp32 (rounding of one long fma chain); RLHIP_STREAMK_F32=2 lifts the cap")
+    # contractions beyond 16384 are cut into chunks of 16384 that accumulate into C (beta applied by the first chunk only); a chunk goes
+    # through the persistent kernel when its own shape passes the work gate, through the split-K kernel otherwise -- the numbers below
+    # hold either way, the path counter is asserted for single-launch shapes only
+    chunked = k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2"
 
     d = _d()
     rng = np.random.default_rng(m + n + k + 1)
@@ -491,7 +493,8 @@ def test_streamk_gemm_f32_entrywise(ctx, m, n, k, ta):
     before = ctx.path_count(1)
     Cd = d.cm_from_numpy(C0)
     ctx.gemm(ta, "N", m, n, k, 1.5, Ad, lda, Bd, k, -0.5, Cd, m)
-    assert ctx.path_count(1) == before + 1, "the fp32 stream-K kernel did not take this shape"
+    if not chunked:
+        assert ctx.path_count(1) == before + 1, "the fp32 stream-K kernel did not take this shape"
     r1 = d.cm_to_numpy(Cd)
     ref = 1.5 * (A.astype(np.float64) @ B.astype(np.float64)) - 0.5 * C0
     assert relerr(r1, ref) <= 4 * EPS32 * np.sqrt(k)            # fp32 fma chains of length k (measured class: ~1e-7 * sum |a b|)
