@@ -100,6 +100,31 @@ __global__ void zero_int_kernel(int* p) { *p = 0; }
 constexpr int PS_MAXN = 448;
 constexpr int PS_LD = 34;          // column stride (doubles) of the LDS copy of U12: conflict-free MFMA fragment reads
 
+// value of lane `src` (0..3) of the caller's quad, in all four lanes (DPP quad_perm broadcast)
+template <typename T>
+__device__ __forceinline__ T quad_bcast(T v, const int src) {
+    if constexpr (sizeof(T) == 8) {
+        const double d = (double)v;
+        int lo = __double2loint(d), hi = __double2hiint(d), lo2, hi2;
+        switch (src) {
+            case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x00, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x00, 0xF, 0xF, false); break;
+            case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x55, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x55, 0xF, 0xF, false); break;
+            case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xAA, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xAA, 0xF, 0xF, false); break;
+            default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xFF, 0xF, 0xF, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xFF, 0xF, 0xF, false); break;
+        }
+        return (T)__hiloint2double(hi2, lo2);
+    } else {
+        int w = __float_as_int((float)v), w2;
+        switch (src) {
+            case 0: w2 = __builtin_amdgcn_update_dpp(0, w, 0x00, 0xF, 0xF, false); break;
+            case 1: w2 = __builtin_amdgcn_update_dpp(0, w, 0x55, 0xF, 0xF, false); break;
+            case 2: w2 = __builtin_amdgcn_update_dpp(0, w, 0xAA, 0xF, 0xF, false); break;
+            default: w2 = __builtin_amdgcn_update_dpp(0, w, 0xFF, 0xF, 0xF, false); break;
+        }
+        return (T)__int_as_float(w2);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict__ A, int64_t lda, int* __restrict__ info, int info_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ps_smem[];
@@ -163,25 +188,32 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
         __syncthreads();
         if (s_bad) break;
         if (rest <= 0) break;
-        // ---- 2. block row: column c of A12 per thread, solve U11^T x = a
-        for (int c = tid; c < rest; c += 1024) {
-            T x[NB];
+        // ---- 2. block row: solve U11^T x = a for every column of A12.  FOUR lanes per column (lane g of the quad owns rows g, g + 4, ...):
+        //      one thread per column left 4 of the 16 waves with ~1000 dependent LDS-read / FMA instructions each (100 of the kernel's
+        //      250 us at n = 256); the quads put 14 waves to work with ~400 instructions each and x[l] travels by a DPP quad broadcast.
+        //      (rest > 0 implies a full 32-column panel)
+        for (int c = tid >> 2; c < rest; c += 256) {
+            const int g = tid & 3;
+            T x[NB / 4];
             T* colp = A + j0 + (int64_t)(j0 + jb + c) * lda;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) { const T t = colp[(i < jb) ? i : (jb - 1)]; x[i] = (i < jb) ? t : T(0); }
-            // right-looking substitution: once x[l] is final every later entry is updated independently (ILP, no serial dot)
+            for (int r = 0; r < NB / 4; ++r) x[r] = colp[g + 4 * r];
 #pragma unroll
             for (int l = 0; l < NB; ++l) {
-                if (l < jb) {
-                    x[l] *= sInv[l];
+                // the owner of row l (lane l % 4 of the quad) finishes x[l]; everybody in the quad gets it
+                const T mine = x[l >> 2] * sInv[l];
+                const T xl = quad_bcast(mine, l & 3);
+                if (g == (l & 3)) x[l >> 2] = xl;
 #pragma unroll
-                    for (int i = l + 1; i < NB; ++i) x[i] -= sU11[l * 33 + i] * x[l];
+                for (int r = l >> 2; r < NB / 4; ++r) {
+                    const int i = g + 4 * r;
+                    if (i > l) x[r] -= sU11[l * 33 + i] * xl;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                if (i < jb) colp[i] = x[i];
-                sU12[c * PS_LD + i] = x[i];
+            for (int r = 0; r < NB / 4; ++r) {
+                colp[g + 4 * r] = x[r];
+                sU12[c * PS_LD + g + 4 * r] = x[r];
             }
         }
         for (int e = tid; e < (((rest + 15) / 16) * 16 - rest) * NB; e += 1024)      // zero the padding columns
