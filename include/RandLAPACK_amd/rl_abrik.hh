@@ -61,6 +61,30 @@ public:
         singular_triplets_found = 0;
     }
 
+    /// ABRIK on a general dense matrix given by its pointer (rl_abrik.hh:122-143): A (m x n, lda) is a DEVICE buffer and is not modified.
+    int call(int64_t m, int64_t n, T* A, int64_t lda, int64_t k, T*& U, T*& V, T*& Sigma, RandBLAS::RNGState<RNG>& state) {
+        randlapack_require(m >= 0) << "m=" << m << " must be >= 0";
+        randlapack_require(n >= 0) << "n=" << n << " must be >= 0";
+        randlapack_require(lda >= m) << "lda=" << lda << " < m=" << m << " (lda must be >= m for ColMajor)";
+        randlapack_require(k > 0) << "target rank k=" << k << " must be > 0";
+        randlapack_require(!(A == nullptr && m > 0 && n > 0)) << "A buffer is null but m=" << m << " and n=" << n << " imply a nonempty matrix";
+        linops::DenseLinOp<T> A_linop(m, n, A, lda, Layout::ColMajor, q);
+        A_linop.row_sharded = q.world() > 1;          // on a sharded queue the pointer is this rank's row block
+        return this->call(A_linop, k, U, V, Sigma, state);
+    }
+
+    /// ABRIK on a sparse matrix (rl_abrik.hh:146-162): SpMat is RandBLAS::sparse_data::CSRMatrix over device arrays (rl_randblas.hh).
+    template <typename SpMat, typename = typename SpMat::index_t>
+    int call(int64_t m, int64_t n, SpMat& A, int64_t k, T*& U, T*& V, T*& Sigma, RandBLAS::RNGState<RNG>& state) {
+        randlapack_require(m >= 0) << "m=" << m << " must be >= 0";
+        randlapack_require(n >= 0) << "n=" << n << " must be >= 0";
+        randlapack_require(k > 0) << "target rank k=" << k << " must be > 0";
+        randlapack_require(A.n_rows == m && A.n_cols == n) << "sparse matrix is " << A.n_rows << " x " << A.n_cols << ", call says " << m << " x " << n;
+        linops::SparseLinOp<T> A_linop(m, n, A.nnz, A.rowptr, A.colidxs, A.vals, q);
+        A_linop.row_sharded = q.world() > 1;
+        return this->call(A_linop, k, U, V, Sigma, state);
+    }
+
     /// A: linear operator (rl_linops.hh).  U (m x triplets), V (n x triplets), Sigma (triplets): allocated HERE on the
     /// device, owned by the caller afterwards (blas::device_free), like the reference's new[] (:678-680).  Returns 0.
     template <typename GLO>

@@ -132,6 +132,13 @@ public:
         check(rlhip_scratch_alloc(q_.ctx(), &p, (size_t)(n > 0 ? n : 1) * sizeof(T)), "scratch_alloc");
         return (T*)p;
     }
+    /// nullptr instead of an exception when the arena cannot grow by n elements (optional workspaces: the caller falls back)
+    template <typename T>
+    T* try_alloc(int64_t n) {
+        void* p = nullptr;
+        if (rlhip_scratch_alloc(q_.ctx(), &p, (size_t)(n > 0 ? n : 1) * sizeof(T)) < 0) return nullptr;
+        return (T*)p;
+    }
 };
 
 // ---- level 3 (ColMajor only, as on the whole reference path)

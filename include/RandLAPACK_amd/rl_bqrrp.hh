@@ -7,12 +7,14 @@
 //                                                                              (correct, BLAS-2 bound: cholqr is the fast one)
 //   apply_trans_q gemqrt -> compact-WY block apply on the MFMA GEMMs        | ormqr -> the same apply (tau is the
 //                                                                             diagonal of T, :490-491, so both name one operator)
-// Every option of the reference is available.  The object DEFAULTS to {luqr, cholqr, gemqrt}: luqr is the reference's own
-// default, cholqr/gemqrt are the BLAS-3 choices (the reference's CPU defaults geqrf/ormqr are supported, just slower here).
+// Every option of the reference is available.  The object DEFAULTS to the reference's {luqr, geqrf, ormqr} (rl_bqrrp.hh:74-76);
+// `use_fast_subroutines()` selects {luqr, cholqr, gemqrt}, the BLAS-3 triple.  The blocked loop itself lives in
+// detail::bqrrp_factor and is shared with BQRRP_GPU (rl_bqrrp_gpu.hh), which differs only in taking the sketch from its caller.
 #pragma once
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <type_traits>
 #include <vector>
 #include "rl_exceptions.hh"
 #include "rl_blaspp.hh"
@@ -35,6 +37,194 @@ struct BQRRPSubroutines {
     enum QRTall { geqrt, cholqr, geqrf };
     enum ApplyTransQ { ormqr, gemqrt };
 };
+
+namespace detail {
+
+/// Per-stage wall time of one factorization in microseconds (armed by BqrrpOpts::timing; every lap drains the stream first).
+/// BQRRP::times folds them into the 9 entries of rl_bqrrp.hh:581-590, BQRRP_GPU::times into the 15 of rl_bqrrp_gpu.hh:829-834.
+struct BqrrpLaps {
+    long qrcp_main = 0;   // qrcp_wide without the sketch permutation: transpose + getrf + pivot conversion + wide geqrf, or geqp3
+    long qrcp_piv = 0;    // col_swap of the sketch
+    long piv_A = 0;       // col_swap of the trailing columns of A, zero test, rank estimate of the block
+    long upd_J = 0;       // J <- J[J_buffer]
+    long precond = 0;     // cholqr panels: A_pre = A_panel * inv(R_sk)
+    long qr_tall = 0;
+    long recon = 0;       // cholqr panels: Householder reconstruction, signs, R11 = R_chol * R_sk
+    long apply = 0;       // Q^T applied to the trailing columns
+    long upd_sk = 0;      // sketch down-date
+};
+
+template <typename T>
+struct BqrrpOpts {
+    int64_t block_size;
+    int64_t internal_nb;
+    T tol;
+    BQRRPSubroutines::QRCPWide qrcp_wide;
+    BQRRPSubroutines::QRTall qr_tall;
+    BQRRPSubroutines::ApplyTransQ apply_trans_q;
+    bool cholqr_fallback;
+    T cholqr_cond_limit_inv;
+    bool timing;
+};
+
+/// The blocked loop of BQRRP (rl_bqrrp.hh:318-661) and of BQRRP_GPU (rl_bqrrp_gpu.hh:336-934) on one device: both classes run
+/// THIS function; they differ in where the d x n sketch A_sk (ld d) comes from -- BQRRP forms S*A (:309-313), BQRRP_GPU receives it
+/// from the caller (rl_bqrrp_gpu.hh:120-129) -- and in how they report the laps.  A_sk is overwritten (the reference's device
+/// class says the same, rl_bqrrp_gpu.hh:354-355).  All pointers are DEVICE pointers.  Sets rank; returns 0.
+template <typename T>
+int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T* A, int64_t lda, T* A_sk, int64_t d, T* tau, int64_t* J,
+                 int64_t& rank, int64_t& cholqr_fallbacks, BqrrpLaps& L) {
+    using Sub = BQRRPSubroutines;
+    using clk = std::chrono::steady_clock;
+    auto stamp = [&]() { if (P.timing) q.sync(); return clk::now(); };
+    auto lap = [&](long& acc, clk::time_point& t0) {
+        if (!P.timing) return;
+        auto t1 = stamp();
+        acc += (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+        t0 = t1;
+    };
+    const int64_t mn = std::min(m, n);
+    int64_t rows = m, cols = n, curr_sz = 0, b_sz = P.block_size;
+    cholqr_fallbacks = 0;
+    rank = 0;
+    const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);                                               // :220
+    const int64_t b_sz_const = b_sz;
+    int64_t sampling_dimension = d, block_rank = b_sz, inb = P.internal_nb;
+    T* A_work = A;
+
+    blas::Scratch ws(q);
+    int64_t* J_buffer = ws.alloc<int64_t>(n);
+    T* R_tall_qr = ws.alloc<T>(b_sz_const * b_sz_const);
+    T* T_dat = ws.alloc<T>(b_sz_const * b_sz_const);
+    T* Work2 = ws.alloc<T>(n);
+    const bool lu = (P.qrcp_wide == Sub::QRCPWide::luqr);
+    T* T_ormqr = ws.alloc<T>(b_sz_const * b_sz_const);
+    T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;                                                       // :262-266
+    int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
+    std::vector<T> diag(b_sz_const);
+    auto transpose_call = [&](int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
+        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+        else return rlhip_transpose_f32(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+    };
+
+    for (int64_t iter = 0; iter < maxiter; ++iter) {
+        b_sz = std::min(b_sz, mn - curr_sz);                                                                // :322-324
+        inb = std::min(inb, b_sz);
+        block_rank = b_sz;
+        auto ta = stamp();
+        if (!lu) {
+            lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                           // :336
+            lap(L.qrcp_main, ta);
+        } else {                                                                                            // :337-357
+            blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
+            lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
+            lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
+            lap(L.qrcp_main, ta);
+            util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
+            lap(L.qrcp_piv, ta);
+            lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
+            lap(L.qrcp_main, ta);
+        }
+        util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);                                 // :369
+        bool block_zero = !lapack::any_abs_gt(rows, A_work, std::numeric_limits<T>::epsilon(), q);         // :373-379
+        lap(L.piv_A, ta);
+        if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);                                      // :383-387 / :402-406
+        else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
+        lap(L.upd_J, ta);
+        if (block_zero) { rank = curr_sz; return 0; }                                                       // :380-399
+        T* Work1 = &A_work[lda * b_sz];
+        T* R_sk = A_sk;
+        lapack::get_diag(b_sz, R_sk, d, diag.data(), q);
+        for (int64_t i = 0; i < b_sz; ++i) {                                                                // :421-427
+            if (std::abs(diag[i]) / std::abs(diag[0]) < P.tol) { block_rank = i; inb = std::min(inb, block_rank); break; }
+        }
+        lap(L.piv_A, ta);
+        T* tau_sub = &tau[curr_sz];
+        T* R11 = A_work;
+        bool have_T = true;
+        if (P.qr_tall == Sub::QRTall::cholqr) {                                                             // :454-505
+            blas::Scratch ws_panel(q);
+            T* panel_copy = nullptr;                    // the unpreconditioned panel, kept for the Householder fallback below
+            if (P.cholqr_fallback) {
+                panel_copy = ws_panel.alloc<T>(rows * block_rank);
+                lapack::lacpy(MatrixType::General, rows, block_rank, A_work, lda, panel_copy, rows, q);
+            }
+            blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
+            lap(L.precond, ta);
+            lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
+            blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
+            const int64_t chol_info = lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);
+            bool chol_bad = chol_info != 0;
+            if (P.cholqr_fallback && !chol_bad && block_rank > 0) {
+                // Cholesky QR is only as orthogonal as eps * cond(A_pre)^2.  The preconditioner should leave cond(A_pre) = O(1); a
+                // graded diagonal of R_chol (a lower bound on cond(A_pre)) says it did not -- the panel sits on the noise floor of
+                // a numerically rank-deficient matrix -- and the panel goes to Householder as well.
+                std::vector<T> dg((size_t)block_rank);
+                lapack::get_diag(block_rank, R_tall_qr, b_sz_const, dg.data(), q);
+                T dmin = std::abs(dg[0]), dmax = std::abs(dg[0]);
+                for (int64_t i = 1; i < block_rank; ++i) { dmin = std::min(dmin, std::abs(dg[(size_t)i])); dmax = std::max(dmax, std::abs(dg[(size_t)i])); }
+                chol_bad = !(dmin > P.cholqr_cond_limit_inv * dmax);          // also catches NaN
+            }
+            if (chol_bad && P.cholqr_fallback) {
+                // On a Cholesky breakdown the reference carries on with the partially factored Gram matrix (:461 "handles potrf failure gracefully");
+                // what the panel then holds depends on where the host potrf happened to stop, and on the device it can blow
+                // up (Kahan matrix, 512 x 512: tau up to 115, ||Q'Q - I|| ~ 1e46).  A Cholesky breakdown means the
+                // preconditioned panel is numerically rank deficient: restore the panel and factor THIS panel with
+                // Householder reflectors instead (the qr_tall = geqrf branch), which needs no positive definiteness.
+                ++cholqr_fallbacks;
+                lapack::lacpy(MatrixType::General, rows, block_rank, panel_copy, rows, A_work, lda, q);   // (multiplying R_sk back would lose cond(R_sk) * eps)
+                lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
+                have_T = false;
+                lap(L.qr_tall, ta);
+            } else {
+                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
+                lap(L.qr_tall, ta);
+                lapack::orhr_col(rows, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work2, q);           // :480
+                lapack::row_sign(block_rank, R_tall_qr, b_sz_const, Work2, q);                              // :485-487
+                lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);                         // :490-491
+                blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, block_rank, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // :497
+                lapack::lacpy(MatrixType::Upper, block_rank, b_sz, R_tall_qr, b_sz_const, A_work, lda, q); // :504
+                lap(L.recon, ta);
+            }
+        } else if (P.qr_tall == Sub::QRTall::geqrt) {                                                       // :438-453
+            lapack::geqrt(rows, b_sz, inb, A_work, lda, T_dat, b_sz_const, Work2, q);
+            lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);
+            lap(L.qr_tall, ta);
+        } else {                                                                                            // geqrf :506-523
+            lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
+            have_T = false;
+            lap(L.qr_tall, ta);
+        }
+        // ---- apply Q^T to the trailing columns (:535-547)
+        const int64_t q_rows = (block_rank != b_sz_const) ? block_rank : rows;
+        if (cols - b_sz > 0 && block_rank > 0) {
+            if (P.apply_trans_q == Sub::ApplyTransQ::gemqrt && have_T)                                      // :535-547
+                lapack::gemqrt(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work1, lda, q);
+            else   // ormqr: the same reflectors applied from (V, tau); T_dat is free to hold the k x k block when T is not needed again
+                lapack::ormqr(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda, T_ormqr, q);
+        }
+        lap(L.apply, ta);
+        T* R12 = &R11[lda * b_sz];
+        curr_sz += b_sz;
+        if (curr_sz >= mn || block_rank != b_sz_const) { rank = curr_sz; return 0; }                        // :576-618
+        A_work = &Work1[b_sz];                                                                               // :624
+        // sketch down-date (:633-651)
+        if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);         // get_U(b, b, R_sk, d)
+        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R11, lda, R_sk, d, q);
+        blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, cols - b_sz, b_sz, (T)-1.0, R_sk, d, R12, lda, (T)1.0, &R_sk[d * b_sz], d, q);
+        sampling_dimension = std::min(sampling_dimension, cols);
+        if (sampling_dimension - b_sz > 1)
+            lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0,
+                          &R_sk[(d + 1) * b_sz] + 1, d, q);
+        A_sk = &A_sk[d * b_sz];
+        rows -= b_sz;
+        cols -= b_sz;
+        lap(L.upd_sk, ta);
+    }
+    return 0;
+}
+
+}  // namespace detail
 
 template <typename T, typename RNG>
 class BQRRP : public BQRRPalg<T, RNG> {
@@ -73,30 +263,10 @@ public:
         using clk = std::chrono::steady_clock;
         auto stamp = [&]() { if (timing) q.sync(); return clk::now(); };
         auto us = [](clk::time_point a, clk::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        long t_skop = 0, t_qrcp = 0, t_pre = 0, t_tall = 0, t_rec = 0, t_apply = 0, t_upd = 0;
         auto t_begin = stamp();
-
-        int64_t rows = m, cols = n, curr_sz = 0, b_sz = block_size;
-        cholqr_fallbacks = 0;
-        const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);                                         // :220
-        const int64_t b_sz_const = b_sz;
-        const int64_t d = (int64_t)(d_factor * b_sz);                                                       // :224
-        int64_t sampling_dimension = d, block_rank = b_sz, inb = internal_nb;
-        T* A_work = A;
-
+        const int64_t d = (int64_t)(d_factor * block_size);                                                  // :224
         blas::Scratch ws(q);
-        int64_t* J_buffer = ws.alloc<int64_t>(n);
-        T* A_sk_base = ws.alloc<T>(d * n);
-        T* R_tall_qr = ws.alloc<T>(b_sz_const * b_sz_const);
-        T* T_dat = ws.alloc<T>(b_sz_const * b_sz_const);
-        T* Work2 = ws.alloc<T>(n);
-        const bool lu = (qrcp_wide == Subroutines::QRCPWide::luqr);
-        T* T_ormqr = ws.alloc<T>(b_sz_const * b_sz_const);
-        T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;                                                   // :262-266
-        int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
-        T* A_sk = A_sk_base;
-
-        auto t0 = stamp();
+        T* A_sk = ws.alloc<T>(d * n);
         if (sketch_override) {
             lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_sk, d, q);
         } else {                                                                                            // :309-313
@@ -107,129 +277,16 @@ public:
             blas::device_free(S, q);
         }
         if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_sk, d, sketch_export, d, q);
-        t_skop = us(t0, stamp());
-        std::vector<T> diag(b_sz_const);
-
-        for (int64_t iter = 0; iter < maxiter; ++iter) {
-            b_sz = std::min(b_sz, mn - curr_sz);                                                            // :322-324
-            inb = std::min(inb, b_sz);
-            block_rank = b_sz;
-            auto ta = stamp();
-            if (!lu) {
-                lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                       // :336
-            } else {                                                                                        // :337-357
-                blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
-                lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
-                lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
-                util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
-                lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
-            }
-            t_qrcp += us(ta, stamp());
-            ta = stamp();
-            util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);                             // :369
-            bool block_zero = !lapack::any_abs_gt(rows, A_work, std::numeric_limits<T>::epsilon(), q);     // :373-379
-            if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);                                  // :383-387 / :402-406
-            else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
-            if (block_zero) { rank = curr_sz; finish(t_begin, t_skop, t_qrcp, t_pre, t_tall, t_rec, t_apply, t_upd); return 0; }   // :380-399
-            T* Work1 = &A_work[lda * b_sz];
-            T* R_sk = A_sk;
-            lapack::get_diag(b_sz, R_sk, d, diag.data(), q);
-            for (int64_t i = 0; i < b_sz; ++i) {                                                            // :421-427
-                if (std::abs(diag[i]) / std::abs(diag[0]) < tol) { block_rank = i; inb = std::min(inb, block_rank); break; }
-            }
-            T* tau_sub = &tau[curr_sz];
-            T* R11 = A_work;
-            bool have_T = true;
-            if (qr_tall == Subroutines::QRTall::cholqr) {                                                   // :454-505
-                blas::Scratch ws_panel(q);
-                T* panel_copy = nullptr;                    // the unpreconditioned panel, kept for the Householder fallback below
-                if (cholqr_fallback) {
-                    panel_copy = ws_panel.alloc<T>(rows * block_rank);
-                    lapack::lacpy(MatrixType::General, rows, block_rank, A_work, lda, panel_copy, rows, q);
-                }
-                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_sk, d, A_work, lda, q);
-                t_pre += us(ta, stamp());
-                ta = stamp();
-                lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
-                blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, block_rank, rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
-                const int64_t chol_info = lapack::potrf(Uplo::Upper, block_rank, R_tall_qr, b_sz_const, q);
-                bool chol_bad = chol_info != 0;
-                if (cholqr_fallback && !chol_bad && block_rank > 0) {
-                    // Cholesky QR is only as orthogonal as eps * cond(A_pre)^2.  The preconditioner should leave cond(A_pre) = O(1); a
-                    // graded diagonal of R_chol (a lower bound on cond(A_pre)) says it did not -- the panel sits on the noise floor of
-                    // a numerically rank-deficient matrix -- and the panel goes to Householder as well.
-                    std::vector<T> dg((size_t)block_rank);
-                    lapack::get_diag(block_rank, R_tall_qr, b_sz_const, dg.data(), q);
-                    T dmin = std::abs(dg[0]), dmax = std::abs(dg[0]);
-                    for (int64_t i = 1; i < block_rank; ++i) { dmin = std::min(dmin, std::abs(dg[(size_t)i])); dmax = std::max(dmax, std::abs(dg[(size_t)i])); }
-                    chol_bad = !(dmin > cholqr_cond_limit_inv * dmax);          // also catches NaN
-                }
-                if (chol_bad && cholqr_fallback) {
-                    // On a Cholesky breakdown the reference carries on with the partially factored Gram matrix (:461 "handles potrf failure gracefully");
-                    // what the panel then holds depends on where the host potrf happened to stop, and on the device it can blow
-                    // up (Kahan matrix, 512 x 512: tau up to 115, ||Q'Q - I|| ~ 1e46).  A Cholesky breakdown means the
-                    // preconditioned panel is numerically rank deficient: restore the panel and factor THIS panel with
-                    // Householder reflectors instead (the qr_tall = geqrf branch), which needs no positive definiteness.
-                    ++cholqr_fallbacks;
-                    lapack::lacpy(MatrixType::General, rows, block_rank, panel_copy, rows, A_work, lda, q);   // (multiplying R_sk back would lose cond(R_sk) * eps)
-                    lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
-                    have_T = false;
-                    t_tall += us(ta, stamp());
-                } else {
-                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
-                t_tall += us(ta, stamp());
-                ta = stamp();
-                lapack::orhr_col(rows, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work2, q);           // :480
-                lapack::row_sign(block_rank, R_tall_qr, b_sz_const, Work2, q);                              // :485-487
-                lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);                         // :490-491
-                blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, block_rank, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // :497
-                lapack::lacpy(MatrixType::Upper, block_rank, b_sz, R_tall_qr, b_sz_const, A_work, lda, q); // :504
-                t_rec += us(ta, stamp());
-                }
-            } else if (qr_tall == Subroutines::QRTall::geqrt) {                                             // :438-453
-                t_pre += us(ta, stamp());
-                ta = stamp();
-                lapack::geqrt(rows, b_sz, inb, A_work, lda, T_dat, b_sz_const, Work2, q);
-                lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);
-                t_tall += us(ta, stamp());
-            } else {                                                                                        // geqrf :506-523
-                t_pre += us(ta, stamp());
-                ta = stamp();
-                lapack::geqrf(rows, b_sz, A_work, lda, tau_sub, q);
-                have_T = false;
-                t_tall += us(ta, stamp());
-            }
-            ta = stamp();
-            // ---- apply Q^T to the trailing columns (:535-547)
-            const int64_t q_rows = (block_rank != b_sz_const) ? block_rank : rows;
-            if (cols - b_sz > 0 && block_rank > 0) {
-                if (apply_trans_q == Subroutines::ApplyTransQ::gemqrt && have_T)                            // :535-547
-                    lapack::gemqrt(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work1, lda, q);
-                else   // ormqr: the same reflectors applied from (V, tau); T_dat is free to hold the k x k block when T is not needed again
-                    lapack::ormqr(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda, T_ormqr, q);
-            }
-            t_apply += us(ta, stamp());
-            T* R12 = &R11[lda * b_sz];
-            curr_sz += b_sz;
-            if (curr_sz >= mn || block_rank != b_sz_const) {                                                 // :576-618
-                rank = curr_sz;
-                finish(t_begin, t_skop, t_qrcp, t_pre, t_tall, t_rec, t_apply, t_upd);
-                return 0;
-            }
-            ta = stamp();
-            A_work = &Work1[b_sz];                                                                           // :624
-            // sketch down-date (:633-651)
-            if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);     // get_U(b, b, R_sk, d)
-            blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R11, lda, R_sk, d, q);
-            blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, cols - b_sz, b_sz, (T)-1.0, R_sk, d, R12, lda, (T)1.0, &R_sk[d * b_sz], d, q);
-            sampling_dimension = std::min(sampling_dimension, cols);
-            if (sampling_dimension - b_sz > 1)
-                lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0,
-                              &R_sk[(d + 1) * b_sz] + 1, d, q);
-            A_sk = &A_sk[d * b_sz];
-            rows -= b_sz;
-            cols -= b_sz;
-            t_upd += us(ta, stamp());
+        const long t_skop = us(t_begin, stamp());
+        detail::BqrrpOpts<T> P{block_size, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, cholqr_fallback, cholqr_cond_limit_inv, timing};
+        detail::BqrrpLaps L;
+        detail::bqrrp_factor(q, P, m, n, A, lda, A_sk, d, tau, J, rank, cholqr_fallbacks, L);
+        if (timing) {                // the reference's 9 entries (:581-590); the laps of the shared loop are finer (BQRRP_GPU reports all of them)
+            q.sync();
+            const long total = us(t_begin, clk::now());
+            const long qrcp = L.qrcp_main + L.qrcp_piv, pre = L.piv_A + L.upd_J + L.precond;
+            times = {t_skop, qrcp, pre, L.qr_tall, L.recon, L.apply, L.upd_sk,
+                     total - (t_skop + qrcp + pre + L.qr_tall + L.recon + L.apply + L.upd_sk), total};
         }
         return 0;
     }
@@ -442,41 +499,6 @@ public:
     // testing hooks (not in the reference): the d x n sketch to use instead of S*A, and a buffer receiving the sketch
     const T* sketch_override = nullptr;
     T* sketch_export = nullptr;
-
-private:
-    void finish(std::chrono::steady_clock::time_point t_begin, long a, long b, long c, long d_, long e, long f, long g) {
-        if (!timing) return;
-        q.sync();
-        long total = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
-        times = {a, b, c, d_, e, f, g, total - (a + b + c + d_ + e + f + g), total};
-    }
-};
-
-/// BQRRP_GPU (reference: drivers/rl_bqrrp_gpu.hh:27-149): the reference's device driver takes the SKETCH as an input
-/// (A_sk_dev, d x n, ld d) instead of generating it; same thing here on top of BQRRP (qr_tall in {cholqr, geqrf} as there).
-template <typename T, typename RNG = RandBLAS::DefaultRNG>
-class BQRRP_GPU {
-public:
-    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
-    BQRRP_GPU(bool time_subroutines, int64_t b_sz) : BQRRP_GPU(blas::default_queue(), time_subroutines, b_sz) {}                         // rl_bqrrp_gpu.hh:63-66
-    BQRRP_GPU(blas::Queue& queue, bool time_subroutines, int64_t b_sz) : impl(queue, time_subroutines, b_sz), rank(0), block_size(b_sz) {
-        impl.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;                                        // LU-QR only (:354-399)
-        impl.qr_tall = BQRRPSubroutines::QRTall::cholqr;
-        impl.apply_trans_q = BQRRPSubroutines::ApplyTransQ::gemqrt;
-    }
-    int call(int64_t m, int64_t n, T* A, int64_t lda, T* A_sk, int64_t d, T* tau, int64_t* J) {
-        randlapack_require(block_size > 0 && d % block_size == 0) << "BQRRP_GPU: d=" << d << " must be a multiple of the block size";
-        impl.sketch_override = A_sk;
-        RandBLAS::RNGState<RNG> unused;
-        const int rc = impl.call(m, n, A, lda, (T)d / (T)block_size, tau, J, unused);
-        rank = impl.rank;
-        times = impl.times;
-        return rc;
-    }
-    BQRRP<T, RNG> impl;
-    int64_t rank;
-    int64_t block_size;
-    std::vector<long> times;
 };
 
 }  // namespace RandLAPACK

@@ -139,7 +139,7 @@ public:
         // separate permutation pass (C3: 3.9 ms of 79).  `fold_pivoting = false` (or a rank-deficient sketch) keeps the reference's
         // statement order below.
         T* W = nullptr;
-        if (fold_pivoting && k == n && m >= 16384) W = ws.alloc<T>(m * n);
+        if (fold_pivoting && k == n && m >= 16384) W = ws.try_alloc<T>(m * n);   // no room for a second m x n matrix: the in-place order below
         if (W) {
             auto t4 = stamp();
             for (int64_t i = 0; i < k; ++i)                                                                 // :296-301 diag_is_nonzero
@@ -270,35 +270,6 @@ public:
     // testing hooks (not in the reference): a d x n sketch to use instead of S*A / a buffer receiving the sketch
     const T* sketch_override = nullptr;
     T* sketch_export = nullptr;
-};
-
-/// CQRRPT_GPU (reference: drivers/rl_cqrrpt_gpu.hh:23-146): same signature as CQRRPT but with HOST pointers -- the driver owns the
-/// transfers.  Here: upload A, run CQRRPT on the device, download Q, R, J.
-template <typename T, typename RNG = RandBLAS::DefaultRNG>
-class CQRRPT_GPU {
-public:
-    // the reference's signature (no queue): the process-wide default queue, as the reference's device drivers use Queue(0)
-    CQRRPT_GPU(bool verb, bool time_subroutines, T ep) : CQRRPT_GPU(blas::default_queue(), verb, time_subroutines, ep) {}                 // rl_cqrrpt_gpu.hh:56-60
-    CQRRPT_GPU(blas::Queue& queue, bool verb, bool time_subroutines, T ep) : impl(queue, time_subroutines, ep), q(queue), rank(0) { (void)verb; }
-    int call(int64_t m, int64_t n, T* A_host, int64_t lda, T* R_host, int64_t ldr, int64_t* J_host, T d_factor, RandBLAS::RNGState<RNG>& state) {
-        randlapack_require(lda == m && ldr == n) << "CQRRPT_GPU: packed host matrices expected (lda = m, ldr = n)";
-        blas::Scratch ws(q);
-        T* A = blas::device_malloc<T>(m * n, q);
-        T* R = ws.alloc<T>(n * n);
-        int64_t* J = ws.alloc<int64_t>(n);
-        blas::copy_to_device(m * n, A_host, A, q);
-        lapack::laset(MatrixType::General, n, n, (T)0, (T)0, R, n, q);
-        const int rc = impl.call(m, n, A, m, R, n, J, d_factor, state);
-        rank = impl.rank;
-        blas::copy_to_host(m * n, A, A_host, q);
-        blas::copy_to_host(n * n, R, R_host, q);
-        blas::copy_to_host(n, J, J_host, q);
-        blas::device_free(A, q);
-        return rc;
-    }
-    CQRRPT<T, RNG> impl;
-    blas::Queue& q;
-    int64_t rank;
 };
 
 }  // namespace RandLAPACK

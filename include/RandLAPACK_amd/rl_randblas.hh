@@ -184,4 +184,23 @@ void sketch_rows(SparseSkOp<float, RNG>& S, int64_t n, float alpha, float const*
     blas::check(rlhip_saso_apply_rows_f32(q.ctx(), S.handle, n, alpha, A_loc, lda, row0, mloc, beta, B, ldb), "saso_apply_rows");
 }
 
+// ---- sparse data matrices (RandBLAS::sparse_data::CSRMatrix as the reference's ABRIK / SparseLinOp take them, rl_abrik.hh:146-162,
+//      rl_sparse_linop.hh): a NON-OWNING view of device CSR arrays with int64 indices.  Field names as in RandBLAS (n_rows, n_cols, nnz,
+//      vals, rowptr, colidxs).  A CSC matrix is passed as the CSR of its transpose.
+namespace sparse_data {
+template <typename T, typename sint_t = int64_t>
+struct CSRMatrix {
+    using scalar_t = T;
+    using index_t = sint_t;
+    const int64_t n_rows, n_cols;
+    int64_t nnz;
+    const T* vals;
+    const sint_t* rowptr;
+    const sint_t* colidxs;
+    CSRMatrix(int64_t rows, int64_t cols, int64_t nnz_, const T* v, const sint_t* rp, const sint_t* ci)
+        : n_rows(rows), n_cols(cols), nnz(nnz_), vals(v), rowptr(rp), colidxs(ci) {}
+};
+}  // namespace sparse_data
+using sparse_data::CSRMatrix;
+
 }  // namespace RandBLAS

@@ -77,7 +77,29 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
                         const double* A_sk_in, double* A_sk_out, int64_t* rank_out, long* times_us, int qrcp_wide, int qr_tall,
                         int apply_trans_q);
 
-/* ABRIK<double>::call on a dense operator (drivers/rl_abrik.hh:166; linops::DenseLinOp rl_dense_linop.hh).  A (m x n, lda) is not
+/* BQRRP_GPU<T>::call (drivers/rl_bqrrp_gpu.hh:120-129, body :152-934): the reference's device class -- the d x n sketch A_sk (ld d,
+ * DEVICE, overwritten) is an INPUT, d >= b_sz is free (not tied to a d_factor).  qr_tall in the reference's enum order
+ * (BQRRPGPUSubroutines::QRTall, :44-46): 0 cholqr, 1 geqrf, -1 = the object's default (geqrf, :84).  tol <= 0 keeps eps.
+ * A (m x n, lda) -> GEQP3 format, tau (n), J (n), all DEVICE.  times15 (may be NULL) receives BQRRP_GPU::times, the 15 entries of
+ * rl_bqrrp_gpu.hh:829-834 in microseconds: {preallocation, qrcp_main, copy_A_sk, qrcp_piv, copy_A, piv_A, copy_J, updating_J,
+ * preconditioning, qr_tall, q_reconstruction, apply_transq, sample_update, rest, total}. */
+int rlhip_drv_bqrrp_gpu_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* A_sk, int64_t d, int64_t b_sz, int qr_tall,
+                            double tol, double* tau, int64_t* J, int64_t* rank_out, long* times15);
+int rlhip_drv_bqrrp_gpu_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* A_sk, int64_t d, int64_t b_sz, int qr_tall,
+                            float tol, float* tau, int64_t* J, int64_t* rank_out, long* times15);
+/* CQRRPT_GPU<T>::call (drivers/rl_cqrrpt_gpu.hh:117-127, body :149-390): HOST matrices in and out as in the reference (A m x n lda -> Q,
+ * R n x n ldr, J n); every stage runs on the device, the class owns the two transfers.  nnz <= 0 keeps the object's default (2);
+ * no_hqrrp: 1 geqp3 (default, :75), 0 hqrrp, -1 default.  A_hat_out_host (may be NULL): HOST buffer receiving the d x n sketch that
+ * was factored (d = (int64)(d_factor * n)) -- the shared-sketch hook of the parity tests.  times8 (may be NULL): CQRRPT_GPU::times
+ * {saso, qrcp, rank_reveal, cholqr, a_mod_piv, a_mod_trsm, rest, total} in microseconds (:371).  Returns 0 or 1. */
+int rlhip_drv_cqrrpt_gpu_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A_host, int64_t lda, double* R_host, int64_t ldr, int64_t* J_host,
+                             double d_factor, int64_t nnz, double eps, int no_hqrrp, uint32_t state[6], double* A_hat_out_host,
+                             int64_t* rank_out, long* times8);
+int rlhip_drv_cqrrpt_gpu_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A_host, int64_t lda, float* R_host, int64_t ldr, int64_t* J_host,
+                             float d_factor, int64_t nnz, float eps, int no_hqrrp, uint32_t state[6], float* A_hat_out_host,
+                             int64_t* rank_out, long* times8);
+
+/* ABRIK<double>::call(m, n, A, lda, k, U, V, Sigma, state), the dense-pointer overload (drivers/rl_abrik.hh:122-143).  A (m x n, lda) is not
  * modified.  *U (m x triplets), *Sigma (triplets), *V (n x triplets) are allocated by the callee (rlhip_malloc), freed by the caller.
  * max_krylov_iters <= 0 keeps the object's default (INT_MAX). */
 int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,

@@ -138,6 +138,14 @@ SIGNATURES.update({
     "rlhip_drv_abrik_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_dbl, c_i64, dpp, dpp, dpp, u32p, C.POINTER(c_i64),
                                     C.POINTER(c_i64), C.POINTER(c_dbl), c_int]),
     "rlhip_drv_cqrrt_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_dbl, c_i64, c_dbl, u32p, c_vp, c_vp]),
+    "rlhip_drv_bqrrp_gpu_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_dbl, c_vp, c_vp, C.POINTER(c_i64),
+                                        C.POINTER(C.c_long)]),
+    "rlhip_drv_bqrrp_gpu_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_flt, c_vp, c_vp, C.POINTER(c_i64),
+                                        C.POINTER(C.c_long)]),
+    "rlhip_drv_cqrrpt_gpu_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_dbl, c_i64, c_dbl, c_int, u32p, c_vp,
+                                         C.POINTER(c_i64), C.POINTER(C.c_long)]),
+    "rlhip_drv_cqrrpt_gpu_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_flt, c_i64, c_flt, c_int, u32p, c_vp,
+                                         C.POINTER(c_i64), C.POINTER(C.c_long)]),
     "rlhip_drv_rsvd_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, C.POINTER(c_i64), c_i64, c_dbl, c_i64, c_i64, c_int,
                                    c_int, c_int, c_int, dpp, dpp, dpp, u32p, C.POINTER(c_int)]),
 })

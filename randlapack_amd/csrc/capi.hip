@@ -64,8 +64,9 @@ void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
         want = align_up(want, 1 << 20);
         char* p = nullptr;
         if (hipMalloc((void**)&p, want) != hipSuccess) {
+            (void)hipGetLastError();                           // a failed allocation must not poison the next launch check
             want = align_up(bytes, 1 << 20);                   // memory is tight: take exactly what is needed
-            if (hipMalloc((void**)&p, want) != hipSuccess) return nullptr;
+            if (hipMalloc((void**)&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         c->segs[c->nsegs].base = p;
         c->segs[c->nsegs].size = want;

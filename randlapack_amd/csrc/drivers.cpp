@@ -357,8 +357,6 @@ int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, i
                         int qr_exp) {
     return guarded([&] {
         blas::Queue q(ctx);
-        RandLAPACK::linops::DenseLinOp<double> Aop(m, n, A, lda, RandLAPACK::Layout::ColMajor, q);
-        Aop.row_sharded = q.world() > 1;
         RandLAPACK::ABRIK<double, RNG> alg(q, false, false, tol);
         if (qr_exp >= 0) {
             if (qr_exp > 1) throw RandLAPACK::Error("qr_exp must be 0 (geqrf_ungqr) or 1 (cqrrt)");
@@ -367,13 +365,78 @@ int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, i
         if (max_krylov_iters > 0) alg.max_krylov_iters = (int)std::min<int64_t>(max_krylov_iters, INT_MAX);
         State st = load_state(state);
         *U = nullptr; *Sigma = nullptr; *V = nullptr;
-        int rc = alg.call(Aop, k, *U, *V, *Sigma, st);
+        int rc = alg.call(m, n, const_cast<double*>(A), lda, k, *U, *V, *Sigma, st);      // the dense-pointer overload (rl_abrik.hh:122-143)
         store_state(st, state);
         if (triplets) *triplets = alg.singular_triplets_found;
         if (iters) *iters = alg.num_krylov_iters;
         if (norm_R_end) *norm_R_end = alg.norm_R_end;
         return rc;
     });
+}
+
+// ---- the reference's device classes (drivers/rl_bqrrp_gpu.hh, rl_cqrrpt_gpu.hh)
+}  // extern "C"
+template <typename T>
+static int drv_bqrrp_gpu(rlhip_ctx* ctx, int64_t m, int64_t n, T* A, int64_t lda, T* A_sk, int64_t d, int64_t b_sz, int qr_tall, T tol, T* tau,
+                         int64_t* J, int64_t* rank_out, long* times15) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::BQRRP_GPU<T, RNG> alg(q, times15 != nullptr, b_sz);
+        using Sub = RandLAPACK::BQRRPGPUSubroutines;
+        if (qr_tall >= 0) {
+            if (qr_tall > 1) throw RandLAPACK::Error("BQRRP_GPU qr_tall must be 0 (cholqr) or 1 (geqrf)");
+            alg.qr_tall = (Sub::QRTall)qr_tall;
+        }
+        if (tol > 0) alg.tol = tol;
+        int rc = alg.call(m, n, A, lda, A_sk, d, tau, J);
+        if (rank_out) *rank_out = alg.rank;
+        if (times15 && alg.times.size() == 15)
+            for (int i = 0; i < 15; ++i) times15[i] = alg.times[(size_t)i];
+        return rc;
+    });
+}
+template <typename T>
+static int drv_cqrrpt_gpu(rlhip_ctx* ctx, int64_t m, int64_t n, T* A_host, int64_t lda, T* R_host, int64_t ldr, int64_t* J_host, T d_factor,
+                          int64_t nnz, T eps, int no_hqrrp, uint32_t state[6], T* A_hat_out_host, int64_t* rank_out, long* times8);
+extern "C" {
+int rlhip_drv_bqrrp_gpu_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* A_sk, int64_t d, int64_t b_sz, int qr_tall,
+                            double tol, double* tau, int64_t* J, int64_t* rank_out, long* times15) {
+    return drv_bqrrp_gpu<double>(ctx, m, n, A, lda, A_sk, d, b_sz, qr_tall, tol, tau, J, rank_out, times15);
+}
+int rlhip_drv_bqrrp_gpu_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* A_sk, int64_t d, int64_t b_sz, int qr_tall,
+                            float tol, float* tau, int64_t* J, int64_t* rank_out, long* times15) {
+    return drv_bqrrp_gpu<float>(ctx, m, n, A, lda, A_sk, d, b_sz, qr_tall, tol, tau, J, rank_out, times15);
+}
+
+}  // extern "C"
+template <typename T>
+static int drv_cqrrpt_gpu(rlhip_ctx* ctx, int64_t m, int64_t n, T* A_host, int64_t lda, T* R_host, int64_t ldr, int64_t* J_host, T d_factor,
+                          int64_t nnz, T eps, int no_hqrrp, uint32_t state[6], T* A_hat_out_host, int64_t* rank_out, long* times8) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        RandLAPACK::CQRRPT_GPU<T, RNG> alg(q, false, times8 != nullptr, eps);
+        if (nnz > 0) alg.nnz = nnz;
+        if (no_hqrrp >= 0) alg.no_hqrrp = no_hqrrp;
+        alg.sketch_export_host = A_hat_out_host;
+        State st = load_state(state);
+        int rc = alg.call(m, n, A_host, lda, R_host, ldr, J_host, d_factor, st);
+        store_state(st, state);
+        if (rank_out) *rank_out = alg.rank;
+        if (times8 && alg.times.size() == 8)
+            for (int i = 0; i < 8; ++i) times8[i] = alg.times[(size_t)i];
+        return rc;
+    });
+}
+extern "C" {
+int rlhip_drv_cqrrpt_gpu_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A_host, int64_t lda, double* R_host, int64_t ldr, int64_t* J_host,
+                             double d_factor, int64_t nnz, double eps, int no_hqrrp, uint32_t state[6], double* A_hat_out_host,
+                             int64_t* rank_out, long* times8) {
+    return drv_cqrrpt_gpu<double>(ctx, m, n, A_host, lda, R_host, ldr, J_host, d_factor, nnz, eps, no_hqrrp, state, A_hat_out_host, rank_out, times8);
+}
+int rlhip_drv_cqrrpt_gpu_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A_host, int64_t lda, float* R_host, int64_t ldr, int64_t* J_host,
+                             float d_factor, int64_t nnz, float eps, int no_hqrrp, uint32_t state[6], float* A_hat_out_host,
+                             int64_t* rank_out, long* times8) {
+    return drv_cqrrpt_gpu<float>(ctx, m, n, A_host, lda, R_host, ldr, J_host, d_factor, nnz, eps, no_hqrrp, state, A_hat_out_host, rank_out, times8);
 }
 
 // ---- fp32 instantiations of the same objects (BASELINE config 4 is fp32)
@@ -493,7 +556,7 @@ static int abrik_linop_impl(rlhip_ctx* ctx, const rlhip_linop_desc* left, const 
         blas::Queue q(ctx);
         if (right) throw RandLAPACK::Error("ABRIK needs fro_nrm(): single dense / sparse operators only (composites have none, as in the reference)");
         if (!left || (left->kind != 0 && left->kind != 1)) throw RandLAPACK::Error("operator kind must be 0 (dense) or 1 (CSR)");
-        auto run = [&](auto& A) -> int {
+        auto run = [&](auto&& invoke) -> int {
             RandLAPACK::ABRIK<double, RNG> alg(q, false, times13 != nullptr, tol);
             if (qr_exp >= 0) {
                 if (qr_exp > 1) throw RandLAPACK::Error("qr_exp must be 0 (geqrf_ungqr) or 1 (cqrrt)");
@@ -502,7 +565,7 @@ static int abrik_linop_impl(rlhip_ctx* ctx, const rlhip_linop_desc* left, const 
             if (max_krylov_iters > 0) alg.max_krylov_iters = (int)std::min<int64_t>(max_krylov_iters, INT_MAX);
             State st = load_state(state);
             *U = nullptr; *Sigma = nullptr; *V = nullptr;
-            int rc = alg.call(A, k, *U, *V, *Sigma, st);
+            int rc = invoke(alg, st);
             store_state(st, state);
             if (triplets) *triplets = alg.singular_triplets_found;
             if (iters) *iters = alg.num_krylov_iters;
@@ -510,9 +573,13 @@ static int abrik_linop_impl(rlhip_ctx* ctx, const rlhip_linop_desc* left, const 
             if (times13) for (size_t i = 0; i < 13; ++i) times13[i] = (i < alg.times.size()) ? alg.times[i] : 0;
             return rc;
         };
-        if (left->kind == 0) { auto A = make_dense<double>(q, *left); return run(*A); }
-        auto A = make_sparse<double>(q, *left);
-        return run(*A);
+        if (left->kind == 0) {
+            auto A = make_dense<double>(q, *left);
+            return run([&](auto& alg, State& st) { return alg.call(*A, k, *U, *V, *Sigma, st); });                 // LinearOperator overload (:164)
+        }
+        // CSR operator: the sparse-matrix overload (rl_abrik.hh:146-162) over a RandBLAS-style view of the caller's arrays
+        RandBLAS::sparse_data::CSRMatrix<double> M(left->rows, left->cols, left->nnz, (const double*)left->vals, left->rowptr, left->colidx);
+        return run([&](auto& alg, State& st) { return alg.call(left->rows, left->cols, M, k, *U, *V, *Sigma, st); });
     });
 }
 

@@ -67,7 +67,8 @@ struct rlhip_ctx {
     size_t pool_idle_bytes = 0, pool_cap_bytes = 0;
     unsigned long pool_clock = 0;
     // diagnostics: how often each specialised kernel path was taken (rlhip_path_count; tests assert the path under test ran)
-    //   0 stream-K f64 GEMM, 1 stream-K f32 GEMM, 2 fused trsm block kernel, 3 substitution trsm sub-block, 4 persistent Jacobi sweep
+    //   0 stream-K f64 GEMM, 1 stream-K f32 GEMM, 2 fused trsm block kernel, 3 substitution trsm sub-block, 4 fused out-of-place trsm
+    //   (rlhip_trsm_gather), 5 sketch-preconditioned Cholesky-QR panel inside geqrf -- the list in include/rlhip.h is the contract
     int64_t path_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 

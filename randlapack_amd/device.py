@@ -565,3 +565,56 @@ def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0,
     if timing:
         out["times_us"] = [int(t) for t in times]
     return out
+
+
+def drv_bqrrp_gpu(ctx: Context, A, m, n, A_sk, d, b_sz, qr_tall=-1, tol=0.0, timing=False, lda=None):
+    """BQRRP_GPU::call (the reference's device class, drivers/rl_bqrrp_gpu.hh:120-129): the d x n sketch A_sk (column-major tensor
+    (n, d), OVERWRITTEN) is an input.  qr_tall 0 cholqr | 1 geqrf | -1 object default (geqrf).  A is overwritten in GEQP3 format.
+    Returns dict(rc, rank, tau, J[, times_us (15 entries)])."""
+    torch = _torch()
+    dev = f"cuda:{ctx.device}"
+    tau = torch.zeros(n, dtype=A.dtype, device=dev)
+    J = torch.zeros(n, dtype=torch.int64, device=dev)
+    rank = C.c_int64(0)
+    times = (C.c_long * 15)() if timing else None
+    rc = getattr(ctx.lib, f"rlhip_drv_bqrrp_gpu_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), lda or m, A_sk.data_ptr(), d, b_sz, qr_tall, tol,
+                                                                   tau.data_ptr(), J.data_ptr(), C.byref(rank), times)
+    _drv_check(ctx, rc, "bqrrp_gpu")
+    out = dict(rc=rc, rank=int(rank.value), tau=tau, J=J)
+    if timing:
+        out["times_us"] = [int(t) for t in times]
+    return out
+
+
+def drv_cqrrpt_gpu(ctx: Context, A_host, d_factor=1.25, nnz=4, eps=None, ctr=(0, 0, 0, 0), key=(0, 0), no_hqrrp=-1, want_sketch=False,
+                   timing=False, lda=None, ldr=None):
+    """CQRRPT_GPU::call (drivers/rl_cqrrpt_gpu.hh:117-127): HOST matrices, as in the reference.  A_host: numpy (m, n); it is NOT
+    modified -- the call runs on a column-major copy with leading dimension lda (default m).  Returns dict(rc, rank, Q (m x n numpy),
+    R (n x n numpy), J, next_ctr[, sketch (d x n numpy)][, times_us], A_buf / R_buf = the raw padded buffers)."""
+    m, n = A_host.shape
+    npdt = A_host.dtype.type
+    lda = lda or m
+    ldr = ldr or n
+    if eps is None:
+        eps = float(np.finfo(npdt).eps ** 0.85)
+    d = int(npdt(d_factor) * n)
+    A_buf = np.full(lda * n, np.nan, dtype=npdt)
+    A_buf.reshape(n, lda)[:, :m] = A_host.T
+    R_buf = np.full(ldr * n, 7.0, dtype=npdt)                       # padding rows keep their marker (checked by the tests)
+    R_buf.reshape(n, ldr)[:, :n] = 0.0
+    J = np.zeros(n, dtype=np.int64)
+    sk = np.zeros(d * n, dtype=npdt) if want_sketch else None
+    rank = C.c_int64(0)
+    st = _state_arr(ctr, key)
+    times = (C.c_long * 8)() if timing else None
+    suffix = "f64" if npdt is np.float64 else "f32"
+    rc = getattr(ctx.lib, f"rlhip_drv_cqrrpt_gpu_{suffix}")(ctx.h, m, n, A_buf.ctypes.data, lda, R_buf.ctypes.data, ldr, J.ctypes.data, d_factor, nnz, eps,
+                                                           no_hqrrp, st, sk.ctypes.data if sk is not None else None, C.byref(rank), times)
+    _drv_check(ctx, rc, "cqrrpt_gpu")
+    out = dict(rc=rc, rank=int(rank.value), Q=A_buf.reshape(n, lda)[:, :m].T.copy(), R=R_buf.reshape(n, ldr)[:, :n].T.copy(), J=J,
+               next_ctr=tuple(int(x) for x in st[:4]), A_buf=A_buf, R_buf=R_buf)
+    if want_sketch:
+        out["sketch"] = sk.reshape(n, d).T.copy()
+    if timing:
+        out["times_us"] = [int(t) for t in times]
+    return out

@@ -68,6 +68,55 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
                       "cpu_baseline": None}))
 
 
+def rsvd_p2(steps):
+    """BASELINE configs[1] with power iterations (C2 at p = 2) on a rank-256-plus-noise matrix: four passes over the
+    200000 x 20000 input (A Omega, A^T., A., A^T Q) instead of two, stabilisers on 200000 x 256 / 20000 x 256 blocks in between."""
+    ctx = d.Context(0)
+    m, n, k, p = 200000, 20000, 256, 2
+    sig = np.geomspace(1.0, 0.1, k)
+    U = d.cm_empty(m, k); ctx.fill_dense(U, m, k, key=(101, 0))
+    V = d.cm_empty(n, k); ctx.fill_dense(V, n, k, key=(102, 0))
+    for X, rows in ((U, m), (V, n)):
+        for _ in range(2): d.drv_stab(ctx, 0, X, rows, k)
+    A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(103, 0))
+    Us = U * torch.as_tensor(sig, device=U.device)[:, None]
+    ctx.gemm("N", "T", m, n, k, 1.0, Us, m, V, n, 1e-12, A, m); ctx.sync()
+    del U, V, Us
+    flops = 2.0 * m * n * k * (2 + p) + (2 + p) * 2.0 * m * k * k / 2 + 2.0 * m * k * k + 2.0 * m * k * k + 6.0 * n * k * k + 8.0 * k**3
+    res = {}
+    for stab, name in ((0, "CholQRQ"), (2, "PLUL")):
+        best, r = None, None
+        for it in range(steps + 1):
+            ctx.sync(); t0 = time.perf_counter(); r = d.drv_rsvd(ctx, A, m, n, k, k, 1e-6, p, 1, rs_stab=stab, key=(5, 0)); ctx.sync(); dt = time.perf_counter() - t0
+            if it > 0: best = dt if best is None else min(best, dt)
+        S = r["S"].cpu().numpy()
+        res[name] = dict(ms=round(best * 1e3, 2), qb_rc=r["qb_rc"], sigma_rel_err=float(np.max(np.abs(S - sig) / sig)))
+    best = res["CholQRQ"]["ms"] * 1e-3
+    # dominant kernel of this variant: the transposed pass A^T X (two of the four passes), timed alone with HIP events
+    X = d.cm_empty(m, k); ctx.fill_dense(X, m, k, key=(9, 0)); Y = d.cm_empty(n, k)
+    ctx.gemm("T", "N", n, k, m, 1.0, A, m, X, m, 0.0, Y, n); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.gemm("T", "N", n, k, m, 1.0, A, m, X, m, 0.0, Y, n)
+    kms = ctx.timer_stop_ms() / 3
+    ach = 2.0 * m * n * k / (kms * 1e-3) / 1e12
+    import oracle
+    oracle.load(); oracle.set_threads(os.cpu_count() or 1)
+    ms = 24576
+    rng = np.random.default_rng(0)
+    As = np.asfortranarray(rng.standard_normal((ms, n)))
+    t0 = time.perf_counter(); o = oracle.rsvd(As, k, k, 1e-12, p, 1); tc = time.perf_counter() - t0
+    fl_s = 2.0 * ms * n * k * (2 + p) + (2 + p) * ms * k * k + 4.0 * ms * k * k + 6.0 * n * k * k + 8.0 * k**3
+    print(json.dumps({"metric": "GFLOP/s (sketch+factor) for RSVD rank-256 on m x n dense fp64, p = 2 power passes", "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s",
+                      "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 2), "best_of": steps, "higher_is_better": True, "dtype": "f64",
+                      "data": "synthetic rank-256 (sigma 1 ... 0.1) + 1e-12 Gaussian noise, generated on-device",
+                      "config": {"workload": "RSVD 200000x20000 fp64 rank 256, one QB block, p=2, q=1 (BASELINE configs[1] at p=2, SURVEY 8(d))", "by_stabiliser": res,
+                                 "algorithmic_flops": flops},
+                      "frac_of_peak_whole_job": round(flops / best / 1e12 / 78.6, 4),
+                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
+                                   "kernel": "gemm_sk_kernel<double, TN> (Y = A^T X, 20000 x 256 x 200000)", "launch_ms": round(kms, 3), "flops_per_launch": 2.0 * m * n * k},
+                      "cpu_baseline": {"value": round(fl_s / tc / 1e9, 1), "unit": "GFLOP/s", "cores": oracle.get_threads(), "kind": "port",
+                                       "sample": f"oracle RSVD (CholQRQ, p=2) on {ms}x{n} fp64 Gaussian, rank {k}, {tc:.2f} s"}}))
+
+
 def abrik(steps):
     """BASELINE configs[4] on ONE device: ABRIK on a 200000 x 200000 operator that is never densified (CSR band of 10 Gaussian entries
     per row with graded row / column scalings, as in tests/test_gpu_fullsize.py), block 32, 8 Krylov iterations (rank 128); and the
@@ -119,10 +168,11 @@ def abrik(steps):
 
 
 if __name__ == "__main__":
-    ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64", "bqrrp_full", "abrik"]); ap.add_argument("--steps", type=int, default=3)
+    ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64", "bqrrp_full", "abrik", "rsvd_p2"]); ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
     if a.what == "cqrrpt": cqrrpt(a.steps)
     elif a.what == "abrik": abrik(a.steps)
+    elif a.what == "rsvd_p2": rsvd_p2(a.steps)
     elif a.what == "bqrrp": bqrrp(a.steps)
     elif a.what == "bqrrp_full": bqrrp(a.steps, torch.float32, 65536, 2048)      # BASELINE configs[3] itself (17 GB) on ONE device
     else: bqrrp(a.steps, torch.float64, 16384, 512)

@@ -28,3 +28,24 @@ def test_reference_qb_test_body_passes_on_the_device():
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
     assert r.stdout.count("FRO NORM OF A - QB") == 3
+
+
+def test_gpu_class_caller_builds_and_links():
+    subprocess.run(["make", "-C", str(CXX), "-s"], check=True)
+    exe = CXX / "test_gpu_classes_caller"
+    assert exe.exists()
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", str(exe)], text=True)
+    assert "rlhip_drv" not in out and "hip" not in out.replace("rlhip", "")
+
+
+@pytest.mark.gpu
+def test_bqrrp_gpu_and_cqrrpt_gpu_classes_from_a_cxx_caller():
+    """tests/cxx/test_gpu_classes_caller.cpp: a freshly written caller of BQRRP_GPU / CQRRPT_GPU (the reference's device classes,
+    rl_bqrrp_gpu.hh:27-149, rl_cqrrpt_gpu.hh:23-146) that sets `.qr_tall`, goes through the `_alg` base classes, reads `.times`
+    (15 / 8 entries) and `.rank`, and verifies the factorizations itself."""
+    exe = CXX / "test_gpu_classes_caller"
+    if not exe.exists():
+        subprocess.run(["make", "-C", str(CXX), "-s"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
+    assert r.stdout.count("BQRRP_GPU<") == 3 and "CQRRPT_GPU 900 x 60" in r.stdout

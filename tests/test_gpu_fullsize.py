@@ -152,6 +152,61 @@ def test_rsvd_full_size_sketch_pass(ctx):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: BQRRP 65536 x 65536 fp32 on one device
 # ---------------------------------------------------------------------------------------------------
+def _planted_c2_matrix(ctx, d, m, n, k, sig, eta):
+    """A = U diag(sig) V^T + eta * G in HBM: U (m x k) and V (n x k) are Cholesky-QR-orthonormalised Gaussian blocks (twice), G iid N(0,1)."""
+    import torch
+
+    U = d.cm_empty(m, k); ctx.fill_dense(U, m, k, key=(101, 0))
+    V = d.cm_empty(n, k); ctx.fill_dense(V, n, k, key=(102, 0))
+    for X, rows in ((U, m), (V, n)):
+        for _ in range(2):
+            rc, fail = d.drv_stab(ctx, 0, X, rows, k)
+            assert rc == 0 and not fail
+    A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(103, 0))
+    Us = U * torch.as_tensor(sig, device=U.device)[:, None]                 # column-major (k, m) view: scales column i of U by sig[i]
+    ctx.gemm("N", "T", m, n, k, 1.0, Us, m, V, n, eta, A, m)                # A <- (U sig) V^T + eta * G
+    ctx.sync()
+    return A, U, V
+
+
+@pytest.mark.parametrize("rs_stab,name", [(0, "CholQRQ"), (2, "PLUL")])
+def test_rsvd_config2_power_iterations_planted_rank256(ctx, rs_stab, name):
+    """BASELINE configs[1] at p = 2 (C2 is defined at p in {0, 2}) on a rank-256-plus-noise matrix of the full size
+    200000 x 20000: the two power passes (rl_rs.hh:126-178) with their stabilisers running on 200000 x 256 and 20000 x 256 blocks.
+    Planted sigma_i from 1 down to 0.1, noise eta = 1e-12 per entry: first-order perturbation of sigma_i is eta (1e-11 relative at the
+    small end), so the computed singular values must match the PLANTED ones to 1e-10 relative; the residual ||A - U S V^T||_F must
+    sit on the noise floor eta * sqrt(m n) and the return codes must be the clean ones (QB reaches tol)."""
+    import torch
+
+    d = _d()
+    m, n, k = 200000, 20000, 256
+    sig = np.geomspace(1.0, 0.1, k)
+    eta = 1e-12
+    A, Ut, Vt = _planted_c2_matrix(ctx, d, m, n, k, sig, eta)
+    before = ctx.path_count(0)
+    r = d.drv_rsvd(ctx, A, m, n, k, k, 1e-6, 2, 1, rs_stab=rs_stab, key=(5, 0))
+    assert ctx.path_count(0) - before >= 4                                  # four passes over A, each through the stream-K kernel
+    assert r["rc"] == 0 and r["qb_rc"] == 0 and r["k"] == k
+    assert r["next_ctr"] == (n * k // 4, 0, 0, 0)                           # one n x k Gaussian fill, whatever p is
+    S = r["S"].cpu().numpy()
+    assert np.max(np.abs(S - sig) / sig) <= 1e-10, f"{name}: sigma vs planted {np.max(np.abs(S - sig) / sig):.2e}"
+    U, V = r["U"], r["V"]
+    I = torch.eye(k, device="cuda", dtype=torch.float64)
+    assert float(torch.linalg.norm(U @ U.T - I)) <= EPS**0.75 * np.sqrt(n)
+    assert float(torch.linalg.norm(V @ V.T - I)) <= EPS**0.75 * np.sqrt(n)
+    # the computed subspaces are the planted ones: ||U_planted^T U|| has all singular values 1 (to the noise level)
+    c = torch.linalg.svdvals(Ut @ U.T)
+    assert float(c.min()) >= 1 - 1e-12
+    c = torch.linalg.svdvals(Vt @ V.T)
+    assert float(c.min()) >= 1 - 1e-12
+    # residual on the noise floor: A <- A - (U S) V^T in place, then its Frobenius norm
+    Us = U * r["S"][:, None]
+    ctx.gemm("N", "T", m, n, k, -1.0, Us, m, V, n, 1.0, A, m)
+    res = ctx.lange_fro(m, n, A, m)
+    floor = eta * np.sqrt(float(m) * n)
+    assert 0.9 * floor <= res <= 1.1 * floor, f"{name}: residual {res:.3e} vs noise floor {floor:.3e}"
+
+
 def _apply_qt_householder(V, tau, X, b):
     """Q^T X for Q = H_1 ... H_k stored LAPACK-style in V (column-major tensor (n, m): V[j] is column j), in fp64 on the device,
     panel by panel through the compact-WY form built here from V and tau alone (T^-1 = striu(V^T V) + diag(1 / tau)).
