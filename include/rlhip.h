@@ -116,7 +116,8 @@ int rlhip_trsm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, 
 /* Out-of-place right-side solve with a column gather:  B <- alpha * (Bsrc * P) * inv(A), where column c of Bsrc * P is column
  * jpvt_dev[c] - 1 of Bsrc (LAPACK-style 1-based pivot vector in device memory; NULL: P = I).  Bsrc (m x n, ldsrc) is not modified and
  * must not overlap B unless it IS B with jpvt_dev == NULL (plain rlhip_trsm).  This is CQRRPT's "util::col_swap(A, J) followed by
- * blas::trsm(A, R_sk)" (rl_cqrrpt.hh:288-300) as ONE pass over A, and its second solve (rl_cqrrpt.hh:329) written straight into A. */
+ * blas::trsm(A, R_sk)" (rl_cqrrpt.hh:288-300) as ONE pass over A, and its second solve (rl_cqrrpt.hh:329) written straight into A.
+ * Returns -7 and writes nothing when jpvt_dev is not a permutation of 1..n (the same refusal as rlhip_col_swap). */
 int rlhip_trsm_gather_f64(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, double alpha, const double* A, int64_t lda,
                           const double* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, double* B, int64_t ldb);
 int rlhip_trsm_gather_f32(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, float alpha, const float* A, int64_t lda,
@@ -336,7 +337,7 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
 /* ---- diagnostics ---- */
 /* number of times this context took a specialised kernel path: 0 persistent stream-K fp64 GEMM (gemm_sk.hip), 1 its fp32 twin,
  * 2 fused MFMA trsm block kernel (tri.hip), 3 row-per-lane substitution trsm sub-block, 4 fused out-of-place trsm (rlhip_trsm_gather),
- * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
+ * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip), 6 persistent one-launch Jacobi sweeps (jacobi.hip).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);

@@ -26,6 +26,10 @@ int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, 
          T beta, T* C, int64_t ldc);
 }
 using rlhip::gemm;
+namespace rlhip {
+template <typename T>
+int lacpy(rlhip_ctx* c, int uplo, int64_t m, int64_t n, const T* A, int64_t lda, T* B, int64_t ldb);
+}
 
 namespace {
 
@@ -186,42 +190,19 @@ __device__ __forceinline__ double row16_allsum(double v) {
     return dpp_ror_add(v, 1);
 }
 
-// JMT = panel rows held in LDS: 256 (1024 threads) or 512 (512 threads: the rotating lanes then carry 32 rows of two columns = 128 VGPRs)
+// The rotation rounds of ONE block pair held in LDS (Xs: [2 JB][JMT] column-major, Js: the 2 JB x 2 JB rotation accumulator, only touched
+// when want_v).  Shared by the per-launch kernel and the persistent kernel below, so both execute the same arithmetic in the same order.
+//   intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
+//   intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs)
+// my_rot / my_cos2 accumulate the rotation count and the largest squared cosine met (per thread; lanes with ql == 0 count).
 template <typename T, int JB, int JMT>
-__global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
-                                                               int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
-                                                               unsigned* __restrict__ nrot) {
+__device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __restrict__ Js, const bool want_v, const int intra, const double tol2,
+                                                   unsigned& my_rot, float& my_cos2) {
     constexpr int JP = 2 * JB;
-    constexpr int NT = (JMT == 256) ? 1024 : 512;                           // all 16 waves move data; the first 16*JB threads rotate
-    constexpr int NW = NT / 64;
-    constexpr int NROT = 16 * JB;                      // JB pairs per round, 16 lanes each
+    constexpr int NROT = 16 * JB;
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
-    T* Js = Xs + JP * JMT;                              // [JP][JP] column-major
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ql = lane & 15;                          // lane inside the quarter
-    // block pair of this workgroup (circle method over NB blocks)
-    int P, Q;
-    {
-        const int sl = blockIdx.x;
-        if (intra) { P = 2 * sl; Q = 2 * sl + 1; }
-        else if (sl == 0) { P = NB - 1; Q = oround % (NB - 1); }
-        else { P = (oround + sl) % (NB - 1); Q = (oround - sl + (NB - 1)) % (NB - 1); }
-        if (P > Q) { int t = P; P = Q; Q = t; }
-    }
-    auto gcol = [&](int c) { return (c < JB) ? (P * JB + c) : (Q * JB + (c - JB)); };   // panel col -> global col
-    // ---- load panel (zero padded), J = I
-    for (int e = tid; e < JP * JMT; e += NT) {
-        const int r = e % JMT, c = e / JMT;
-        const int gc = gcol(c);
-        Xs[e] = (r < m && gc < n) ? A[r + (int64_t)gc * lda] : T(0);
-    }
-    for (int e = tid; e < JP * JP; e += NT) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
-    __syncthreads();
-    unsigned my_rot = 0;
-    float my_cos2 = 0.f;                               // largest squared cosine met before rotating (convergence shortcut)
-    const double tol2 = (double)tol * (double)tol;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ql = lane & 15;
     // intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
     // intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs): every column pair of the
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
@@ -286,7 +267,7 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
                 x[r] = xn;
                 xq[16 * r] = yn;
             }
-            if (V != nullptr) {                // the rotation accumulator is only needed when V is wanted
+            if (want_v) {                // the rotation accumulator is only needed when V is wanted
 #pragma unroll
                 for (int r = 0; r < JP / 16; ++r) {
                     const double jp = Js[ql + 16 * r + p * JP], jq = Js[ql + 16 * r + q * JP];
@@ -304,6 +285,41 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
         for (int r = 0; r < RL; ++r) xp[16 * r] = x[r];
     }
     __syncthreads();
+}
+
+// JMT = panel rows held in LDS: 256 (1024 threads) or 512 (512 threads: the rotating lanes then carry 32 rows of two columns = 128 VGPRs)
+template <typename T, int JB, int JMT>
+__global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
+                                                               int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
+                                                               unsigned* __restrict__ nrot) {
+    constexpr int JP = 2 * JB;
+    constexpr int NT = (JMT == 256) ? 1024 : 512;                           // all 16 waves move data; the first 16*JB threads rotate
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
+    T* Js = Xs + JP * JMT;                              // [JP][JP] column-major
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // block pair of this workgroup (circle method over NB blocks)
+    int P, Q;
+    {
+        const int sl = blockIdx.x;
+        if (intra) { P = 2 * sl; Q = 2 * sl + 1; }
+        else if (sl == 0) { P = NB - 1; Q = oround % (NB - 1); }
+        else { P = (oround + sl) % (NB - 1); Q = (oround - sl + (NB - 1)) % (NB - 1); }
+        if (P > Q) { int t = P; P = Q; Q = t; }
+    }
+    auto gcol = [&](int c) { return (c < JB) ? (P * JB + c) : (Q * JB + (c - JB)); };   // panel col -> global col
+    // ---- load panel (zero padded), J = I
+    for (int e = tid; e < JP * JMT; e += NT) {
+        const int r = e % JMT, c = e / JMT;
+        const int gc = gcol(c);
+        Xs[e] = (r < m && gc < n) ? A[r + (int64_t)gc * lda] : T(0);
+    }
+    for (int e = tid; e < JP * JP; e += NT) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
+    __syncthreads();
+    unsigned my_rot = 0;
+    float my_cos2 = 0.f;                               // largest squared cosine met before rotating (convergence shortcut)
+    jacobi_pair_rounds<T, JB, JMT>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2);
     // one atomic pair per wavefront
     {
         unsigned r = my_rot;
@@ -361,6 +377,156 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One launch for MANY sweeps (the k x k factor of the RSVD tail, singular values and left vectors only).
+//
+// The per-launch kernel above pays ~14 us of fixed cost around ~5.5 us of rotations for each of the 16 steps of a sweep (launch gap,
+// panel load / store through L2, pipeline refill) and the host reads a counter after every sweep.  Here NB/2 workgroups stay resident
+// (cooperative launch), keep their block pair in LDS and hand blocks to one another through an UNCACHED exchange buffer:
+//   * a block is published as 8-byte agent-scope stores, then `s_waitcnt vmcnt(0)`, then ONE tagged word {step : block} -- the only
+//     reader of version s of a block is its next owner, which is also the only next writer, so the buffer needs no double buffering;
+//   * the circle-method pairing and the round order inside a pair are those of the per-launch kernel (jacobi_pair_rounds is shared), so
+//     the two paths produce bitwise identical matrices -- tests compare them;
+//   * at the end of a sweep every workgroup publishes {sweep : max cos^2} and {sweep : rotations} and reads everybody's: all take
+//     the same decision (converged / every cosine <= 1e-9 -> hand back for the Gram verification / next sweep) without the host;
+//   * the input is only READ; results leave through the exchange buffer (column-major m x NB JB, ld m) and the host copies them over A
+//     when the launch reports success.  A lost word (bounded spins) reports -7 and A is untouched: the caller then takes the
+//     per-launch path.
+template <typename T>
+struct JpArgs {
+    int m, n, NB, sweep0, max_sweeps;
+    const T* A;
+    int64_t lda;
+    unsigned long long* X;        // NB * JB * m values (as bit patterns)
+    unsigned long long* bflag;    // [NB]      {step : 1}
+    unsigned long long* sflag;    // [2][NB/2][2]  {sweep : cos^2 bits}, {sweep : rotations}; indexed by sweep parity
+    T tol;
+    int* out;                     // [0] status: 1 converged (a sweep without rotations), 2 every cosine <= 1e-9 (verify), 3 sweep limit, -7 lost word
+                                  // [1] sweeps done (absolute)
+};
+
+__device__ __forceinline__ bool jp_wait(const unsigned long long* w, unsigned tag, unsigned long long* got) {
+    for (int spins = 0; spins < (1 << 22); ++spins) {
+        const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == tag) { *got = v; return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+template <typename T, int JB, int JMT>
+__global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
+    static_assert(sizeof(T) == 8, "fp64 only");
+    constexpr int JP = 2 * JB, NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
+    __shared__ unsigned s_rot, s_cos, s_lost;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = blockIdx.x, NW = g.NB / 2, m = g.m;
+    const double tol2 = (double)g.tol * (double)g.tol;
+    int held[2] = {2 * w, 2 * w + 1};
+    for (int e = tid; e < JP * JMT; e += NT) {
+        const int r = e % JMT, c = e / JMT;
+        const int gc = held[c / JB] * JB + (c % JB);
+        Xs[e] = (r < m && gc < g.n) ? g.A[r + (int64_t)gc * g.lda] : T(0);
+    }
+    if (tid == 0) { s_lost = 0; }
+    __syncthreads();
+    auto publish = [&](int half, int blk) {            // LDS half -> exchange buffer
+        unsigned long long* dst = g.X + (size_t)blk * JB * m;
+        for (int e = tid; e < JB * m; e += NT) {
+            const int r = e % m, c = e / m;
+            __hip_atomic_store(dst + e, (unsigned long long)__double_as_longlong((double)Xs[(half * JB + c) * JMT + r]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto fetch = [&](int half, int blk) {
+        const unsigned long long* src = g.X + (size_t)blk * JB * m;
+        for (int e = tid; e < JB * m; e += NT) {
+            const int r = e % m, c = e / m;
+            Xs[(half * JB + c) * JMT + r] = (T)__longlong_as_double((long long)__hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    };
+    unsigned gs = 0;                                   // exchange steps taken by this launch
+    int status = 3, sweep = g.sweep0;
+    bool lost = false;
+    for (; sweep < g.max_sweeps && !lost; ++sweep) {
+        unsigned my_rot = 0;
+        float my_cos2 = 0.f;
+        jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 1, tol2, my_rot, my_cos2);          // pairs inside whichever two blocks are here
+        for (int oround = 0; oround < g.NB - 1; ++oround) {
+            int P, Q;
+            if (w == 0) { P = g.NB - 1; Q = oround % (g.NB - 1); }
+            else { P = (oround + w) % (g.NB - 1); Q = (oround - w + (g.NB - 1)) % (g.NB - 1); }
+            if (P > Q) { const int t = P; P = Q; Q = t; }
+            const int want[2] = {P, Q};
+            ++gs;
+            const bool out0 = held[0] != want[0], out1 = held[1] != want[1];
+            if (out0) publish(0, held[0]);
+            if (out1) publish(1, held[1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the block's words have been acknowledged ...
+            __syncthreads();
+            if (tid == 0) {                                              // ... before its version word goes out
+                if (out0) __hip_atomic_store(g.bflag + held[0], ((unsigned long long)gs << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (out1) __hip_atomic_store(g.bflag + held[1], ((unsigned long long)gs << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < 2 && (tid == 0 ? out0 : out1)) {
+                unsigned long long got;
+                if (!jp_wait(g.bflag + want[tid], gs, &got)) atomicExch(&s_lost, 1u);
+            }
+            __syncthreads();
+            if (s_lost) { lost = true; break; }
+            if (out0) fetch(0, want[0]);
+            if (out1) fetch(1, want[1]);
+            held[0] = want[0]; held[1] = want[1];
+            __syncthreads();
+            jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2);
+        }
+        if (lost) break;
+        // ---- end of the sweep: everybody learns the sweep's rotation count and largest cosine
+        if (tid == 0) { s_rot = 0; s_cos = 0; }
+        __syncthreads();
+        {
+            unsigned r = my_rot;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+            float c2 = my_cos2;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
+            if (lane == 0 && r) { atomicAdd(&s_rot, r); atomicMax(&s_cos, __float_as_uint(c2)); }
+        }
+        __syncthreads();
+        const unsigned tag = (unsigned)(sweep - g.sweep0 + 1);
+        unsigned long long* sf = g.sflag + (size_t)(tag & 1u) * NW * 2;
+        if (tid == 0) {
+            __hip_atomic_store(sf + 2 * w, ((unsigned long long)tag << 32) | s_cos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sf + 2 * w + 1, ((unsigned long long)tag << 32) | s_rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid == 0) { s_rot = 0; s_cos = 0; }
+        __syncthreads();
+        if (tid < 2 * NW) {
+            unsigned long long got = 0;
+            if (!jp_wait(sf + tid, tag, &got)) atomicExch(&s_lost, 1u);
+            else if (tid & 1) atomicAdd(&s_rot, ((unsigned)got) ? 1u : 0u);
+            else atomicMax(&s_cos, (unsigned)got);
+        }
+        __syncthreads();
+        if (s_lost) { lost = true; break; }
+        const unsigned any_rot = s_rot;
+        const float cos2 = __uint_as_float(s_cos);
+        __syncthreads();
+        if (any_rot == 0) { status = 1; ++sweep; break; }
+        if (cos2 <= 1e-18f) { status = 2; ++sweep; break; }
+    }
+    if (lost) status = -7;
+    else {
+        publish(0, held[0]);
+        publish(1, held[1]);
+    }
+    if (w == 0 && tid == 0) { g.out[0] = status; g.out[1] = sweep; }
 }
 
 // dst (ldd) = (TD) src (lds), m x n
@@ -435,6 +601,80 @@ __global__ void gram_offdiag_kernel(int n, const T* __restrict__ G, T tol, unsig
     if (gi > 0 && gj > 0 && g * g > (double)tol * (double)tol * gi * gj) atomicOr(flag, 1u);
 }
 
+// the Gram-matrix verification shared by the two sweep drivers: true iff every off-diagonal cosine of A^T A is <= tol
+template <typename T>
+int jacobi_verify_converged(rlhip_ctx* c, int m, int n, const T* A, int64_t lda, T tol, unsigned* d_nrot, bool* ok) {
+    *ok = false;
+    size_t gm = rlhip_ws_mark(c);
+    T* G = ws_alloc<T>(c, (size_t)n * n);
+    unsigned* flag = d_nrot + 1;
+    if (G) {
+        int grc = gemm<T>(c, 1, 0, n, n, m, T(1), A, lda, A, lda, T(0), G, n);
+        if (!grc) {
+            hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
+            hipLaunchKernelGGL(gram_offdiag_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, G, tol, flag);
+            RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            *ok = (*((unsigned*)(c->h_mail + 16) + 1) == 0u);
+        }
+    }
+    rlhip_ws_release(c, gm);
+    return 0;
+}
+
+// Sweeps of the persistent kernel (V not accumulated).  Returns 0 and the number of sweeps when it ran to a verdict, 1 when the path is
+// not available or reported a lost word -- A then still holds a valid (possibly partially swept) matrix and the caller continues with the
+// per-launch sweeps.
+template <typename T>
+int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out, bool* done) {
+    constexpr int JB = 16, JMT = JM;
+    *done = false;
+    int NBk = (n + JB - 1) / JB;
+    if (NBk < 2) NBk = 2;
+    if (NBk % 2) ++NBk;
+    const int NW = NBk / 2;
+    if (NW > c->num_cu || NW > 512) return 1;
+    const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 4 * (size_t)NW;
+    unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
+    size_t mark = rlhip_ws_mark(c);
+    int* out = ws_alloc<int>(c, 32);
+    if (!buf || !out) { rlhip_ws_release(c, mark); return 1; }
+    constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
+    RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT>), smem);
+    int sweep = *sweeps_out;
+    while (sweep < max_sweeps) {
+        JpArgs<T> g;
+        g.m = m; g.n = n; g.NB = NBk; g.sweep0 = sweep; g.max_sweeps = max_sweeps; g.A = A; g.lda = lda; g.X = buf; g.bflag = buf + xwords;
+        g.sflag = g.bflag + NBk; g.tol = tol; g.out = out;
+        RLHIP_CHECK(hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 4 * (size_t)NW) * sizeof(unsigned long long), c->stream));
+        RLHIP_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(int), c->stream));
+        void* kargs[] = {(void*)&g};
+        if (hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            rlhip_ws_release(c, mark);
+            return 1;
+        }
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, out, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        const int status = *(int*)(c->h_mail + 16), done_sweeps = *((int*)(c->h_mail + 16) + 1);
+        if (status != 1 && status != 2 && status != 3) { rlhip_ws_release(c, mark); *sweeps_out = sweep; return 1; }   // -7 (or nothing written): A untouched by this launch
+        int rc = rlhip::lacpy<T>(c, 2, m, n, reinterpret_cast<const T*>(buf), m, A, lda);
+        if (rc) { rlhip_ws_release(c, mark); return rc < 0 ? rc : 1; }
+        sweep = done_sweeps;
+        if (status == 1) { *done = true; break; }
+        if (status == 2) {
+            bool ok = false;
+            jacobi_verify_converged<T>(c, m, n, A, lda, tol, d_nrot, &ok);
+            if (ok) { *done = true; break; }
+            continue;                                  // clustered singular values: tiny cosines, large angles -- keep sweeping
+        }
+        break;                                         // sweep limit
+    }
+    rlhip_ws_release(c, mark);
+    *sweeps_out = sweep;
+    return 0;
+}
+
 template <typename T, int JB, int JMT>
 int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
     constexpr int JP = 2 * JB;
@@ -444,7 +684,7 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
     constexpr int smem = (JP * JMT + JP * JP) * (int)sizeof(T);
     constexpr int NT = (JMT == 256) ? 1024 : 512;
     RLHIP_FUNC_LDS(c, (jacobi_block_kernel<T, JB, JMT>), smem);
-    int sweep = 0;
+    int sweep = *sweeps_out;                           // sweeps already done by the persistent kernel (0 otherwise)
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
         hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
@@ -464,21 +704,8 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
         // singular values that argument fails (tiny cosines still rotate by large angles), so the claim is VERIFIED with one
         // Gram matrix (2 launches instead of a 16-launch sweep): converged iff every off-diagonal cosine of A^T A is <= tol.
         if (cos2 <= 1e-18f) {
-            size_t gm = rlhip_ws_mark(c);
-            T* G = ws_alloc<T>(c, (size_t)n * n);
-            unsigned* flag = d_nrot + 1;
             bool ok = false;
-            if (G) {
-                int grc = gemm<T>(c, 1, 0, n, n, m, T(1), A, lda, A, lda, T(0), G, n);
-                if (!grc) {
-                    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
-                    hipLaunchKernelGGL(gram_offdiag_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, G, tol, flag);
-                    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-                    RLHIP_CHECK(hipStreamSynchronize(c->stream));
-                    ok = (*((unsigned*)(c->h_mail + 16) + 1) == 0u);
-                }
-            }
-            rlhip_ws_release(c, gm);
+            jacobi_verify_converged<T>(c, m, n, A, lda, tol, d_nrot, &ok);
             if (ok) { ++sweep; break; }
         }
     }
@@ -552,7 +779,19 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
         // LDS-resident block Jacobi (see jacobi_block_kernel)
         static int jb_sel = 0;
         if (!jb_sel) { const char* e = getenv("RLHIP_JACOBI_JB"); jb_sel = (e && atoi(e) == 32) ? 32 : 16; }
-        if (m > JM) rc = block_jacobi_sweeps<T, 16, 2 * JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);   // 257 .. 512 rows: 32 x 512 panel = 128 KiB
+        const char* pe = getenv("RLHIP_JACOBI_PERSIST");          // read per call: tests switch paths inside one process
+        const bool persist = !(pe && atoi(pe) == 0);
+        bool done = false;
+        if constexpr (sizeof(T) == 8) {
+            // singular values / left vectors only and at most 256 rows: all sweeps in one resident launch (see jacobi_persist_kernel)
+            if (persist && V == nullptr && m <= JM && jb_sel == 16 && n > 32) {
+                const int prc = persistent_jacobi_sweeps<T>(c, (int)m, n, A, lda, tol, d_nrot, max_sweeps, &sweep, &done);
+                if (prc < 0) { rlhip_ws_release(c, mark); return prc; }
+                if (prc == 0) c->path_count[6]++;
+            }
+        }
+        if (done || sweep >= max_sweeps) rc = 0;
+        else if (m > JM) rc = block_jacobi_sweeps<T, 16, 2 * JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);   // 257 .. 512 rows: 32 x 512 panel = 128 KiB
         else if (jb_sel == 32 || n <= 32) rc = block_jacobi_sweeps<T, 32, JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
         else rc = block_jacobi_sweeps<T, 16, JM>(c, (int)m, n, A, lda, V, tol, d_nrot, max_sweeps, &sweep);
         if (rc) { rlhip_ws_release(c, mark); return rc; }

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
 template <typename T>
 struct QrcpTagArgs {
     int64_t m, n;
-    T* A; int64_t lda;
-    int64_t* jpvt; T* tau;
+    T* A; int64_t lda;        // input, only READ by the kernel
+    T* Aout; int64_t ldo;     // the factored columns leave here (the host copies them over A when info == 0: a lost word leaves A intact)
+    int64_t* jpvt; T* tau;    // jpvt: scratch of n entries, copied to the caller's vector on success
     unsigned long long* tw;   // 2 x words_per_parity, zeroed by the host before the launch
     int* info;                // -7: a spin ran out (lost word): the host reports an error instead of hanging the device
     T tol3z;
@@ -359,7 +360,10 @@ __device__ __forceinline__ void qt_get(const unsigned long long* q, const int64_
         bool ok = (unsigned)(xw >> 32) == tag;
 #pragma unroll
         for (int r = 0; r < QT_NV * W; ++r) ok = ok && (r / W >= cnt || (unsigned)(w[r] >> 32) == tag);
-        if (ok || spins > 64) {
+        // every failed batch waits (paced, bounded by qt_get_u32's own 2^22 sleeps) on the FIRST word that is still missing, so each trip
+        // retires at least one word: QT_NV * W + 2 trips cover any arrival order; a word that never arrives sets info in the wait
+        const bool give_up = spins > QT_NV * W + 2 || *(volatile int*)info != 0;
+        if (ok || give_up) {
             if (!ok) atomicExch(info, -7);
 #pragma unroll
             for (int r = 0; r < QT_NV; ++r) {
@@ -369,8 +373,12 @@ __device__ __forceinline__ void qt_get(const unsigned long long* q, const int64_
             if (xout) *xout = (unsigned)xw;
             return;
         }
-        // wait on ONE word (the last one this thread needs: stores tend to land in order), then the whole batch again
-        (void)qt_get_u32(xq ? xq : q + idx[cnt - 1] * W + (W - 1), tag, info);
+        const unsigned long long* missing = nullptr;
+#pragma unroll
+        for (int r = QT_NV * W - 1; r >= 0; --r)
+            if (r / W < cnt && (unsigned)(w[r] >> 32) != tag) missing = q + idx[r / W] * W + (r % W);
+        if (!missing) missing = xq;
+        (void)qt_get_u32(missing, tag, info);
     }
 }
 // one value (both halves of a double) plus one 32-bit word, requested together
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
 #endif
     for (int sl = 0, j = me; j < n; ++sl, j += G) {
         const T* src = colslot(sl);
-        T* dst = g.A + (int64_t)j * g.lda;
+        T* dst = g.Aout + (int64_t)j * g.ldo;
         for (int i = tid; i < m; i += 256) dst[i] = src[i];
         if (tid == 0) g.jpvt[j] = l_jp[sl];
     }
@@ -1094,6 +1102,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: g_env (4) per workgroup
         int64_t Gt = (n + g_env - 1) / g_env;
         if (Gt > num_cu) Gt = num_cu;
+        if (Gt > 256) Gt = 256;           // the speculation bookkeeping of the kernel holds one record per thread of a 256-thread workgroup
         if (Gt < 1) Gt = 1;
         const size_t cpw_t = (size_t)((n + Gt - 1) / Gt);
         const size_t dyn = cpw_t * sizeof(int64_t) + (2 * cpw_t + (size_t)m) * sizeof(T) + cpw_t * (size_t)m * sizeof(T);
@@ -1101,11 +1110,13 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
             RLHIP_FUNC_LDS(c, qrcp_tag_kernel<T>, 150 * 1024);
             size_t mark = rlhip_ws_mark(c);
             QrcpTagArgs<T> t;
-            t.m = m; t.n = n; t.A = A; t.lda = lda; t.jpvt = jpvt_dev; t.tau = tau_dev;
+            t.m = m; t.n = n; t.A = A; t.lda = lda; t.tau = tau_dev;
+            t.Aout = ws_alloc<T>(c, (size_t)m * n); t.ldo = m;
+            t.jpvt = ws_alloc<int64_t>(c, (size_t)n);
             const size_t words = 2 * qt_words<T>(m, Gt);
             t.tw = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
             t.info = (int*)ws_alloc<int>(c, 32);
-            if (!t.tw || !t.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            if (!t.tw || !t.info || !t.Aout || !t.jpvt) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
             t.tol3z = std::sqrt(std::numeric_limits<T>::epsilon() / 2);
             t.max_steps = max_steps; t.hq_formula = hq_formula;
             RLHIP_CHECK(hipMemsetAsync(t.tw, 0, words * sizeof(unsigned long long), c->stream));
@@ -1123,9 +1134,15 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
                         pf[0] / 100.0 / kq, pf[1] / 100.0 / kq, pf[2] / 100.0 / kq, pf[3] / 100.0 / kq, pf[4] / 100.0 / kq, pf[5] / 100.0 / kq);
             }
 #endif
+            if (*(int*)(c->h_mail + 56) == 0) {
+                // the kernel only read A: its results are taken over now (10 MB at 1280 x 1024: microseconds)
+                RLHIP_CHECK(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), t.Aout, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+                RLHIP_CHECK(hipMemcpyAsync(jpvt_dev, t.jpvt, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+                rlhip_ws_release(c, mark);
+                return 0;
+            }
+            // a published word never arrived (bounded spins).  A and jpvt are untouched: fall through to the rendezvous kernel below.
             rlhip_ws_release(c, mark);
-            if (*(int*)(c->h_mail + 56) != 0) return -9;     // a published word never arrived (bounded spins): report instead of hanging
-            return 0;
         }
     }
     size_t mark = rlhip_ws_mark(c);

@@ -1,6 +1,9 @@
 // Internal (non-ABI) declarations shared by the HIP translation units of librlhip.so.
 // Everything here is MI355X / gfx950 only: 64-lane wavefronts, MFMA, 160 KiB LDS.
 #pragma once
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
@@ -30,6 +33,23 @@
             RLHIP_CHECK(hipSetDevice((c)->device));                                                                        \
             RLHIP_CHECK(hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
             _rlhip_lds_done[_d] = true;                                                                                    \
+        }                                                                                                                  \
+    } while (0)
+
+// The same for call sites where the kernel is a RUN-TIME value (a generic lambda over several instantiations shares one static per
+// function-pointer TYPE, so the macro above would raise the limit of the first variant only): one flag per (device, kernel address).
+#define RLHIP_FUNC_LDS_DYN(c, func, bytes)                                                                                 \
+    do {                                                                                                                   \
+        static std::mutex _rlhip_lds_mu;                                                                                   \
+        static std::vector<std::pair<int, const void*>> _rlhip_lds_seen;                                                   \
+        std::lock_guard<std::mutex> _rlhip_lds_lock(_rlhip_lds_mu);                                                        \
+        const std::pair<int, const void*> _key((c)->device, (const void*)(func));                                          \
+        bool _found = false;                                                                                               \
+        for (auto const& _e : _rlhip_lds_seen) _found = _found || (_e == _key);                                            \
+        if (!_found) {                                                                                                     \
+            RLHIP_CHECK(hipSetDevice((c)->device));                                                                        \
+            RLHIP_CHECK(hipFuncSetAttribute(_key.second, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));       \
+            _rlhip_lds_seen.push_back(_key);                                                                               \
         }                                                                                                                  \
     } while (0)
 

@@ -641,7 +641,7 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     // sketch rows per thread and pass: 5 (d <= 1280, the CQRRPT sketches of the benchmark configurations: 40 accumulator registers
     // instead of 64) or 8
     auto launch = [&](auto kern, int nr) -> int {
-        RLHIP_FUNC_LDS(c, kern, lds_cap);
+        RLHIP_FUNC_LDS_DYN(c, kern, lds_cap);       // per kernel ADDRESS: the twelve instantiations share this lambda's statics
         for (int64_t r_base = 0; r_base < d; r_base += 256 * nr)
             hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, tpg, r_base,
                                partial, row0, mloc, tb0, tb1, op->ptr);

@@ -584,6 +584,16 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
 #endif
 }
 
+// *bad = 1 unless perm[0..n) - pbase is a permutation of 0..n-1 (seen: n bits, zeroed by the caller)
+__global__ void perm_check_kernel(int64_t n, const int64_t* __restrict__ perm, int64_t pbase, unsigned* __restrict__ seen, int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t sidx = perm[i] - pbase;
+    if (sidx < 0 || sidx >= n) { atomicExch(bad, 1); return; }
+    const unsigned bit = 1u << (sidx & 31);
+    if (atomicOr(seen + (sidx >> 5), bit) & bit) atomicExch(bad, 1);
+}
+
 // dst[:, c] = src[:, perm[c] - pbase] (perm == nullptr: plain copy); threads along rows
 template <typename T>
 __global__ __launch_bounds__(256) void gather_cols_kernel(int64_t m, int64_t n, const T* __restrict__ src, int64_t lds_, const int64_t* __restrict__ perm,
@@ -780,19 +790,28 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
     const int64_t nblk = (n + BW - 1) / BW;
     bool fused = blk_on && fused_on && m >= fused_min_rows && n >= BW && n % BW == 0 && nblk <= 32 && (4 * ldb + m) < ((int64_t)1 << 28);
     size_t mark = rlhip_ws_mark(c);
+    bool perm_checked = false;
     if (fused) {
         T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
         T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
-        int* bad_dev = ws_alloc<int>(c, 32);
+        int* bad_dev = ws_alloc<int>(c, 40);
+        unsigned* seen = ws_alloc<unsigned>(c, (size_t)n / 32 + 2);
         T* Uneg = ws_alloc<T>(c, (size_t)n * n);
         T* fdump = ws_alloc<T>(c, 512);
-        if (!Upk_all || !Dinv_all || !bad_dev || !Uneg || !fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-        RLHIP_CHECK(hipMemsetAsync(bad_dev, 0, 32 * sizeof(int), c->stream));
+        if (!Upk_all || !Dinv_all || !bad_dev || !seen || !Uneg || !fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        RLHIP_CHECK(hipMemsetAsync(bad_dev, 0, 33 * sizeof(int), c->stream));
         hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, n, diag, A, lda, Upk_all, Dinv_all, bad_dev,
                            1.0e6);
         RLHIP_LAUNCH_CHECK();
-        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (perm_dev) {     // the pivot vector is validated on the device; its verdict rides on the guard's read-back (slot 32)
+            RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
+            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad_dev + 32);
+            RLHIP_LAUNCH_CHECK();
+            perm_checked = true;
+        }
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        if (perm_checked && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }     // jpvt is not a permutation of 1..n (as col_swap reports it)
         for (int64_t b = 0; b < nblk; ++b) fused = fused && ((int*)(c->h_mail + 16))[b] == 0;
         if (fused) {
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
@@ -807,6 +826,20 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         }
     }
     rlhip_ws_release(c, mark);
+    if (perm_dev && !perm_checked) {     // gather-copy route: validate before anything is written
+        size_t mk2 = rlhip_ws_mark(c);
+        unsigned* seen = ws_alloc<unsigned>(c, (size_t)n / 32 + 2);
+        int* bad = ws_alloc<int>(c, 8);
+        if (!seen || !bad) { rlhip_ws_release(c, mk2); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
+        RLHIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        rlhip_ws_release(c, mk2);
+        if (*(int*)(c->h_mail + 16) != 0) return -7;
+    }
     {
         unsigned gx = (unsigned)((m + 256 * 8 - 1) / (256 * 8));
         if (gx < 1) gx = 1;

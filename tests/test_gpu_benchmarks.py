@@ -221,3 +221,34 @@ def test_cqrrt_linops_composite_applications_main(tmp_path):
         assert float(r[12]) < 1e-10                                       # right singular vectors of R orthonormal
     blines = [ln for ln in open(brk).read().splitlines() if not ln.startswith("#")]
     assert blines[0].startswith("m,n,run,algorithm,t0") and len(blines) == 5 and all(len(ln.split(",")) == 22 for ln in blines)
+
+
+def test_bqrrp_gpu_benchmark_main(tmp_path):
+    """benchmarks/bqrrp_gpu.py = BQRRP_GPU_benchmark.cu on the BQRRP_GPU class: the reference's four files (names, 6 header lines,
+    `qrf  cholqr  geqrf` speed rows, 15-entry breakdown rows that add up to their total), both modes."""
+    from benchmarks import bqrrp_gpu
+
+    f3, f1, f2, rows = bqrrp_gpu.run_block_size_sweep(str(tmp_path), 1024, 1024, [64, 128, 256], True, True)
+    for path, name in ((f3, "_BQRRP_GPU_speed_comparisons_block_size_num_info_lines_6.txt"), (f1, "_BQRRP_GPU_runtime_breakdown_qrf_num_info_lines_6.txt"),
+                       (f2, "_BQRRP_GPU_runtime_breakdown_cholqr_num_info_lines_6.txt")):
+        assert path.endswith(name)
+    lines = open(f3).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("Description:") and lines[5].startswith("Additional parameters: BQRRP block sizes: 64,128,256")
+    body = lines[6:]
+    assert body[-1].startswith("Total benchmark execution time:") and len(body) == 4
+    for ln, r in zip(body[:3], rows):
+        t = [int(x) for x in ln.split()]
+        assert len(t) == 3 and all(x > 0 for x in t) and tuple(t) == tuple(r)
+    for path, chol in ((f1, False), (f2, True)):
+        data = _rows(path)
+        assert len(data) == 3
+        for r in data:
+            t = [int(x) for x in r]
+            assert len(t) == 15 and sum(t[:14]) == t[14] and t[2] == t[4] == t[6] == 0
+            assert (t[8] > 0) == chol and (t[10] > 0) == chol
+    path, rows = bqrrp_gpu.run_mat_size_sweep(str(tmp_path), [512, 1024], False, False)
+    assert path.endswith("BQRRP_GPU_speed_comparisons_mat_size_num_info_lines_6.txt") and not path.split("/")[-1].startswith("_")
+    lines = open(path).read().rstrip("\n").split("\n")
+    assert lines[4].startswith("Input size: dim start: 512,1024") and len(lines) == 8
+    assert all(len(ln.split()) == 3 and int(ln.split()[2]) == 0 for ln in lines[6:])
+    assert bqrrp_gpu.main([]) == 1

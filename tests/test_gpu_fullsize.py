@@ -469,6 +469,35 @@ def test_trsm_gather_out_of_place_vs_lapack(ctx, m, n, dtype, perm, fused):
         assert torch.equal(Xd, Pd)                               # both take the fused kernel: identical arithmetic per entry
 
 
+@pytest.mark.parametrize("m,n", [(20000, 512), (3000, 200)])
+def test_trsm_gather_rejects_a_pivot_vector_that_is_not_a_permutation(ctx, m, n):
+    """rlhip_trsm_gather validates jpvt on the device before anything is written (fused route: the verdict rides on the conditioning
+    guard's read-back; gather-copy route: its own check): a repeated or out-of-range entry returns -7 and leaves B untouched."""
+    import torch
+    from randlapack_amd import _lib
+
+    d = _d()
+    rng = np.random.default_rng(n)
+    U = np.triu(rng.standard_normal((n, n))) + 30 * np.eye(n)
+    Ud, Src = d.cm_from_numpy(U), d.cm_from_numpy(rng.standard_normal((m, n)))
+    for bad in ("repeat", "range"):
+        J = np.arange(1, n + 1, dtype=np.int64)[::-1].copy()
+        if bad == "repeat":
+            J[7] = J[3]
+        else:
+            J[5] = n + 1
+        B = d.cm_zeros(m, n)
+        B.fill_(-3.0)
+        with pytest.raises(_lib.RlhipError):
+            ctx.trsm_gather(m, n, 1.0, Ud, n, Src, m, torch.from_numpy(J).cuda(), B, m)
+        assert bool((B == -3.0).all())
+    J = torch.arange(n, 0, -1, dtype=torch.int64, device="cuda")
+    B = d.cm_zeros(m, n)
+    ctx.trsm_gather(m, n, 1.0, Ud, n, Src, m, J, B, m)
+    X = d.cm_to_numpy(B)
+    assert np.linalg.norm(X @ U - d.cm_to_numpy(Src)[:, ::-1]) <= 1e-12 * np.linalg.norm(d.cm_to_numpy(Src)) * np.sqrt(n)
+
+
 def test_trsm_gather_with_an_ill_conditioned_block_takes_the_copy_route(ctx):
     """One 256-block fails the conditioning guard -> no fused out-of-place launch: columns gathered by the copy kernel, then the
     in-place solver (fused runs around the bad block, substitution inside it).  Same accuracy as the in-place solve of the permuted input."""

@@ -711,6 +711,39 @@ def test_gesdd_clustered_singular_values(ctx, m, n, kind):
     np.testing.assert_allclose(Sn, s, rtol=1e-12)
 
 
+@pytest.mark.parametrize("m,n,kind", [(20000, 256, "flat"), (5000, 256, "cond10"), (3000, 200, "flat"), (4000, 96, "cluster"), (2000, 256, "identity")])
+def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n, kind):
+    """The one-launch Jacobi (resident workgroups exchanging blocks through the uncached buffer, jacobi_persist_kernel) runs the same
+    pairing and the same round arithmetic as the per-launch sweeps: S, U and V^T come out BITWISE identical, with the same sweep count;
+    path counter 6 proves which one ran.  `cluster` / `identity` take the hand-back to the host's Gram verification and a relaunch."""
+    import ctypes as C
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    if kind == "flat":
+        A = rng.standard_normal((m, n))
+    else:
+        s = {"cond10": np.logspace(0, -1, n), "cluster": 1.0 - 1e-7 * rng.random(n), "identity": np.ones(n)}[kind]
+        A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RLHIP_JACOBI_PERSIST", mode)
+        Ad = d.cm_from_numpy(A)
+        S = torch.zeros(n, dtype=torch.float64, device="cuda")
+        U, VT = d.cm_empty(m, n), d.cm_empty(n, n)
+        sw = C.c_int(0)
+        before = ctx.path_count(6)
+        assert ctx.lib.rlhip_gesdd_f64(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n, C.byref(sw)) == 0
+        res[mode] = (d.cm_to_numpy(U), S.cpu().numpy(), d.cm_to_numpy(VT), sw.value, ctx.path_count(6) - before)
+    (U1, S1, V1, sw1, c1), (U0, S0, V0, sw0, c0) = res["1"], res["0"]
+    assert c1 == 1 and c0 == 0, "the persistent kernel did not run (or ran with RLHIP_JACOBI_PERSIST=0)"
+    assert sw1 == sw0 and sw1 > 0
+    assert np.array_equal(S1, S0) and np.array_equal(U1, U0) and np.array_equal(V1, V0)
+    assert np.linalg.norm((U1 * S1) @ V1 - A) <= 1e-13 * np.linalg.norm(A) * np.sqrt(n)
+    assert np.linalg.norm(U1.T @ U1 - np.eye(n)) <= 1e-11 * np.sqrt(n)
+
+
 @pytest.mark.parametrize("m,n,cond", [(20000, 128, 1e2), (20000, 64, 1e12), (100000, 32, 1.0), (9000, 16, 1e9)])
 def test_geqrf_tall_skinny_matches_lapack(ctx, m, n, cond):
     """Tall-skinny geqrf: Cholesky-QR twice + Householder reconstruction when it can be trusted; for cond 1e9 / 1e12 plain Cholesky-QR
