@@ -15,6 +15,7 @@
 //     in both, after the exchange everybody knows the winner, the two owners swap rows and every workgroup eliminates its own rows.
 //   * dlaswp on the columns outside the panel is a thread-per-column kernel walking the 32 swaps in order.
 #include "rlhip_internal.h"
+#include <algorithm>
 #include <cstdio>
 
 namespace rlhip {
@@ -419,7 +420,7 @@ __device__ __forceinline__ void lu_reg_steps(const LuArgs<T>& g, LuRegState<T, R
     }
 }
 template <typename T, int RPT, bool TAG>
-__global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
+__global__ __launch_bounds__(256, (sizeof(T) == 8) ? 2 : 1) void getrf_panel_reg_kernel(LuArgs<T> g) {
     __shared__ T s_wv[4];
     __shared__ int64_t s_wr[4];
     __shared__ int s_ww[4];
@@ -456,6 +457,86 @@ __global__ __launch_bounds__(256) void getrf_panel_reg_kernel(LuArgs<T> g) {
             for (int c = 0; c < PB; ++c)
                 if (c < pb) g.A[st.gr[q] + (j0 + c) * g.lda] = st.x[q][c];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Panels taller than the device can hold resident (the register kernels keep every row of the panel in VGPRs: 256 rows x RPT per
+// workgroup, every workgroup resident at once because they rendezvous every column): dgetf2 as three small launches per column --
+// partial maxima, pivot + interchange, scale + rank-1 update of the panel -- with the panel living in L2 / Infinity Cache
+// (200000 x 32 fp64 = 51 MB).  Any number of rows; ~12 us per column instead of ~4, taken only above the resident capacity
+// (131072 / 262144 rows, below).  Same arithmetic and the same first-maximum pivot rule as the resident kernels and LAPACK.
+template <typename T>
+__global__ __launch_bounds__(256) void getf2_colmax_kernel(int64_t m, int64_t j, const T* __restrict__ A, int64_t lda, T* __restrict__ pval,
+                                                           int64_t* __restrict__ prow) {
+    __shared__ T s_v[4];
+    __shared__ int64_t s_r[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    T bv = T(-1); int64_t br = m;
+    for (int64_t i = j + (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) {
+        const T v = fabs(A[i + j * lda]);
+        if (v > bv) { bv = v; br = i; }                              // rows increase along the walk: ties keep the first
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T v2 = __shfl_xor(bv, off); const int64_t r2 = __shfl_xor(br, off);
+        argmax_take(bv, br, v2, r2, m);
+    }
+    if (lane == 0) { s_v[wid] = bv; s_r[wid] = br; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) argmax_take(s_v[0], s_r[0], s_v[w], s_r[w], m);
+        pval[blockIdx.x] = s_v[0]; prow[blockIdx.x] = s_r[0];
+    }
+}
+// one workgroup: the column's pivot from the partial maxima, ipiv[j], the interchange of rows j and p inside the panel, info
+template <typename T>
+__global__ __launch_bounds__(256) void getf2_pivot_kernel(int64_t m, int64_t j0, int pb, int64_t j, int nparts, T* __restrict__ A, int64_t lda,
+                                                          const T* __restrict__ pval, const int64_t* __restrict__ prow, int64_t* __restrict__ ipiv,
+                                                          int* __restrict__ info) {
+    __shared__ T s_v[4];
+    __shared__ int64_t s_r[4];
+    __shared__ int64_t s_p;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    T bv = T(-1); int64_t br = m;
+    for (int i = tid; i < nparts; i += 256) argmax_take(bv, br, pval[i], prow[i], m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T v2 = __shfl_xor(bv, off); const int64_t r2 = __shfl_xor(br, off);
+        argmax_take(bv, br, v2, r2, m);
+    }
+    if (lane == 0) { s_v[wid] = bv; s_r[wid] = br; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) argmax_take(s_v[0], s_r[0], s_v[w], s_r[w], m);
+        const int64_t p = (s_r[0] < m) ? s_r[0] : j;
+        s_p = p;
+        ipiv[j] = p + 1;
+        if (A[p + j * lda] == T(0) && *info == 0) *info = (int)(j + 1);
+    }
+    __syncthreads();
+    const int64_t p = s_p;
+    if (p != j && tid < pb) {
+        const int64_t c = j0 + tid;
+        const T a = A[j + c * lda], b = A[p + c * lda];
+        A[j + c * lda] = b; A[p + c * lda] = a;
+    }
+}
+// rows i > j: l = a_ij / pivot (left alone when the pivot is zero, as dgetf2), a_ic -= l * u_c for the panel columns right of j
+template <typename T>
+__global__ __launch_bounds__(256) void getf2_update_kernel(int64_t m, int64_t j0, int pb, int64_t j, T* __restrict__ A, int64_t lda) {
+    __shared__ T s_u[PB];
+    const int tid = threadIdx.x;
+    const int nc = (int)(j0 + pb - 1 - j);                          // columns right of j inside the panel
+    if (tid <= nc) s_u[tid] = A[j + (j + tid) * lda];                // s_u[0] = pivot
+    __syncthreads();
+    const T piv = s_u[0];
+    if (piv == T(0)) return;
+    const T rp = T(1) / piv;
+    for (int64_t i = j + 1 + (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) {
+        const T l = A[i + j * lda] * rp;
+        A[i + j * lda] = l;
+        for (int c = 1; c <= nc; ++c) A[i + (j + c) * lda] -= l * s_u[c];
     }
 }
 
@@ -592,7 +673,9 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     if (tag_on < 0) { const char* e = getenv("RLHIP_LU_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
     const bool use_tag = tag_on && m < ((int64_t)1 << 31);
     constexpr size_t TW = sizeof(T) / 4;
-    const size_t tw_words = 2 * (size_t)(TW * Gmax + Gmax + TW * Gmax * PB + TW * PB);
+    // (the general register kernel may run more workgroups than CUs: the word buffer is sized -- and cleared -- for the largest grid of this call)
+    const int64_t Gtw = std::max<int64_t>(Gmax, (m + 511) / 512 + 1);
+    const size_t tw_words = 2 * (size_t)(TW * Gtw + Gtw + TW * Gtw * PB + TW * PB);
     g.tw = use_tag ? (unsigned long long*)rlhip_xchg_buffer(c, tw_words * sizeof(unsigned long long)) : nullptr;   // uncached exchange memory of the context
     g.tag_base = 0;
     // tags: (panel index + 1) * 64 + column.  The word buffer is cleared at the start of every call and belongs to this call's workspace, so
@@ -630,6 +713,27 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
         const int reg_panel = reg_panel_on();
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
+        // resident capacity of the general register kernel (every workgroup spins on the others: all of them must be on the device at once)
+        static int64_t reg_cap[64] = {};
+        if (!reg_cap[c->device & 63]) {
+            int nb = 0;
+            RLHIP_CHECK(hipSetDevice(c->device));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)getrf_panel_reg_kernel<T, RPT_BIG, true>, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+            reg_cap[c->device & 63] = (int64_t)nb * num_cu;
+        }
+        const int64_t G_reg = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
+        if (G_reg > reg_cap[c->device & 63] && G_reg > 64) {
+            // taller than the resident kernels can hold (fp64: 262144 rows, fp32: 262144): column-at-a-time launches on the L2-resident panel
+            const int nparts = (int)((rows / 2048 < 1) ? 1 : (rows / 2048 > 1024 ? 1024 : rows / 2048));
+            T* pval = ws_alloc<T>(c, 1024); int64_t* prow = ws_alloc<int64_t>(c, 1024);
+            if (!pval || !prow) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            for (int64_t j = j0; j < j0 + pb; ++j) {
+                hipLaunchKernelGGL(getf2_colmax_kernel<T>, dim3((unsigned)nparts), dim3(256), 0, c->stream, m, j, A, lda, pval, prow);
+                hipLaunchKernelGGL(getf2_pivot_kernel<T>, dim3(1), dim3(256), 0, c->stream, m, j0, pb, j, nparts, A, lda, pval, prow, ipiv_dev, g.info);
+                if (j + 1 < m) hipLaunchKernelGGL(getf2_update_kernel<T>, dim3((unsigned)nparts), dim3(256), 0, c->stream, m, j0, pb, j, A, lda);
+            }
+            c->path_count[7]++;
+        } else
         if (reg_panel && use_tag && rows >= 1024) {          // RLHIP_LU_TAG=0 / RLHIP_LU_REG_PANEL=0: the barrier-based LDS kernel (debug knob)
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
             g.tag_base = (unsigned)(j0 / PB + 1) * 64u;

@@ -72,7 +72,8 @@ def main():
                           "   (three separate passes: FETCH_SIZE | WRITE_SIZE | " + " ".join(SQ) + "; scripts/pmc_all.py)",
                "correction": "FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports 1/2 of the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM) -> "
                              "fetch_bytes_corrected = 2 x raw; WRITE_SIZE taken as is (uncalibrated).  The counters sit on the L2's fabric side: Infinity-Cache hits are counted."}
-        for group in ("fetch", "write", "sq"):
+        groups = ("fetch", "sq") if bound == "latency" else ("fetch", "write", "sq")     # latency-bound kernels: no WRITE_SIZE pass
+        for group in groups:
             od = f"/tmp/pmc_{name}_{group}"
             try:
                 rc, tail = run_pass(name, group, od)

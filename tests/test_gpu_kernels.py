@@ -523,6 +523,31 @@ def test_getrf_tall_f64_fast_step_pivots_match_lapack(ctx, m, n):
     np.testing.assert_allclose(d.cm_to_numpy(Ad), lu_ref, atol=1e-12 * np.abs(lu_ref).max(), rtol=0)
 
 
+@pytest.mark.parametrize("m,n,dtype,path7", [(200000, 96, "f64", False), (300000, 40, "f64", True), (400000, 48, "f32", True), (200000, 64, "f32", False)])
+def test_getrf_very_tall_panels_match_lapack(ctx, m, n, dtype, path7):
+    """PLUL's shape at BASELINE configs[1] with power iterations is 200000 x 256: more rows than ONE workgroup per CU of the register
+    panel kernel can hold.  200000 fp64 rows run the general register kernel on 391 co-resident workgroups (two per CU); beyond the
+    resident capacity (262144 rows) the column-at-a-time panel takes over (path counter 7).  Pivots identical to LAPACK, factors to
+    rounding, an exact tie between the first and the last workgroup's rows included.  (Round 3 found the 200000-row case timing out.)"""
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    npdt = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.default_rng(m + n)
+    A = (rng.standard_normal((m, n)) * np.logspace(0, -2, n)).astype(npdt)
+    A[3] = A[m - 5]
+    Ad = d.cm_from_numpy(A)
+    ip = torch.zeros(n, dtype=torch.int64, device="cuda")
+    before = ctx.path_count(7)
+    assert getattr(ctx.lib, f"rlhip_getrf_{dtype}")(ctx.h, m, n, Ad.data_ptr(), m, ip.data_ptr()) == 0
+    assert (ctx.path_count(7) > before) == path7
+    lu_ref, piv_ref, info_ref = (ll.dgetrf if dtype == "f64" else ll.sgetrf)(A)
+    np.testing.assert_array_equal(ip.cpu().numpy() - 1, piv_ref)
+    tol = (1e-12 if dtype == "f64" else 2e-4) * np.abs(lu_ref).max()
+    assert np.abs(d.cm_to_numpy(Ad) - lu_ref).max() <= tol
+
+
 def test_getrf_outer_blocking_knob_matches_lapack():
     """RLHIP_LU_OUTER (two-level blocking; read once per process, hence the subprocess): same pivots and factors as LAPACK for a
     tall, a wide and a ragged shape, with full and pivots-only factorizations"""
