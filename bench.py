@@ -186,12 +186,14 @@ def main():
         if world == 1 and (m, n, k) == (M, N, K):
             import glob
             here = os.path.dirname(os.path.abspath(__file__))
-            tfile = sorted(glob.glob(os.path.join(here, "profiles", "round*_pmc_traffic.json")))[-1]      # the latest committed pass
+            # the latest committed pass (round 3 on: scripts/pmc_all.py writes one file per kernel; earlier rounds: pmc_traffic.sh)
+            cands = glob.glob(os.path.join(here, "profiles", "round*_pmc_traffic.json")) + glob.glob(os.path.join(here, "profiles", "round*_pmc_gemm_sk_nn.json"))
+            tfile = sorted(cands, key=lambda f: os.path.basename(f).split("_")[0])[-1]
             with open(tfile) as fh:
                 tj = json.load(fh)
             traffic = float(tj["traffic_bytes"])
             tfile = os.path.relpath(tfile, here)
-            traffic_source = f"{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape, scripts/pmc_traffic.sh; not re-measured by this run)"
+            traffic_source = f"{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape, scripts/pmc_all.py; not re-measured by this run)"
     except Exception:
         traffic, traffic_source = None, None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",

@@ -75,7 +75,27 @@ struct SkArgs {
     double* ssq_part;         // nullptr, or gridDim.x partial sums of squares of op(A) (fused ||A||_F^2)
     int tri;                  // 1: syrk-upper -- only tiles touching i <= j are computed, only i <= j is written
     int64_t ntiles;           // number of active tiles
+    int gs;                   // workgroups per lockstep group (see sk_group below); 1 = every workgroup on its own
 };
+
+// Lockstep groups.  With one share per workgroup, the workgroups of an XCD sit at unrelated k offsets, so the operand every tile needs
+// in full (Omega of Y = A Omega: 41 MB; Q of B^T = A^T Q: 410 MB) streams through the 4 MiB L2 once PER TILE and the L2's fabric side
+// carries 2.3x the algorithmic bytes (PMC, profiles/round3_pmc_gemm_sk_nn.json).  Here `gs` consecutive tiles form one unit of the
+// (unit, k-tile) iteration space, a GROUP of gs workgroups owns an equal contiguous share of it, and member j of the group walks tile
+// gs * unit + j over the same k range at the same time: the members request the same k-rows of the shared operand within
+// microseconds of each other and all but one of them hit in L2.  Members of a group must share an L2, i.e. an XCD: workgroups are dealt
+// to the XCDs round-robin (blockIdx % 8), so group = XCD + 8 * (slot in the XCD / gs).  (The placement only decides who shares a
+// cache: any other dispatch order costs hits, never correctness.)
+struct SkWho { int64_t group, member; };
+__device__ __host__ __forceinline__ SkWho sk_group(int64_t w, int gs) {
+    if (gs <= 1) return SkWho{w, 0};
+    const int64_t slot = w / 8;
+    return SkWho{(w % 8) + 8 * (slot / gs), slot % gs};
+}
+__device__ __host__ __forceinline__ int64_t sk_workgroup(int64_t group, int64_t member, int gs) {
+    if (gs <= 1) return group;
+    return (group % 8) + 8 * (gs * (group / 8) + member);
+}
 
 // active tile index -> tile descriptor: first row m0 of the 128-row operand block, first column of the tile's left 128 columns (nA0)
 // and of its right 128 columns MINUS 128 (nB0: column jl >= 128 of the tile is global column nB0 + jl), and whether the tile is
@@ -135,10 +155,13 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
     const int fr = lane & 15, fk = lane >> 4;
 
     const int64_t KT = g.ktiles;
-    const int64_t W = g.ntiles * KT;
-    const int64_t P = gridDim.x, w = blockIdx.x;
-    const int64_t ws = (w * W) / P, we = ((w + 1) * W) / P;
-    const int64_t first_tile = ws / KT;
+    const int64_t GS = g.gs, w = blockIdx.x;
+    const int64_t units = (g.ntiles + GS - 1) / GS;                   // a unit = GS consecutive tiles walked in lockstep by a group
+    const int64_t W = units * KT;
+    const int64_t P = (int64_t)gridDim.x / GS;                         // groups
+    const SkWho who = sk_group(w, (int)GS);
+    const int64_t ws = (who.group * W) / P, we = ((who.group + 1) * W) / P;
+    const int64_t first_tile = ws / KT;                                // (first UNIT of the share)
 
     // ---- per-lane constants of the fragment reads (see header for the index re-enumeration)
     // KC image: 16-byte piece c of row r lives at byte r*128 + ((c ^ ((r>>1)&7)) << 4); with r = 16*x + fr the
@@ -175,10 +198,12 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 
     double ssq_acc = 0.0;
     for (int64_t pos = ws; pos < we;) {
-        const int64_t tile = pos / KT;
-        const int64_t kt0 = pos - tile * KT;
+        const int64_t unit = pos / KT;
+        const int64_t kt0 = pos - unit * KT;
         int64_t nk = KT - kt0;
         if (nk > we - pos) nk = we - pos;
+        const int64_t tile = GS * unit + who.member;
+        if (tile >= g.ntiles) { pos += nk; continue; }                 // the last unit may be short: this member has nothing there
         const SkTile td = sk_tile(g, tile);
         const int64_t m0 = td.m0, n0 = td.nA0, k0 = kt0 * BK;
 
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                         }
                     }
             } else {
-                T* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+                T* out = g.slab + (2 * w + (unit != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                         g.C[i + j * g.ldc] = v;
                     }
         } else {
-            T* out = g.slab + (2 * w + (tile != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+            T* out = g.slab + (2 * w + (unit != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -375,9 +400,11 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t P) {
     const int64_t KT = g.ktiles, tile = blockIdx.x;
-    const int64_t W = g.ntiles * KT;
-    const int64_t lo = tile * KT, hi = lo + KT;
-    // first / last share intersecting [lo, hi)
+    const int64_t GS = g.gs;
+    const int64_t unit = tile / GS, member = tile - unit * GS;
+    const int64_t W = ((g.ntiles + GS - 1) / GS) * KT;
+    const int64_t lo = unit * KT, hi = lo + KT;
+    // first / last share (group) intersecting [lo, hi)      (P = number of groups)
     int64_t w0 = (lo * P) / W;
     while (w0 > 0 && (w0 * W) / P > lo) --w0;
     while (((w0 + 1) * W) / P <= lo) ++w0;
@@ -390,8 +417,8 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t
     for (int e = blockIdx.y * per + threadIdx.x; e < (int)(blockIdx.y + 1) * per; e += 256) {
         T s = 0;
         for (int64_t w = w0; w <= w1; ++w) {
-            const int64_t first_tile_w = ((w * W) / P) / KT;
-            const T* slab = g.slab + (2 * w + (tile != first_tile_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
+            const int64_t first_unit_w = ((w * W) / P) / KT;
+            const T* slab = g.slab + (2 * sk_workgroup(w, member, (int)GS) + (unit != first_unit_w ? 1 : 0)) * (int64_t)SLAB_ELEMS;
             s += slab[e];
         }
         int64_t i, j;
@@ -455,6 +482,14 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;
     g.tri = tri; g.ntiles = ntiles;
     const int64_t P = num_cu;
+    // Lockstep group size (sk_group).  Measured at C2 (200000 x 20000 x 256 fp64, kernel ms / FETCH_SIZE GB against 32.5 GB algorithmic):
+    //   Y = A Omega (NN):   1: 29.8 / 72.8   2: 29.9 / 68.8   4: 29.9 / 52.1   8: 30.0 / 34.4   (16, 32: as 8)
+    //   B^T = A^T Q (TN):   1: 30.1 / 63.0   2: 30.0 / 58.8   4: 30.6 / 58.7   8: 31.2 / 34.9
+    // NN takes 8 (fabric traffic 2.27x -> 1.08x of the algorithmic bytes for 0.5 % of kernel time).  TN loses 4 % at 8 -- its members read
+    // the SAME k-rows of neighbouring column blocks of A, 1.6 MB apart, at the same instant, which camps on memory channels -- and stays
+    // at 2.  The triangular map has too few tiles for whole units (18 at n = 1024) and runs ungrouped.
+    const int gs_want = tri ? 1 : (transA ? 2 : 8);
+    g.gs = (gs_want > 1 && P % (8 * gs_want) == 0 && ntiles >= 4 * (int64_t)gs_want) ? gs_want : 1;
     size_t mark = rlhip_ws_mark(c);
     g.slab = ws_alloc<T>(c, (size_t)2 * P * SLAB_ELEMS);
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
@@ -468,7 +503,7 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
         hipLaunchKernelGGL((gemm_sk_kernel<T, false>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
     }
     RLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P);
+    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P / g.gs);
     RLHIP_LAUNCH_CHECK();
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);

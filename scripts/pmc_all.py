@@ -73,6 +73,8 @@ def main():
                "correction": "FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports 1/2 of the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM) -> "
                              "fetch_bytes_corrected = 2 x raw; WRITE_SIZE taken as is (uncalibrated).  The counters sit on the L2's fabric side: Infinity-Cache hits are counted."}
         groups = ("fetch", "sq") if bound == "latency" else ("fetch", "write", "sq")     # latency-bound kernels: no WRITE_SIZE pass
+        if os.environ.get("PMC_GROUPS"):
+            groups = tuple(x for x in os.environ["PMC_GROUPS"].split(",") if x in GROUPS)
         for group in groups:
             od = f"/tmp/pmc_{name}_{group}"
             try:

@@ -184,7 +184,7 @@ WORKLOADS = {
                     4.0 * (65536 * 2048 + 2 * 65536 * 16384 + 2048 * 16384), 2.0 * 65536 * 16384 * 2048, "mfma"),
     "getrf_panel_f32": (getrf_panel_f32, "getrf_panel_f32_kernel", "row-pivoted LU panel steps of the 65536 x 2048 fp32 transposed sketch (C4 qrcp_wide)",
                         None, None, "latency"),
-    "jacobi": (jacobi, "jacobi_block_kernel", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),
+    "jacobi": (jacobi, "jacobi_", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),
     "qrcp_tag": (qrcp_tag, "qrcp_tag_kernel", "geqp3 of the 1280 x 1024 fp64 sketch (C3)", None, None, "latency"),
 }
 

@@ -196,9 +196,9 @@ def test_rsvd_config2_power_iterations_planted_rank256(ctx, rs_stab, name):
     assert float(torch.linalg.norm(V @ V.T - I)) <= EPS**0.75 * np.sqrt(n)
     # the computed subspaces are the planted ones: ||U_planted^T U|| has all singular values 1 (to the noise level)
     c = torch.linalg.svdvals(Ut @ U.T)
-    assert float(c.min()) >= 1 - 1e-12
+    assert float(c.min()) >= 1 - 1e-10
     c = torch.linalg.svdvals(Vt @ V.T)
-    assert float(c.min()) >= 1 - 1e-12
+    assert float(c.min()) >= 1 - 1e-10
     # residual on the noise floor: A <- A - (U S) V^T in place, then its Frobenius norm
     Us = U * r["S"][:, None]
     ctx.gemm("N", "T", m, n, k, -1.0, Us, m, V, n, 1.0, A, m)
