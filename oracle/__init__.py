@@ -266,20 +266,23 @@ def geqp3(A):
 def bqrrp(A, b_sz, d_factor=1.0, qrcp_wide=0, qr_tall=2, apply_trans_q=0, internal_nb=None, tol=None, sketch=None,
           ctr=(0, 0, 0, 0), key=(0, 0)):
     """BQRRP::call.  qrcp_wide 0 luqr / 1 geqp3; qr_tall 0 geqrt / 1 cholqr / 2 geqrf; apply_trans_q 0 ormqr / 1 gemqrt.
-    returns dict(rc, rank, A (GEQP3 format), tau, J, next_ctr)"""
+    A float32 input runs the SAME restatement instantiated on float over the s-prefixed LAPACK routines (the like-for-like oracle of
+    the fp32 device path); anything else runs in float64.  returns dict(rc, rank, A (GEQP3 format), tau, J, next_ctr)"""
     lib = load()
-    A = _f(A).copy(order="F")
+    f32 = np.asarray(A).dtype == np.float32
+    npdt, fl, fn = (np.float32, C.c_float, lib.oracle_bqrrp_f32) if f32 else (np.float64, dbl, lib.oracle_bqrrp_f64)
+    A = np.array(A, dtype=npdt, order="F", copy=True)
     m, n = A.shape
-    tau = np.zeros(min(m, n))
+    tau = np.zeros(min(m, n), dtype=npdt)
     J = np.zeros(n, dtype=np.int64)
     rank = i64(0)
     st = _state(ctr, key)
     if tol is None:
-        tol = float(np.finfo(np.float64).eps)
-    sk = None if sketch is None else _f(sketch).copy(order="F")
-    rc = lib.oracle_bqrrp_f64(i64(m), i64(n), _p(A), i64(m), dbl(d_factor), i64(b_sz), i64(internal_nb or b_sz), dbl(tol),
-                              C.c_int(qrcp_wide), C.c_int(qr_tall), C.c_int(apply_trans_q), _p(tau), _p(J), _p(st),
-                              _p(sk) if sk is not None else None, C.byref(rank))
+        tol = float(np.finfo(npdt).eps)
+    sk = None if sketch is None else np.array(sketch, dtype=npdt, order="F", copy=True)
+    rc = fn(i64(m), i64(n), _p(A), i64(m), fl(d_factor), i64(b_sz), i64(internal_nb or b_sz), fl(tol),
+            C.c_int(qrcp_wide), C.c_int(qr_tall), C.c_int(apply_trans_q), _p(tau), _p(J), _p(st),
+            _p(sk) if sk is not None else None, C.byref(rank))
     return dict(rc=rc, rank=int(rank.value), A=A, tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
 
 

@@ -48,7 +48,12 @@ const char* lapack_open(const char* path) {
               bind(h, prefix, "dgemqrt_", L.dgemqrt) && bind(h, prefix, "dlarfg_", L.dlarfg) &&
               bind(h, prefix, "dlarf_", L.dlarf) && bind(h, prefix, "dlarfb_", L.dlarfb) &&
               bind(h, prefix, "dlarft_", L.dlarft) && bind(h, prefix, "dnrm2_", L.dnrm2) &&
-              bind(h, prefix, "idamax_", L.idamax) && bind(h, prefix, "dswap_", L.dswap);
+              bind(h, prefix, "idamax_", L.idamax) && bind(h, prefix, "dswap_", L.dswap) &&
+              bind(h, prefix, "sgemm_", L.sgemm) && bind(h, prefix, "ssyrk_", L.ssyrk) && bind(h, prefix, "strsm_", L.strsm) &&
+              bind(h, prefix, "strmm_", L.strmm) && bind(h, prefix, "spotrf_", L.spotrf) && bind(h, prefix, "sgeqrf_", L.sgeqrf) &&
+              bind(h, prefix, "sormqr_", L.sormqr) && bind(h, prefix, "sgeqp3_", L.sgeqp3) && bind(h, prefix, "sgetrf_", L.sgetrf) &&
+              bind(h, prefix, "slacpy_", L.slacpy) && bind(h, prefix, "slaset_", L.slaset) && bind(h, prefix, "sorhr_col_", L.sorhr_col) &&
+              bind(h, prefix, "sgeqrt_", L.sgeqrt) && bind(h, prefix, "sgemqrt_", L.sgemqrt) && bind(h, prefix, "sorgqr_", L.sorgqr);
     if (!ok) {
         dlclose(h);
         return g_err;

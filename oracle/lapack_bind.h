@@ -64,6 +64,28 @@ struct Lapack {
     double (*dnrm2)(const lint*, const double*, const lint*);
     lint (*idamax)(const lint*, const double*, const lint*);
     void (*dswap)(const lint*, double*, const lint*, double*, const lint*);
+    // single precision twins of the routines the BQRRP restatement calls (the fp32 leg of the oracle: BASELINE configs[3] is fp32)
+    void (*sgemm)(const char*, const char*, const lint*, const lint*, const lint*, const float*, const float*, const lint*, const float*, const lint*,
+                  const float*, float*, const lint*, size_t, size_t);
+    void (*ssyrk)(const char*, const char*, const lint*, const lint*, const float*, const float*, const lint*, const float*, float*, const lint*, size_t,
+                  size_t);
+    void (*strsm)(const char*, const char*, const char*, const char*, const lint*, const lint*, const float*, const float*, const lint*, float*,
+                  const lint*, size_t, size_t, size_t, size_t);
+    void (*strmm)(const char*, const char*, const char*, const char*, const lint*, const lint*, const float*, const float*, const lint*, float*,
+                  const lint*, size_t, size_t, size_t, size_t);
+    void (*spotrf)(const char*, const lint*, float*, const lint*, lint*, size_t);
+    void (*sgeqrf)(const lint*, const lint*, float*, const lint*, float*, float*, const lint*, lint*);
+    void (*sormqr)(const char*, const char*, const lint*, const lint*, const lint*, const float*, const lint*, const float*, float*, const lint*, float*,
+                   const lint*, lint*, size_t, size_t);
+    void (*sgeqp3)(const lint*, const lint*, float*, const lint*, lint*, float*, float*, const lint*, lint*);
+    void (*sgetrf)(const lint*, const lint*, float*, const lint*, lint*, lint*);
+    void (*slacpy)(const char*, const lint*, const lint*, const float*, const lint*, float*, const lint*, size_t);
+    void (*slaset)(const char*, const lint*, const lint*, const float*, const float*, float*, const lint*, size_t);
+    void (*sorhr_col)(const lint*, const lint*, const lint*, float*, const lint*, float*, const lint*, float*, lint*);
+    void (*sgeqrt)(const lint*, const lint*, const lint*, float*, const lint*, float*, const lint*, float*, lint*);
+    void (*sgemqrt)(const char*, const char*, const lint*, const lint*, const lint*, const lint*, const float*, const lint*, const float*, const lint*,
+                    float*, const lint*, float*, lint*, size_t, size_t);
+    void (*sorgqr)(const lint*, const lint*, const lint*, float*, const lint*, const float*, float*, const lint*, lint*);
     void (*set_threads)(int);
     int (*get_threads)(void);
 };

@@ -234,6 +234,115 @@ int orhr_col(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T
 }
 
 // ---------------------------------------------------------------------------------------------------
+// single precision overloads of the helpers the BQRRP restatement uses (same call, s-prefixed routine)
+// ---------------------------------------------------------------------------------------------------
+void gemm(char ta, char tb, int64_t m, int64_t n, int64_t k, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb, float beta,
+          float* C, int64_t ldc) {
+    lint m_ = L(m), n_ = L(n), k_ = L(k), lda_ = L(lda), ldb_ = L(ldb), ldc_ = L(ldc);
+    lapack().sgemm(&ta, &tb, &m_, &n_, &k_, &alpha, A, &lda_, B, &ldb_, &beta, C, &ldc_, 1, 1);
+}
+void syrk_upper_trans(int64_t n, int64_t k, float alpha, const float* A, int64_t lda, float beta, float* C, int64_t ldc) {
+    char u = 'U', t = 'T';
+    lint n_ = L(n), k_ = L(k), lda_ = L(lda), ldc_ = L(ldc);
+    lapack().ssyrk(&u, &t, &n_, &k_, &alpha, A, &lda_, &beta, C, &ldc_, 1, 1);
+}
+void trsm_right_upper(int64_t m, int64_t n, float alpha, const float* A, int64_t lda, float* B, int64_t ldb) {
+    char s = 'R', u = 'U', t = 'N', d = 'N';
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), ldb_ = L(ldb);
+    lapack().strsm(&s, &u, &t, &d, &m_, &n_, &alpha, A, &lda_, B, &ldb_, 1, 1, 1, 1);
+}
+void trmm_right_upper(int64_t m, int64_t n, float alpha, const float* A, int64_t lda, float* B, int64_t ldb) {
+    char s = 'R', u = 'U', t = 'N', d = 'N';
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), ldb_ = L(ldb);
+    lapack().strmm(&s, &u, &t, &d, &m_, &n_, &alpha, A, &lda_, B, &ldb_, 1, 1, 1, 1);
+}
+int potrf_upper(int64_t n, float* A, int64_t lda) {
+    char u = 'U';
+    lint n_ = L(n), lda_ = L(lda), info = 0;
+    lapack().spotrf(&u, &n_, A, &lda_, &info, 1);
+    return (int)info;
+}
+void lacpy(char uplo, int64_t m, int64_t n, const float* A, int64_t lda, float* B, int64_t ldb) {
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), ldb_ = L(ldb);
+    lapack().slacpy(&uplo, &m_, &n_, A, &lda_, B, &ldb_, 1);
+}
+void laset(char uplo, int64_t m, int64_t n, float offd, float diag, float* A, int64_t lda) {
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda);
+    lapack().slaset(&uplo, &m_, &n_, &offd, &diag, A, &lda_, 1);
+}
+int geqrf(int64_t m, int64_t n, float* A, int64_t lda, float* tau) {
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), info = 0, lwork = -1;
+    float wq = 0;
+    lapack().sgeqrf(&m_, &n_, A, &lda_, tau, &wq, &lwork, &info);
+    lwork = (lint)wq;
+    std::vector<float> work(std::max<lint>(1, lwork));
+    lapack().sgeqrf(&m_, &n_, A, &lda_, tau, work.data(), &lwork, &info);
+    return (int)info;
+}
+int orgqr(int64_t m, int64_t n, int64_t k, float* A, int64_t lda, const float* tau) {
+    lint m_ = L(m), n_ = L(n), k_ = L(k), lda_ = L(lda), info = 0, lwork = -1;
+    float wq = 0;
+    lapack().sorgqr(&m_, &n_, &k_, A, &lda_, tau, &wq, &lwork, &info);
+    lwork = (lint)wq;
+    std::vector<float> work(std::max<lint>(1, lwork));
+    lapack().sorgqr(&m_, &n_, &k_, A, &lda_, tau, work.data(), &lwork, &info);
+    return (int)info;
+}
+int geqp3(int64_t m, int64_t n, float* A, int64_t lda, int64_t* jpvt, float* tau) {
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), info = 0, lwork = -1;
+    std::vector<lint> jp(n);
+    for (int64_t i = 0; i < n; ++i) jp[i] = (lint)jpvt[i];
+    float wq = 0;
+    lapack().sgeqp3(&m_, &n_, A, &lda_, jp.data(), tau, &wq, &lwork, &info);
+    lwork = (lint)wq;
+    std::vector<float> work(std::max<lint>(1, lwork));
+    lapack().sgeqp3(&m_, &n_, A, &lda_, jp.data(), tau, work.data(), &lwork, &info);
+    for (int64_t i = 0; i < n; ++i) jpvt[i] = jp[i];
+    return (int)info;
+}
+int getrf(int64_t m, int64_t n, float* A, int64_t lda, int64_t* ipiv) {
+    lint m_ = L(m), n_ = L(n), lda_ = L(lda), info = 0;
+    std::vector<lint> ip(std::min(m, n));
+    lapack().sgetrf(&m_, &n_, A, &lda_, ip.data(), &info);
+    for (int64_t i = 0; i < std::min(m, n); ++i) ipiv[i] = ip[i];
+    return (int)info;
+}
+int ormqr_lt(int64_t m, int64_t n, int64_t k, const float* A, int64_t lda, const float* tau, float* C, int64_t ldc) {
+    char s = 'L', t = 'T';
+    lint m_ = L(m), n_ = L(n), k_ = L(k), lda_ = L(lda), ldc_ = L(ldc), info = 0, lwork = -1;
+    float wq = 0;
+    lapack().sormqr(&s, &t, &m_, &n_, &k_, A, &lda_, tau, C, &ldc_, &wq, &lwork, &info, 1, 1);
+    lwork = (lint)wq;
+    std::vector<float> work(std::max<lint>(1, lwork));
+    lapack().sormqr(&s, &t, &m_, &n_, &k_, A, &lda_, tau, C, &ldc_, work.data(), &lwork, &info, 1, 1);
+    return (int)info;
+}
+int gemqrt_lt(int64_t m, int64_t n, int64_t k, int64_t nb, const float* V, int64_t ldv, const float* T, int64_t ldt, float* C, int64_t ldc) {
+    char s = 'L', t = 'T';
+    lint m_ = L(m), n_ = L(n), k_ = L(k), nb_ = L(nb), ldv_ = L(ldv), ldt_ = L(ldt), ldc_ = L(ldc), info = 0;
+    std::vector<float> work((size_t)std::max<int64_t>(1, n * nb));
+    lapack().sgemqrt(&s, &t, &m_, &n_, &k_, &nb_, V, &ldv_, T, &ldt_, C, &ldc_, work.data(), &info, 1, 1);
+    return (int)info;
+}
+int geqrt(int64_t m, int64_t n, int64_t nb, float* A, int64_t lda, float* T, int64_t ldt) {
+    lint m_ = L(m), n_ = L(n), nb_ = L(nb), lda_ = L(lda), ldt_ = L(ldt), info = 0;
+    std::vector<float> work((size_t)std::max<int64_t>(1, n * nb));
+    lapack().sgeqrt(&m_, &n_, &nb_, A, &lda_, T, &ldt_, work.data(), &info);
+    return (int)info;
+}
+int orhr_col(int64_t m, int64_t n, int64_t nb, float* A, int64_t lda, float* T, int64_t ldt, float* D) {
+    lint m_ = L(m), n_ = L(n), nb_ = L(nb), lda_ = L(lda), ldt_ = L(ldt), info = 0;
+    lapack().sorhr_col(&m_, &n_, &nb_, A, &lda_, T, &ldt_, D, &info);
+    return (int)info;
+}
+// the device's fp32 fill (randlapack_amd/csrc/fill.hip) draws the SAME stream as the fp64 one and rounds each value to float
+void fill_dense(int dist, int64_t rows, int64_t cols, float* buf, RNGState& st) {
+    std::vector<double> tmp((size_t)rows * cols);
+    fill_dense(dist, rows, cols, tmp.data(), st);
+    for (size_t i = 0; i < tmp.size(); ++i) buf[i] = (float)tmp[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // util:: helpers (misc/rl_util.hh)
 // ---------------------------------------------------------------------------------------------------
 
@@ -243,8 +352,9 @@ void get_L(int64_t m, int64_t n, double* A, int overwrite_diagonal) {
     else if (n > 1) laset('U', m, n - 1, 0.0, 0.0, A + m, m);
 }
 // misc/rl_util.hh:120-131  get_U: zero the strictly lower triangle
-void get_U(int64_t m, int64_t n, double* A, int64_t lda) {
-    if (m > 1) laset('L', m - 1, n, 0.0, 0.0, A + 1, lda);
+template <typename T>
+void get_U(int64_t m, int64_t n, T* A, int64_t lda) {
+    if (m > 1) laset('L', m - 1, n, (T)0, (T)0, A + 1, lda);
 }
 // misc/rl_util.hh:138-142
 bool diag_is_nonzero(int64_t n, const double* R, int64_t ldr) {
@@ -254,7 +364,8 @@ bool diag_is_nonzero(int64_t n, const double* R, int64_t ldr) {
 }
 // misc/rl_util.hh:151-164  matrix col_swap == LAPACK lapmt(forward): column i <- former column idx[i]-1,
 // idx restored.  Restated as explicit cycle following (the LAPACK routine is cross-checked in tests).
-int col_swap_matrix(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, int64_t* idx) {
+template <typename T>
+int col_swap_matrix(int64_t m, int64_t n, int64_t k, T* A, int64_t lda, int64_t* idx) {
     if (k > n) return -1;  // reference throws std::runtime_error (rl_util.hh:159-160)
     for (int64_t i = 0; i < n; ++i) idx[i] = -idx[i];
     for (int64_t i = 0; i < n; ++i) {
@@ -289,7 +400,8 @@ int col_swap_int(int64_t n, int64_t k, int64_t* A, int64_t* idx) {
     return 0;
 }
 // misc/rl_util.hh:315-334
-void transposition(int64_t m, int64_t n, const double* A, int64_t lda, double* AT, int64_t ldat, int upper_only) {
+template <typename T>
+void transposition(int64_t m, int64_t n, const T* A, int64_t lda, T* AT, int64_t ldat, int upper_only) {
     for (int64_t j = 0; j < n; ++j) {
         int64_t rows = upper_only ? (j + 1) : m;
         for (int64_t i = 0; i < rows; ++i) AT[j + i * ldat] = A[i + j * lda];
@@ -467,26 +579,27 @@ struct QB {
 // 2 geqrf (default).  apply_trans_q: 0 ormqr (default), 1 gemqrt.  The d x n sketch A_sk = S*A is SUPPLIED when
 // A_sk_in != nullptr (shared-sketch parity, test/drivers/test_bqrrp_gpu.cu:91-110), else generated from the
 // oracle's own Gaussian stream (:309-313; the reference passes m where lda is meant, SURVEY.md B -- lda is used).
-int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz_in, int64_t internal_nb_in,
-               double tol, int qrcp_wide, int qr_tall, int apply_trans_q, double* tau, int64_t* J, RNGState& st,
-               const double* A_sk_in, int64_t* rank_out) {
+template <typename T>
+int bqrrp_call(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, int64_t b_sz_in, int64_t internal_nb_in,
+               T tol, int qrcp_wide, int qr_tall, int apply_trans_q, T* tau, int64_t* J, RNGState& st,
+               const T* A_sk_in, int64_t* rank_out) {
     int64_t rows = m, cols = n, curr_sz = 0, b_sz = b_sz_in;
     const int64_t mn = std::min(m, n);
-    const int64_t maxiter = (int64_t)std::ceil(mn / (double)b_sz);                            // :220
+    const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);                            // :220
     const int64_t b_sz_const = b_sz;
     const int64_t d = (int64_t)(d_factor * b_sz);                                             // :224
     int64_t sampling_dimension = d, block_rank = b_sz, internal_nb = internal_nb_in;
-    double* A_work = A;
+    T* A_work = A;
     std::vector<int64_t> J_buffer(n, 0), J_buffer_lu(std::max<int64_t>(1, std::min(d, n)), 0);
-    std::vector<double> A_sk_store((size_t)d * n, 0.0), A_sk_trans((size_t)n * d, 0.0);
-    std::vector<double> R_tall_qr((size_t)b_sz_const * b_sz_const, 0.0), T_dat((size_t)b_sz_const * b_sz_const, 0.0), Work2(n, 0.0);
-    double* A_sk = A_sk_store.data();
+    std::vector<T> A_sk_store((size_t)d * n, (T)0), A_sk_trans((size_t)n * d, (T)0);
+    std::vector<T> R_tall_qr((size_t)b_sz_const * b_sz_const, (T)0), T_dat((size_t)b_sz_const * b_sz_const, (T)0), Work2(n, (T)0);
+    T* A_sk = A_sk_store.data();
     if (A_sk_in) {
-        std::memcpy(A_sk, A_sk_in, sizeof(double) * (size_t)d * n);
+        std::memcpy(A_sk, A_sk_in, sizeof(T) * (size_t)d * n);
     } else {
-        std::vector<double> S((size_t)d * m);
+        std::vector<T> S((size_t)d * m);
         fill_dense(0, d, m, S.data(), st);                                                     // :310-311
-        gemm('N', 'N', d, n, m, 1.0, S.data(), d, A, lda, 0.0, A_sk, d);                       // :312
+        gemm('N', 'N', d, n, m, (T)1, S.data(), d, A, lda, (T)0, A_sk, d);                       // :312
     }
     *rank_out = 0;
     for (int64_t iter = 0; iter < maxiter; ++iter) {
@@ -495,7 +608,7 @@ int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, in
         block_rank = b_sz;
         std::fill(J_buffer.begin(), J_buffer.end(), 0);
         std::fill(J_buffer_lu.begin(), J_buffer_lu.end(), 0);
-        std::fill(Work2.begin(), Work2.end(), 0.0);
+        std::fill(Work2.begin(), Work2.end(), (T)0);
         if (qrcp_wide == 1) {
             geqp3(sampling_dimension, cols, A_sk, d, J_buffer.data(), Work2.data());          // :336
         } else {
@@ -510,12 +623,12 @@ int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, in
         col_swap_matrix(m, cols, cols, A + lda * curr_sz, lda, J_buffer.data());               // :369
         bool block_zero = true;                                                                // :373-379
         for (int64_t i = 0; i < rows; ++i)
-            if (std::abs(A_work[i]) > std::numeric_limits<double>::epsilon()) { block_zero = false; break; }
+            if (std::abs(A_work[i]) > std::numeric_limits<T>::epsilon()) { block_zero = false; break; }
         if (iter == 0) std::copy(J_buffer.begin(), J_buffer.begin() + cols, J);                // :383-387 / :402-406
         else col_swap_int(cols, cols, J + curr_sz, J_buffer.data());
         if (block_zero) { *rank_out = curr_sz; return 0; }                                     // :380-399
-        double* Work1 = A_work + lda * b_sz;
-        double* R_sk = A_sk;
+        T* Work1 = A_work + lda * b_sz;
+        T* R_sk = A_sk;
         for (int64_t i = 0; i < b_sz; ++i) {                                                   // :421-427
             if (std::abs(R_sk[i * d + i]) / std::abs(R_sk[0]) < tol) {
                 block_rank = i;
@@ -523,21 +636,21 @@ int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, in
                 break;
             }
         }
-        double* tau_sub = tau + curr_sz;
-        double* R11 = A_work;
+        T* tau_sub = tau + curr_sz;
+        T* R11 = A_work;
         if (qr_tall == 0) {                                                                    // geqrt :438-446
             geqrt(rows, b_sz, internal_nb, A_work, lda, T_dat.data(), b_sz_const);
             for (int64_t i = 0; i < block_rank; ++i) tau_sub[i] = T_dat[b_sz_const * i + (i % internal_nb)];
         } else if (qr_tall == 1) {                                                             // cholqr :454-505
-            trsm_right_upper(rows, block_rank, 1.0, R_sk, d, A_work, lda);
-            syrk_upper_trans(block_rank, rows, 1.0, A_work, lda, 0.0, R_tall_qr.data(), b_sz_const);
+            trsm_right_upper(rows, block_rank, (T)1, R_sk, d, A_work, lda);
+            syrk_upper_trans(block_rank, rows, (T)1, A_work, lda, (T)0, R_tall_qr.data(), b_sz_const);
             potrf_upper(block_rank, R_tall_qr.data(), b_sz_const);
-            trsm_right_upper(rows, block_rank, 1.0, R_tall_qr.data(), b_sz_const, A_work, lda);
+            trsm_right_upper(rows, block_rank, (T)1, R_tall_qr.data(), b_sz_const, A_work, lda);
             orhr_col(rows, block_rank, internal_nb, A_work, lda, T_dat.data(), b_sz_const, Work2.data());
             for (int64_t i = 0; i < block_rank; ++i)
                 for (int64_t j = 0; j < i + 1; ++j) R_tall_qr[b_sz_const * i + j] *= Work2[j];
             for (int64_t i = 0; i < block_rank; ++i) tau_sub[i] = T_dat[b_sz_const * i + (i % internal_nb)];
-            trmm_right_upper(block_rank, b_sz, 1.0, R_sk, d, R_tall_qr.data(), b_sz_const);
+            trmm_right_upper(block_rank, b_sz, (T)1, R_sk, d, R_tall_qr.data(), b_sz_const);
             lacpy('U', block_rank, b_sz, R_tall_qr.data(), b_sz_const, A_work, lda);
         } else {                                                                               // geqrf :513-517
             geqrf(rows, b_sz, A_work, lda, tau_sub);
@@ -548,13 +661,13 @@ int bqrrp_call(int64_t m, int64_t n, double* A, int64_t lda, double d_factor, in
             if (use_gemqrt) gemqrt_lt(q_rows, cols - b_sz, block_rank, internal_nb, A_work, lda, T_dat.data(), b_sz_const, Work1, lda);
             else ormqr_lt(q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda);
         }
-        double* R12 = R11 + lda * b_sz;
+        T* R12 = R11 + lda * b_sz;
         curr_sz += b_sz;
         if (curr_sz >= mn || block_rank != b_sz_const) { *rank_out = curr_sz; return 0; }      // :576-618
         A_work = Work1 + b_sz;                                                                 // :624
         get_U(b_sz, b_sz, R_sk, d);                                                            // :633
-        trsm_right_upper(b_sz, b_sz, 1.0, R11, lda, R_sk, d);                                  // :634
-        gemm('N', 'N', b_sz, cols - b_sz, b_sz, -1.0, R_sk, d, R12, lda, 1.0, R_sk + d * b_sz, d);   // :638
+        trsm_right_upper(b_sz, b_sz, (T)1, R11, lda, R_sk, d);                                  // :634
+        gemm('N', 'N', b_sz, cols - b_sz, b_sz, (T)-1, R_sk, d, R12, lda, (T)1, R_sk + d * b_sz, d);   // :638
         sampling_dimension = std::min(sampling_dimension, cols);                               // :641
         if (sampling_dimension - b_sz > 0)                                                     // :645-646
             get_U(sampling_dimension - b_sz, sampling_dimension - b_sz, R_sk + (d + 1) * b_sz, d);
@@ -979,7 +1092,7 @@ int oracle_cqrrpt_f64(int64_t m, int64_t n, double* A, int64_t lda, double* R, i
         RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
         int64_t rk = 0;
         const int64_t bsz = (int64_t)(n * ratio);
-        bqrrp_call(d, n, A_hat, d, 1.0, bsz, bsz, std::numeric_limits<double>::epsilon(), 0, 2, 0, tau.data(), J, st, nullptr, &rk);
+        bqrrp_call<double>(d, n, A_hat, d, 1.0, bsz, bsz, std::numeric_limits<double>::epsilon(), 0, 2, 0, tau.data(), J, st, nullptr, &rk);
         std::memcpy(state, st.ctr, 16);
     } else {
         geqp3(d, n, A_hat, d, J, tau.data());                                                 // :247
@@ -1049,11 +1162,21 @@ int oracle_bqrrp_f64(int64_t m, int64_t n, double* A, int64_t lda, double d_fact
                      double tol, int qrcp_wide, int qr_tall, int apply_trans_q, double* tau, int64_t* J, uint32_t state[6],
                      const double* A_sk_in, int64_t* rank_out) {
     RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
-    int rc = bqrrp_call(m, n, A, lda, d_factor, b_sz, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, tau, J, st, A_sk_in,
-                        rank_out);
+    int rc = bqrrp_call<double>(m, n, A, lda, d_factor, b_sz, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, tau, J, st, A_sk_in,
+                                rank_out);
     std::memcpy(state, st.ctr, 16);
     return rc;
 }
+// the same restatement instantiated on float over the s-prefixed LAPACK routines: the like-for-like oracle of the fp32 device path
+// (BASELINE configs[3]); pivots of an fp32 factorization are compared with THIS, not with the fp64 run
+int oracle_bqrrp_f32(int64_t m, int64_t n, float* A, int64_t lda, float d_factor, int64_t b_sz, int64_t internal_nb, float tol, int qrcp_wide,
+                     int qr_tall, int apply_trans_q, float* tau, int64_t* J, uint32_t state[6], const float* A_sk_in, int64_t* rank_out) {
+    RNGState st; std::memcpy(st.ctr, state, 16); std::memcpy(st.key, state + 4, 8);
+    int rc = bqrrp_call<float>(m, n, A, lda, d_factor, b_sz, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, tau, J, st, A_sk_in, rank_out);
+    std::memcpy(state, st.ctr, 16);
+    return rc;
+}
+int oracle_ungqr_f32(int64_t m, int64_t n, int64_t k, float* A, int64_t lda, const float* tau) { return orgqr(m, n, k, A, lda, tau); }
 // ungqr on a GEQP3-format result (what the reference's tests do to verify, test/drivers/test_bqrrp.cc:138)
 int oracle_ungqr_f64(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau) { return orgqr(m, n, k, A, lda, tau); }
 int oracle_orhr_col_f64(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, double* T, int64_t ldt, double* D) {

@@ -136,6 +136,7 @@ def getrf_panel_f32():
 
 
 def jacobi():
+    os.environ["RLHIP_JACOBI_PERSIST"] = "0"      # rocprofv3 --pmc aborts on cooperative launches (rc -11): the per-launch sweeps carry the counters
     d, ctx = _ctx()
     import torch
 
@@ -180,11 +181,11 @@ WORKLOADS = {
                    8.0 * 1048576 * 1024 + 8.0 * 1280 * 1024, 2.0 * 4 * 1048576 * 1024, "hbm"),
     "gemm_f32_tn": (gemm_f32_tn, "gemm_sk_kernel<float, true>", "W = V^T C, 2048 x 16384 x 16384 fp32 (one chunk of C4's compact-WY apply)",
                     4.0 * (16384 * 2048 + 16384 * 16384 + 2048 * 16384), 2.0 * 2048 * 16384 * 16384, "mfma"),
-    "gemm_f32_nn": (gemm_f32_nn, "gemm_", "C -= V W, 65536 x 16384 x 2048 fp32 (C4's compact-WY apply)",
+    "gemm_f32_nn": (gemm_f32_nn, "gemm_sk_kernel<float, false>", "C -= V W, 65536 x 16384 x 2048 fp32 (C4's compact-WY apply)",
                     4.0 * (65536 * 2048 + 2 * 65536 * 16384 + 2048 * 16384), 2.0 * 65536 * 16384 * 2048, "mfma"),
     "getrf_panel_f32": (getrf_panel_f32, "getrf_panel_f32_kernel", "row-pivoted LU panel steps of the 65536 x 2048 fp32 transposed sketch (C4 qrcp_wide)",
                         None, None, "latency"),
-    "jacobi": (jacobi, "jacobi_", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),
+    "jacobi": (jacobi, "jacobi_block_kernel", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),
     "qrcp_tag": (qrcp_tag, "qrcp_tag_kernel", "geqp3 of the 1280 x 1024 fp64 sketch (C3)", None, None, "latency"),
 }
 

@@ -306,6 +306,18 @@ def test_bqrrp_4096_f32_vs_f64_oracle_shared_sketch(ctx, orc):
     R = np.triu(Aout)
     assert np.linalg.norm(A[:, J - 1] - Q @ R) <= 4 * EPS32**0.75 * np.linalg.norm(A)
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= 4 * EPS32**0.75 * np.sqrt(n)
+    # like for like: the restatement instantiated on float (s-prefixed LAPACK) on the same float matrix and float sketch.  Both sides now
+    # carry fp32 rounding, in different summation orders: the pivot sequences agree wherever a decision is not a float-level near-tie.
+    o32 = orc.bqrrp(A.astype(np.float32), b, 1.0, qrcp_wide=0, qr_tall=1, apply_trans_q=1, sketch=d.cm_to_numpy(r["sketch"]))
+    assert o32["rc"] == 0 and o32["rank"] == n and o32["A"].dtype == np.float32
+    J32 = o32["J"]
+    np.testing.assert_array_equal(J[:b], J32[:b])                       # the whole first block: exact
+    ov32 = [len(set(J[i:i + b].tolist()) & set(J32[i:i + b].tolist())) / b for i in range(0, n, b)]
+    same = float(np.mean(J == J32))
+    assert np.mean(ov32) >= np.mean(overlap) - 0.02 and same >= 0.25, (ov32, same)
+    dR32 = np.abs(np.diag(o32["A"].astype(np.float64)))
+    gm32 = np.exp(np.log(dR).reshape(-1, b).mean(1)) / np.exp(np.log(dR32).reshape(-1, b).mean(1))
+    assert np.abs(gm32 - 1).max() <= 1e-2
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -116,6 +116,12 @@ def test_bqrrp_gpu_single_precision(ctx, orc, qr_tall):
     np.testing.assert_array_equal(J[:16], o["J"][:16])
     overlap = [len(set(J[i:i + b].tolist()) & set(o["J"][i:i + b].tolist())) / len(J[i:i + b]) for i in range(0, n, b)]
     assert overlap[0] >= 0.97 and np.mean(overlap) >= 0.8
+    # like for like: the float instantiation of the restatement on the float sketch -- the first block's pivots are identical
+    o32 = orc.bqrrp(A, b, 1.0, qrcp_wide=0, qr_tall=ORC_QR_TALL[qr_tall], apply_trans_q=0, sketch=sk.astype(np.float32))
+    assert o32["rc"] == 0 and o32["rank"] == n
+    np.testing.assert_array_equal(J[:b], o32["J"][:b])
+    ov32 = [len(set(J[i:i + b].tolist()) & set(o32["J"][i:i + b].tolist())) / len(J[i:i + b]) for i in range(0, n, b)]
+    assert np.mean(ov32) >= 0.8
 
 
 def test_bqrrp_gpu_rank_deficient_and_zero_inputs(ctx, orc):

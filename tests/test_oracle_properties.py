@@ -161,6 +161,28 @@ def test_bqrrp_full_rank(orc, b_sz, opts):
     _bqrrp_checks(orc, A, r)
 
 
+@pytest.mark.parametrize("opts", [(0, 1, 1), (0, 2, 0), (1, 0, 0)])
+def test_bqrrp_single_precision_leg(orc, opts):
+    """the restatement instantiated on float (oracle_bqrrp_f32: s-prefixed LAPACK): the reference's BQRRP checks at float eps
+    (test_bqrrp.cc is typed on T), the same Gaussian stream rounded to float, and -- on columns whose norms are separated far beyond
+    float rounding -- the same pivots as the double run"""
+    rng = np.random.default_rng(7)
+    m, n, b = 600, 240, 60
+    A = (rng.standard_normal((m, n)) * 1.02 ** (-rng.permutation(n).astype(np.float64))).astype(np.float32)
+    r32 = orc.bqrrp(A, b, 1.0, qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2], key=(3, 0))
+    r64 = orc.bqrrp(A.astype(np.float64), b, 1.0, qrcp_wide=opts[0], qr_tall=opts[1], apply_trans_q=opts[2], key=(3, 0))
+    assert r32["A"].dtype == np.float32 and r32["tau"].dtype == np.float32
+    assert r32["rc"] == r64["rc"] == 0 and r32["rank"] == r64["rank"] == n and r32["next_ctr"] == r64["next_ctr"]
+    np.testing.assert_array_equal(r32["J"], r64["J"])
+    eps32 = float(np.finfo(np.float32).eps)
+    A32, t32 = r32["A"].astype(np.float64), r32["tau"].astype(np.float64)
+    Q = orc.ungqr(A32, t32)
+    R = np.triu(A32)[:n]
+    assert np.linalg.norm(A.astype(np.float64)[:, r32["J"] - 1] - Q @ R) <= eps32**0.75 * np.linalg.norm(A)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= eps32**0.75 * np.sqrt(n)
+    assert np.linalg.norm(R - np.triu(r64["A"])[:n]) <= 50 * eps32 * np.linalg.norm(R) * np.sqrt(n)
+
+
 def test_bqrrp_low_rank_and_step_spectrum(orc):
     rng = np.random.default_rng(8)
     A = poly_mat(600, 300, 120, rng, cond=1e3)                 # test_bqrrp.cc:188-207 (low rank)
