@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void hbm_read_kernel(const double2* __restrict
 }  // namespace
 
 extern "C" int64_t rlhip_path_count(rlhip_ctx* c, int which) {
-    return (c && which >= 0 && which < 8) ? c->path_count[which] : -1;
+    return (c && which >= 0 && which < 12) ? c->path_count[which] : -1;
 }
 
 extern "C" int rlhip_mfma_peak(rlhip_ctx* c, int is_f64, int iters, double* tflops) {

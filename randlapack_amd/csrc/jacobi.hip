@@ -434,19 +434,40 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     }
     if (tid == 0) { s_lost = 0; }
     __syncthreads();
+    // A block is JB x m values = PER_T per thread (4 at m = 256).  All of a thread's loads of a hand-over are issued before the first one is
+    // consumed: one round trip to the uncached buffer instead of PER_T dependent ones (the first version took ~11 us per hand-over, two
+    // thirds of every step; rocprof timeline in DESIGN.md 4.3).
+    constexpr int PER_T = (JB * JMT + NT - 1) / NT;
     auto publish = [&](int half, int blk) {            // LDS half -> exchange buffer
         unsigned long long* dst = g.X + (size_t)blk * JB * m;
-        for (int e = tid; e < JB * m; e += NT) {
-            const int r = e % m, c = e / m;
-            __hip_atomic_store(dst + e, (unsigned long long)__double_as_longlong((double)Xs[(half * JB + c) * JMT + r]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int e = tid + q * NT;
+            if (e < JB * m) {
+                const int r = e % m, c = e / m;
+                __hip_atomic_store(dst + e, (unsigned long long)__double_as_longlong((double)Xs[(half * JB + c) * JMT + r]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     };
-    auto fetch = [&](int half, int blk) {
-        const unsigned long long* src = g.X + (size_t)blk * JB * m;
-        for (int e = tid; e < JB * m; e += NT) {
-            const int r = e % m, c = e / m;
-            Xs[(half * JB + c) * JMT + r] = (T)__longlong_as_double((long long)__hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    auto fetch2 = [&](bool f0, int blk0, bool f1, int blk1) {      // both halves in ONE batch of loads
+        unsigned long long v[2][PER_T];
+        const unsigned long long* src0 = g.X + (size_t)blk0 * JB * m;
+        const unsigned long long* src1 = g.X + (size_t)blk1 * JB * m;
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int e = tid + q * NT;
+            v[0][q] = (f0 && e < JB * m) ? __hip_atomic_load(src0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            v[1][q] = (f1 && e < JB * m) ? __hip_atomic_load(src1 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int e = tid + q * NT;
+            if (e < JB * m) {
+                const int r = e % m, c = e / m;
+                if (f0) Xs[c * JMT + r] = (T)__longlong_as_double((long long)v[0][q]);
+                if (f1) Xs[(JB + c) * JMT + r] = (T)__longlong_as_double((long long)v[1][q]);
+            }
         }
     };
     unsigned gs = 0;                                   // exchange steps taken by this launch
@@ -478,8 +499,7 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
             }
             __syncthreads();
             if (s_lost) { lost = true; break; }
-            if (out0) fetch(0, want[0]);
-            if (out1) fetch(1, want[1]);
+            fetch2(out0, want[0], out1, want[1]);
             held[0] = want[0]; held[1] = want[1];
             __syncthreads();
             jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2);

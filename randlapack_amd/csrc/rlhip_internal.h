@@ -89,7 +89,7 @@ struct rlhip_ctx {
     // diagnostics: how often each specialised kernel path was taken (rlhip_path_count; tests assert the path under test ran)
     //   0 stream-K f64 GEMM, 1 stream-K f32 GEMM, 2 fused trsm block kernel, 3 substitution trsm sub-block, 4 fused out-of-place trsm
     //   (rlhip_trsm_gather), 5 sketch-preconditioned Cholesky-QR panel inside geqrf -- the list in include/rlhip.h is the contract
-    int64_t path_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t path_count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // scratch arena helpers (capi.hip)

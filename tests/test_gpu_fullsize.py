@@ -323,6 +323,36 @@ def test_bqrrp_4096_f32_vs_f64_oracle_shared_sketch(ctx, orc):
 # ---------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: ABRIK, rank 128, the largest single-device operators
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,nc", [(200000, 20000, 32), (65544, 4096, 64), (50001, 2000, 16)])
+def test_skinny_operator_products_entrywise(ctx, m, n, nc):
+    """ABRIK's operator products on a dense linop (rl_abrik.hh:311,358; BASELINE configs[4] dense leg: 200000 x 20000 against 32
+    vectors): A X and A^T Y entry by entry against numpy on row / column samples, alpha / beta honoured, ragged row counts, bitwise
+    repeatable.  (A dedicated streaming kernel for these shapes was built and measured in round 3 -- 4.53 TB/s at 32 columns against
+    4.54 for the tiled kernel that serves them -- and not adopted)"""
+    import torch
+
+    d = _d()
+    A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(21, 0))
+    X = d.cm_empty(n, nc); ctx.fill_dense(X, n, nc, key=(22, 0))
+    Y = d.cm_empty(m, nc); ctx.fill_dense(Y, m, nc, key=(23, 0))
+    C = d.cm_empty(m, nc); ctx.fill_dense(C, m, nc, key=(24, 0))
+    C0 = C.clone()
+    ctx.gemm("N", "N", m, nc, n, 0.75, A, m, X, n, -0.5, C, m)
+    rows = torch.cat([torch.arange(0, 40), torch.arange(m // 2, m // 2 + 40), torch.arange(m - 40, m)]).cuda()
+    ref = 0.75 * (A[:, rows].T.cpu().numpy() @ X.T.cpu().numpy()) - 0.5 * C0[:, rows].T.cpu().numpy()
+    got = C[:, rows].T.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.sqrt(n) * np.max(np.abs(ref))
+    Z = d.cm_empty(n, nc); ctx.fill_dense(Z, n, nc, key=(25, 0))
+    ctx.gemm("T", "N", n, nc, m, 1.0, A, m, Y, m, 0.0, Z, n)
+    cols = torch.cat([torch.arange(0, 24), torch.arange(n - 24, n)]).cuda()
+    ref = A[cols].cpu().numpy() @ Y.T.cpu().numpy()
+    got = Z[:, cols].T.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.sqrt(m) * np.max(np.abs(ref))
+    Z2 = d.cm_empty(n, nc)
+    ctx.gemm("T", "N", n, nc, m, 1.0, A, m, Y, m, 0.0, Z2, n)
+    assert torch.equal(Z, Z2)
+
+
 def _abrik_residual(AV, ATU, U, S, V):
     """test/drivers/test_abrik.cc:96-123: hypot(||A V - U S||_F, ||A^T U - V S||_F) (column-major tensors (t, rows))"""
     import torch
