@@ -77,8 +77,7 @@ void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
 
 void* rlhip_xchg_buffer(rlhip_ctx* c, size_t bytes) {
     if (bytes <= c->xchg_bytes) return c->xchg;
-    static int kind = -1;
-    if (kind < 0) { const char* e = getenv("RLHIP_XCHG"); kind = e ? atoi(e) : 2; }   // uncached: polled words never sit in an L2 (measured: geqp3 1280 x 1024 8.37 -> 8.15 ms)
+    constexpr int kind = 2;   // uncached: polled words never sit in an L2 (measured against ordinary / fine-grained memory: geqp3 1280 x 1024 8.37 -> 8.15 ms)
     if (c->xchg) { hipStreamSynchronize(c->stream); hipFree(c->xchg); c->xchg = nullptr; c->xchg_bytes = 0; }
     bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     void* p = nullptr;

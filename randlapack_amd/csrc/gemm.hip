@@ -365,14 +365,12 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
     bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % V == 0) && (g.ldb % V == 0);
 
     // tile shape by N (the narrow dimension on this path), then split-K to fill 256 CUs
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("RLHIP_GEMM_VARIANT"); variant = e ? atoi(e) : 0; }
+    constexpr int variant = 0;         // (bit 1: one 128 x 256 workgroup per CU for N > 128; bit 0: early LDS staging -- both measured slower)
     int cfg;
     int64_t bm, bn;
     // 128 x 128 tiles with two workgroups per CU beat one 128 x 256 workgroup per CU on every driver measured (the second workgroup's
     // MFMAs cover the first one's barrier + fragment-read bubble at each K tile): BQRRP 32768^2 fp32 1397 -> 1366 ms, 65536^2 fp32
     // 5389 -> 5299 ms, 16384^2 fp64 588 -> 572 ms; RSVD and CQRRPT (stream-K kernel for their big products) unchanged.
-    // RLHIP_GEMM_VARIANT bit 1 selects the 128 x 256 shape again.
     if (N > 128 && !tri && !(variant & 2)) { cfg = 5; bm = 128; bn = 128; }
     else if (N > 128 && !tri) { cfg = 0; bm = 128; bn = 256; }
     else if (N > 64 || tri) { cfg = 1; bm = 128; bn = 128; }

@@ -758,9 +758,7 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
         // fp32 problems run the fp64 kernels on a widened copy.  Short factors (the k x k matrix of an fp32 RSVD / ABRIK tail) then get the
         // LDS-resident block Jacobi (3.5 ms at n = 256 against 25 ms for 255 per-round launches x ~11 sweeps), and tall ones lose the
         // drift of thousands of fp32 rotations (measured at 3000 x 256: ||V^T V - I|| = 7e3 eps32 in fp32 arithmetic, 5 eps32 widened).
-        static int widen = -1;
-        if (widen < 0) { const char* e = getenv("RLHIP_JACOBI_WIDEN_F32"); widen = (e && atoi(e) == 0) ? 0 : 1; }
-        if (widen && n > 1) {
+        if (n > 1) {
             size_t mk = rlhip_ws_mark(c);
             double* Ad = ws_alloc<double>(c, (size_t)m * n);
             double* Sd = ws_alloc<double>(c, (size_t)n);
@@ -793,12 +791,9 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     const int max_sweeps = 60;
     int sweep = 0;
     int info = 0;
-    static int jm512 = -1;
-    if (jm512 < 0) { const char* e = getenv("RLHIP_JACOBI_512"); jm512 = (e && atoi(e) == 0) ? 0 : 1; }
-    if (n > 1 && m <= (jm512 ? 2 * JM : JM) && sizeof(T) == 8) {
+    if (n > 1 && m <= 2 * JM && sizeof(T) == 8) {
         // LDS-resident block Jacobi (see jacobi_block_kernel)
-        static int jb_sel = 0;
-        if (!jb_sel) { const char* e = getenv("RLHIP_JACOBI_JB"); jb_sel = (e && atoi(e) == 32) ? 32 : 16; }
+        constexpr int jb_sel = 16;         // block width (32: half the launches, four times the pairs per launch -- measured slower)
         const char* pe = getenv("RLHIP_JACOBI_PERSIST");          // read per call: tests switch paths inside one process
         const bool persist = !(pe && atoi(pe) == 0);
         bool done = false;

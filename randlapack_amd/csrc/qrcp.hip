@@ -936,8 +936,7 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     // have trailing columns beyond the last reflector.
     constexpr int64_t NBQ = 256;       // a BLAS-3 panel costs ~1.3 ms of launch latency whatever its width: few, wide panels
     const int64_t kmax = m < n ? m : n;
-    static int64_t pipe_max = -1;
-    if (pipe_max < 0) { const char* e = getenv("RLHIP_GEQRF_PIPE_MAX"); pipe_max = e ? atoll(e) : 1280; }
+    constexpr int64_t pipe_max = 1280;
     // sketch-sized, nearly square problems: the pipelined kernel alone beats blocking (1280 x 1024: 11.2 vs 12.3 ms); from about twice
     // as tall as wide the CholQR-panel route wins (2000 x 1000: 13.0 vs 14.3 ms, 2560 x 1024: 12.2 vs 17.4 ms)
     if (kmax <= pipe_max && (m < 16 * kmax && (10 * m < 19 * kmax || kmax < 600))) {
@@ -1067,9 +1066,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         pa.m = m; pa.n = n; pa.A = A; pa.lda = lda; pa.tau = tau_dev; pa.use_lds = use_lds;
         pa.v_in_lds = use_lds || ((size_t)m * sizeof(T) <= 64 * 1024);
         pa.wg_per_col = 0;
-        static int chunk_env = -1;
-        if (chunk_env < 0) { const char* e = getenv("RLHIP_QR_CHUNK"); chunk_env = e ? atoi(e) : 8; if (chunk_env < 1) chunk_env = 1; }
-        pa.chunk = chunk_env;
+        pa.chunk = 8;                          // columns dealt to a workgroup at a time (measured best of 1 / 4 / 8 / 16)
         int64_t Gp = G;
         if (!use_lds && m > 8 * n) {          // tall-skinny: spread the columns over as many workgroups as there are CUs
             Gp = n < num_cu ? n : num_cu;
@@ -1097,8 +1094,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     static int tag_on = -1;
     if (tag_on < 0) { const char* e = getenv("RLHIP_QRCP_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (pivot && use_lds && tag_on && m < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) - 2) {
-        static int64_t g_env = -2;
-        if (g_env == -2) { const char* e = getenv("RLHIP_QRCP_TAG_COLS"); g_env = e ? atoll(e) : 4; if (g_env < 1) g_env = 1; }
+        constexpr int64_t g_env = 4;
         // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: g_env (4) per workgroup
         int64_t Gt = (n + g_env - 1) / g_env;
         if (Gt > num_cu) Gt = num_cu;

@@ -717,11 +717,10 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             a = T(1);
         }
         if (try_blk && !bad_host[j0 / BW]) {
-            // RLHIP_TRSM_HALF = 128 / 64 lets the fused kernel solve narrower pieces of the block with a GEMM in between (more of the
+            // (narrower pieces, 128 / 64 columns, let the fused kernel solve pieces of the block with a GEMM in between -- more of the
             // flops at GEMM speed).  Measured at C3 (m = 2^20, n = 1024): CQRRPT 105.5 ms whole blocks, 107.8 ms halves, 117.2 ms quarters:
             // the extra passes over B cost more than the fused kernel's lower rate, so whole blocks stay the default.
-            static int hb_env = -1;
-            if (hb_env < 0) { const char* e = getenv("RLHIP_TRSM_HALF"); hb_env = e ? atoi(e) : BW; if (hb_env < 32 || hb_env > BW || hb_env % 32) hb_env = BW; }
+            constexpr int hb_env = BW;
             const T* Upk_b = Upk_all + (j0 / BW) * (int64_t)BW * BW;
             const T* Dinv_b = Dinv_all + (j0 / BW) * (int64_t)(BW / 32) * 1024;
             for (int h0 = 0; h0 < nb; h0 += hb_env) {
