@@ -256,3 +256,21 @@ def test_bqrrp_gpu_benchmark_main(tmp_path):
     assert lines[3].startswith("Input size: dim start: 512,1024") and len(lines) == 7
     assert all(len(ln.split()) == 3 and int(ln.split()[2]) == 0 for ln in lines[5:])
     assert bqrrp_gpu.main([]) == 1
+
+
+def test_flop_count_mains(capsys):
+    """benchmarks/flop_count.py = bench_general/GEMM_flop_count.cc + LAPACK_flop_count.cc: LAWN-41 flop counts, best of N, the
+    reference's output lines"""
+    from benchmarks import flop_count
+
+    g = flop_count.gemm_flops(2048, 3)
+    assert g > 5e3                                                    # an MFMA GEMM, not a fallback (GFLOP/s)
+    q = flop_count.geqrf_flops(4096, 1024, 2)
+    t = flop_count.getrf_flops(4096, 1024, 2)
+    p = flop_count.potrf_flops(1024, 2)
+    assert min(q, t, p) > 10
+    out = capsys.readouterr().out
+    assert "THE SYSTEM IS CAPABLE OF" in out and "RUNNING GEQRF." in out and "RUNNING GETRF." in out and "RUNNING POTRF." in out
+    assert flop_count.main(["potrf", "300", "200", "1"]) == 0
+    with pytest.raises(RuntimeError):
+        flop_count.main(["gesvd", "10", "10", "1"])
