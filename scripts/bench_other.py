@@ -22,12 +22,29 @@ def cqrrpt(steps):
         ctx.fill_dense(A, m, n, key=(3, 0)); ctx.sync()
         t0 = time.perf_counter(); r = d.drv_cqrrpt(ctx, A, m, n, 1.25, nnz, timing=(it == steps)); ctx.sync(); dt = time.perf_counter() - t0
         if it > 0: best = dt if best is None else min(best, dt)
-    # dominant kernel: the stream-K Gram kernel (syrk, upper tiles): 1.1e12 flop
-    ctx.fill_dense(A, m, n, key=(3, 0)); G = d.cm_zeros(n, n)
-    ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n); ctx.sync(); ctx.timer_start()
-    for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n)
+    # dominant kernel (rocprofv3 kernel stats of this line: 2 of the 3 tall BLAS-3 sweeps are this one): the fused out-of-place
+    # triangular solve W = (A P) inv(R_sk) / Q = W inv(R_chol), m n^2 = 1.1e12 flop per launch; timed alone with HIP events
+    ctx.fill_dense(A, m, n, key=(3, 0)); U = d.cm_empty(n, n); ctx.fill_dense(U, n, n, key=(2, 0))
+    ctx.lib.rlhip_add_diag_f64(ctx.h, n, 40.0, U.data_ptr(), n)
+    W = d.cm_empty(m, n); Jp = torch.arange(n, 0, -1, dtype=torch.int64, device="cuda")
+    ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, m); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, m)
     kms = ctx.timer_stop_ms() / 3
     ach = 1.0 * m * n * n / (kms * 1e-3) / 1e12
+    del W
+    # the Gram kernel (syrk, upper tiles: 1.1e12 flop), reported beside it
+    G = d.cm_zeros(n, n)
+    ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n)
+    gms = ctx.timer_stop_ms() / 3
+    traffic = None
+    try:
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_trsm_fused_oop.json")))[-1]
+        traffic = json.load(open(tf)).get("traffic_bytes")
+        traffic_source = os.path.relpath(tf, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape; not re-measured by this run)"
+    except Exception:
+        traffic_source = None
     # CPU baseline: oracle CQRRPT (sketch supplied, so the reference's SASO apply is excluded) on a 131072-row sample
     import oracle
     oracle.load(); oracle.set_threads(os.cpu_count() or 1)
@@ -40,8 +57,12 @@ def cqrrpt(steps):
     print(json.dumps({"metric": "GFLOP/s CQRRPT 1048576 x 1024 fp64 (BASELINE configs[2])", "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s",
                       "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 2), "best_of": steps, "dtype": "f64", "data": "synthetic iid N(0,1), generated on-device",
                       "config": {"workload": "CQRRPT m=1048576 n=1024 d=1280 nnz=4 qrcp=geqp3", "rank": r["rank"], "times_us": r.get("times_us")},
-                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
-                                   "kernel": "gemm_sk_kernel<TN, tri> (Gram matrix A^T A, upper tiles)", "launch_ms": round(kms, 3)},
+                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": traffic,
+                                   "traffic_source": traffic_source,
+                                   "kernel": "trsm_fused_kernel<double, 8, 16, OOP> (right-upper solve with the pivoting folded in, 2 launches per call)",
+                                   "launch_ms": round(kms, 3), "flops_per_launch": 1.0 * m * n * n,
+                                   "also": {"kernel": "gemm_sk_kernel<TN, tri> (Gram matrix A^T A, upper tiles)", "launch_ms": round(gms, 3),
+                                            "achieved": round(1.0 * m * n * n / (gms * 1e-3) / 1e12, 2)}},
                       "cpu_baseline": {"value": round(fl_s / tc / 1e9, 1), "unit": "GFLOP/s", "cores": oracle.get_threads(), "kind": "port",
                                        "sample": f"oracle CQRRPT (geqp3 onward, sketch supplied) on {ms}x{n}, {tc:.2f} s"}}))
 

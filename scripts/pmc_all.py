@@ -84,9 +84,11 @@ def main():
                 continue
             disp = collect(od, filt)
             shutil.rmtree(od, ignore_errors=True)
-            if rc != 0 or not disp:
-                rec[group + "_error"] = f"rc={rc}, {len(disp)} dispatches; " + tail[-400:]
+            if not disp:
+                rec[group + "_error"] = f"rc={rc}, no dispatches; " + tail[-400:]
                 continue
+            if rc != 0:       # rocprofv3 7.2 aborts at EXIT of a process that made a cooperative launch; the counter rows are complete by then
+                rec.setdefault("profiler_exit_codes", {})[group] = rc
             rec.setdefault("dispatches", {})[group] = len(disp)
             rec.setdefault("kernel_name", next(iter(disp.values()))["name"][:160])
             ms = median_of(disp, "ms")
