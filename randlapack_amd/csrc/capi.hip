@@ -513,7 +513,7 @@ int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, i
     int done = 0;
     int rc = rlhip::gemm_impl<double>(c, fa, fb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, d_ssq, &done);
     if (rc) return rc;
-    if (fused_host) *fused_host = done;
+    if (fused_host) *fused_host = done ? 1 : 0;
     const int64_t arows = fa ? k : m, acols = fa ? m : k;
     if (!done) return rlhip::lange_fro<double>(c, arows, acols, A, lda, norm_a_host);
     double ssq_main = 0, rest = 0;
@@ -521,7 +521,7 @@ int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, i
     RLHIP_CHECK(hipStreamSynchronize(c->stream));
     ssq_main = *(double*)(c->h_mail + 40);
     const int64_t m_main = (m / 128) * 128;
-    if (m_main < m) {   // rows (or, for op = T, columns) peeled off to the generic kernel
+    if (m_main < m && done != 2) {   // rows (or, for op = T, columns) peeled off to the generic kernel
         const double* A2 = fa ? (A + m_main * lda) : (A + m_main);
         rc = rlhip::lange_fro<double>(c, fa ? k : (m - m_main), fa ? (m - m_main) : k, A2, lda, &rest);
         if (rc) return rc;

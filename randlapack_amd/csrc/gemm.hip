@@ -515,12 +515,15 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
         if (rc == 1) return 0;
     }
     if (!tri && !transB && m >= 128 && n % 256 == 0 && k % SKK == 0) {
-        // big data passes: persistent stream-K kernel on the multiple-of-128 row block, generic kernel on the rest
-        const int64_t m_main = (m / 128) * 128;
+        // big data passes: persistent stream-K kernel.  A partial last tile row (m % 128 rows) rides along in the same launch when it is made
+        // of whole 16-byte pieces (200000 = 1562 x 128 + 64, a shard of 25000 = 195 x 128 + 40); otherwise the multiple-of-128 row block
+        // goes down the persistent path and the generic kernel takes the rest
+        constexpr int64_t EPP_ = 16 / (int64_t)sizeof(T);
+        const int64_t m_main = ((m % 128) % EPP_ == 0) ? m : (m / 128) * 128;
         int rc = try_streamk<T>(c, transA, transB, m_main, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssqA_dev, 0);
         if (rc < 0) return rc;
         if (rc == 1) {
-            if (ssqA_dev && ssq_done) *ssq_done = 1;   // covers op(A)'s first m_main rows; caller adds the peeled block
+            if (ssqA_dev && ssq_done) *ssq_done = (m_main == m) ? 2 : 1;   // 1: covers op(A)'s first (m / 128) * 128 rows, the caller adds the peeled block; 2: all of it
             if (m_main == m) return 0;
             const T* A2 = transA ? (A + m_main * lda) : (A + m_main);
             return gemm_impl<T>(c, transA, transB, m - m_main, n, k, alpha, A2, lda, B, ldb, beta, C + m_main, ldc, 0,

@@ -65,7 +65,8 @@ template <> struct SkT<float> {
 
 template <typename T>
 struct SkArgs {
-    int64_t M, N, K;          // M multiple of 128, N multiple of 256, K multiple of BK (caller peels the rest)
+    int64_t M, N, K;          // N multiple of 256, K multiple of BK (caller peels the rest); M a multiple of 128 for the tri map, else any
+                              // M >= 128 whose last, partial tile row has a multiple of EPP rows (its DMA pieces re-read the last valid rows)
     const T* A; int64_t lda;
     const T* B; int64_t ldb;
     T* C; int64_t ldc;
@@ -195,6 +196,35 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         b_src[h] = (int64_t)r * g.ldb + EPP * (q ^ ((r >> 1) & 7));
     }
     const int64_t a_step = A_KC ? (int64_t)BK : (int64_t)BK * g.lda;
+    // the last tile row may be partial (M % 128 rows): its DMA pieces take the rows past the end from the last valid piece instead -- a row
+    // of C depends on the same row of op(A) only, so what those rows hold never reaches a stored entry
+    const int64_t m_rag0 = (g.tri || g.M % BM == 0) ? g.M : (g.M / BM) * BM;     // first row of the partial tile row (M: there is none)
+    const int m_rem = (int)(g.M - m_rag0);
+    int64_t a_src_rag[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = wid + 8 * h;
+        if constexpr (A_KC) {
+            const int r = 8 * c + (lane >> 3), q = lane & 7;
+            const int re = (r < m_rem) ? r : (m_rem > 0 ? m_rem - 1 : 0);
+            a_src_rag[h] = (int64_t)re * g.lda + EPP * (q ^ ((r >> 1) & 7));
+        } else if constexpr (F64) {
+            const int ro = (2 * lane < m_rem) ? 2 * lane : (m_rem > 1 ? m_rem - 2 : 0);
+            a_src_rag[h] = (int64_t)c * g.lda + ro;
+        } else {
+            const int ro = (4 * (lane & 31) < m_rem) ? 4 * (lane & 31) : (m_rem > 3 ? m_rem - 4 : 0);
+            a_src_rag[h] = (int64_t)(2 * c + (lane >> 5)) * g.lda + ro;
+        }
+    }
+    // which of this thread's two 16-byte pieces of an A stage (pieces tid and tid + 512) hold rows of the partial tile that exist
+    bool ssq_ok_rag[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pc = tid + 512 * h;
+        if constexpr (A_KC) ssq_ok_rag[h] = (pc >> 3) < m_rem;
+        else if constexpr (F64) ssq_ok_rag[h] = 2 * (pc & 63) < m_rem;
+        else ssq_ok_rag[h] = 4 * (pc & 31) < m_rem;
+    }
 
     double ssq_acc = 0.0;
     for (int64_t pos = ws; pos < we;) {
@@ -206,6 +236,9 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         if (tile >= g.ntiles) { pos += nk; continue; }                 // the last unit may be short: this member has nothing there
         const SkTile td = sk_tile(g, tile);
         const int64_t m0 = td.m0, n0 = td.nA0, k0 = kt0 * BK;
+        const bool rag = (m0 >= m_rag0);                                // (never for the tri map)
+        const int64_t as0 = rag ? a_src_rag[0] : a_src[0], as1 = rag ? a_src_rag[1] : a_src[1];
+        const int64_t m_lim = g.tri ? ((int64_t)1 << 62) : g.M;
 
         const T* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
         const T* Bg = g.B + k0 + td.nA0 * g.ldb;              // columns 0 .. 127 of the tile
@@ -217,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
             const T* Bp = Bg + t * BK;
             const T* Bp1 = Bg1 + t * BK;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) glds16(Ap + a_src[h], st + (wid + 8 * h) * 1024);
+            for (int h = 0; h < 2; ++h) glds16(Ap + (h ? as1 : as0), st + (wid + 8 * h) * 1024);
 #pragma unroll
             for (int h = 0; h < 4; ++h) glds16((h < 2 ? Bp : Bp1) + b_src[h], st + STAGE_A + (wid + 8 * h) * 1024);
         };
@@ -287,7 +320,11 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
             fetch(smem + st_cur * STAGE, 1, fa1, fb1);
             if (do_ssq) {   // the A stage = 16 KiB / 512 threads = two b128 reads per thread (layout-agnostic)
                 const frag_t* sa = reinterpret_cast<const frag_t*>(smem + st_cur * STAGE);
-                const frag_t v0 = sa[tid], v1 = sa[tid + 512];
+                frag_t v0 = sa[tid], v1 = sa[tid + 512];
+                if (rag) {
+                    if (!ssq_ok_rag[0]) v0 = frag_t{};
+                    if (!ssq_ok_rag[1]) v1 = frag_t{};
+                }
                 if constexpr (F64) {
                     ssq_acc = fma(v0[0], v0[0], fma(v0[1], v0[1], fma(v1[0], v1[0], fma(v1[1], v1[1], ssq_acc))));
                 } else {
@@ -333,6 +370,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                         const int64_t j = n0 + wn0 + 16 * u + S::ccol(fk, r);
                         f4_t v = f4_t{acc[0][u][r], acc[1][u][r], acc[2][u][r], acc[3][u][r]} * g.alpha;
                         T* dst = g.C + i0 + j * g.ldc;
+                        if (i0 >= m_lim) continue;                     // rows of a partial tile that do not exist (4 | M % 128: all four or none)
                         if (g.tri) {                      // (the tri map is only used with A_KC operands; kept for completeness)
 #pragma unroll
                             for (int x = 0; x < 4; ++x)
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         int64_t i, j;
-                        if (!sk_cpos(td, g.tri, crow(x), wn0 + 16 * u + S::ccol(fk, r), i, j)) continue;
+                        if (!sk_cpos(td, g.tri, crow(x), wn0 + 16 * u + S::ccol(fk, r), i, j) || i >= m_lim) continue;
                         T v = g.alpha * acc[x][u][r];
                         if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
                         g.C[i + j * g.ldc] = v;
@@ -422,7 +460,7 @@ __global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t
             s += slab[e];
         }
         int64_t i, j;
-        if (!sk_cpos(td, g.tri, e % BM, e / BM, i, j)) continue;
+        if (!sk_cpos(td, g.tri, e % BM, e / BM, i, j) || (!g.tri && i >= g.M)) continue;
         T v = g.alpha * s;
         if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
         g.C[i + j * g.ldc] = v;
@@ -465,9 +503,10 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     // BQRRP 65536^2: residual per column 4e-5 -> 7.5e-5; a second accumulator level costs more registers than the kernel has: 137 ->
     // 123 TFLOP/s), so longer contractions stay on the generic kernel.  RLHIP_STREAMK_F32=2 lifts the cap (A/B measurements).
     if (sizeof(T) == 4 && k > 16384 && enabled_f32 != 2) return 0;
-    if (m % BM || n % BN || k % BK || m <= 0 || n <= 0 || k <= 0) return 0;
+    if (n % BN || k % BK || m < BM || n <= 0 || k <= 0) return 0;
+    if (m % BM && (tri || (m % BM) % EPP)) return 0;          // a partial last tile row: whole 16-byte pieces only, never in the tri map
     if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % EPP || ldb % EPP) return 0;    // 16-byte aligned DMA pieces
-    const int64_t tiles_m = m / BM, tiles_n = n / BN, ktiles = k / BK;
+    const int64_t tiles_m = (m + BM - 1) / BM, tiles_n = n / BN, ktiles = k / BK;
     int64_t ntiles = tiles_m * tiles_n;
     if (tri) {
         if (m != n) return 0;

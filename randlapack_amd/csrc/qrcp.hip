@@ -900,6 +900,8 @@ int gemm(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, 
 
 template <typename T>
 int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done);
+template <typename T>
+int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev);
 
 template <typename T>
 static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev, int64_t max_steps = -1,
@@ -936,6 +938,28 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     // have trailing columns beyond the last reflector.
     constexpr int64_t NBQ = 256;       // a BLAS-3 panel costs ~1.3 ms of launch latency whatever its width: few, wide panels
     const int64_t kmax = m < n ? m : n;
+    // sketch-sized, nearly square or wide (up to 2048 rows, 8 columns per CU): the register-resident block-pipelined kernel (qr_blk.hip)
+    // factors the leading kmax columns in one launch -- 2048 x 2048 fp32: 12 ms of pipelined / blocked panels before; the columns beyond
+    // the last reflector (BQRRP's permuted sketch is 2048 x cols) then get Q^T in compact-WY blocks of NBQ reflectors on the MFMA GEMMs
+    if (kmax >= 64 && 10 * m < 19 * kmax) {
+        const int rb = geqrf_blk<T>(c, m, kmax, A, lda, tau_dev);
+        if (rb < 0) return rb;
+        if (rb == 1) {
+            if (n <= kmax) return 0;
+            size_t markb = rlhip_ws_mark(c);
+            T* Tb = ws_alloc<T>(c, (size_t)NBQ * NBQ);
+            if (!Tb) { rlhip_ws_release(c, markb); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            int rcb = 0;
+            for (int64_t j0 = 0; j0 < kmax && !rcb; j0 += NBQ) {
+                const int64_t jb = (kmax - j0 < NBQ) ? (kmax - j0) : NBQ;
+                T* P = A + j0 + j0 * lda;
+                rcb = larft_gram<T>(c, m - j0, jb, P, lda, tau_dev + j0, Tb, jb);
+                if (!rcb) rcb = gemqrt_lt<T>(c, m - j0, n - kmax, jb, jb, P, lda, Tb, jb, A + j0 + kmax * lda, lda);
+            }
+            rlhip_ws_release(c, markb);
+            return rcb;
+        }
+    }
     constexpr int64_t pipe_max = 1280;
     // sketch-sized, nearly square problems: the pipelined kernel alone beats blocking (1280 x 1024: 11.2 vs 12.3 ms); from about twice
     // as tall as wide the CholQR-panel route wins (2000 x 1000: 13.0 vs 14.3 ms, 2560 x 1024: 12.2 vs 17.4 ms)

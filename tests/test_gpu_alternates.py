@@ -103,7 +103,7 @@ BATTERY = textwrap.dedent("""
 # knob -> alternate value (the default is the other one); each selects a different kernel / algorithm
 ALTERNATES = [("RLHIP_TRSM_FUSED", "0"), ("RLHIP_TRSM_BLK", "0"), ("RLHIP_STREAMK", "0"), ("RLHIP_STREAMK_F32", "0"), ("RLHIP_STREAMK_F32", "2"),
               ("RLHIP_STREAMK_F32_CHUNK", "0"), ("RLHIP_RECOVER_V", "0"), ("RLHIP_CHOLQR2_SKIP", "0"), ("RLHIP_JACOBI_PERSIST", "0"),
-              ("RLHIP_QR_PIPE", "0"), ("RLHIP_QRCP_TAG", "0"), ("RLHIP_LU_TAG", "0"), ("RLHIP_LU_REG_PANEL", "0"), ("RLHIP_LU_F64_FAST", "0"),
+              ("RLHIP_QR_PIPE", "0"), ("RLHIP_QR_BLK", "0"), ("RLHIP_QRCP_TAG", "0"), ("RLHIP_LU_TAG", "0"), ("RLHIP_LU_REG_PANEL", "0"), ("RLHIP_LU_F64_FAST", "0"),
               ("RLHIP_LU_F32_FAST", "0"), ("RLHIP_HQRRP_TALL_PANEL", "0"), ("RLHIP_GEQRF_PRECOND", "0"), ("RLHIP_TRSM_FUSED_MIN_ROWS", "1000")]
 
 

@@ -31,7 +31,8 @@ def relerr(got, ref):
 # stream-K GEMM, direct
 # ---------------------------------------------------------------------------------------------------
 # (M, N, K, transA): W = tiles * ktiles >= 256 * 64 so that the persistent kernel takes the problem (gemm_sk.hip gate);
-# 1446 and 645 rows leave a peeled block for the generic kernel (lda must be even: 16-byte aligned columns for the LDS DMA)
+# 645 rows leave a peeled block for the generic kernel (an odd remainder is not made of whole 16-byte pieces), 1446 a partial last tile row
+# inside the persistent launch (lda must be even: 16-byte aligned columns for the LDS DMA)
 SK_SHAPES = [(38400, 256, 1024, "N"), (1280, 512, 16384, "N"), (1408 + 38, 256, 32768, "N"), (256, 256, 131072, "T"),
              (640 + 5, 256, 65536, "T"), (2048, 512, 8192, "T")]
 
@@ -59,6 +60,39 @@ def test_streamk_gemm_entrywise(ctx, m, n, k, ta):
     Cd3 = d.cm_from_numpy(np.full((m, n), np.nan))
     ctx.gemm(ta, "N", m, n, k, 1.0, Ad, lda, Bd, k, 0.0, Cd3, m)
     assert relerr(d.cm_to_numpy(Cd3), A @ B) <= 50 * EPS * np.sqrt(k)
+
+
+# a partial last tile row made of whole 16-byte pieces stays inside the persistent launch (its DMA pieces re-read the last valid rows and the
+# epilogue drops the rows that do not exist): nothing is written below row m, nothing of the duplicated rows reaches C or the fused norm
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("ta", ["N", "T"])
+@pytest.mark.parametrize("rem", [4, 64, 124])
+def test_streamk_partial_last_tile_row(ctx, dt, ta, rem):
+    d = _d()
+    import torch
+
+    f64 = dt == "f64"
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    m, n, k = (1280 if f64 else 5120) + rem, 256, (32768 if f64 else 16384)     # above the work gate of the persistent kernel
+    rng = np.random.default_rng(rem + (7 if f64 else 9))
+    A = rng.standard_normal((m, k)).astype(npdt); B = rng.standard_normal((k, n)).astype(npdt)
+    Ad = d.cm_from_numpy(A if ta == "N" else A.T.copy()); Bd = d.cm_from_numpy(B)
+    ldc = m + 4
+    C0 = rng.standard_normal((ldc, n)).astype(npdt)
+    Cd = d.cm_from_numpy(C0)
+    which = 0 if f64 else 1
+    before = ctx.path_count(which)
+    ctx.gemm(ta, "N", m, n, k, 2.0, Ad, m if ta == "N" else k, Bd, k, 1.0, Cd, ldc)
+    assert ctx.path_count(which) == before + 1
+    got = d.cm_to_numpy(Cd)
+    ref = 2.0 * (A.astype(np.float64) @ B.astype(np.float64)) + C0[:m]
+    tol = (50 * EPS if f64 else 4 * EPS32) * np.sqrt(k)
+    assert relerr(got[:m], ref) <= tol
+    assert np.array_equal(got[m:], C0[m:])                      # the four guard rows below every column are untouched
+    if f64:
+        Cz = d.cm_zeros(m, n)
+        nrm, fused = ctx.gemm_norma(ta, "N", m, n, k, 1.0, Ad, m if ta == "N" else k, Bd, k, 0.0, Cz, m)
+        assert fused == 1 and abs(nrm - np.linalg.norm(A)) <= 1e-13 * np.linalg.norm(A)
 
 
 @pytest.mark.parametrize("m,n,k,ta", [(38400, 256, 1024, "N"), (1408 + 38, 256, 32768, "N"), (256, 256, 131072, "T"), (645, 256, 65536, "T")])

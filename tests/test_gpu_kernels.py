@@ -627,6 +627,43 @@ def test_geqrf_ungqr_match_lapack(ctx, m, n):
         assert np.linalg.norm(Q.T @ Q - np.eye(n)) <= EPS**0.75 * np.sqrt(n)
 
 
+# the register-resident block-pipelined kernel (qr_blk.hip: sketch-sized, nearly square or wide inputs up to 2048 rows / 8 columns per CU):
+# the geqrf output of LAPACK entry for entry (same reflectors, same signs), in both precisions, with a ragged last chunk (n % 8 != 0), a
+# row count that is not a multiple of the workgroup, a leading dimension larger than m, and columns beyond the last reflector
+@pytest.mark.parametrize("m,n,dt", [(2048, 2048, "f32"), (2048, 2048 + 700, "f32"), (1280, 1024, "f64"), (1000, 1000, "f64"), (700, 653, "f64"),
+                                    (2041, 2041, "f32"), (512, 4096, "f64"), (1536, 1100, "f32"), (96, 80, "f64")])
+def test_geqrf_block_pipelined_matches_lapack(ctx, m, n, dt):
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    f64 = dt == "f64"
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    rng = np.random.default_rng(m + 5 * n)
+    A = rng.standard_normal((m, n)).astype(npdt)
+    lda = m + 6
+    buf = np.full((lda, n), 7.0, dtype=npdt); buf[:m] = A
+    Ad = d.cm_from_numpy(buf)
+    k = min(m, n)
+    tau = torch.zeros(k, dtype=tdt, device="cuda")
+    before = ctx.path_count(8)
+    fn = ctx.lib.rlhip_geqrf_f64 if f64 else ctx.lib.rlhip_geqrf_f32
+    assert fn(ctx.h, m, n, Ad.data_ptr(), lda, tau.data_ptr()) == 0
+    ctx.sync()
+    assert ctx.path_count(8) == before + 1, "the block-pipelined kernel did not take this shape"
+    qr_ref, tau_ref, _, _ = (ll.dgeqrf if f64 else ll.sgeqrf)(A)
+    got = d.cm_to_numpy(Ad)
+    tol = (2e-12 if f64 else 2e-3) * np.abs(qr_ref).max() * np.sqrt(k / 1000 + 1)       # rounding of ~k block updates per entry
+    np.testing.assert_allclose(got[:m], qr_ref, atol=tol, rtol=0)
+    np.testing.assert_allclose(tau.cpu().numpy(), tau_ref, atol=(1e-12 if f64 else 1e-4), rtol=0)
+    assert np.all(got[m:] == 7.0)                                                      # nothing written below row m
+    # the factorization itself: ||A - Q R|| at working precision
+    Qref = (ll.dorgqr if f64 else ll.sorgqr)(np.asfortranarray(got[:m, :k].copy()), tau.cpu().numpy())[0]
+    R = np.triu(got[:k])
+    eps = np.finfo(npdt).eps
+    assert np.linalg.norm(A.astype(np.float64) - Qref.astype(np.float64) @ R.astype(np.float64)) <= 30 * eps * np.linalg.norm(A) * np.sqrt(k)
+
+
 @pytest.mark.parametrize("m,n,nb", [(60, 12, 12), (500, 64, 32), (2000, 256, 256), (300, 100, 40)])
 def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
     import torch
