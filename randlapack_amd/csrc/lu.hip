@@ -436,10 +436,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8) ? 2 : 1) void getrf_panel_reg
         st.gr[q] = lo + tid + 256 * q;
         const int64_t rr = st.gr[q] < m ? st.gr[q] : m - 1;           // clamped row: unconditional coalesced loads
 #pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            const T t = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];
-            st.x[q][c] = (st.gr[q] < m && c < pb) ? t : T(0);
-        }
+        for (int c = 0; c < PB; ++c) st.x[q][c] = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];    // clamped row and column: unconditional, all in flight together
+    }
+    // (the selects come after ALL loads: written as `cond ? load : 0` per entry, hipcc sinks every load into its own branch with an
+    // s_waitcnt vmcnt(0) behind it -- 128 dependent L2 round trips = ~30 us per panel launch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) st.x[q][c] = (st.gr[q] < m && c < pb) ? st.x[q][c] : T(0);
     }
 #ifdef RLHIP_LU_PROF
     for (int i = 0; i < 5; ++i) st.pf[i] = 0;
@@ -545,13 +550,22 @@ __global__ __launch_bounds__(256) void getf2_update_kernel(int64_t m, int64_t j0
 // panel touch at most 2 pb rows, so every workgroup first composes them into ONE net permutation "row dst receives the old row
 // src" (wave 0, in LDS, ~1 us), and each thread then gathers its column's <= 2 pb source values with independent loads and
 // scatters them: two memory round trips per column instead of pb.
-template <typename T>
-__global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* __restrict__ A, int64_t lda,
+// SOLVE: the same thread then forward-substitutes its column with the panel's unit lower triangle (U12 = L11^-1 A12, what
+// unit_lower_solve_kernel does as a launch of its own): the two steps of a panel that act on the columns to its right, column by column.
+template <typename T, bool SOLVE>
+__global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* A, int64_t lda,
                                                    const int64_t* __restrict__ ipiv) {
     __shared__ int64_t s_pos[2 * PB], s_src[2 * PB];
     __shared__ int s_act[2 * PB];
     __shared__ int s_n;
+    __shared__ T sL[SOLVE ? PB : 1][PB + 1];
     const int tid = threadIdx.x;
+    if constexpr (SOLVE) {
+        for (int e = tid; e < PB * PB; e += 256) {
+            const int i = e % PB, j = e / PB;
+            sL[i][j] = (i < pb && j < pb && i > j) ? A[(j0 + i) + (j0 + j) * lda] : T(0);
+        }
+    }
     if (tid < 64) {                                    // one wave: wave-synchronous, no barriers inside
         const int e = tid;
         int64_t pos = -1;
@@ -585,14 +599,34 @@ __global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, 
     const int64_t c = c_lo + (int64_t)blockIdx.x * 256 + tid;
     if (c >= c_hi) return;
     const int nmv = s_n;
-    if (nmv == 0) return;
     T* col = A + c * lda;
-    T v[2 * PB];
+    if (nmv != 0) {
+        T v[2 * PB];
 #pragma unroll
-    for (int e = 0; e < 2 * PB; ++e) v[e] = col[s_src[e < nmv ? e : 0]];      // clamped index: loads stay unconditional and pipelined
+        for (int e = 0; e < 2 * PB; ++e) v[e] = col[s_src[e < nmv ? e : 0]];      // clamped index: loads stay unconditional and pipelined
 #pragma unroll
-    for (int e = 0; e < 2 * PB; ++e)
-        if (e < nmv) col[s_pos[e]] = v[e];
+        for (int e = 0; e < 2 * PB; ++e)
+            if (e < nmv) col[s_pos[e]] = v[e];
+    }
+    if constexpr (SOLVE) {
+        T x[PB];
+        T* cj = col + j0;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) x[i] = cj[(i < pb) ? i : (pb - 1)];            // (this thread's own stores above are behind these loads in program order)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            if (i < pb) {
+                T sacc = x[i];
+#pragma unroll
+                for (int l = 0; l < PB; ++l)
+                    if (l < i) sacc -= sL[i][l] * x[l];
+                x[i] = sacc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            if (i < pb) cj[i] = x[i];
+    }
 }
 
 // U12 = L11^-1 A12 (unit lower, jb x jb at A[j0,j0]) on the columns [c_lo, c_hi); one column per thread
@@ -710,8 +744,10 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         if (rpw > rpw_max && !(reg_panel_on() && use_tag && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
         int64_t G = (rows + rpw - 1) / rpw;
         g.j0 = j0; g.pb = pb; g.rpw = rpw;
-        hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
         const int reg_panel = reg_panel_on();
+        // (the tagged-word kernels never touch the barrier counter: only the first panel of a call needs the launch, for `info`)
+        if (j0 == 0 || !(reg_panel && use_tag && rows >= 1024))
+            hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
         // resident capacity of the general register kernel (every workgroup spins on the others: all of them must be on the device at once)
         static int64_t reg_cap[64] = {};
@@ -764,11 +800,11 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         // columns of earlier blocks only keep L consistent and never feed a later pivot decision
         const int64_t left_lo = pivots_only ? J0 : 0;
         if (j0 > left_lo)
-            hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((j0 - left_lo + 255) / 256)), dim3(256), 0, c->stream, left_lo, j0, j0, pb, A, lda, ipiv_dev);
+            hipLaunchKernelGGL((laswp_kernel<T, false>), dim3((unsigned)((j0 - left_lo + 255) / 256)), dim3(256), 0, c->stream, left_lo, j0, j0, pb, A, lda, ipiv_dev);
         const int64_t rest = Cin - j0 - pb;
         if (rest > 0) {
-            hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, j0 + pb, Cin, j0, pb, A, lda, ipiv_dev);
-            hipLaunchKernelGGL(unit_lower_solve_kernel<T>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, j0 + pb, Cin, j0, pb, A, lda);
+            // interchanges + U12 = L11^-1 A12 of the columns right of the panel, one launch
+            hipLaunchKernelGGL((laswp_kernel<T, true>), dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, j0 + pb, Cin, j0, pb, A, lda, ipiv_dev);
             RLHIP_LAUNCH_CHECK();
             const int64_t mrest = m - j0 - pb;
             if (mrest > 0) {
@@ -784,7 +820,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         const unsigned gr = (unsigned)((right + 255) / 256);
         for (int64_t q0 = J0; q0 < Jend; q0 += PB) {
             const int cnt = (int)((Jend - q0 < PB) ? (Jend - q0) : PB);
-            hipLaunchKernelGGL(laswp_kernel<T>, dim3(gr), dim3(256), 0, c->stream, Cin, n, q0, cnt, A, lda, ipiv_dev);
+            hipLaunchKernelGGL((laswp_kernel<T, false>), dim3(gr), dim3(256), 0, c->stream, Cin, n, q0, cnt, A, lda, ipiv_dev);
         }
         for (int64_t s0 = J0; s0 < Jend; s0 += PB) {
             const int sb = (int)((Jend - s0 < PB) ? (Jend - s0) : PB);
@@ -831,7 +867,7 @@ int laswp(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int64_t k1, int64_t k2, co
     if (n <= 0 || k2 < k1) return 0;
     for (int64_t q0 = k1 - 1; q0 < k2; q0 += PB) {           // the kernel composes up to PB interchanges at a time, in order
         const int cnt = (int)((k2 - q0 < PB) ? (k2 - q0) : PB);
-        hipLaunchKernelGGL(laswp_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, q0, cnt, A, lda, ipiv_dev);
+        hipLaunchKernelGGL((laswp_kernel<T, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, q0, cnt, A, lda, ipiv_dev);
     }
     RLHIP_LAUNCH_CHECK();
     return 0;

@@ -198,10 +198,15 @@ __global__ __launch_bounds__(256) void getrf_panel_f64_kernel(LuArgs<double> g) 
         st.gr[q] = lo + tid + 256 * q;
         const int64_t rr = st.gr[q] < m ? st.gr[q] : m - 1;
 #pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            const double t = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];
-            st.x[q][c] = (st.gr[q] < m && c < pb) ? t : 0.0;
-        }
+        for (int c = 0; c < PB; ++c) st.x[q][c] = g.A[rr + (j0 + (c < pb ? c : pb - 1)) * g.lda];    // clamped row and column: unconditional, all in flight together
+    }
+    // (the selects come after ALL loads: written as `cond ? load : 0` per entry, hipcc sinks every load into its own branch with an
+    // s_waitcnt vmcnt(0) behind it -- 128 dependent L2 round trips = ~30 us per panel launch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < LD_RPT; ++q) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) st.x[q][c] = (st.gr[q] < m && c < pb) ? st.x[q][c] : 0.0;
     }
 #ifdef RLHIP_LU_PROF
     for (int i = 0; i < 5; ++i) st.pf[i] = 0;
