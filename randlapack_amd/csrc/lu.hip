@@ -548,18 +548,19 @@ __global__ __launch_bounds__(256) void getf2_update_kernel(int64_t m, int64_t j0
 // dlaswp on column range [c_lo, c_hi): for j in [j0, j0+pb): swap rows j and ipiv[j]-1.
 // Walking the pb swaps in order costs pb dependent load/store round trips per column (34 us per launch at pb = 32).  The swaps of a
 // panel touch at most 2 pb rows, so every workgroup first composes them into ONE net permutation "row dst receives the old row
-// src" (wave 0, in LDS, ~1 us), and each thread then gathers its column's <= 2 pb source values with independent loads and
-// scatters them: two memory round trips per column instead of pb.
-// SOLVE: the same thread then forward-substitutes its column with the panel's unit lower triangle (U12 = L11^-1 A12, what
-// unit_lower_solve_kernel does as a launch of its own): the two steps of a panel that act on the columns to its right, column by column.
+// src" (wave 0, in LDS, ~1 us).  One WAVE then moves one column: lane e gathers source value e and scatters it (two memory round trips
+// for the whole column, 64 independent requests each; a thread per column walked its 64 strided elements alone: 32 us per launch on 8
+// workgroups).
+// SOLVE: the wave then forward-substitutes the column with the panel's unit lower triangle (U12 = L11^-1 A12): lane i holds x_i and row
+// i of L11 in registers, step s broadcasts x_s by v_readlane -- the two steps of a panel that act on the columns to its right, in one launch
+// (the thread-per-column solve took 14 us on its own).
 template <typename T, bool SOLVE>
 __global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* A, int64_t lda,
                                                    const int64_t* __restrict__ ipiv) {
     __shared__ int64_t s_pos[2 * PB], s_src[2 * PB];
-    __shared__ int s_act[2 * PB];
     __shared__ int s_n;
     __shared__ T sL[SOLVE ? PB : 1][PB + 1];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if constexpr (SOLVE) {
         for (int e = tid; e < PB * PB; e += 256) {
             const int i = e % PB, j = e / PB;
@@ -593,39 +594,37 @@ __global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, 
         const int slot = __popcll(mm & ((1ull << e) - 1ull));
         if (moved) { s_pos[slot] = pos; s_src[slot] = content; }   // compaction: slot <= e, and every lane has read s_pos already
         if (e == 0) s_n = __popcll(mm);
-        (void)s_act;
     }
     __syncthreads();
-    const int64_t c = c_lo + (int64_t)blockIdx.x * 256 + tid;
-    if (c >= c_hi) return;
     const int nmv = s_n;
-    T* col = A + c * lda;
-    if (nmv != 0) {
-        T v[2 * PB];
-#pragma unroll
-        for (int e = 0; e < 2 * PB; ++e) v[e] = col[s_src[e < nmv ? e : 0]];      // clamped index: loads stay unconditional and pipelined
-#pragma unroll
-        for (int e = 0; e < 2 * PB; ++e)
-            if (e < nmv) col[s_pos[e]] = v[e];
-    }
+    if (!SOLVE && nmv == 0) return;
+    const int64_t src = s_src[lane < nmv ? lane : 0], dst = s_pos[lane < nmv ? lane : 0];
+    T lrow[SOLVE ? PB : 1];
     if constexpr (SOLVE) {
-        T x[PB];
-        T* cj = col + j0;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) x[i] = cj[(i < pb) ? i : (pb - 1)];            // (this thread's own stores above are behind these loads in program order)
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            if (i < pb) {
-                T sacc = x[i];
-#pragma unroll
-                for (int l = 0; l < PB; ++l)
-                    if (l < i) sacc -= sL[i][l] * x[l];
-                x[i] = sacc;
-            }
+        for (int l = 0; l < PB; ++l) lrow[l] = sL[lane & (PB - 1)][l];
+    }
+    for (int64_t c = c_lo + (int64_t)blockIdx.x * 4 + wid; c < c_hi; c += (int64_t)gridDim.x * 4) {
+        T* col = A + c * lda;
+        if (nmv != 0) {
+            const T v = col[src];                                      // every lane's load is back before the store instruction issues
+            if (lane < nmv) col[dst] = v;
         }
+        if constexpr (SOLVE) {
+            T* cj = col + j0;
+            T x = cj[(lane < pb) ? lane : (pb - 1)];                   // (after the wave's own stores, in program order)
+            if (lane >= pb) x = T(0);
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            if (i < pb) cj[i] = x[i];
+            for (int st = 0; st < PB; ++st) {
+                if (st < pb) {                                         // uniform
+                    T xs;
+                    if constexpr (sizeof(T) == 4) xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)x), st));
+                    else xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint((double)x), st), __builtin_amdgcn_readlane(__double2loint((double)x), st));
+                    if (lane > st) x -= lrow[st] * xs;                 // (lrow is zero on and above the diagonal and for lanes >= pb)
+                }
+            }
+            if (lane < pb) cj[lane] = x;
+        }
     }
 }
 
@@ -679,6 +678,12 @@ __global__ void lu_zero_kernel(unsigned* bar, int* info, int zero_info) { *bar =
 }  // namespace
 
 namespace rlhip {
+
+// grid of laswp_kernel: one column per wave, four per workgroup; very wide ranges loop
+static unsigned laswp_grid(int64_t ncols) {
+    int64_t g = (ncols + 3) / 4;
+    return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
 
 static int reg_panel_on() {
     static int v = -1;
@@ -800,11 +805,11 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         // columns of earlier blocks only keep L consistent and never feed a later pivot decision
         const int64_t left_lo = pivots_only ? J0 : 0;
         if (j0 > left_lo)
-            hipLaunchKernelGGL((laswp_kernel<T, false>), dim3((unsigned)((j0 - left_lo + 255) / 256)), dim3(256), 0, c->stream, left_lo, j0, j0, pb, A, lda, ipiv_dev);
+            hipLaunchKernelGGL((laswp_kernel<T, false>), dim3(laswp_grid(j0 - left_lo)), dim3(256), 0, c->stream, left_lo, j0, j0, pb, A, lda, ipiv_dev);
         const int64_t rest = Cin - j0 - pb;
         if (rest > 0) {
             // interchanges + U12 = L11^-1 A12 of the columns right of the panel, one launch
-            hipLaunchKernelGGL((laswp_kernel<T, true>), dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, c->stream, j0 + pb, Cin, j0, pb, A, lda, ipiv_dev);
+            hipLaunchKernelGGL((laswp_kernel<T, true>), dim3(laswp_grid(rest)), dim3(256), 0, c->stream, j0 + pb, Cin, j0, pb, A, lda, ipiv_dev);
             RLHIP_LAUNCH_CHECK();
             const int64_t mrest = m - j0 - pb;
             if (mrest > 0) {
@@ -817,14 +822,17 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     // ---- the columns right of the outer block: interchanges, U12 = L11^-1 A12 by 32-row blocks, A22 -= L21 U12
     const int64_t right = n - Cin;
     if (right > 0) {
-        const unsigned gr = (unsigned)((right + 255) / 256);
+        const unsigned gr = laswp_grid(right);
+        const bool one_panel = (Jend - J0 <= PB);                  // the outer block is a single panel: interchanges + its forward substitution in one launch
         for (int64_t q0 = J0; q0 < Jend; q0 += PB) {
             const int cnt = (int)((Jend - q0 < PB) ? (Jend - q0) : PB);
-            hipLaunchKernelGGL((laswp_kernel<T, false>), dim3(gr), dim3(256), 0, c->stream, Cin, n, q0, cnt, A, lda, ipiv_dev);
+            if (one_panel) hipLaunchKernelGGL((laswp_kernel<T, true>), dim3(gr), dim3(256), 0, c->stream, Cin, n, q0, cnt, A, lda, ipiv_dev);
+            else hipLaunchKernelGGL((laswp_kernel<T, false>), dim3(gr), dim3(256), 0, c->stream, Cin, n, q0, cnt, A, lda, ipiv_dev);
         }
-        for (int64_t s0 = J0; s0 < Jend; s0 += PB) {
+        const unsigned gs = (unsigned)((right + 255) / 256);
+        for (int64_t s0 = J0; s0 < Jend && !one_panel; s0 += PB) {
             const int sb = (int)((Jend - s0 < PB) ? (Jend - s0) : PB);
-            hipLaunchKernelGGL(unit_lower_solve_kernel<T>, dim3(gr), dim3(256), 0, c->stream, Cin, n, s0, sb, A, lda);
+            hipLaunchKernelGGL(unit_lower_solve_kernel<T>, dim3(gs), dim3(256), 0, c->stream, Cin, n, s0, sb, A, lda);
             RLHIP_LAUNCH_CHECK();
             const int64_t below = Jend - (s0 + sb);
             if (below > 0) {
@@ -833,6 +841,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
                 if (rc) { rlhip_ws_release(c, mark); return rc; }
             }
         }
+        RLHIP_LAUNCH_CHECK();
         const int64_t mrest = m - Jend;
         if (mrest > 0) {
             int rc = gemm_impl<T>(c, 0, 0, mrest, right, Jend - J0, T(-1), A + Jend + J0 * lda, lda, A + J0 + Cin * lda, lda, T(1),
@@ -867,7 +876,7 @@ int laswp(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int64_t k1, int64_t k2, co
     if (n <= 0 || k2 < k1) return 0;
     for (int64_t q0 = k1 - 1; q0 < k2; q0 += PB) {           // the kernel composes up to PB interchanges at a time, in order
         const int cnt = (int)((k2 - q0 < PB) ? (k2 - q0) : PB);
-        hipLaunchKernelGGL((laswp_kernel<T, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)0, n, q0, cnt, A, lda, ipiv_dev);
+        hipLaunchKernelGGL((laswp_kernel<T, false>), dim3(laswp_grid(n)), dim3(256), 0, c->stream, (int64_t)0, n, q0, cnt, A, lda, ipiv_dev);
     }
     RLHIP_LAUNCH_CHECK();
     return 0;
