@@ -339,7 +339,7 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
  * 2 fused MFMA trsm block kernel (tri.hip), 3 row-per-lane substitution trsm sub-block, 4 fused out-of-place trsm (rlhip_trsm_gather),
  * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip), 6 persistent one-launch Jacobi sweeps (jacobi.hip),
  * 7 column-at-a-time LU panel of a matrix taller than the resident register kernels hold (lu.hip), 8 register-resident block-pipelined
- * Householder QR of a sketch-sized matrix (qr_blk.hip).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
+ * Householder QR of a sketch-sized matrix (qr_blk.hip), 9 its sign-modified LU twin inside orhr_col.  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);

@@ -161,6 +161,9 @@ template <typename T> int lacpy(rlhip_ctx*, int, int64_t, int64_t, const T*, int
 template <typename T> int trsm_right_upper(rlhip_ctx*, int, int64_t, int64_t, T, const T*, int64_t, T*, int64_t);
 template <typename T> int gemm(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, T, const T*, int64_t, const T*, int64_t, T, T*, int64_t);
 
+template <typename T>
+int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D);
+
 // A (m x n, orthonormal columns) -> V (unit lower trapezoidal, in place), T (nb x n), D (n)
 template <typename T>
 int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* D) {
@@ -171,8 +174,10 @@ int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, 
     if (nb > n) nb = n;
     if (ldt < (nb > 1 ? nb : 1)) return -8;
     if (n == 0) return 0;
-    // (1) sign-modified LU of the top n x n block
-    for (int64_t j0 = 0; j0 < n; j0 += LB) {
+    // (1) sign-modified LU of the top n x n block: one launch of the block-pipelined kernel when it fits (qr_blk.hip), else 32-column panels
+    const int rb = lunp_blk<T>(c, n, A, lda, D);
+    if (rb < 0) return rb;
+    for (int64_t j0 = (rb == 1) ? n : 0; j0 < n; j0 += LB) {
         const int jb = (int)((n - j0 < LB) ? (n - j0) : LB);
         const int64_t rest = n - j0 - jb;
         unsigned blocks = (unsigned)((rest + 255) / 256);

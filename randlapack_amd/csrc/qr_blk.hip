@@ -315,6 +315,139 @@ __global__ __launch_bounds__(NT) void qr_blk_kernel(QbArgs<T> g) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same ownership for the sign-modified LU WITHOUT pivoting of Householder reconstruction (lapack::orhr_col -> dlaorhr_col_getrfnp,
+// rl_bqrrp.hh:480 / rl_cqrrt.hh): for i: D(i) = -sign(a_ii), a_ii -= D(i), column below /= a_ii, trailing -= column * row.
+// No pivot search, so a column step needs NO reduction at all -- the thread that holds the diagonal row broadcasts it through LDS -- and
+// a block application is  U_kc = L_kk^-1 C(block rows),  C(below) -= L_k U_kc  with the 8 x 8 pieces handed over by the eight threads
+// that hold the block's rows.  2048 x 2048 fp32 took 64 panels x (panel kernel + trsm + GEMM) = 5.5 ms of launches before.
+template <typename T>
+struct LbArgs {
+    int64_t n;                // n x n block, n <= 8 * gridDim.x
+    T* A; int64_t lda;
+    T* D;                     // n signs
+    unsigned* flag;
+};
+
+template <typename T, int NT, int RPT>
+__global__ __launch_bounds__(NT) void lunp_blk_kernel(LbArgs<T> g) {
+    const int tid = threadIdx.x;
+    const int me = blockIdx.x;
+    const int64_t lda = g.lda;
+    const int ni = (int)g.n;
+    __shared__ T s_piv[2][8];
+    __shared__ T s_d[8];
+    __shared__ T s_x[8][8], s_l[8][8], s_u[8][8];
+    const int j0m = me * 8;
+    const int cw = (ni - j0m < 8) ? (ni - j0m) : 8;
+    T c[RPT][8];
+    T* rowp[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + NT * q;
+        rowp[q] = g.A + (r < ni ? r : ni - 1);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) c[q][cc] = (r < ni && cc < cw) ? rowp[q][(int64_t)(j0m + cc) * lda] : T(0);
+    }
+    // ---- the blocks to the left, in order
+    for (int k = 0; k < me; ++k) {
+        const int j0 = k * 8;
+        if (tid == 0) {
+            while (__hip_atomic_load(g.flag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        T lv[RPT][8];
+        const int64_t cb = (int64_t)j0 * lda;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const T* lp = rowp[q] + cb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lv[q][i] = lp[i * lda];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the eight threads that hold rows j0 .. j0 + 7 hand over their rows of this chunk (X) and of the block (L_kk below its diagonal)
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + NT * q;
+            if (r >= j0 && r < j0 + 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s_x[r - j0][j] = c[q][j]; s_l[r - j0][j] = lv[q][j]; }
+            }
+        }
+        __syncthreads();
+        if (tid < 8) {                                     // column tid of U_kc = L_kk^-1 X (unit lower: forward substitution)
+            T u[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                T a = s_x[i][tid];
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                    if (l < i) a -= s_l[i][l] * u[l];
+                u[i] = a;
+                s_u[i][tid] = a;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + NT * q;
+            const bool below = (r >= j0 + 8) && (r < ni);
+            const bool inblk = (r >= j0) && (r < j0 + 8);
+            const int ri = inblk ? (r - j0) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                T a = c[q][j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a -= (below ? lv[q][i] : T(0)) * s_u[i][j];
+                c[q][j] = inblk ? s_u[ri][j] : a;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // (see qr_blk_kernel: no conservative vmcnt(0) in front of the rounds' stores)
+    // ---- this chunk: eight elimination steps, one rendezvous each, no reduction
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        if (cc < cw) {
+            const int j = j0m + cc;
+            const int par = cc & 1;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + NT * q;
+                if (r == j) {
+                    const T a = c[q][cc];
+                    const T dd = (a == T(0)) ? T(1) : ((a > T(0)) ? T(-1) : T(1));
+                    c[q][cc] = a - dd;
+                    s_d[cc] = dd;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s_piv[par][k] = c[q][k];
+                }
+            }
+            qb_barrier_lds();
+            const T piv = s_piv[par][cc];
+            T urow[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) urow[k] = s_piv[par][k];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + NT * q;
+                const bool act = (r > j) && (r < ni);
+                const T l = act ? c[q][cc] / piv : T(0);
+#pragma unroll
+                for (int k = cc + 1; k < 8; ++k) c[q][k] -= l * urow[k];
+                c[q][cc] = act ? l : c[q][cc];
+                if (r < ni) qb_store_wt(rowp[q] + (int64_t)j * lda, c[q][cc]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < cw) qb_pub(g.D + j0m + tid, s_d[tid]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(g.flag + me, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -359,5 +492,30 @@ int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev)
 }
 template int geqrf_blk<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*);
 template int geqrf_blk<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*);
+
+// Sign-modified LU without pivoting of the n x n matrix A (what lapack::orhr_col runs on the top block of Q): L (unit lower) and U in
+// place, D(i) = -sign of the i-th pivot before its modification.  Returns 1 when done here, 0 when the problem does not fit the kernel.
+template <typename T>
+int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
+    constexpr int NT = 512, RPT = 4;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("RLHIP_QR_BLK"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!on || n < 1 || n > (int64_t)NT * RPT) return 0;
+    const int64_t G = (n + 7) / 8;
+    if (G > c->num_cu) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    LbArgs<T> g;
+    g.n = n; g.A = A; g.lda = lda; g.D = D;
+    g.flag = ws_alloc<unsigned>(c, (size_t)G + 4);
+    if (!g.flag) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    RLHIP_CHECK(hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream));
+    void* kargs[] = {(void*)&g};
+    RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)lunp_blk_kernel<T, NT, RPT>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream));
+    rlhip_ws_release(c, mark);
+    c->path_count[9]++;
+    return 1;
+}
+template int lunp_blk<double>(rlhip_ctx*, int64_t, double*, int64_t, double*);
+template int lunp_blk<float>(rlhip_ctx*, int64_t, float*, int64_t, float*);
 
 }  // namespace rlhip

@@ -1,4 +1,5 @@
-import sys, torch
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from randlapack_amd import device as d
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 2048

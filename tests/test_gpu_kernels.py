@@ -664,7 +664,7 @@ def test_geqrf_block_pipelined_matches_lapack(ctx, m, n, dt):
     assert np.linalg.norm(A.astype(np.float64) - Qref.astype(np.float64) @ R.astype(np.float64)) <= 30 * eps * np.linalg.norm(A) * np.sqrt(k)
 
 
-@pytest.mark.parametrize("m,n,nb", [(60, 12, 12), (500, 64, 32), (2000, 256, 256), (300, 100, 40)])
+@pytest.mark.parametrize("m,n,nb", [(60, 12, 12), (500, 64, 32), (2000, 256, 256), (300, 100, 40), (2500, 2048, 2048), (1500, 1003, 1003)])
 def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
     import torch
 
@@ -674,8 +674,10 @@ def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
     Qd = d.cm_from_numpy(Q)
     Td = d.cm_zeros(nb, n)
     Dd = torch.zeros(n, dtype=torch.float64, device="cuda")
+    lu0 = ctx.path_count(9)
     assert ctx.lib.rlhip_orhr_col_f64(ctx.h, m, n, nb, Qd.data_ptr(), m, Td.data_ptr(), nb, Dd.data_ptr()) == 0
     ctx.sync()
+    assert ctx.path_count(9) == lu0 + 1                       # the sign-modified LU ran as one block-pipelined launch (qr_blk.hip)
     info, Ao, To, Do = orc.lapack_orhr_col(Q, nb)
     assert info == 0
     np.testing.assert_array_equal(Dd.cpu().numpy(), Do)                               # sign vector: exact
