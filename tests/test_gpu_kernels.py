@@ -600,6 +600,19 @@ def test_getrf_singular_reports_info_and_luqrcp_piv(ctx):
         a = ipiv[i] - 1
         ref[a], ref[i] = ref[i], ref[a]
     np.testing.assert_array_equal(J.cpu().numpy(), ref)
+    # at sketch size (the LDS-resident walk of lu.hip): positions beyond the sketch dimension chosen repeatedly, pivots inside it, identities
+    rng = np.random.default_rng(11)
+    for sd, cols in ((2048, 50000), (2048, 2048), (700, 701), (2048, 2100)):
+        ipiv = np.array([rng.integers(i, cols) if rng.random() < 0.8 else i for i in range(sd)], dtype=np.int64) + 1
+        ipiv[5:40] = np.minimum(cols, 2077)                                      # the same far row picked again and again
+        ipiv = np.maximum(ipiv, np.arange(1, sd + 1))
+        J = torch.zeros(cols, dtype=torch.int64, device="cuda")
+        assert ctx.lib.rlhip_luqrcp_piv(ctx.h, sd, cols, torch.from_numpy(ipiv).cuda().data_ptr(), J.data_ptr()) == 0
+        ref = np.arange(1, cols + 1)
+        for i in range(min(sd, cols)):
+            a = ipiv[i] - 1
+            ref[a], ref[i] = ref[i], ref[a]
+        np.testing.assert_array_equal(J.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("m,n", [(60, 12), (500, 64), (2000, 256), (300, 300), (64, 200), (512, 4096)])
