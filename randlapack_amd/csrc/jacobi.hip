@@ -438,16 +438,21 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     // consumed: one round trip to the uncached buffer instead of PER_T dependent ones (the first version took ~11 us per hand-over, two
     // thirds of every step; rocprof timeline in DESIGN.md 4.3).
     constexpr int PER_T = (JB * JMT + NT - 1) / NT;
+    // (write-through stores issued from inline asm: in front of every agent-scope atomic store of such a loop hipcc places an
+    // s_waitcnt vmcnt(0), i.e. the PER_T stores of a thread went out one acknowledged round trip at a time -- most of the 4.5 us a hand-over took)
     auto publish = [&](int half, int blk) {            // LDS half -> exchange buffer
         unsigned long long* dst = g.X + (size_t)blk * JB * m;
+        unsigned long long val[PER_T];
 #pragma unroll
         for (int q = 0; q < PER_T; ++q) {
             const int e = tid + q * NT;
-            if (e < JB * m) {
-                const int r = e % m, c = e / m;
-                __hip_atomic_store(dst + e, (unsigned long long)__double_as_longlong((double)Xs[(half * JB + c) * JMT + r]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const int ee = (e < JB * m) ? e : 0;
+            val[q] = (unsigned long long)__double_as_longlong((double)Xs[(half * JB + ee / m) * JMT + ee % m]);
+        }
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+            const int e = tid + q * NT;
+            if (e < JB * m) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst + e), "v"(val[q]) : "memory");
         }
     };
     auto fetch2 = [&](bool f0, int blk0, bool f1, int blk1) {      // both halves in ONE batch of loads
@@ -485,6 +490,7 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
             const int want[2] = {P, Q};
             ++gs;
             const bool out0 = held[0] != want[0], out1 = held[1] != want[1];
+            __builtin_amdgcn_s_waitcnt(0x0F70);                         // (vmcnt(0), said to the compiler: no conservative wait between the two hand-overs below)
             if (out0) publish(0, held[0]);
             if (out1) publish(1, held[1]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the block's words have been acknowledged ...
