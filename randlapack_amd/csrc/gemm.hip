@@ -287,6 +287,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(
                     int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
                     if (i < g.M && j < g.N) out[i + j * g.M] = acc[t][u][r];
                 }
+    } else if (g.beta != T(0)) {
+        // C is read for one row of 16 x 16 tiles at a time, ALL of those loads before the first use (clamped indices keep them unconditional):
+        // written as `v += beta * C[..]` inside the store loop, every element was its own load -> s_waitcnt vmcnt(0) -> store round trip,
+        // 64 in a row per thread (15-20 us of every accumulating launch, e.g. the rank-32 updates of the LU)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            T cv[TN][4];
+            const int64_t i = m0 + wm0 + 16 * t + fr;
+            const int64_t ic = i < g.M ? i : g.M - 1;
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
+                    cv[u][r] = g.C[ic + (j < g.N ? j : g.N - 1) * g.ldc];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
+                    if (i < g.M && j < g.N && !(g.tri && i > j))     // tri: LAPACK uplo contract, strictly lower part untouched
+                        g.C[i + j * g.ldc] = g.alpha * acc[t][u][r] + g.beta * cv[u][r];
+                }
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < TM; ++t)
@@ -296,11 +322,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(
                 for (int r = 0; r < 4; ++r) {
                     int64_t i = m0 + wm0 + 16 * t + fr;
                     int64_t j = n0 + wn0 + 16 * u + Mma<T>::drow(lane, r);
-                    if (i < g.M && j < g.N && !(g.tri && i > j)) {   // tri: LAPACK uplo contract, strictly lower part untouched
-                        T v = g.alpha * acc[t][u][r];
-                        if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
-                        g.C[i + j * g.ldc] = v;
-                    }
+                    if (i < g.M && j < g.N && !(g.tri && i > j)) g.C[i + j * g.ldc] = g.alpha * acc[t][u][r];
                 }
     }
 }
