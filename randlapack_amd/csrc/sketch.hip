@@ -346,10 +346,17 @@ __global__ __launch_bounds__(256, (NR == 5) ? 4 : 1) void saso_apply_kernel(int6
             int32_t p0[NR], len[NR];
             int4 ea[NR], eb[NR];
 #pragma unroll
+            for (int q = 0; q < NR; ++q) {                       // (clamped, not branched: written as `if (r < d) load`, hipcc gives every bound its own
+                const int64_t r = r_base + tid + 256 * q;        //  branch with an s_waitcnt vmcnt(0) behind it -- NR dependent round trips per block)
+                const int64_t rc = (r < d) ? r : d - 1;
+                const int32_t a0 = ptr[t * d + rc], a1 = ptr[t * d + rc + 1];
+                p0[q] = a0; len[q] = a1 - a0;
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // all NR bounds in flight before the first one is used
+#pragma unroll
             for (int q = 0; q < NR; ++q) {
-                const int64_t r = r_base + tid + 256 * q;
-                p0[q] = 0; len[q] = 0;
-                if (r < d) { p0[q] = ptr[t * d + r]; len[q] = ptr[t * d + r + 1] - p0[q]; }
+                const bool ok = (r_base + tid + 256 * q) < d;
+                p0[q] = ok ? p0[q] : 0; len[q] = ok ? len[q] : 0;
             }
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
