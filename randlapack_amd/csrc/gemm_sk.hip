@@ -362,7 +362,22 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
             // fp32 MC image: the lane's four fragments are the four CONSECUTIVE rows 4 fr .. 4 fr + 3 -> one 16-byte access per column
             // (16 lanes cover 256 contiguous bytes of a column of C) instead of four 4-byte accesses 16 bytes apart
             const int64_t i0 = m0 + wm0 + 4 * fr;
-            if (whole) {
+            if (whole && !g.tri && g.beta != T(0) && i0 < m_lim && (g.ldc & 3) == 0 && (((uintptr_t)g.C) & 15) == 0) {
+                // accumulating tile (BQRRP's C -= V W): the 16-byte pieces of C are read four at a time BEFORE the first is used -- written as
+                // `v += beta * C[..]` inside the store loop every piece was its own load -> s_waitcnt vmcnt(0) -> store round trip to HBM, sixteen in
+                // a row per thread with the matrix pipe idle behind them (~7 % of a K = 2048 tile)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f4_t cv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[r] = *reinterpret_cast<const f4_t*>(g.C + i0 + (n0 + wn0 + 16 * u + S::ccol(fk, r)) * g.ldc);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<f4_t*>(g.C + i0 + (n0 + wn0 + 16 * u + S::ccol(fk, r)) * g.ldc) =
+                            f4_t{acc[0][u][r], acc[1][u][r], acc[2][u][r], acc[3][u][r]} * g.alpha + g.beta * cv[r];
+                }
+            } else if (whole) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -393,7 +408,29 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                             f4_t{acc[0][u][r], acc[1][u][r], acc[2][u][r], acc[3][u][r]};
             }
         } else
-        if (whole) {
+        if (whole && g.beta != T(0)) {
+            // accumulating tile: the sixteen entries of a fragment row are read together (entries that are not written read C[0]), then stored
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                T cv[4][4];
+                int64_t off[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int64_t i, j;
+                        const bool ok = sk_cpos(td, g.tri, crow(x), wn0 + 16 * u + S::ccol(fk, r), i, j) && i < m_lim;
+                        off[u][r] = ok ? i + j * g.ldc : (int64_t)-1;
+                        cv[u][r] = g.C[ok ? off[u][r] : 0];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (off[u][r] >= 0) g.C[off[u][r]] = g.alpha * acc[x][u][r] + g.beta * cv[u][r];
+            }
+        } else if (whole) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -402,9 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
                     for (int r = 0; r < 4; ++r) {
                         int64_t i, j;
                         if (!sk_cpos(td, g.tri, crow(x), wn0 + 16 * u + S::ccol(fk, r), i, j) || i >= m_lim) continue;
-                        T v = g.alpha * acc[x][u][r];
-                        if (g.beta != T(0)) v += g.beta * g.C[i + j * g.ldc];
-                        g.C[i + j * g.ldc] = v;
+                        g.C[i + j * g.ldc] = g.alpha * acc[x][u][r];
                     }
         } else {
             T* out = g.slab + (2 * w + (unit != first_tile ? 1 : 0)) * (int64_t)SLAB_ELEMS;
