@@ -137,9 +137,11 @@ def test_potrf_upper(ctx, n):
     Gm = X.T @ X
     Gd = d.cm_from_numpy(Gm)
     assert ctx.potrf(n, Gd, n) == 0
-    R = np.triu(d.cm_to_numpy(Gd))
+    got = d.cm_to_numpy(Gd)
+    R = np.triu(got)
     assert relerr(R.T @ R, Gm) < 1e-13
     assert (np.diag(R) > 0).all()
+    assert np.array_equal(np.tril(got, -1), np.tril(Gm, -1))               # LAPACK's uplo contract: the strictly lower triangle is not touched
 
 
 def test_potrf_reports_first_bad_minor(ctx, orc):
