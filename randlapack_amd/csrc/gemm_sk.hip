@@ -206,13 +206,13 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         const int c = wid + 8 * h;
         if constexpr (A_KC) {
             const int r = 8 * c + (lane >> 3), q = lane & 7;
-            const int re = (r < m_rem) ? r : (m_rem > 0 ? m_rem - 1 : 0);
+            const int re = (m_rem > 0) ? r % m_rem : 0;                               // (spread over the valid rows: 96 lanes on ONE line would serialise in the texture path)
             a_src_rag[h] = (int64_t)re * g.lda + EPP * (q ^ ((r >> 1) & 7));
         } else if constexpr (F64) {
-            const int ro = (2 * lane < m_rem) ? 2 * lane : (m_rem > 1 ? m_rem - 2 : 0);
+            const int ro = (m_rem > 1) ? (2 * lane) % m_rem : 0;                      // (m_rem is even here)
             a_src_rag[h] = (int64_t)c * g.lda + ro;
         } else {
-            const int ro = (4 * (lane & 31) < m_rem) ? 4 * (lane & 31) : (m_rem > 3 ? m_rem - 4 : 0);
+            const int ro = (m_rem > 3) ? (4 * (lane & 31)) % m_rem : 0;               // (m_rem is a multiple of 4 here)
             a_src_rag[h] = (int64_t)(2 * c + (lane >> 5)) * g.lda + ro;
         }
     }
