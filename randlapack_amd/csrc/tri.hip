@@ -376,11 +376,34 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t row = ((int64_t)blockIdx.x * NW + wid) * 16 + fr;
     const bool live = row < m;
-    T* __restrict__ Brow = B + (live ? row : m - 1);            // clamped: loads unconditional, dead rows store to a scratch line
     // tile element (j, r) of this lane sits in column 16 j + CS * r + CL * fk: a wave-uniform column (scalar base address) plus the lane
     // offset `loff` (32 bits: the host takes this path only while 4 ldb + m < 2^28)
     constexpr int CS = M::CS, CL = M::CL;
     const unsigned loff = (unsigned)((live ? row : m - 1) + (int64_t)CL * fk * ldb);
+    // X operand of a k-step: column 4 q + fk of the panel.  A BYTE offset (< 2^31, see the host) so that uniform pointer + zero-extended lane
+    // offset is an address the scalar-base form of global_load takes: no per-lane 64-bit pointers to keep (hipcc spilled and reloaded them)
+    const unsigned xoffb = (unsigned)(((live ? row : m - 1) + (int64_t)fk * ldb) * (int64_t)sizeof(T));
+    // The loads are issued from inline asm in that form and tracked by the kernel's own counted waits (they are the oldest requests of a
+    // step, the P panel pieces the youngest, so `s_waitcnt vmcnt(P)` at the top of the next step covers them).  Left to hipcc the four
+    // lane pointers lived in scratch and every panel step reloaded each one behind an s_waitcnt vmcnt(0) -- which also drained the panel
+    // pieces in flight -- and the register copy xc = xn at the end of a step forced one more full drain: ~0.9 us of a 4.4 us step.
+    auto xissue = [&](const T* ubase, T (&dst)[NQ]) {
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+            const T* bq = ubase + 4 * qq * ldb;                 // uniform
+#ifdef RLHIP_TF_NOXASM
+            dst[qq] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(bq) + xoffb);
+#else
+            if constexpr (sizeof(T) == 8) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(dst[qq]) : "v"(xoffb), "s"(bq) : "memory");   // (s_nop: the base may have been written by the instruction before -- hipcc does not look into asm for that hazard)
+            else asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(dst[qq]) : "v"(xoffb), "s"(bq) : "memory");
+#endif
+        }
+    };
+    // after a counted wait: the registers the asm loads filled are defined from here on (nothing hipcc scheduled earlier may stand in for them)
+    auto xlanded = [&](T (&v)[NQ]) {
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) asm volatile("" : "+v"(v[qq]));
+    };
     // raw right-hand-side element of this lane in tile (jj, r) of the 256-block starting at column cb0
     auto load_raw = [&](int64_t cb0, int jj, int r) -> T {
         if constexpr (!OOP) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
@@ -393,7 +416,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         }
     };
     // per-lane source offsets (elements, relative to the panel's first element) and LDS byte offsets of this wave's DMA pieces
-    int poff[P], pdst[P];
+    unsigned poff[P];                                           // BYTE offsets, unsigned 32-bit: with the uniform panel pointer they make a scalar-base + lane-offset address
+    int pdst[P];                                                // (kept as 64-bit element offsets hipcc spilled them and reloaded each one, behind an s_waitcnt vmcnt(0), in every panel step)
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         int c = wid + NW * i;
@@ -402,14 +426,14 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         const int pr = e / FSTR;
         int pc = e - pr * FSTR;
         if (pc >= 256) pc = 0;                                  // padding columns: any valid address
-        poff[i] = (int)(pr * n_pad + pc);
+        poff[i] = (unsigned)((pr * n_pad + pc) * (int64_t)sizeof(T));
         pdst[i] = c * 1024;
     }
     const int dsrc = (wid % DCH) * EPC + lane * EPL, ddst = (wid % DCH) * 1024;
     auto issue_panel = [&](const T* base, int buf) {            // P pieces of the panel whose first element is `base` into ring stage `buf`
 #pragma unroll
         for (int i = 0; i < P; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(base + poff[i]), (lds_void_t*)(tf_smem + buf * HPB + pdst[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(base) + poff[i]), (lds_void_t*)(tf_smem + buf * HPB + pdst[i]), 16, 0, 0);
     };
     auto issue_dinv = [&](int64_t sblk) {                       // ONE piece per wave: inverse of global diagonal sub-block sblk -> stage sblk & 1
         __builtin_amdgcn_global_load_lds((glb_void_t*)(Dinv + sblk * 1024 + dsrc), (lds_void_t*)(sD + (int)(sblk & 1) * DBY + ddst), 16, 0, 0);
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     // fragments of the next group fetched before the MFMAs of the current one are queued; `side()` runs behind the first group.
     auto panel_mma = [&](auto jlo_c, acc_t (&acc)[16], const T* sU, const T (&y)[NQ], auto&& side) {
         constexpr int JLO = decltype(jlo_c)::value;
-        constexpr int NTL = 16 - JLO, TOT = NQ * NTL, G = 8, NG = (TOT + G - 1) / G;
+        constexpr int NTL = 16 - JLO, TOT = NQ * NTL, G = 4, NG = (TOT + G - 1) / G;
         const T* su = sU + fk * FSTR + fr;
         T fa[G], fb[G];
 #pragma unroll
@@ -470,7 +494,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     for (int q = 0; q < NQ; ++q) { xc[q] = T(0); xn[q] = T(0); }
     if (J0 > K0blk) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];
+        for (int q = 0; q < NQ; ++q) xc[q] = T(0);
+        xissue(B + (int64_t)K0blk * 256 * ldb, xc);
     }
     for (int J = J0; J < J1; ++J) {
         const int64_t col0 = (int64_t)J * 256;
@@ -481,28 +506,31 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         for (int j = 0; j < 16; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[j][r] = alpha * acc[j][r];
-        const T* xp = Brow + ((int64_t)K0blk * 256 + fk) * ldb;          // X[row][first column of panel t + fk]
+        const T* xp = B + (int64_t)K0blk * 256 * ldb;                    // first column of panel t (uniform); the lane adds xoff = row + fk * ldb
         const int64_t xstep = (int64_t)HPR * ldb;
         // ---- blocks left of the diagonal block: X from memory, all 16 tiles
-        for (int t = 0; t < ntoff; ++t) {
+        // two steps per trip: the operand registers alternate (xc: even panels, xn: odd panels; ntoff is a multiple of 16), no copies.
+        // (A rendezvous in the MIDDLE of a panel with the next panel's first fragments prefetched across the boundary, as in the stream-K
+        // GEMM, was built and measured: 4.18 us per panel step either way -- the boundary bubble is not what the step loses.)
+        auto pstep = [&](int t, T (&cur)[NQ], T (&nxt)[NQ]) {
             // panel t and the X operands of this step have landed; the P pieces of panel t + 1 (issued one step ago) may still fly.
             // (t == 0: the X operands were the LAST thing requested before this block, so everything must have landed)
             if (t == 0) wait_vm<0>(); else wait_vm<P>();
+            xlanded(cur);
             __builtin_amdgcn_s_barrier();
             const int nring = (ring + 2 >= RING) ? ring + 2 - RING : ring + 2;
             const T* nbase = panel_ptr(J, t + 2);               // (always inside this block: the diagonal panels follow)
             xp += xstep;
             const bool more_x = (t + 1 < ntoff);
-            panel_mma(IntC<0>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), xc, [&]() {
-                if (more_x) {
-#pragma unroll
-                    for (int qq = 0; qq < NQ; ++qq) xn[qq] = xp[4 * qq * ldb];
-                }
+            panel_mma(IntC<0>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), cur, [&]() {
+                if (more_x) xissue(xp, nxt);
                 issue_panel(nbase, nring);
             });
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) xc[q] = xn[q];
             ring = (ring + 1 >= RING) ? 0 : ring + 1;
+        };
+        for (int t = 0; t < ntoff; t += 2) {
+            pstep(t, xc, xn);
+            pstep(t + 1, xn, xc);
         }
         TF_MARK(0)
         // ---- diagonal block: right-looking over the 32-column sub-blocks, X in registers
@@ -576,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         if (has_next) {
             issue_dinv((int64_t)(J + 1) * 8);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) xc[q] = Brow[((int64_t)K0blk * 256 + 4 * q + fk) * ldb];     // the next block always has blocks to its left
+            xissue(B + (int64_t)K0blk * 256 * ldb, xc);                                               // the next block always has blocks to its left
         }
     }
 #ifdef RLHIP_TF_PROF
