@@ -603,7 +603,6 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         TF_MARK(15)
         if (has_next) {
             issue_dinv((int64_t)(J + 1) * 8);
-#pragma unroll
             xissue(B + (int64_t)K0blk * 256 * ldb, xc);                                               // the next block always has blocks to its left
         }
     }
