@@ -405,14 +405,26 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         for (int qq = 0; qq < NQ; ++qq) asm volatile("" : "+v"(v[qq]));
     };
     // raw right-hand-side element of this lane in tile (jj, r) of the 256-block starting at column cb0
+    // OOP: the source column of every column of a 256-block is staged in LDS once per block (identity without a pivot vector), so a tile
+    // element is ONE lane-indexed LDS read + ONE global load.  (With four scalar loads of the pivot entries and a per-lane choice per element
+    // hipcc built ~390 branches with an s_waitcnt vmcnt(0) in most of them: the eight loads of a retired tile went out one HBM round trip at a time.)
+    __shared__ long long s_perm[OOP ? 2 : 1][OOP ? 256 : 1];
+    auto fill_perm = [&](int Jb) {
+        if constexpr (OOP) {
+            if (threadIdx.x < 256) {
+                int64_t cidx = (int64_t)Jb * 256 + threadIdx.x;
+                if (cidx > n - 1) cidx = n - 1;
+                s_perm[Jb & 1][threadIdx.x] = perm ? (long long)(perm[cidx] - pbase) : (long long)cidx;
+            }
+        }
+    };
+    const int64_t rowc = live ? row : m - 1;
+    // raw right-hand-side element of this lane in tile (jj, r) of the 256-block starting at column cb0
     auto load_raw = [&](int64_t cb0, int jj, int r) -> T {
         if constexpr (!OOP) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
         else {
-            const int64_t cb = cb0 + 16 * jj + CS * r;                  // wave-uniform
-            int64_t p0 = cb, p1 = cb + CL, p2 = cb + 2 * CL, p3 = cb + 3 * CL;
-            if (perm) { p0 = perm[p0] - pbase; p1 = perm[p1] - pbase; p2 = perm[p2] - pbase; p3 = perm[p3] - pbase; }
-            const int64_t mc = (fk == 0) ? p0 : (fk == 1) ? p1 : (fk == 2) ? p2 : p3;
-            return Bsrc[mc * ldsrc + (live ? row : m - 1)];
+            const long long mc = s_perm[(int)(cb0 >> 8) & 1][16 * jj + CS * r + CL * fk];
+            return Bsrc[mc * ldsrc + rowc];
         }
     };
     // per-lane source offsets (elements, relative to the panel's first element) and LDS byte offsets of this wave's DMA pieces
@@ -481,6 +493,10 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     T xc[NQ], xn[NQ];
     int ring = 0;                                               // ring stage of the panel the next step consumes
     // ---- prologue: the first two panels, the first inverse, the first tile, the first X operands
+    if constexpr (OOP) {
+        fill_perm(J0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     issue_panel(panel_ptr(J0, 0), 0);
     issue_panel(panel_ptr(J0, 1), 1);
     issue_dinv((int64_t)J0 * 8);
@@ -501,6 +517,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         const int64_t col0 = (int64_t)J * 256;
         const int ntoff = PPB * (J - K0blk);                    // panels of the blocks left of the diagonal block
         const bool has_next = (J + 1 < J1);
+        if (has_next) fill_perm(J + 1);                          // read from the third diagonal step on: many rendezvous later
         // the raw tile (loaded in the prologue or behind the previous block's diagonal steps) -> alpha * B_J
 #pragma unroll
         for (int j = 0; j < 16; ++j)
