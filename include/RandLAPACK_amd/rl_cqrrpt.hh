@@ -138,15 +138,18 @@ public:
         // reads W and writes Q into A.  Same arithmetic per entry as col_swap + in-place trsm; saves the 2 x 8 m n bytes of the
         // separate permutation pass (C3: 3.9 ms of 79).  `fold_pivoting = false` (or a rank-deficient sketch) keeps the reference's
         // statement order below.
+        // The scratch matrix has its own leading dimension: with ldw = m a column stride that is a multiple of 4 KiB (m = 2^20: 8 MiB)
+        // puts the 384 column pieces a Gram tile reads per K-step on the same memory channels -- 20.7 against 18.7 ms for C3's Gram matrix.
         T* W = nullptr;
-        if (fold_pivoting && k == n && m >= 16384) W = ws.try_alloc<T>(m * n);   // no room for a second m x n matrix: the in-place order below
+        const int64_t ldw = (m % 512 == 0) ? m + 32 : m;
+        if (fold_pivoting && k == n && m >= 16384) W = ws.try_alloc<T>(ldw * n);   // no room for a second m x n matrix: the in-place order below
         if (W) {
             auto t4 = stamp();
             for (int64_t i = 0; i < k; ++i)                                                                 // :296-301 diag_is_nonzero
                 if (diag[i] == (T)0) { util::col_swap(m, n, k, A, lda, J, q); return 1; }                   // (A leaves permuted, as in the reference)
-            blas::trsm_gather(Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, J, W, m, q);                     // :288 + :302
+            blas::trsm_gather(Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, J, W, ldw, q);                   // :288 + :302
             auto t5 = stamp();
-            blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, W, m, (T)0.0, R, ldr, q);   // :310
+            blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, W, ldw, (T)0.0, R, ldr, q);   // :310
             if (q.world() > 1) {
                 T* G = ws.alloc<T>(k * k);
                 lapack::laset(MatrixType::General, k, k, (T)0, (T)0, G, k, q);
@@ -168,9 +171,9 @@ public:
             }
             rank = new_rank;                                                                                 // :335
             if (new_rank == n) {
-                blas::trsm_gather(Diag::NonUnit, m, n, (T)1.0, R, ldr, W, m, (int64_t const*)nullptr, A, lda, q);   // :338, W -> A
+                blas::trsm_gather(Diag::NonUnit, m, n, (T)1.0, R, ldr, W, ldw, (int64_t const*)nullptr, A, lda, q);   // :338, W -> A
             } else {       // the Cholesky factorization stopped early: A takes A_pre and the leading columns are solved in place, as in the reference
-                lapack::lacpy(MatrixType::General, m, n, W, m, A, lda, q);
+                lapack::lacpy(MatrixType::General, m, n, W, ldw, A, lda, q);
                 blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, new_rank, (T)1.0, R, ldr, A, lda, q);
             }
             auto t6 = stamp();
