@@ -26,17 +26,19 @@ def cqrrpt(steps):
     # triangular solve W = (A P) inv(R_sk) / Q = W inv(R_chol), m n^2 = 1.1e12 flop per launch; timed alone with HIP events
     ctx.fill_dense(A, m, n, key=(3, 0)); U = d.cm_empty(n, n); ctx.fill_dense(U, n, n, key=(2, 0))
     ctx.lib.rlhip_add_diag_f64(ctx.h, n, 40.0, U.data_ptr(), n)
-    W = d.cm_empty(m, n); Jp = torch.arange(n, 0, -1, dtype=torch.int64, device="cuda")
-    ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, m); ctx.sync(); ctx.timer_start()
-    for _ in range(3): ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, m)
+    # (W has the padded leading dimension CQRRPT gives its scratch matrix: m + 32 when m is a multiple of 512)
+    ldw = m + 32 if m % 512 == 0 else m
+    W = torch.empty((n, ldw), dtype=torch.float64, device="cuda"); Jp = torch.arange(n, 0, -1, dtype=torch.int64, device="cuda")
+    ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, ldw); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, ldw)
     kms = ctx.timer_stop_ms() / 3
     ach = 1.0 * m * n * n / (kms * 1e-3) / 1e12
-    del W
-    # the Gram kernel (syrk, upper tiles: 1.1e12 flop), reported beside it
+    # the Gram kernel (syrk of W, upper tiles: 1.1e12 flop), reported beside it
     G = d.cm_zeros(n, n)
-    ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n); ctx.sync(); ctx.timer_start()
-    for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n)
+    ctx.syrk("U", "T", n, m, 1.0, W, ldw, 0.0, G, n); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, W, ldw, 0.0, G, n)
     gms = ctx.timer_stop_ms() / 3
+    del W
     traffic = None
     try:
         import glob
