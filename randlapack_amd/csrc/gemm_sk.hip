@@ -577,7 +577,12 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
         hipLaunchKernelGGL((gemm_sk_kernel<T, false>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
     }
     RLHIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, 16), dim3(256), 0, c->stream, g, P / g.gs);
+    // (few tiles cut into many slabs -- the Gram matrix of a 200000 x 256 factor: 2 tiles x 128 slabs -- get more slices per tile: with 16 the
+    // 32 blocks of that fix-up took as long as the product itself, 0.42 ms)
+    int64_t fy = 2048 / ntiles;
+    fy = fy < 16 ? 16 : (fy > 128 ? 128 : fy);
+    while (SLAB_ELEMS % fy) --fy;
+    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, (unsigned)fy), dim3(256), 0, c->stream, g, P / g.gs);
     RLHIP_LAUNCH_CHECK();
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);
