@@ -2,6 +2,7 @@
 # re-measure every committed line under profiles/ with the current build (run on the GPU box; outputs under gpurun_out/refresh/).
 # usage: bash scripts/refresh_profiles.sh <round tag, e.g. round3>      (every number quoted in DESIGN.md / README.md comes from a file this writes)
 # other scripts kept here: stress_matrix_types.py, hqrrp_tall_check.py, trsm_bench.py, saso_time.py, linops_time.py, sk_group_ab.py
+#   qrcp_wide_parts.py + lu_only.py (per-part timing of BQRRP's qrcp_wide step / the LU alone: DESIGN 4.10), ld_ab.py (leading-dimension A/B at C3's shape: DESIGN 4.10)
 R=$GRAFT_REPO_ROOT
 TAG=${1:-round3}
 export PYTHONPATH=$R
