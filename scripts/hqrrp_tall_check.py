@@ -1,5 +1,7 @@
 """hqrrp with pivoted panels at a size where the tall-panel split (pivots from the QRCP of the panel's R factor) is active: residual,
 orthogonality and |diag R| against the singular values, with the split on and off (RLHIP_HQRRP_TALL_PANEL=0 in a second process)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import os, sys, numpy as np, torch
 from randlapack_amd import device as d
 from benchmarks import _common as c

@@ -1,5 +1,7 @@
 """Timing of the sparse-operator kernels and the linop QR drivers at benchmark scale (tall sparse A, bench_CQRRT_linops sizes
 scaled to one MI355X).  usage: python scripts/linops_time.py [m n nnz_per_row]"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import sys
 import time
 

@@ -1,4 +1,6 @@
 """Validity sweep: every pivoted-QR driver on the reference's hard test matrices (error-analysis set + adversarial)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import numpy as np, torch, itertools
 from randlapack_amd import device as d
 import oracle, sys
