@@ -476,7 +476,11 @@ int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev)
     // every workgroup waits for flags raised by others: the grid must be co-resident (cooperative launch: checked against the device's
     // occupancy and gang-scheduled)
     void* kargs[] = {(void*)&g};
-    RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qr_blk_kernel<T, NT, RPT, IW>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream));
+    if (hipLaunchCooperativeKernel((const void*)qr_blk_kernel<T, NT, RPT, IW>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream) != hipSuccess) {
+        (void)hipGetLastError();                           // the grid cannot be made resident here (shared or partitioned device): the caller's other routes
+        rlhip_ws_release(c, mark);
+        return 0;
+    }
 #ifdef RLHIP_QB_PROF
     {
         unsigned long long pf[3];
@@ -510,7 +514,11 @@ int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
     if (!g.flag) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
     RLHIP_CHECK(hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream));
     void* kargs[] = {(void*)&g};
-    RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)lunp_blk_kernel<T, NT, RPT>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream));
+    if (hipLaunchCooperativeKernel((const void*)lunp_blk_kernel<T, NT, RPT>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        rlhip_ws_release(c, mark);
+        return 0;
+    }
     rlhip_ws_release(c, mark);
     c->path_count[9]++;
     return 1;
