@@ -1,6 +1,6 @@
-"""The C++ object layer used the way a caller of the reference uses it (tests/cxx/test_qb_caller.cpp = the reference's QB test body,
-test/comps/test_qb.cc:126-176, with only the include, the allocations and one stream sync changed): built with plain g++ against
-librlhip.so by `make -C tests/cxx` (__graft_entry__.build()), run on the device here."""
+"""The C++ object layer used the way a caller of the reference uses it: tests/cxx/test_qb_caller.cpp (QB / RSVD object graph) and
+tests/cxx/test_gpu_classes_caller.cpp (the two device classes) are user programs written from scratch against RandLAPACK_amd.hh,
+built with plain g++ against librlhip.so by `make -C tests/cxx` (__graft_entry__.build()) and run on the device here."""
 import subprocess
 from pathlib import Path
 
@@ -21,13 +21,15 @@ def test_cxx_caller_program_builds_and_links():
 
 
 @pytest.mark.gpu
-def test_reference_qb_test_body_passes_on_the_device():
+def test_qb_rsvd_object_graph_from_a_cxx_caller():
+    """tests/cxx/test_qb_caller.cpp: planted-rank QB at several block sizes and stabilisers, the tolerance exit, RSVD through the
+    abstract bases in double and float, argument errors -- every check is made by the program itself"""
     exe = CXX / "test_qb_caller"
     if not exe.exists():
         subprocess.run(["make", "-C", str(CXX), "-s"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
-    assert r.stdout.count("FRO NORM OF A - QB") == 3
+    assert r.stdout.count("\nQB ") + r.stdout.startswith("QB ") == 5 and r.stdout.count("RSVD ") == 3 and "3 of 3 invalid calls raised" in r.stdout
 
 
 def test_gpu_class_caller_builds_and_links():
