@@ -339,10 +339,14 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
  * 2 fused MFMA trsm block kernel (tri.hip), 3 row-per-lane substitution trsm sub-block, 4 fused out-of-place trsm (rlhip_trsm_gather),
  * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip), 6 persistent one-launch Jacobi sweeps (jacobi.hip),
  * 7 column-at-a-time LU panel of a matrix taller than the resident register kernels hold (lu.hip), 8 register-resident block-pipelined
- * Householder QR of a sketch-sized matrix (qr_blk.hip), 9 its sign-modified LU twin inside orhr_col.  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
+ * Householder QR of a sketch-sized matrix (qr_blk.hip), 9 its sign-modified LU twin inside orhr_col, 10 the Gram route of the device SVD
+ * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);
+/* diagnostic: keep `blocks` workgroups busy for `usec` microseconds (mode 0 sleeping, 1 fp64 FMA chain, 2 fp64 MFMA stream), on the context's
+ * stream (side = 0) or on a second stream beside it (side = 1); scripts/dvfs_probe.py maps the part's clock response to load with it */
+int rlhip_dvfs_burn(rlhip_ctx* ctx, int blocks, int mode, int usec, int side);
 /* streaming-read bandwidth microbenchmark over `bytes` of device memory (GB/s) */
 int rlhip_hbm_read_peak(rlhip_ctx* ctx, const void* buf, size_t bytes, double* gbps_host);
 

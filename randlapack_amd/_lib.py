@@ -105,6 +105,7 @@ SIGNATURES = {
     "rlhip_luqrcp_piv": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_path_count": (c_i64, [c_vp, c_int]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
+    "rlhip_dvfs_burn": (c_int, [c_vp, c_int, c_int, c_int, c_int]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),
 }
 HOOK = C.CFUNCTYPE(c_int, c_vp, c_vp, c_i64, c_int)

@@ -178,6 +178,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -581,7 +582,45 @@ __global__ __launch_bounds__(256) void hbm_read_kernel(const double2* __restrict
     }
     if (acc == 12345.678) out[0] = acc;
 }
+// keeps `blockDim.x / 64` waves per workgroup busy for `ticks` of the 100 MHz wall clock: mode 0 s_sleep, 1 fp64 FMA chain, 2 fp64 MFMA stream
+__global__ __launch_bounds__(256) void dvfs_burn_kernel(int mode, long long ticks, double* out) {
+    const long long t0 = wall_clock64();
+    d4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9, z = 0.5;
+    while (wall_clock64() - t0 < ticks) {
+        if (mode == 0) {
+            __builtin_amdgcn_s_sleep(64);
+        } else if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) z = fma(z, x, y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a3, 0, 0, 0);
+            }
+        }
+    }
+    d4_t s = a0 + a1 + a2 + a3;
+    if (s[0] + z == 12345.678) out[0] = s[1];
+}
 }  // namespace
+
+// diagnostic: occupy `blocks` workgroups of 256 threads for `usec` microseconds (mode 0 sleeping, 1 fp64 FMA, 2 fp64 MFMA) on the context's
+// stream (side = 0) or on a second stream beside it (side = 1).  scripts/dvfs_probe.py uses it to map how the part's clock follows the load.
+extern "C" int rlhip_dvfs_burn(rlhip_ctx* c, int blocks, int mode, int usec, int side) {
+    if (blocks <= 0 || usec <= 0) return 0;
+    hipStream_t st = c->stream;
+    if (side) {
+        if (!c->side) RLHIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        st = c->side;
+    }
+    hipLaunchKernelGGL(dvfs_burn_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mode, (long long)usec * 100, (double*)c->d_mail + 32);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int64_t rlhip_path_count(rlhip_ctx* c, int which) {
     return (c && which >= 0 && which < 12) ? c->path_count[which] : -1;

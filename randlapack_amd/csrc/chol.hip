@@ -259,6 +259,20 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
     }
 }
 
+// The one-workgroup factorization ENQUEUED only: LAPACK's info (0, or the 1-based index of the first non-positive pivot) goes to the DEVICE
+// word `info_dev`, which later kernels of the stream may test; nothing is read back.  n <= 448 only (returns 1 otherwise: not available).
+template <typename T>
+int potrf_upper_enqueue(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_dev) {
+    if (n <= 0 || n > PS_MAXN || lda < n) return 1;
+    const size_t smem = (size_t)(32 * 33 + 64 + (size_t)(n + 16) * PS_LD) * sizeof(T);
+    RLHIP_FUNC_LDS(c, potrf_small_kernel<T>, 150 * 1024);
+    hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, info_dev, 0);
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+template int potrf_upper_enqueue<double>(rlhip_ctx*, int64_t, double*, int64_t, int*);
+template int potrf_upper_enqueue<float>(rlhip_ctx*, int64_t, float*, int64_t, int*);
+
 template int potrf_upper<double>(rlhip_ctx*, int64_t, double*, int64_t, int*);
 template int potrf_upper<float>(rlhip_ctx*, int64_t, float*, int64_t, int*);
 

@@ -29,6 +29,7 @@
 //     fragment x, lane fr  <->  row 4*fr + x.  Accumulator layout of the f32 MFMA: lane (fr, fk), register r = C[row(fr)][16u + 4fk + r].
 #include "rlhip_internal.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -77,6 +78,7 @@ struct SkArgs {
     int tri;                  // 1: syrk-upper -- only tiles touching i <= j are computed, only i <= j is written
     int64_t ntiles;           // number of active tiles
     int gs;                   // workgroups per lockstep group (see sk_group below); 1 = every workgroup on its own
+    unsigned long long* clk;  // nullptr, or 4 words: workgroup 0's shader-clock and 100 MHz timestamps at entry and exit (RLHIP_SK_CLOCK=1: effective clock)
 };
 
 // Lockstep groups.  With one share per workgroup, the workgroups of an XCD sit at unrelated k offsets, so the operand every tile needs
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
     const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
 
+    if (g.clk && blockIdx.x == 0 && tid == 0) { g.clk[0] = __builtin_readcyclecounter(); g.clk[1] = wall_clock64(); }
     const int64_t KT = g.ktiles;
     const int64_t GS = g.gs, w = blockIdx.x;
     const int64_t units = (g.ntiles + GS - 1) / GS;                   // a unit = GS consecutive tiles walked in lockstep by a group
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         }
         pos += nk;
     }
+    if (g.clk && blockIdx.x == 0 && tid == 0) { g.clk[2] = __builtin_readcyclecounter(); g.clk[3] = wall_clock64(); }
     if (g.ssq_part) {   // deterministic: fixed lane->element map, fixed reduction tree, one partial per workgroup
         double v = ssq_acc;
 #pragma unroll
@@ -555,19 +559,30 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;
     g.tri = tri; g.ntiles = ntiles;
-    const int64_t P = num_cu;
+    int64_t P = num_cu;
+    // experiments only (scripts/shard_gemm_ab.py): RLHIP_SK_TUNE="gs_nn,gs_tn,workgroups", 0 keeps the default
+    static int tune[3] = {-1, 0, 0};
+    if (tune[0] < 0) {
+        tune[0] = 0;
+        if (const char* e = getenv("RLHIP_SK_TUNE")) sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
+    }
+    if (tune[2] > 0 && tune[2] <= num_cu) P = tune[2];
     // Lockstep group size (sk_group).  Measured at C2 (200000 x 20000 x 256 fp64, kernel ms / FETCH_SIZE GB against 32.5 GB algorithmic):
     //   Y = A Omega (NN):   1: 29.8 / 72.8   2: 29.9 / 68.8   4: 29.9 / 52.1   8: 30.0 / 34.4   (16, 32: as 8)
     //   B^T = A^T Q (TN):   1: 30.1 / 63.0   2: 30.0 / 58.8   4: 30.6 / 58.7   8: 31.2 / 34.9
     // NN takes 8 (fabric traffic 2.27x -> 1.08x of the algorithmic bytes for 0.5 % of kernel time).  TN loses 4 % at 8 -- its members read
     // the SAME k-rows of neighbouring column blocks of A, 1.6 MB apart, at the same instant, which camps on memory channels -- and stays
     // at 2.  The triangular map has too few tiles for whole units (18 at n = 1024) and runs ungrouped.
-    const int gs_want = tri ? 1 : (transA ? 2 : 8);
+    int gs_want = tri ? 1 : (transA ? 2 : 8);
+    if (!tri && tune[transA ? 1 : 0] > 0) gs_want = tune[transA ? 1 : 0];
     g.gs = (gs_want > 1 && P % (8 * gs_want) == 0 && ntiles >= 4 * (int64_t)gs_want) ? gs_want : 1;
     size_t mark = rlhip_ws_mark(c);
     g.slab = ws_alloc<T>(c, (size_t)2 * P * SLAB_ELEMS);
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     g.ssq_part = ssqA_dev ? ws_alloc<double>(c, (size_t)P) : nullptr;
+    static int want_clk = -1;
+    if (want_clk < 0) { const char* e = getenv("RLHIP_SK_CLOCK"); want_clk = e ? atoi(e) : 0; }
+    g.clk = want_clk ? ws_alloc<unsigned long long>(c, 4) : nullptr;
     constexpr int smem = NSTAGE * STAGE;
     if (transA) {
         RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, true>), smem);
@@ -587,6 +602,12 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);
         RLHIP_LAUNCH_CHECK();
+    }
+    if (g.clk) {   // debug: effective shader clock of this launch (costs a host sync)
+        unsigned long long h[4];
+        if (hipMemcpyAsync(h, g.clk, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && h[3] > h[1])
+            fprintf(stderr, "[sk clock] %s m %lld n %lld k %lld: %.1f us at %.0f MHz\n", transA ? "TN" : "NN", (long long)m, (long long)n, (long long)k,
+                    (double)(h[3] - h[1]) / 100.0, (double)(h[2] - h[0]) / ((double)(h[3] - h[1]) / 100.0));
     }
     rlhip_ws_release(c, mark);
     c->path_count[sizeof(T) == 8 ? 0 : 1]++;

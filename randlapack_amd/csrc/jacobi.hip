@@ -195,9 +195,15 @@ __device__ __forceinline__ double row16_allsum(double v) {
 //   intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
 //   intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs)
 // my_rot / my_cos2 accumulate the rotation count and the largest squared cosine met (per thread; lanes with ql == 0 count).
+// Cross rounds MAINTAIN the squared column norms instead of recomputing them: the quarter's own column carries its norm in a register, the
+// travelling partner column carries it through the LDS array Ns (one value per panel column), and a rotation updates both by Rutishauser's
+// formulas ||x'||^2 = aa - t ab, ||y'||^2 = bb + t ab.  Fresh norms are taken in round 0 of every call (= every 16 rounds), so the drift
+// is that of 16 updates.  Only the inner product of the pair is reduced in a round: one dot product and one 16-lane all-reduce instead
+// of three of each (a third of a round's instructions).  my_cos2 is a FLAG (1: some pair met a cosine above 1e-9), my_nmax / my_nmin the
+// largest / smallest non-zero fresh squared norm seen (the persistent kernel's condition monitor).
 template <typename T, int JB, int JMT>
 __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __restrict__ Js, const bool want_v, const int intra, const double tol2,
-                                                   unsigned& my_rot, float& my_cos2) {
+                                                   unsigned& my_rot, float& my_cos2, double* __restrict__ Ns, float& my_nmax, float& my_nmin) {
     constexpr int JP = 2 * JB;
     constexpr int NROT = 16 * JB;
     typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -209,7 +215,9 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
     const int nrounds = intra ? (JB - 1) : JB;
     const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
     constexpr int RL = JMT / 32;                       // 16-byte row pairs per lane
+    constexpr bool MAINT = (JB == 16);                  // (the 32-wide panels of tiny problems fill the whole LDS: no room for Ns, norms recomputed)
     d2_t x[RL], y[RL];
+    double aa = 0;                                      // squared norm of the quarter's own column (cross rounds: carried from round to round)
     for (int round = 0; round < nrounds; ++round) {
         if (tid >= NROT) { __syncthreads(); continue; }     // wave-uniform: whole wavefronts sit the rounds out
         int p, q;
@@ -228,26 +236,39 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
         // Cross rounds keep the quarter's own column p (= its slot) in registers from the first round to the last: only the
         // partner column q makes the LDS round trip.  The rounds are bound by LDS bandwidth (16 pairs x 2 columns x 2 KiB read and
         // written = 1024 clocks of the CU's 128 B/clk pipe), so this halves their cost.
-        double aa = 0, bb = 0, ab = 0;
-        if (intra || round == 0) {
+        double bb = 0, ab = 0;
+        const bool fresh = !MAINT || intra || round == 0;
+        if (fresh) {
 #pragma unroll
             for (int r = 0; r < RL; ++r) x[r] = xp[16 * r];
         }
 #pragma unroll
         for (int r = 0; r < RL; ++r) y[r] = xq[16 * r];
+        if (fresh) {
+            aa = 0;
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            aa = fma(x[r].x, x[r].x, aa); aa = fma(x[r].y, x[r].y, aa);
-            bb = fma(y[r].x, y[r].x, bb); bb = fma(y[r].y, y[r].y, bb);
-            ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab);
+            for (int r = 0; r < RL; ++r) {
+                aa = fma(x[r].x, x[r].x, aa); aa = fma(x[r].y, x[r].y, aa);
+                bb = fma(y[r].x, y[r].x, bb); bb = fma(y[r].y, y[r].y, bb);
+                ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab);
+            }
+            aa = row16_allsum(aa);
+            bb = row16_allsum(bb);
+            ab = row16_allsum(ab);
+            const float fa = (float)aa, fb = (float)bb;
+            my_nmax = fmaxf(my_nmax, fmaxf(fa, fb));
+            if (fa > 0.f) my_nmin = fminf(my_nmin, fa);
+            if (fb > 0.f) my_nmin = fminf(my_nmin, fb);
+        } else {
+            if constexpr (MAINT) bb = Ns[q];                                // the partner's norm travels with it
+#pragma unroll
+            for (int r = 0; r < RL; ++r) { ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab); }
+            ab = row16_allsum(ab);
         }
-        aa = row16_allsum(aa);
-        bb = row16_allsum(bb);
-        ab = row16_allsum(ab);
-        const double nn = aa * bb;
+        const double nn = aa * bb, ab2 = ab * ab;
         const bool live = (aa > 0.0) && (bb > 0.0);
-        const bool rot = live && (ab * ab > tol2 * nn);                     // |ab| > tol*||x||*||y||
-        if (live) my_cos2 = fmaxf(my_cos2, (float)(ab * ab * fast_rcp(nn)) * 1.000001f);
+        const bool rot = live && (ab2 > tol2 * nn);                         // |ab| > tol*||x||*||y||
+        if (live && ab2 > 1e-18 * nn) my_cos2 = 1.0f;                       // a cosine above 1e-9 was met
         // t = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)),  d = bb - aa, g = 2ab.  t only has to make the (p,q) inner product small
         // (one Newton step on the seeds = ~48 bits); cs = rsqrt(1 + t^2) keeps two steps so that cs^2 + sn^2 = 1 to rounding.
         const double dd = bb - aa, gg = 2.0 * ab;
@@ -257,6 +278,12 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
         tt = (dd < 0.0) ? -tt : tt;
         tt = rot ? tt : 0.0;                                                // also discards inf/NaN from ab == 0
         const double cs = fast_rsqrt(fma(tt, tt, 1.0)), sn = cs * tt;
+        if constexpr (MAINT) {
+            if (!intra) {                                                   // (intra rounds take fresh norms every time)
+                aa = fma(-tt, ab, aa);                                      // (explicit fmas: the two kernels that inline this must round alike)
+                if (ql == 0) Ns[q] = fma(tt, ab, bb);
+            }
+        }
         if (__builtin_amdgcn_ballot_w64(rot)) {                             // skip the stores when no quarter rotates
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
@@ -318,8 +345,10 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
     for (int e = tid; e < JP * JP; e += NT) Js[e] = ((e % JP) == (e / JP)) ? T(1) : T(0);
     __syncthreads();
     unsigned my_rot = 0;
-    float my_cos2 = 0.f;                               // largest squared cosine met before rotating (convergence shortcut)
-    jacobi_pair_rounds<T, JB, JMT>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2);
+    float my_cos2 = 0.f;                               // 1: a cosine above 1e-9 was met before rotating (convergence shortcut)
+    float my_nmax = 0.f, my_nmin = 3e38f;
+    __shared__ double Ns[JB == 16 ? JP : 1];
+    jacobi_pair_rounds<T, JB, JMT>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2, Ns, my_nmax, my_nmin);
     // one atomic pair per wavefront
     {
         unsigned r = my_rot;
@@ -404,8 +433,45 @@ struct JpArgs {
     unsigned long long* sflag;    // [2][NB/2][2]  {sweep : cos^2 bits}, {sweep : rotations}; indexed by sweep parity
     T tol;
     int* out;                     // [0] status: 1 converged (a sweep without rotations), 2 every cosine <= 1e-9 (verify), 3 sweep limit, -7 lost word
-                                  // [1] sweeps done (absolute)
+                                  // [1] sweeps done (absolute)   [2] != 0: SOME workgroup lost a word (its blocks in X are stale whatever [0] says)
+    unsigned long long* done;     // one word of the exchange buffer: set by workgroup 0 when it leaves; releases the clock holders (below)
+    int hold_mode;                // what the holders issue: 1 bursts of 128 fp64 FMAs with hold_nap x s_sleep(8) between, 2 s_sleep only (experiments)
+    int hold_nap, hold_delay_us;  // holders only sleep for the first hold_delay_us of the launch
+    float norm_ratio_lim;         // > 0: give up (status -9) when max / min of the squared column norms exceeds it at the end of a sweep
+    int trans_upper;              // 1: the input is X = R^T of the UPPER triangle stored in A (X(r, c) = A(c, r) for c <= r, else 0): the Cholesky factor as potrf left it
+    const int* skip;              // nullptr, or a device word: != 0 -> the launch does nothing and reports status -8 (an earlier kernel of the stream failed)
 };
+
+// Clock holders.  The part's clock follows the occupancy of the shader array, not the power budget: with 8 of 256 CUs at work (this
+// kernel) it sinks from 2.4 to ~2.05 GHz within 4 ms and needs ~20 ms of full load to come back (scripts/dvfs_probe.py) --
+// which slows the rotation rounds (pure VALU / LDS latency chains) AND the tall product that follows.  The launch therefore covers every
+// CU: workgroups >= NB/2 do nothing but keep their SIMDs issuing fp64 FMAs at low priority until workgroup 0 reports the end (one
+// poller per workgroup, every ~2 us, bounded by the wall clock).  They share no CU with a worker (1024 threads x 128 VGPRs fill one).
+__device__ __forceinline__ void jacobi_clock_holder(const unsigned long long* done, unsigned* lds_flag, const int mode, const int nap, const long long delay_ticks) {
+    __builtin_amdgcn_s_setprio(0);
+    const int tid = threadIdx.x;
+    double z = 0.5;
+    const double x = 1.0 - 1e-9 * (tid + 1), y = 1e-9 * (tid + 1);
+    const long long t0 = wall_clock64();
+    if (tid == 0) *lds_flag = 0;
+    __syncthreads();
+    for (int it = 0;; ++it) {
+        const bool napping = (mode == 2) || (wall_clock64() - t0 < delay_ticks);
+        if (!napping) {
+#pragma unroll
+            for (int i = 0; i < 128; ++i) z = fma(z, x, y);
+            for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(8);
+        } else {
+            __builtin_amdgcn_s_sleep(127);
+        }
+        if (tid == 0 && (it & 3) == 0) {
+            const unsigned long long v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0ull || wall_clock64() - t0 > 3000000ll) *(volatile unsigned*)lds_flag = 1u;     // released, or 30 ms: never outlive a failed launch
+        }
+        if (*(volatile unsigned*)lds_flag) break;
+    }
+    if (z == 12345.678) *lds_flag = 2u;                // (keeps the chain)
+}
 
 __device__ __forceinline__ bool jp_wait(const unsigned long long* w, unsigned tag, unsigned long long* got) {
     for (int spins = 0; spins < (1 << 22); ++spins) {
@@ -422,15 +488,27 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     constexpr int JP = 2 * JB, NT = 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
-    __shared__ unsigned s_rot, s_cos, s_lost;
+    __shared__ unsigned s_rot, s_cos, s_lost, s_nmax, s_nmin;
+    __shared__ double Ns[JP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = blockIdx.x, NW = g.NB / 2, m = g.m;
+    if (w >= NW) { jacobi_clock_holder(g.done, &s_lost, g.hold_mode, g.hold_nap, (long long)g.hold_delay_us * 100); return; }
+    if (g.skip != nullptr && *g.skip != 0) {           // (every worker reads the same word: all of them leave)
+        if (w == 0 && tid == 0) {
+            g.out[0] = -8; g.out[1] = g.sweep0;
+            __hip_atomic_store(g.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    unsigned long long clk0 = 0, wall0 = 0;
+    if (w == 0 && tid == 0) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
     const double tol2 = (double)g.tol * (double)g.tol;
     int held[2] = {2 * w, 2 * w + 1};
     for (int e = tid; e < JP * JMT; e += NT) {
         const int r = e % JMT, c = e / JMT;
         const int gc = held[c / JB] * JB + (c % JB);
-        Xs[e] = (r < m && gc < g.n) ? g.A[r + (int64_t)gc * g.lda] : T(0);
+        if (g.trans_upper) Xs[e] = (r < m && gc < g.n && gc <= r) ? g.A[gc + (int64_t)r * g.lda] : T(0);
+        else Xs[e] = (r < m && gc < g.n) ? g.A[r + (int64_t)gc * g.lda] : T(0);
     }
     if (tid == 0) { s_lost = 0; }
     __syncthreads();
@@ -480,8 +558,8 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     bool lost = false;
     for (; sweep < g.max_sweeps && !lost; ++sweep) {
         unsigned my_rot = 0;
-        float my_cos2 = 0.f;
-        jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 1, tol2, my_rot, my_cos2);          // pairs inside whichever two blocks are here
+        float my_cos2 = 0.f, my_nmax = 0.f, my_nmin = 3e38f;
+        jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 1, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);          // pairs inside whichever two blocks are here
         for (int oround = 0; oround < g.NB - 1; ++oround) {
             int P, Q;
             if (w == 0) { P = g.NB - 1; Q = oround % (g.NB - 1); }
@@ -508,51 +586,71 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
             fetch2(out0, want[0], out1, want[1]);
             held[0] = want[0]; held[1] = want[1];
             __syncthreads();
-            jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2);
+            jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);
         }
         if (lost) break;
-        // ---- end of the sweep: everybody learns the sweep's rotation count and largest cosine
-        if (tid == 0) { s_rot = 0; s_cos = 0; }
+        // ---- end of the sweep: everybody learns the sweep's rotation count, whether a cosine above 1e-9 was met, and the range of the column norms
+        if (tid == 0) { s_rot = 0; s_cos = 0; s_nmax = 0; s_nmin = __float_as_uint(3e38f); }
         __syncthreads();
         {
             unsigned r = my_rot;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-            float c2 = my_cos2;
+            float c2 = my_cos2, hi = my_nmax, lo = my_nmin;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
-            if (lane == 0 && r) { atomicAdd(&s_rot, r); atomicMax(&s_cos, __float_as_uint(c2)); }
+            for (int off = 32; off > 0; off >>= 1) {
+                c2 = fmaxf(c2, __shfl_xor(c2, off, 64));
+                hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+                lo = fminf(lo, __shfl_xor(lo, off, 64));
+            }
+            if (lane == 0) {                            // non-negative floats order like their bit patterns
+                if (r) { atomicAdd(&s_rot, r); atomicMax(&s_cos, __float_as_uint(c2)); }
+                atomicMax(&s_nmax, __float_as_uint(hi));
+                atomicMin(&s_nmin, __float_as_uint(lo));
+            }
         }
         __syncthreads();
         const unsigned tag = (unsigned)(sweep - g.sweep0 + 1);
-        unsigned long long* sf = g.sflag + (size_t)(tag & 1u) * NW * 2;
-        if (tid == 0) {
-            __hip_atomic_store(sf + 2 * w, ((unsigned long long)tag << 32) | s_cos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sf + 2 * w + 1, ((unsigned long long)tag << 32) | s_rot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* sf = g.sflag + (size_t)(tag & 1u) * NW * 4;
+        if (tid < 4) {
+            const unsigned v = (tid == 0) ? s_cos : (tid == 1) ? s_rot : (tid == 2) ? s_nmax : s_nmin;
+            __hip_atomic_store(sf + 4 * w + tid, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (tid == 0) { s_rot = 0; s_cos = 0; }
+        if (tid == 0) { s_rot = 0; s_cos = 0; s_nmax = 0; s_nmin = __float_as_uint(3e38f); }
         __syncthreads();
-        if (tid < 2 * NW) {
+        if (tid < 4 * NW) {
             unsigned long long got = 0;
             if (!jp_wait(sf + tid, tag, &got)) atomicExch(&s_lost, 1u);
-            else if (tid & 1) atomicAdd(&s_rot, ((unsigned)got) ? 1u : 0u);
-            else atomicMax(&s_cos, (unsigned)got);
+            else if ((tid & 3) == 0) atomicMax(&s_cos, (unsigned)got);
+            else if ((tid & 3) == 1) atomicAdd(&s_rot, ((unsigned)got) ? 1u : 0u);
+            else if ((tid & 3) == 2) atomicMax(&s_nmax, (unsigned)got);
+            else atomicMin(&s_nmin, (unsigned)got);
         }
         __syncthreads();
         if (s_lost) { lost = true; break; }
         const unsigned any_rot = s_rot;
-        const float cos2 = __uint_as_float(s_cos);
+        const float cos2 = __uint_as_float(s_cos), nhi = __uint_as_float(s_nmax), nlo = __uint_as_float(s_nmin);
         __syncthreads();
         if (any_rot == 0) { status = 1; ++sweep; break; }
         if (cos2 <= 1e-18f) { status = 2; ++sweep; break; }
+        // condition monitor (the Gram route): the squared column norms approach the squared singular values from inside, so their range
+        // only grows; once it exceeds the limit the caller's accuracy test cannot pass any more and the remaining sweeps are not worth running
+        if (g.norm_ratio_lim > 0.f && !(nhi <= g.norm_ratio_lim * nlo)) { status = -9; ++sweep; break; }
     }
-    if (lost) status = -7;
-    else {
+    if (lost) {
+        status = -7;
+        if (tid == 0) atomicExch(g.out + 2, 1);        // whoever loses a word says so: workgroup 0 may well have run to a verdict
+    } else {
         publish(0, held[0]);
         publish(1, held[1]);
     }
-    if (w == 0 && tid == 0) { g.out[0] = status; g.out[1] = sweep; }
+    if (w == 0 && tid == 0) {
+        g.out[0] = status; g.out[1] = sweep;
+        __hip_atomic_store(g.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* tk = reinterpret_cast<unsigned long long*>(g.out + 4);      // diagnostics: shader cycles and 100 MHz ticks of this launch
+        tk[0] = __builtin_readcyclecounter() - clk0; tk[1] = wall_clock64() - wall0;
+    }
 }
 
 // dst (ldd) = (TD) src (lds), m x n
@@ -651,42 +749,78 @@ int jacobi_verify_converged(rlhip_ctx* c, int m, int n, const T* A, int64_t lda,
     return 0;
 }
 
+struct JpHold { int mode = 1, nap = 4, delay = 0, wgs = 1 << 20; };
+static const JpHold& jp_hold() {
+    static JpHold h;
+    static bool read = false;
+    if (!read) {
+        read = true;
+        if (const char* e = getenv("RLHIP_JACOBI_HOLD")) sscanf(e, "%d,%d,%d,%d", &h.mode, &h.nap, &h.delay, &h.wgs);   // mode (0 off), naps per burst, delay (us), holder workgroups
+    }
+    return h;
+}
+
+// clears the flag words and enqueues ONE persistent launch; g.A / lda / trans_upper / skip / sweep0 / max_sweeps / tol / out are the caller's
+template <typename T>
+int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NBk) {
+    constexpr int JB = 16, JMT = JM;
+    const int NW = NBk / 2;
+    const size_t xwords = (size_t)NBk * JB * m;
+    const JpHold& h = jp_hold();
+    g.m = m; g.NB = NBk; g.X = buf; g.bflag = buf + xwords; g.sflag = g.bflag + NBk; g.done = g.sflag + 8 * (size_t)NW;
+    g.hold_mode = h.mode; g.hold_nap = h.nap; g.hold_delay_us = h.delay;
+    hipError_t e1 = hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 8 * (size_t)NW + 1) * sizeof(unsigned long long), c->stream);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(g.out, 0, 8 * sizeof(int), c->stream);
+    if (e1 != hipSuccess) return RLHIP_ERR_HIP(e1);
+    constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
+    RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT>), smem);
+    void* kargs[] = {(void*)&g};
+    // the whole device when the clock holders are wanted and fit (one 1024-thread workgroup per CU), else the workers alone
+    const unsigned grid_hold = (h.mode && c->num_cu > NW) ? (unsigned)(NW + (h.wgs < c->num_cu - NW ? h.wgs : c->num_cu - NW)) : (unsigned)NW;
+    hipError_t le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3(grid_hold), dim3(1024), kargs, (unsigned)smem, c->stream);
+    if (le != hipSuccess && grid_hold != (unsigned)NW) {
+        (void)hipGetLastError();
+        le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream);
+    }
+    if (le != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return 0;
+}
+
 // Sweeps of the persistent kernel (V not accumulated).  Returns 0 and the number of sweeps when it ran to a verdict, 1 when the path is
 // not available or reported a lost word -- A then still holds a valid (possibly partially swept) matrix and the caller continues with the
 // per-launch sweeps.
 template <typename T>
 int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out, bool* done) {
-    constexpr int JB = 16, JMT = JM;
+    constexpr int JB = 16;
     *done = false;
     int NBk = (n + JB - 1) / JB;
     if (NBk < 2) NBk = 2;
     if (NBk % 2) ++NBk;
     const int NW = NBk / 2;
     if (NW > c->num_cu || NW > 512) return 1;
-    const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 4 * (size_t)NW;
+    const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1;
+    const int hold = jp_hold().mode;
     unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
     size_t mark = rlhip_ws_mark(c);
     int* out = ws_alloc<int>(c, 32);
     if (!buf || !out) { rlhip_ws_release(c, mark); return 1; }
-    constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
-    RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT>), smem);
     int sweep = *sweeps_out;
     while (sweep < max_sweeps) {
         JpArgs<T> g;
-        g.m = m; g.n = n; g.NB = NBk; g.sweep0 = sweep; g.max_sweeps = max_sweeps; g.A = A; g.lda = lda; g.X = buf; g.bflag = buf + xwords;
-        g.sflag = g.bflag + NBk; g.tol = tol; g.out = out;
-        RLHIP_CHECK(hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 4 * (size_t)NW) * sizeof(unsigned long long), c->stream));
-        RLHIP_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(int), c->stream));
-        void* kargs[] = {(void*)&g};
-        if (hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream) != hipSuccess) {
-            (void)hipGetLastError();
-            rlhip_ws_release(c, mark);
-            return 1;
+        g.n = n; g.sweep0 = sweep; g.max_sweeps = max_sweeps; g.A = A; g.lda = lda; g.tol = tol; g.out = out; g.trans_upper = 0; g.skip = nullptr; g.norm_ratio_lim = 0.f;
+        const int lrc = jp_launch<T>(c, g, buf, m, NBk);
+        if (lrc) { rlhip_ws_release(c, mark); return lrc; }
+        hipError_t e2 = hipMemcpyAsync(c->h_mail + 16, out, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(e2); }
+        const int status = *(int*)(c->h_mail + 16), done_sweeps = *((int*)(c->h_mail + 16) + 1), any_lost = *((int*)(c->h_mail + 16) + 2);
+        {
+            static int want_clk = -1;
+            if (want_clk < 0) { const char* e = getenv("RLHIP_JACOBI_CLOCK"); want_clk = e ? atoi(e) : 0; }
+            const unsigned long long* tk = reinterpret_cast<const unsigned long long*>((const int*)(c->h_mail + 16) + 4);
+            if (want_clk && tk[1]) fprintf(stderr, "[jacobi clock] %d sweeps, %.1f us at %.0f MHz (hold %d)\n", done_sweeps - sweep, (double)tk[1] / 100.0, (double)tk[0] / ((double)tk[1] / 100.0), hold);
         }
-        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, out, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
-        const int status = *(int*)(c->h_mail + 16), done_sweeps = *((int*)(c->h_mail + 16) + 1);
-        if (status != 1 && status != 2 && status != 3) { rlhip_ws_release(c, mark); *sweeps_out = sweep; return 1; }   // -7 (or nothing written): A untouched by this launch
+        if ((status != 1 && status != 2 && status != 3) || any_lost) { rlhip_ws_release(c, mark); *sweeps_out = sweep; return 1; }   // -7, a lost word anywhere, or nothing written: A untouched by this launch
         int rc = rlhip::lacpy<T>(c, 2, m, n, reinterpret_cast<const T*>(buf), m, A, lda);
         if (rc) { rlhip_ws_release(c, mark); return rc < 0 ? rc : 1; }
         sweep = done_sweeps;
@@ -750,6 +884,39 @@ template <typename T>
 int lacpy(rlhip_ctx* c, int uplo, int64_t m, int64_t n, const T* A, int64_t lda, T* B, int64_t ldb);
 template <typename T>
 int laset(rlhip_ctx* c, int uplo, int64_t m, int64_t n, T offdiag, T diag, T* A, int64_t lda);
+
+// ENQUEUES the one-launch Jacobi sweeps of an n x n matrix X -- trans_upper = 0: X = the matrix stored in `R` (e.g. a full symmetric Gram
+// matrix); 1: X = R^T of the upper triangle stored in `R` (a Cholesky factor as potrf left it) -- and returns without touching the host: the swept columns (X J, mutually orthogonal, norms = singular values) land in the
+// context's exchange buffer (*X_out, column-major, leading dimension n), status / sweeps / lost flag in out_dev[0..2] (see JpArgs::out).
+// `skip_dev` != nullptr: the launch does nothing (status -8) when that device word is non-zero.  Returns 0 when enqueued, 1 when the
+// path is not available (the caller takes another route), < 0 on error.  fp64, 32 < n <= 256.
+template <typename T>
+int jacobi_enqueue_rt(rlhip_ctx* c, int n, const T* R, int64_t ldr, int trans_upper, float norm_ratio_lim, const int* skip_dev, int* out_dev, const T** X_out) {
+    if constexpr (sizeof(T) != 8) { return 1; }
+    else {
+        constexpr int JB = 16;
+        if (n <= 32 || n > JM) return 1;
+        const char* pe = getenv("RLHIP_JACOBI_PERSIST");
+        if (pe && atoi(pe) == 0) return 1;
+        int NBk = (n + JB - 1) / JB;
+        if (NBk % 2) ++NBk;
+        const int NW = NBk / 2;
+        if (NW > c->num_cu) return 1;
+        const size_t xwords = (size_t)NBk * JB * n, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1;
+        unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
+        if (!buf) return 1;
+        JpArgs<T> g;
+        g.n = n; g.sweep0 = 0; g.max_sweeps = 60; g.A = R; g.lda = ldr; g.out = out_dev; g.trans_upper = trans_upper; g.skip = skip_dev; g.norm_ratio_lim = norm_ratio_lim;
+        g.tol = std::sqrt((T)n) * std::numeric_limits<T>::epsilon();
+        const int rc = jp_launch<T>(c, g, buf, n, NBk);
+        if (rc) return rc;
+        *X_out = reinterpret_cast<const T*>(buf);
+        c->path_count[6]++;
+        return 0;
+    }
+}
+template int jacobi_enqueue_rt<double>(rlhip_ctx*, int, const double*, int64_t, int, float, const int*, int*, const double**);
+template int jacobi_enqueue_rt<float>(rlhip_ctx*, int, const float*, int64_t, int, float, const int*, int*, const float**);
 
 template <typename T>
 int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT, int64_t ldvt,

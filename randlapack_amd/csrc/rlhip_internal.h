@@ -77,6 +77,7 @@ struct rlhip_ctx {
     size_t xchg_bytes = 0;
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU
     void* comm = nullptr;
     // caching pool behind rlhip_malloc/rlhip_free (outputs the drivers allocate for the caller: Q, BT, U, S, V).

@@ -806,6 +806,7 @@ def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n
         s = {"cond10": np.logspace(0, -1, n), "cluster": 1.0 - 1e-7 * rng.random(n), "identity": np.ones(n)}[kind]
         A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
     res = {}
+    monkeypatch.setenv("RLHIP_GESDD_GRAM", "0")        # the classic route (Cholesky-QR + Jacobi on R^T): the one that has both sweep drivers
     for mode in ("1", "0"):
         monkeypatch.setenv("RLHIP_JACOBI_PERSIST", mode)
         Ad = d.cm_from_numpy(A)
@@ -821,6 +822,51 @@ def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n
     assert np.array_equal(S1, S0) and np.array_equal(U1, U0) and np.array_equal(V1, V0)
     assert np.linalg.norm((U1 * S1) @ V1 - A) <= 1e-13 * np.linalg.norm(A) * np.sqrt(n)
     assert np.linalg.norm(U1.T @ U1 - np.eye(n)) <= 1e-11 * np.sqrt(n)
+
+
+@pytest.mark.parametrize("m,n,kind,gram", [(20000, 256, "flat", True), (3000, 200, "flat", True), (5000, 128, "cond5", True), (1000, 256, "flat", True), (300, 256, "flat", None),
+                                           (2000, 256, "cond100", False), (4000, 96, "cond1e6", False), (1500, 64, "rank-deficient", False)])
+def test_gesdd_gram_route(ctx, monkeypatch, m, n, kind, gram):
+    """The Gram route of the device SVD (one-sided Jacobi on A^T A itself, U = A W, one host read; svd.hip::gesdd_tall_gram) serves
+    well-conditioned tall factors -- path counter 10 says when -- and hands everything else to the classic route untouched: either way
+    the result is LAPACK's to rounding, and the two routes agree on a well-conditioned input."""
+    import ctypes as C
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(3 * m + n)
+    if kind == "flat":
+        A = rng.standard_normal((m, n))
+    else:
+        s = {"cond5": np.linspace(5, 1, n), "cond100": np.logspace(0, -2, n), "cond1e6": np.logspace(0, -6, n),
+             "rank-deficient": np.concatenate([np.linspace(2, 1, n - 4), np.zeros(4)])}[kind]
+        A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    s_ref = np.linalg.svd(A, compute_uv=False)
+    out = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("RLHIP_GESDD_GRAM", route)
+        Ad = d.cm_from_numpy(A)
+        S = torch.zeros(n, dtype=torch.float64, device="cuda")
+        U, VT = d.cm_empty(m, n), d.cm_empty(n, n)
+        sw = C.c_int(0)
+        before = ctx.path_count(10)
+        assert ctx.lib.rlhip_gesdd_f64(ctx.h, m, n, Ad.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n, C.byref(sw)) >= 0
+        took = ctx.path_count(10) - before
+        if gram is not None or route == "0":                        # (None: cond ~ 25, eps cond^2 sits at the route's threshold -- either route may serve it)
+            assert took == (1 if (gram and route == "1") else 0), f"route {route}: Gram route taken {took} times"
+        Un, Sn, VTn = d.cm_to_numpy(U), S.cpu().numpy(), d.cm_to_numpy(VT)
+        keep = s_ref > 1e-12 * s_ref[0]
+        np.testing.assert_allclose(Sn[keep], s_ref[keep], rtol=1e-11 if kind == "cond1e6" else 1e-12)
+        assert np.all(np.diff(Sn) <= 0)
+        assert np.linalg.norm((Un * Sn) @ VTn - A) <= 1e-13 * np.linalg.norm(A) * np.sqrt(n)
+        assert np.linalg.norm(VTn @ VTn.T - np.eye(n)) <= 1e-11 * np.sqrt(n)
+        if kind != "rank-deficient":
+            assert np.linalg.norm(Un.T @ Un - np.eye(n)) <= 1e-11 * np.sqrt(n)
+        out[route] = (Un, Sn, VTn)
+    if gram and kind != "flat":                                     # separated singular values: the two routes deliver the same vectors up to sign
+        (U1, S1, V1), (U0, S0, V0) = out["1"], out["0"]
+        sgn = np.sign(np.sum(V1 * V0, axis=1))
+        assert np.max(np.abs(V1 - sgn[:, None] * V0)) <= 1e-9 and np.max(np.abs(U1 - U0 * sgn)) <= 1e-9
 
 
 @pytest.mark.parametrize("m,n,cond", [(20000, 128, 1e2), (20000, 64, 1e12), (100000, 32, 1.0), (9000, 16, 1e9)])
