@@ -135,7 +135,7 @@ def main():
             step()
         transport = getattr(ctx, "comm_transport", "rccl")
     for _ in range(args.warmup):
-        step()
+        r = step()       # (held like the timed steps' results: the output pool then owns both alternating sets of U, S, V before the clock starts)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -55,8 +55,13 @@ public:
     // sharded dimension (m-long objects: A, Y, Q, Omega_1) or replicated (n- or k-long objects: Omega, B^T, R).
     // Fused-norm request (QB): the next blas::gemm whose A operand is exactly this matrix also returns ||A||_F
     // (one pass over A instead of two).  Consumed at most once.
-    struct NormRequest { const void* ptr = nullptr; int64_t rows = 0, cols = 0, ld = 0; bool done = false; double value = 0; };
+    // `defer`: the product does not wait for the norm; collect_norm() fetches it after the caller's next synchronisation (QB's ||B_i||_F).
+    struct NormRequest { const void* ptr = nullptr; int64_t rows = 0, cols = 0, ld = 0; bool done = false; double value = 0; bool defer = false, pending = false; };
     NormRequest norm_req;
+    double collect_norm() {
+        if (norm_req.pending) { check(rlhip_norma_collect_f64(ctx_, &norm_req.value), "norma_collect"); norm_req.pending = false; }
+        return norm_req.value;
+    }
     bool rows_sharded = false;
     bool reduce_over_rows() const { return rows_sharded && world() > 1; }
     void allreduce_sum(double* buf, int64_t count) { check(rlhip_allreduce_sum_f64(ctx_, buf, count), "allreduce"); }
@@ -148,9 +153,10 @@ inline void gemm(Layout, Op ta, Op tb, int64_t m, int64_t n, int64_t k, double a
     if (nr.ptr == (const void*)A && !nr.done && nr.ld == lda &&
         ((ta == Op::NoTrans && nr.rows == m && nr.cols == k) || (ta != Op::NoTrans && nr.rows == k && nr.cols == m))) {
         double nrm = 0;
-        check(rlhip_gemm_norma_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &nrm,
+        check(rlhip_gemm_norma_f64(q.ctx(), (char)ta, (char)tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nr.defer ? nullptr : &nrm,
                                    nullptr), "gemm_norma");
         nr.done = true;
+        nr.pending = nr.defer;
         nr.value = nrm;
         return;
     }

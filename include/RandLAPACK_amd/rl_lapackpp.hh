@@ -20,6 +20,17 @@ inline int64_t potrf(blas::Uplo u, int64_t n, double* A, int64_t lda, Queue& q =
 inline int64_t potrf(blas::Uplo u, int64_t n, float* A, int64_t lda, Queue& q = blas::default_queue()) {
     int rc = rlhip_potrf_f32(q.ctx(), (char)u, n, A, lda); blas::check(rc, "potrf"); return rc;
 }
+// CholQRQ's syrk + potrf + trsm as one call (rlhip_cholqrq): 0 done (info = potrf's), 1 shape not served
+inline int cholqrq(int64_t m, int64_t k, double* A, int64_t lda, double* R, bool reduce_gram, int& info, Queue& q = blas::default_queue()) {
+    const int rc = rlhip_cholqrq_f64(q.ctx(), m, k, A, lda, R, reduce_gram ? 1 : 0, &info);
+    blas::check(rc, "cholqrq");
+    return rc;
+}
+inline int cholqrq(int64_t m, int64_t k, float* A, int64_t lda, float* R, bool reduce_gram, int& info, Queue& q = blas::default_queue()) {
+    const int rc = rlhip_cholqrq_f32(q.ctx(), m, k, A, lda, R, reduce_gram ? 1 : 0, &info);
+    blas::check(rc, "cholqrq");
+    return rc;
+}
 inline double lange(Norm nt, int64_t m, int64_t n, double const* A, int64_t lda, Queue& q = blas::default_queue()) {
     if (nt != Norm::Fro) throw blas::Error("lange: only Norm::Fro is on the path");
     double r = 0; blas::check(rlhip_lange_fro_f64(q.ctx(), m, n, A, lda, &r), "lange"); return r;

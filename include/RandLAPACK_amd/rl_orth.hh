@@ -32,6 +32,15 @@ public:
     int call(int64_t m, int64_t k, T* A) override {
         blas::Scratch ws(q);
         T* gram = ws.alloc<T>(k * k);
+        if (!cond_check) {
+            // the three calls below as one stream of kernels with one host read (tall, 256-aligned k); 1 = not served, fall through
+            int info = 0;
+            const int frc = lapack::cholqrq(m, k, A, m, gram, q.reduce_over_rows(), info, q);
+            if (frc == 0) {
+                if (info) { chol_fail = true; return 1; }
+                return 0;
+            }
+        }
         lapack::laset(MatrixType::General, k, k, T(0), T(0), gram, k, q);
         blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, T(1), A, m, T(0), gram, k, q);      // :78
         if (q.reduce_over_rows()) q.allreduce_sum(gram, k * k);   // row-sharded: Gram = sum of the ranks' Grams

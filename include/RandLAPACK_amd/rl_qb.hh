@@ -62,9 +62,10 @@ public:
         if constexpr (sizeof(T) == 8) {
             q.norm_req = blas::Queue::NormRequest();
             q.norm_req.ptr = A_cpy; q.norm_req.rows = m; q.norm_req.cols = n; q.norm_req.ld = m;
+            q.norm_req.defer = true;                               // read together with ||B_1||_F below: one host round trip for both
         }
         blas::RowsSharded sh(q, true);                             // Q_i, Q: rows sharded
-        auto done = [&](int code) { if (A_own) blas::device_free(A_own, q); return code; };
+        auto done = [&](int code) { q.norm_req = blas::Queue::NormRequest(); if (A_own) blas::device_free(A_own, q); return code; };
 
         while (curr_sz < k) {
             b_sz = std::min(b_sz, k - curr_sz);                                                           // :175
@@ -72,17 +73,8 @@ public:
             T* Q_i = Q + m * curr_sz;
             T* BT_i = BT + n * curr_sz;
             if (rf.call(m, n, A_cpy, b_sz, Q_i, state)) { k = curr_sz; q.norm_req = blas::Queue::NormRequest(); return done(6); }   // :190-196
-            if (!have_norm) {
-                if (q.norm_req.done) norm_A = (T)q.norm_req.value;
-                else norm_A = lapack::lange(Norm::Fro, m, n, A_cpy, m, q);   // A_cpy still equals A here
-                q.norm_req = blas::Queue::NormRequest();
-                if (q.world() > 1) {                                   // ||A||_F^2 = sum over the row blocks
-                    double ssq = (double)norm_A * (double)norm_A;
-                    q.allreduce_sum_host(&ssq, 1);
-                    norm_A = (T)std::sqrt(ssq);
-                }
-                have_norm = true;
-            }
+            const bool norm_rides = !have_norm && q.norm_req.done;  // ||A||_F came out of rf.call's product; its value is collected below
+            if (!have_norm && !norm_rides) norm_A = lapack::lange(Norm::Fro, m, n, A_cpy, m, q);   // A_cpy still equals A here
             if (orth_check && util::orthogonality_check(m, b_sz, Q_i, verbose, q)) { k = curr_sz; return done(4); }   // :198-206
             if (curr_sz != 0) {                                                                           // :209-215
                 blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, curr_sz, b_sz, m, T(1), Q, m, Q_i, m, T(0), QtQi, next_sz, q);
@@ -93,6 +85,16 @@ public:
             blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, n, b_sz, m, T(1), A_cpy, m, Q_i, m, T(0), BT_i, n, q);   // :218
             if (q.world() > 1) q.allreduce_sum(BT_i, n * b_sz);     // B_i^T = sum_g A_g^T Q_g : the n x b exchange
             T norm_B_i = lapack::lange(Norm::Fro, n, b_sz, BT_i, n, q);                                   // :221
+            if (!have_norm) {
+                if (norm_rides) norm_A = (T)q.collect_norm();      // (the stream has just been drained by lange: no second wait)
+                q.norm_req = blas::Queue::NormRequest();
+                if (q.world() > 1) {                                   // ||A||_F^2 = sum over the row blocks
+                    double ssq = (double)norm_A * (double)norm_A;
+                    q.allreduce_sum_host(&ssq, 1);
+                    norm_A = (T)std::sqrt(ssq);
+                }
+                have_norm = true;
+            }
             norm_B = std::hypot(norm_B, norm_B_i);
             prev_err = approx_err;
             approx_err = std::sqrt(std::abs(norm_A - norm_B)) * (std::sqrt(norm_A + norm_B) / norm_A);    // :225

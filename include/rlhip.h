@@ -99,10 +99,15 @@ int rlhip_gemm_f32(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t 
                    int64_t ldc);
 /* gemm + ||A||_F in ONE pass over A (QB needs both: rl_qb.hh:168 then rl_rf.hh:123 read A twice in the
  * reference).  A is (m x k) for transa 'N', (k x m) for 'T'.  *fused_host = 1 when the norm came out of the GEMM
- * kernel itself (stream-K path), 0 when a separate lange pass was needed.  Synchronises the stream. */
+ * kernel itself (stream-K path), 0 when a separate lange pass was needed.  Synchronises the stream -- unless norm_a_host is NULL:
+ * the norm is then DEFERRED (when it came out of the product, its sum of squares follows the stream into a pinned mailbox) and
+ * rlhip_norma_collect_f64 returns it later, after the caller's next synchronisation (rl_qb.hh:168,221: ||A||_F and ||B_i||_F with one
+ * host round trip).  One norm can be pending per context. */
 int rlhip_gemm_norma_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                          int64_t ldc, double* norm_a_host, int* fused_host);
+/* the norm a rlhip_gemm_norma_f64 call with a NULL result pointer left pending; -3 when there is none */
+int rlhip_norma_collect_f64(rlhip_ctx* ctx, double* norm_a_host);
 /* uplo must be 'U' (the only form the path uses); the strictly lower triangle of C is not touched. */
 int rlhip_syrk_f64(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, double alpha, const double* A,
                    int64_t lda, double beta, double* C, int64_t ldc);
@@ -133,6 +138,12 @@ int rlhip_trmm_f32(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, 
  *      returns info (0, or the 1-based order of the first non-positive leading minor). ---- */
 int rlhip_potrf_f64(rlhip_ctx* ctx, char uplo, int64_t n, double* A, int64_t lda);
 int rlhip_potrf_f32(rlhip_ctx* ctx, char uplo, int64_t n, float* A, int64_t lda);
+/* CholQRQ::call (rl_orth.hh:69-98: syrk :78, potrf :81, trsm :95) as ONE stream of kernels with ONE host read: R (k x k, ld k) receives the
+ * Cholesky factor of A^T A, A (m x k) is overwritten by A R^-1, *info_host = potrf's info (!= 0: A is untouched, as the reference returns
+ * before its trsm).  reduce_gram != 0: row-sharded A, the Gram matrix is all-reduced before it is factored.  Returns 0 when done, 1 when
+ * this shape is not served (the caller issues syrk / potrf / trsm itself), < 0 on error. */
+int rlhip_cholqrq_f64(rlhip_ctx* ctx, int64_t m, int64_t k, double* A, int64_t lda, double* R, int reduce_gram, int* info_host);
+int rlhip_cholqrq_f32(rlhip_ctx* ctx, int64_t m, int64_t k, float* A, int64_t lda, float* R, int reduce_gram, int* info_host);
 /* lapack::lange(Norm::Fro) (rl_qb.hh:168,221) */
 int rlhip_lange_fro_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, double* result_host);
 int rlhip_lange_fro_f32(rlhip_ctx* ctx, int64_t m, int64_t n, const float* A, int64_t lda, float* result_host);
@@ -340,7 +351,7 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
  * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip), 6 persistent one-launch Jacobi sweeps (jacobi.hip),
  * 7 column-at-a-time LU panel of a matrix taller than the resident register kernels hold (lu.hip), 8 register-resident block-pipelined
  * Householder QR of a sketch-sized matrix (qr_blk.hip), 9 its sign-modified LU twin inside orhr_col, 10 the Gram route of the device SVD
- * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
+ * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read), 11 the one-stream Cholesky-QR (rlhip_cholqrq).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);

@@ -98,6 +98,9 @@ SIGNATURES = {
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
     "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
+    "rlhip_norma_collect_f64": (c_int, [c_vp, C.POINTER(c_dbl)]),
+    "rlhip_cholqrq_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),
+    "rlhip_cholqrq_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),
     "rlhip_saso_create": (c_int, [c_vp, c_i64, c_i64, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
     "rlhip_saso_create_mode": (c_int, [c_vp, c_i64, c_i64, c_int, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
     "rlhip_saso_destroy": (c_int, [c_vp, c_vp]),

@@ -146,7 +146,7 @@ int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* re
     hipLaunchKernelGGL(ssq_final_kernel, dim3(1), dim3(256), 0, c->stream, np, partial, d_out);
     RLHIP_LAUNCH_CHECK();
     RLHIP_CHECK(hipMemcpyAsync(c->h_mail, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     double ssq = *(double*)c->h_mail;
     if (!(ssq > 0.0) || ssq > 1.7e308) {
         // all zeros, NaN, or the plain sum of squares over- / underflowed (entries beyond ~1e154 or below ~1e-154): redo it the way
@@ -156,7 +156,7 @@ int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* re
         hipLaunchKernelGGL(absmax_kernel<T>, grid, dim3(256), 0, c->stream, m, n, A, lda, d_mx);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 1, d_mx, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         double mx;
         memcpy(&mx, c->h_mail + 1, sizeof(double));
         if (mx != mx || mx > 1.7e308) { rlhip_ws_release(c, mark); *result_host = (T)mx; return 0; }     // NaN / inf entries: that is the norm
@@ -165,7 +165,7 @@ int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* re
         hipLaunchKernelGGL(ssq_final_kernel, dim3(1), dim3(256), 0, c->stream, np, partial, d_out);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail, d_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         rlhip_ws_release(c, mark);
         *result_host = (T)(mx * sqrt(*(double*)c->h_mail));
         return 0;

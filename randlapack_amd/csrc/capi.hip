@@ -17,6 +17,7 @@ template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, 
 template <typename T> int saso_apply_csr(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const int64_t* rowptrT, const int64_t* colidxT,
                                          const T* valsT, T beta, T* B, int64_t ldb, int64_t row0);
 template <typename T> int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx);
+template <typename T> int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int reduce_gram, int* info_host);
 int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev);
 template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
 template <typename T> int orhr_col(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);
@@ -78,7 +79,7 @@ void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes) {
 void* rlhip_xchg_buffer(rlhip_ctx* c, size_t bytes) {
     if (bytes <= c->xchg_bytes) return c->xchg;
     constexpr int kind = 2;   // uncached: polled words never sit in an L2 (measured against ordinary / fine-grained memory: geqp3 1280 x 1024 8.37 -> 8.15 ms)
-    if (c->xchg) { hipStreamSynchronize(c->stream); hipFree(c->xchg); c->xchg = nullptr; c->xchg_bytes = 0; }
+    if (c->xchg) { rlhip_stream_sync(c); hipFree(c->xchg); c->xchg = nullptr; c->xchg_bytes = 0; }
     bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
     void* p = nullptr;
     hipError_t e;
@@ -106,7 +107,7 @@ void rlhip_ws_release(rlhip_ctx* c, size_t mark) {
     c->cur_used = (c->nsegs && mark >= v) ? (mark - v) : 0;
     if (mark == 0 && c->nsegs > 1) {
         // stack empty: merge the segments into one arena of the high-water size
-        hipStreamSynchronize(c->stream);
+        rlhip_stream_sync(c);
         for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
         c->nsegs = 0; c->cur_seg = 0; c->cur_used = 0;
         size_t want = align_up(c->ws_highwater + (c->ws_highwater >> 3), 1 << 20);
@@ -170,7 +171,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     if (!c) return 0;
     rlhip_comm_destroy(c);
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    rlhip_stream_sync(c);
     for (int i = 0; i < c->npool; ++i) hipFree(c->pool[i].p);
     for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
     if (c->d_mail) hipFree(c->d_mail);
@@ -184,7 +185,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     return 0;
 }
 
-int rlhip_sync(rlhip_ctx* c) { RLHIP_CHECK(hipStreamSynchronize(c->stream)); return 0; }
+int rlhip_sync(rlhip_ctx* c) { RLHIP_CHECK(rlhip_stream_sync(c)); return 0; }
 void* rlhip_stream(rlhip_ctx* c) { return (void*)c->stream; }
 
 static void pool_drop(rlhip_ctx* c, int i) {
@@ -199,12 +200,12 @@ int rlhip_malloc_host(rlhip_ctx* c, void** p, size_t bytes) {
 }
 int rlhip_free_host(rlhip_ctx* c, void* p) {
     if (!p) return 0;
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     RLHIP_CHECK(hipHostFree(p));
     return 0;
 }
 int rlhip_trim(rlhip_ctx* c) {
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     for (int i = c->npool - 1; i >= 0; --i)
         if (!c->pool[i].in_use) pool_drop(c, i);
     return 0;
@@ -219,6 +220,9 @@ int rlhip_malloc(rlhip_ctx* c, void** p, size_t bytes) {
             *p = c->pool[i].p;
             return 0;
         }
+    static int trace = -1;
+    if (trace < 0) { const char* t = getenv("RLHIP_POOL_TRACE"); trace = t ? atoi(t) : 0; }
+    if (trace) fprintf(stderr, "[rlhip pool] miss: %zu bytes (%d blocks, %zu idle bytes)\n", bytes, c->npool, c->pool_idle_bytes);
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {                       // give the idle blocks back and try once more
         (void)hipGetLastError();
@@ -237,7 +241,7 @@ int rlhip_free(rlhip_ctx* c, void* p) {
             c->pool[i].stamp = ++c->pool_clock;
             c->pool_idle_bytes += c->pool[i].bytes;
             if (c->pool_idle_bytes > c->pool_cap_bytes) {          // over the cap: release least recently freed blocks
-                RLHIP_CHECK(hipStreamSynchronize(c->stream));
+                RLHIP_CHECK(rlhip_stream_sync(c));
                 while (c->pool_idle_bytes > c->pool_cap_bytes) {
                     int lru = -1;
                     for (int j = 0; j < c->npool; ++j)
@@ -248,18 +252,18 @@ int rlhip_free(rlhip_ctx* c, void* p) {
             }
             return 0;
         }
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));                 // not one of ours (table was full): plain free
+    RLHIP_CHECK(rlhip_stream_sync(c));                 // not one of ours (table was full): plain free
     RLHIP_CHECK(hipFree(p));
     return 0;
 }
 int rlhip_memcpy_h2d(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     RLHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     return 0;
 }
 int rlhip_memcpy_d2h(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
     RLHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     return 0;
 }
 int rlhip_memcpy_d2d(rlhip_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -275,7 +279,7 @@ int rlhip_reserve_workspace(rlhip_ctx* c, size_t bytes) {
     size_t total = 0;
     for (int i = 0; i < c->nsegs; ++i) total += c->segs[i].size;
     if (c->nsegs == 1 && bytes <= total) return 0;
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
     c->nsegs = 0; c->cur_seg = 0; c->cur_used = 0;
     bytes = align_up(bytes > total ? bytes : total, 1 << 20);
@@ -392,6 +396,12 @@ static inline int op_flag(char t, int* out) {
         int rc = rlhip::potrf_upper<T>(c, n, A, lda, &info);                                                     \
         return rc ? rc : info;                                                                                  \
     }                                                                                                           \
+    int rlhip_cholqrq_##SUF(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int reduce_gram, int* info_host) { \
+        if (!info_host) return -8;                                                                              \
+        if (m < 0) return -2;                                                                                   \
+        if (k < 0) return -3;                                                                                   \
+        return rlhip::cholqrq<T>(c, m, k, A, lda, R, reduce_gram, info_host);                                    \
+    }                                                                                                           \
     int rlhip_lange_fro_##SUF(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* res) {            \
         return rlhip::lange_fro<T>(c, m, n, A, lda, res);                                                        \
     }                                                                                                           \
@@ -429,7 +439,7 @@ static inline int op_flag(char t, int* out) {
         if (n <= 0) return 0;                                                                                   \
         RLHIP_CHECK(hipMemcpy2DAsync(diag_host, sizeof(T), A, (size_t)(lda + 1) * sizeof(T), sizeof(T), (size_t)n, \
                                      hipMemcpyDeviceToHost, c->stream));                                        \
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));                                                           \
+        RLHIP_CHECK(rlhip_stream_sync(c));                                                           \
         return 0;                                                                                               \
     }                                                                                                           \
     int rlhip_orhr_col_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* D) { \
@@ -516,18 +526,48 @@ int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, i
     if (rc) return rc;
     if (fused_host) *fused_host = done ? 1 : 0;
     const int64_t arows = fa ? k : m, acols = fa ? m : k;
-    if (!done) return rlhip::lange_fro<double>(c, arows, acols, A, lda, norm_a_host);
-    double ssq_main = 0, rest = 0;
-    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 40, d_ssq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
-    ssq_main = *(double*)(c->h_mail + 40);
-    const int64_t m_main = (m / 128) * 128;
-    if (m_main < m && done != 2) {   // rows (or, for op = T, columns) peeled off to the generic kernel
-        const double* A2 = fa ? (A + m_main * lda) : (A + m_main);
-        rc = rlhip::lange_fro<double>(c, fa ? k : (m - m_main), fa ? (m - m_main) : k, A2, lda, &rest);
-        if (rc) return rc;
+    c->norma_state = 0;
+    if (done == 2 && norm_a_host == nullptr) {
+        // deferred: the sum of squares travels to the pinned mailbox behind the stream; rlhip_norma_collect_f64 picks it up after whatever
+        // synchronisation comes next (QB reads ||A||_F and ||B_i||_F with ONE host round trip this way)
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 40, d_ssq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        c->norma_state = 1;
+        c->norma_epoch = c->sync_epoch;
+        return 0;
     }
-    *norm_a_host = sqrt(ssq_main + rest * rest);
+    double result = 0;
+    if (!done) {
+        rc = rlhip::lange_fro<double>(c, arows, acols, A, lda, &result);
+        if (rc) return rc;
+    } else {
+        double ssq_main = 0, rest = 0;
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 40, d_ssq, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
+        ssq_main = *(double*)(c->h_mail + 40);
+        const int64_t m_main = (m / 128) * 128;
+        if (m_main < m && done != 2) {   // rows (or, for op = T, columns) peeled off to the generic kernel
+            const double* A2 = fa ? (A + m_main * lda) : (A + m_main);
+            rc = rlhip::lange_fro<double>(c, fa ? k : (m - m_main), fa ? (m - m_main) : k, A2, lda, &rest);
+            if (rc) return rc;
+        }
+        result = sqrt(ssq_main + rest * rest);
+    }
+    if (norm_a_host) *norm_a_host = result;
+    else { c->norma_value = result; c->norma_state = 2; }
+    return 0;
+}
+
+int rlhip_norma_collect_f64(rlhip_ctx* c, double* norm_a_host) {
+    if (!norm_a_host) return -2;
+    if (c->norma_state == 1) {
+        if (c->sync_epoch == c->norma_epoch) RLHIP_CHECK(rlhip_stream_sync(c));      // (normally a later call has already waited on the stream: no second round trip)
+        *norm_a_host = sqrt(*(double*)(c->h_mail + 40));
+    } else if (c->norma_state == 2) {
+        *norm_a_host = c->norma_value;
+    } else {
+        return -3;                                               // nothing pending
+    }
+    c->norma_state = 0;
     return 0;
 }
 

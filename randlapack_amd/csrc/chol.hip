@@ -217,7 +217,7 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
         hipLaunchKernelGGL(potrf_small_kernel<T>, dim3(1), dim3(1024), smem, c->stream, (int)n, A, lda, d_info, 0);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         *info_host = *(int*)(c->h_mail + 8);
         return 0;
     }
@@ -252,7 +252,7 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
         rlhip_ws_release(c, mark);
         if (rc) return rc;
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 8, d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         const int v = *(int*)(c->h_mail + 8);
         *info_host = v ? v - 1 : 0;
         return 0;

@@ -147,7 +147,7 @@ int rlhip_comm_destroy(rlhip_ctx* c) {
     if (!c->comm) return 0;
     rlhip_comm* cm = comm_of(c);
     if (cm->comm && g_rccl.destroy) {
-        hipStreamSynchronize(c->stream);
+        rlhip_stream_sync(c);
         g_rccl.destroy(cm->comm);
     }
     delete cm;
@@ -180,7 +180,7 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* c, double* x_host, int64_t n) {
     int rc = allreduce_impl(c, d, n, 1);
     if (rc) return rc;
     RLHIP_CHECK(hipMemcpyAsync(x_host, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     return 0;
 }
 

@@ -19,6 +19,7 @@
 //    to scratch and a second kernel sums the slabs in fixed order (bitwise reproducible run to run,
 //    unlike atomics).
 #include "rlhip_internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -354,6 +355,62 @@ __global__ void scale_kernel(int64_t M, int64_t N, T beta, T* __restrict__ C, in
     }
 }
 
+
+// ---- small products (the k x k matrices of the SVD / Cholesky-QR tails: 256^3 and the like).  The tiled kernel above gives such a product
+// 4 workgroups (128 x 128 tiles, no split: the K loop is 16 tiles long) = 40 us at 256^3 on 4 of 256 CUs.  Here a workgroup of four waves
+// owns a 32 x 32 block of C (one 16 x 16 MFMA tile per wave), operands come straight from L2 with element strides (any transposition), eight
+// k-steps of loads in flight per lane: 64 workgroups, ~6 us at 256^3.  Operands are swapped (B as the MFMA A operand) so that a lane's
+// results run along the rows of column-major C.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, T alpha, const T* __restrict__ A, int64_t sai, int64_t sak, const T* __restrict__ B,
+                                                         int64_t sbk, int64_t sbj, T beta, T* __restrict__ C, int64_t ldc) {
+    typedef double d4s_t __attribute__((ext_vector_type(4)));
+    typedef float f4s_t __attribute__((ext_vector_type(4)));
+    using acc_t = typename std::conditional<sizeof(T) == 8, d4s_t, f4s_t>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int i0 = blockIdx.x * 32 + (wid & 1) * 16, j0 = blockIdx.y * 32 + (wid >> 1) * 16;
+    if (i0 >= M || j0 >= N) return;
+    const int ia = (i0 + fr < M) ? i0 + fr : M - 1, jb = (j0 + fr < N) ? j0 + fr : N - 1;      // clamped: every load is unconditional
+    const T* pa = A + (int64_t)ia * sai;
+    const T* pb = B + (int64_t)jb * sbj;
+    acc_t acc = {0, 0, 0, 0};
+    const int K8 = (K / 32) * 32;
+    for (int k0 = 0; k0 < K8; k0 += 32) {
+        T av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k0 + 4 * u + fk;
+            av[u] = pa[(int64_t)kk * sak];
+            bv[u] = pb[(int64_t)kk * sbk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if constexpr (sizeof(T) == 8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[u], av[u], acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[u], av[u], acc, 0, 0, 0);
+        }
+    }
+    for (int k0 = K8; k0 < K; k0 += 4) {
+        const int kk = k0 + fk;
+        const int kc = (kk < K) ? kk : K - 1;
+        T a = pa[(int64_t)kc * sak], b = pb[(int64_t)kc * sbk];
+        if (kk >= K) { a = T(0); b = T(0); }
+        if constexpr (sizeof(T) == 8) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc, 0, 0, 0);
+    }
+    // swapped operands: D[m = column index j][n = row index i];  f64: register r <-> m = 4 r + fk;  f32: m = 4 fk + r
+    const int i = i0 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ((sizeof(T) == 8) ? (4 * r + fk) : (4 * fk + r));
+        if (i < M && j < N) {
+            T v = alpha * (T)acc[r];
+            if (beta != T(0)) v += beta * C[i + (int64_t)j * ldc];
+            C[i + (int64_t)j * ldc] = v;
+        }
+    }
+}
+
 template <typename T, bool A_KC, bool B_KC, int BM, int BN, int BK, int WM, int WN, int MINW, bool EARLY, bool VEC, int DBG = 0>
 int launch_one(rlhip_ctx* c, GemmArgs<T>& g, int64_t splitk) {
     using GA = TileGeom<T, BM, BK, A_KC>;
@@ -550,6 +607,17 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
             const T* A2 = transA ? (A + m_main * lda) : (A + m_main);
             return gemm_impl<T>(c, transA, transB, m - m_main, n, k, alpha, A2, lda, B, ldb, beta, C + m_main, ldc, 0,
                                 nullptr, nullptr);
+        }
+    }
+    if (!tri && m <= 512 && n <= 512 && k <= 2048 && m * n >= 1024 && ((m + 127) / 128) * ((n + 127) / 128) <= 16) {
+        static int small_on = -1;
+        if (small_on < 0) { const char* e = getenv("RLHIP_GEMM_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
+        if (small_on) {
+            // op(A)(i, kk): NoTrans A[i + kk lda], Trans A[kk + i lda];  op(B)(kk, j): NoTrans B[kk + j ldb], Trans B[j + kk ldb]
+            hipLaunchKernelGGL(gemm_small_kernel<T>, dim3((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, c->stream, (int)m, (int)n, (int)k, alpha, A,
+                               transA ? lda : (int64_t)1, transA ? (int64_t)1 : lda, B, transB ? ldb : (int64_t)1, transB ? (int64_t)1 : ldb, beta, C, ldc);
+            RLHIP_LAUNCH_CHECK();
+            return 0;
         }
     }
     GemmArgs<T> g;

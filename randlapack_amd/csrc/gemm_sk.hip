@@ -605,7 +605,7 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     }
     if (g.clk) {   // debug: effective shader clock of this launch (costs a host sync)
         unsigned long long h[4];
-        if (hipMemcpyAsync(h, g.clk, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess && h[3] > h[1])
+        if (hipMemcpyAsync(h, g.clk, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess && rlhip_stream_sync(c) == hipSuccess && h[3] > h[1])
             fprintf(stderr, "[sk clock] %s m %lld n %lld k %lld: %.1f us at %.0f MHz\n", transA ? "TN" : "NN", (long long)m, (long long)n, (long long)k,
                     (double)(h[3] - h[1]) / 100.0, (double)(h[2] - h[0]) / ((double)(h[3] - h[1]) / 100.0));
     }

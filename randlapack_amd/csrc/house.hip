@@ -328,7 +328,7 @@ int any_abs_gt(rlhip_ctx* c, int64_t n, const T* x, T thr, int* any_host) {
     hipLaunchKernelGGL(any_abs_gt_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, x, thr, d_flag);
     RLHIP_LAUNCH_CHECK();
     RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 48, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    RLHIP_CHECK(hipStreamSynchronize(c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
     *any_host = *(int*)(c->h_mail + 48);
     return 0;
 }
@@ -385,7 +385,7 @@ static int cholqr2_inplace(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda
         hipLaunchKernelGGL(r2_identity_dev_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R2, (int64_t)n, dev1);
         T dev_h = 0;
         RLHIP_CHECK(hipMemcpyAsync(&dev_h, dev1, sizeof(T), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         ok = (dev_h <= T(1e-2));                                                     // Q1 was orthonormal to ~1e-2: pass 2 is accurate
     }
     if (!ok) {                                                                       // restore A = Q1 R1
@@ -442,7 +442,7 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
             std::vector<T> dg((size_t)n);
             if (!rc) {
                 RLHIP_CHECK(hipMemcpy2DAsync(dg.data(), sizeof(T), Ask, (size_t)(d + 1) * sizeof(T), sizeof(T), (size_t)n, hipMemcpyDeviceToHost, c->stream));
-                RLHIP_CHECK(hipStreamSynchronize(c->stream));
+                RLHIP_CHECK(rlhip_stream_sync(c));
             }
             bool usable = !rc;
             if (usable) {

@@ -741,7 +741,7 @@ int jacobi_verify_converged(rlhip_ctx* c, int m, int n, const T* A, int64_t lda,
             // rotated nothing: 0.23 ms of the 3.66 ms device SVD of the RSVD tail.  The sweeps' own rotation criterion stays at tol.)
             hipLaunchKernelGGL(gram_offdiag_kernel<T>, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, c->stream, n, G, (T)(4 * tol), flag);
             RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            RLHIP_CHECK(rlhip_stream_sync(c));
             *ok = (*((unsigned*)(c->h_mail + 16) + 1) == 0u);
         }
     }
@@ -770,7 +770,7 @@ int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NB
     g.m = m; g.NB = NBk; g.X = buf; g.bflag = buf + xwords; g.sflag = g.bflag + NBk; g.done = g.sflag + 8 * (size_t)NW;
     g.hold_mode = h.mode; g.hold_nap = h.nap; g.hold_delay_us = h.delay;
     hipError_t e1 = hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 8 * (size_t)NW + 1) * sizeof(unsigned long long), c->stream);
-    if (e1 == hipSuccess) e1 = hipMemsetAsync(g.out, 0, 8 * sizeof(int), c->stream);
+    if (e1 == hipSuccess) e1 = hipMemsetAsync(g.out, 0, 16 * sizeof(int), c->stream)     /* (out has >= 16 ints: the Gram route keeps its defect word behind the 8 of this launch) */;
     if (e1 != hipSuccess) return RLHIP_ERR_HIP(e1);
     constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
     RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT>), smem);
@@ -811,7 +811,7 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
         const int lrc = jp_launch<T>(c, g, buf, m, NBk);
         if (lrc) { rlhip_ws_release(c, mark); return lrc; }
         hipError_t e2 = hipMemcpyAsync(c->h_mail + 16, out, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 == hipSuccess) e2 = rlhip_stream_sync(c);
         if (e2 != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(e2); }
         const int status = *(int*)(c->h_mail + 16), done_sweeps = *((int*)(c->h_mail + 16) + 1), any_lost = *((int*)(c->h_mail + 16) + 2);
         {
@@ -857,7 +857,7 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
                                V, (int64_t)n, tol, d_nrot);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         const unsigned nrot = *(unsigned*)(c->h_mail + 16);
         float cos2;
         memcpy(&cos2, (const char*)(c->h_mail + 16) + sizeof(unsigned), sizeof(float));
@@ -996,7 +996,7 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
             }
             RLHIP_LAUNCH_CHECK();
             RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            RLHIP_CHECK(rlhip_stream_sync(c));
             unsigned nrot = *(unsigned*)(c->h_mail + 16);
             if (nrot == 0) { ++sweep; break; }
         }

@@ -883,7 +883,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
 #ifdef RLHIP_LU_PROF
     {
         unsigned long long pf[5];
-        hipStreamSynchronize(c->stream);
+        rlhip_stream_sync(c);
         hipMemcpy(pf, (unsigned long long*)(g.diag_data + 2 * PB), sizeof(pf), hipMemcpyDeviceToHost);
         const double cols = (double)mn;
         fprintf(stderr, "[lu prof %ld x %ld] us per column: candidate %.2f  publish %.2f  exchange %.2f  decision %.2f  eliminate %.2f\n", (long)m, (long)n,
@@ -892,7 +892,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
 #endif
     if (info_host) {
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, g.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         *info_host = *(int*)(c->h_mail + 56);
         if (*info_host < 0) { rlhip_ws_release(c, mark); return -9; }   // the flag-less exchange timed out (bounded so that a lost word cannot hang the device)
     }

@@ -484,7 +484,7 @@ int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev)
 #ifdef RLHIP_QB_PROF
     {
         unsigned long long pf[3];
-        hipStreamSynchronize(c->stream);
+        rlhip_stream_sync(c);
         hipMemcpy(pf, g.prof, sizeof(pf), hipMemcpyDeviceToHost);
         fprintf(stderr, "[qr_blk prof %ld x %ld] us per chunk: last application %.2f  factorization %.2f  publication %.2f\n", (long)m, (long)n,
                 pf[0] / 100.0 / G, pf[1] / 100.0 / G, pf[2] / 100.0 / G);

@@ -1145,7 +1145,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
             void* kargs[] = {(void*)&t};
             RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qrcp_tag_kernel<T>, dim3((unsigned)Gt), dim3(256), kargs, (unsigned)dyn, c->stream));
             RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, t.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            RLHIP_CHECK(rlhip_stream_sync(c));
 #ifdef RLHIP_QT_PROF
             {
                 long long pf[6];

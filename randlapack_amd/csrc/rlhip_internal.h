@@ -77,6 +77,12 @@ struct rlhip_ctx {
     size_t xchg_bytes = 0;
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ||A||_F fused into a product and not yet collected (rlhip_gemm_norma_f64 with a null result pointer): 0 nothing, 1 the sum of squares
+    // is on its way to h_mail[40] behind the stream, 2 norma_value holds the norm
+    int norma_state = 0;
+    double norma_value = 0;
+    unsigned long norma_epoch = 0;   // sync_epoch when the deferred copy was enqueued
+    unsigned long sync_epoch = 0;    // completed host waits on the stream (rlhip_stream_sync): anything enqueued before the last one has landed
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU
     void* comm = nullptr;
@@ -92,6 +98,13 @@ struct rlhip_ctx {
     //   (rlhip_trsm_gather), 5 sketch-preconditioned Cholesky-QR panel inside geqrf -- the list in include/rlhip.h is the contract
     int64_t path_count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// every host wait of the library goes through here: the epoch lets deferred read-backs know that an earlier wait already covered them
+static inline hipError_t rlhip_stream_sync(rlhip_ctx* c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) ++c->sync_epoch;
+    return e;
+}
 
 // scratch arena helpers (capi.hip)
 void* rlhip_ws_alloc(rlhip_ctx* c, size_t bytes);           // 256-B aligned, never fails softly (nullptr on OOM)

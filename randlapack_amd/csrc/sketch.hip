@@ -591,7 +591,7 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
 
 int saso_destroy(rlhip_ctx* c, SasoOp* op) {
     if (!op) return 0;
-    hipStreamSynchronize(c->stream);
+    rlhip_stream_sync(c);
     hipFree(op->src); hipFree(op->ainv); hipFree(op->b); hipFree(op->afwd); hipFree(op->rows); hipFree(op->ptr);
     delete op;
     return 0;
@@ -711,7 +711,7 @@ int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, c
         std::vector<int64_t> h_idx((size_t)n), h_moves((size_t)(2 * n + 2));
         std::vector<unsigned char> h_seen((size_t)n, 0);
         RLHIP_CHECK(hipMemcpyAsync(h_idx.data(), idx_dev, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         int64_t w = 0;
         for (int64_t i = 0; i < n; ++i) {
             if (h_seen[(size_t)i]) continue;
@@ -732,7 +732,7 @@ int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, c
         h_moves[(size_t)(2 * n + 1)] = w;                       // nmoves travels in the same copy when adjacent
         RLHIP_CHECK(hipMemcpyAsync(moves, h_moves.data(), sizeof(int64_t) * (size_t)std::max<int64_t>(w, 1), hipMemcpyHostToDevice, c->stream));
         RLHIP_CHECK(hipMemcpyAsync(nmoves, &h_moves[(size_t)(2 * n + 1)], sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));           // the host vectors die at the end of this scope
+        RLHIP_CHECK(rlhip_stream_sync(c));           // the host vectors die at the end of this scope
     } else
         hipLaunchKernelGGL(perm_moves_kernel, dim3(1), dim3(1), 0, c->stream, n, idx_dev, moves, nmoves, seen);
     hipLaunchKernelGGL(perm_apply_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, A, lda, moves,

@@ -233,7 +233,7 @@ int csr_transpose(rlhip_ctx* c, int64_t m, int64_t k, const int64_t* rowptr, con
     int64_t nnz = 0;
     if (m > 0) {
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 50, rowptr + m, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         nnz = c->h_mail[50];
     }
     if (nnz < 0 || nnz >= ((int64_t)1 << 31)) return -2;      // per-column counters are 32-bit
@@ -255,7 +255,7 @@ int csr_transpose(rlhip_ctx* c, int64_t m, int64_t k, const int64_t* rowptr, con
         if (nnz > 0) hipLaunchKernelGGL(ct_count_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, nnz, per, k, colidx, cnt, d_bad);
         hipLaunchKernelGGL(ct_chunk_scan_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream, nb, k, cnt, total);
         hipLaunchKernelGGL(ct_rowptr_kernel, dim3(1), dim3(1024), 0, c->stream, k, total, rowptrT);
-        if (hipMemcpyAsync(c->h_mail + 51, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = -1; break; }
+        if (hipMemcpyAsync(c->h_mail + 51, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || rlhip_stream_sync(c) != hipSuccess) { rc = -1; break; }
         if (*(int*)(c->h_mail + 51)) { rc = -2; break; }                                   // a column index outside [0, k)
         if (nnz > 0)
             hipLaunchKernelGGL(ct_scatter_kernel<T>, dim3((unsigned)nb), dim3(64), 0, c->stream, m, nnz, per, k, rowptr, colidx, vals, rowptrT, cnt, colidxT, valsT);

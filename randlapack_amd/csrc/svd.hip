@@ -136,23 +136,26 @@ __global__ __launch_bounds__(256) void gram_finalize_kernel(int n, const T* __re
     if (threadIdx.x == 0) S[r] = sigma;
 }
 
-// out[0] = max |M - I| over the n x n matrix M (NaN counts as infinite); one workgroup
+// out[0] = max(out[0], max |M - I|) over the n x n matrix M (NaN counts as infinite); out[0] must start at 0.  Non-negative doubles order
+// like their bit patterns, so the workgroups combine with an integer atomic max.
 template <typename T>
-__global__ __launch_bounds__(1024) void identity_defect_kernel(int n, const T* __restrict__ M, double* __restrict__ out) {
-    __shared__ double red[1024];
+__global__ __launch_bounds__(256) void identity_defect_kernel(int n, const T* __restrict__ M, double* __restrict__ out) {
+    __shared__ double red[4];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     double v = 0;
-    for (int e = threadIdx.x; e < n * n; e += 1024) {
-        const int i = e % n, j = e / n;
-        const double dv = fabs((double)M[e] - (i == j ? 1.0 : 0.0));
-        if (dv > v || dv != dv) v = (dv != dv) ? 1e300 : dv;
+    if (idx < n * n) {
+        const int i = idx % n, j = idx / n;
+        v = fabs((double)M[idx] - (i == j ? 1.0 : 0.0));
+        if (v != v) v = 1e300;
     }
-    red[threadIdx.x] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(v, off, 64); v = (o > v) ? o : v; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st && red[threadIdx.x + st] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + st];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        const double w = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(w));
     }
-    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 }  // namespace
@@ -194,7 +197,7 @@ int gesdd_tall_gram(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda,
         T* W = ws_alloc<T>(c, (size_t)n * n);
         T* M1 = ws_alloc<T>(c, (size_t)n * n);
         T* sig = ws_alloc<T>(c, (size_t)n);
-        int64_t* mb = ws_alloc<int64_t>(c, 8);       // [0..3] the Jacobi launch's 8 ints, [4] defect (double)
+        int64_t* mb = ws_alloc<int64_t>(c, 8);       // [0..3] the Jacobi launch's 8 ints, [4] defect (double); the launch clears all of it
         if (!G || !Gf || !W || !M1 || !sig || !mb) { rlhip_ws_release(c, mark); return 1; }
         int* jout = (int*)mb;
         double* defect = (double*)(mb + 4);
@@ -213,10 +216,10 @@ int gesdd_tall_gram(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda,
         if (!rc) rc = gemm<T>(c, 0, 0, n, n, n, T(1), Gf, n, W, n, T(0), M1, n);          // U^T U = W^T (G W)
         if (!rc) rc = gemm<T>(c, 1, 0, n, n, n, T(1), W, n, M1, n, T(0), G, n);
         if (rc) { rlhip_ws_release(c, mark); return rc < 0 ? rc : 1; }
-        hipLaunchKernelGGL(identity_defect_kernel<T>, dim3(1), dim3(1024), 0, c->stream, nn, G, defect);
+        hipLaunchKernelGGL(identity_defect_kernel<T>, dim3(g2), dim3(256), 0, c->stream, nn, G, defect);            // (defect starts at 0: the Jacobi launch cleared the mailbox)
         RLHIP_LAUNCH_CHECK();
         hipError_t e = hipMemcpyAsync(c->h_mail + 32, mb, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = rlhip_stream_sync(c);
         rlhip_ws_release(c, mark);
         if (e != hipSuccess) return RLHIP_ERR_HIP(e);
         const int* jo = (const int*)(c->h_mail + 32);
@@ -261,7 +264,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
         double* d_ratio = (double*)(c->d_mail + 24);
         hipLaunchKernelGGL(diag_ratio_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R1, (int64_t)n, d_ratio);
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 24, d_ratio, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         ratio = *(double*)(c->h_mail + 24);
         const double lim = (sizeof(T) == 8) ? 1e7 : 1e3;
         if (!(ratio < lim)) fallback = true;
@@ -283,7 +286,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
             double* d_dev = (double*)(c->d_mail + 25);
             hipLaunchKernelGGL(gram_identity_dev_kernel<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, R2, (int64_t)n, d_dev);
             RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 25, d_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(hipStreamSynchronize(c->stream));
+            RLHIP_CHECK(rlhip_stream_sync(c));
             const double dev = *(double*)(c->h_mail + 25);
             one_pass = (dev <= ((sizeof(T) == 8) ? 1e-13 : 5e-6));
         }

@@ -15,6 +15,7 @@
 //     registers, earlier x values of the same row in an LDS tile.
 #include <cstdlib>
 #include "rlhip_internal.h"
+#include "rlhip.h"
 #include <cstdio>
 
 namespace rlhip {
@@ -346,11 +347,21 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // CQRRPT's column pivoting folded into the solve, rl_cqrrpt.hh:288-300) and the solution is WRITTEN to B; the solved tiles needed by
 // later blocks are re-read from B.  The pivot entries of a tile are wave-uniform (scalar loads), only the choice among the lane
 // group's four columns is per lane, so the number of vector-memory requests per step -- which the counted waits rely on -- is unchanged.
-template <typename T, int NW, int HPR, bool OOP>
+// XASM: the X-operand loads of a panel step are issued from inline asm behind the kernel's own counted waits (false: plain C++ loads, the
+// compiler's waits).  The asm form is only correct as long as the register allocator neither spills nor copies a destination register
+// between its issue and the counted wait that covers it -- scripts/check_trsm_asm.py proves that on the disassembly of every build, and
+// the build falls back to XASM = false when the proof fails.  gate / ngate: the launch does nothing when any of the ngate device words is
+// non-zero (cholqrq below: the Cholesky factorization failed, or a diagonal block failed the conditioning guard).
+template <typename T, int NW, int HPR, bool OOP, bool XASM>
 __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64_t n, int64_t n_pad, T alpha, const T* __restrict__ Uneg,
                                                                 const T* __restrict__ Dinv, T* __restrict__ B, int64_t ldb, int J0, int J1,
                                                                 int K0blk, T* __restrict__ dump, const T* __restrict__ Bsrc, int64_t ldsrc,
-                                                                const int64_t* __restrict__ perm, int64_t pbase) {
+                                                                const int64_t* __restrict__ perm, int64_t pbase, const int* __restrict__ gate, int ngate) {
+    if (gate != nullptr) {
+        int closed = 0;
+        for (int i = 0; i < ngate; ++i) closed |= gate[i];
+        if (closed) return;
+    }
     static_assert(HPR == 16, "the diagonal phase below is written for 16-row panels (two per 32-column sub-block)");
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
@@ -391,12 +402,9 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
 #pragma unroll
         for (int qq = 0; qq < NQ; ++qq) {
             const T* bq = ubase + 4 * qq * ldb;                 // uniform
-#ifdef RLHIP_TF_NOXASM
-            dst[qq] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(bq) + xoffb);
-#else
-            if constexpr (sizeof(T) == 8) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(dst[qq]) : "v"(xoffb), "s"(bq) : "memory");   // (s_nop: the base may have been written by the instruction before -- hipcc does not look into asm for that hazard)
+            if constexpr (!XASM) dst[qq] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(bq) + xoffb);
+            else if constexpr (sizeof(T) == 8) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(dst[qq]) : "v"(xoffb), "s"(bq) : "memory");   // (s_nop: the base may have been written by the instruction before -- hipcc does not look into asm for that hazard)
             else asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(dst[qq]) : "v"(xoffb), "s"(bq) : "memory");
-#endif
         }
     };
     // after a counted wait: the registers the asm loads filled are defined from here on (nothing hipcc scheduled earlier may stand in for them)
@@ -647,6 +655,34 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(int64_t m, int64_t n, 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) dst[i + c * ldd] = src[i + sc * lds_];
 }
 
+
+// RLHIP_TF_XASM_DEFAULT comes from the build (Makefile: 1 when scripts/check_trsm_asm.py has proven the asm-issued loads of THIS build safe,
+// else 0); RLHIP_TRSM_XASM = 0 / 1 overrides it per call (tests compare the two builds of the kernel bit for bit).
+#ifndef RLHIP_TF_XASM_DEFAULT
+#define RLHIP_TF_XASM_DEFAULT 1
+#endif
+inline bool tf_xasm() {
+    const char* e = getenv("RLHIP_TRSM_XASM");
+    return e ? (atoi(e) != 0) : (RLHIP_TF_XASM_DEFAULT != 0);
+}
+
+template <typename T, bool OOP>
+int tf_launch(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
+              const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
+    const dim3 grid((unsigned)((m + 127) / 128));
+    if (tf_xasm()) {
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, OOP, true>), fused_lds_bytes<T>());
+        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, OOP, true>), grid, dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+                           dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
+    } else {
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, OOP, false>), fused_lds_bytes<T>());
+        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, OOP, false>), grid, dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+                           dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
+    }
+    RLHIP_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -684,7 +720,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
                            1.0e6);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         for (int i = 0; i < 32; ++i) bad_host[i] = ((int*)(c->h_mail + 16))[i];
     }
     // Two-level blocking.  Outer 256-column blocks: the contribution of everything to the left is ONE wide MFMA
@@ -719,7 +755,6 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
             if (!Uneg) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, c->stream, n, n_pad, A, lda, Uneg);
             RLHIP_LAUNCH_CHECK();
-            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, false>), fused_lds_bytes<T>());
             fdump = ws_alloc<T>(c, 512 + 64);
             if (!fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         }
@@ -738,13 +773,15 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
                 if (rc) { rlhip_ws_release(c, mark); return rc; }
                 a = T(1);
             }
-            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, false>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, a, Uneg,
-                               Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0);
-            RLHIP_LAUNCH_CHECK();
+            {
+                const int lrc = tf_launch<T, false>(c, m, n, n_pad, a, Uneg, Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0,
+                                                    (const int*)nullptr, 0);
+                if (lrc) { rlhip_ws_release(c, mark); return lrc; }
+            }
 #ifdef RLHIP_TF_PROF
             {
                 long long pf[16];
-                hipStreamSynchronize(c->stream);
+                rlhip_stream_sync(c);
                 hipMemcpy(pf, fdump + 512, sizeof(pf), hipMemcpyDeviceToHost);
                 fprintf(stderr, "[trsm prof, one workgroup, us over %d blocks] off-diagonal %.1f | diag steps", Je - Jb, pf[0] / 100.0);
                 for (int i = 1; i <= 14; ++i) fprintf(stderr, " %.1f", pf[i] / 100.0);
@@ -853,16 +890,16 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
             perm_checked = true;
         }
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         if (perm_checked && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }     // jpvt is not a permutation of 1..n (as col_swap reports it)
         for (int64_t b = 0; b < nblk; ++b) fused = fused && ((int*)(c->h_mail + 16))[b] == 0;
         if (fused) {
             hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
             RLHIP_LAUNCH_CHECK();
-            RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, true>), fused_lds_bytes<T>());
-            hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, true>), dim3((unsigned)((m + 127) / 128)), dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n, alpha, Uneg,
-                               Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1);
-            RLHIP_LAUNCH_CHECK();
+            {
+                const int lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)nullptr, 0);
+                if (lrc) { rlhip_ws_release(c, mark); return lrc; }
+            }
             c->path_count[4]++;
             rlhip_ws_release(c, mark);
             return 0;
@@ -879,7 +916,7 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipStreamSynchronize(c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
         rlhip_ws_release(c, mk2);
         if (*(int*)(c->h_mail + 16) != 0) return -7;
     }
@@ -935,6 +972,70 @@ int trmm_left_upper(rlhip_ctx* c, int trans, int diag, int64_t m, int64_t n, T a
 }
 template int trmm_left_upper<double>(rlhip_ctx*, int, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trmm_left_upper<float>(rlhip_ctx*, int, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
+
+template <typename T>
+int potrf_upper_enqueue(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_dev);
+
+// Cholesky-QR, Q factor only (RandLAPACK/comps/rl_orth.hh:69-98: syrk -> potrf -> trsm) as ONE stream of kernels with ONE host read:
+//   R (k x k, ld k) = chol(A^T A) (upper; the strictly lower part is zero), A <- A R^-1, *info_host = LAPACK's potrf info.
+// The factorization leaves its info in a device word; the conditioning guard of the fused solve leaves its verdicts next to it; the
+// fused solve is launched unconditionally and does nothing when any of those words is set.  The host reads them all at the end: info != 0
+// -> A is untouched (the reference returns before its trsm as well); a guard verdict -> the solve is repeated by the ordinary route
+// (substitution where the explicit 32 x 32 inverses are not trustworthy).  `reduce_gram`: row-sharded input, the Gram matrix is summed over
+// the ranks before it is factored.  Returns 1 when the shape is not served here (short or ragged inputs): the caller runs the three calls.
+template <typename T>
+int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int reduce_gram, int* info_host) {
+    static int fused_on = -1, fused_min_rows = 0, blk_on = -1;
+    if (fused_on < 0) {
+        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
+        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;
+        const char* b = getenv("RLHIP_TRSM_BLK"); blk_on = (b && atoi(b) == 0) ? 0 : 1;
+    }
+    const char* fe = getenv("RLHIP_CHOLQRQ_FUSED");              // read per call (tests)
+    const int64_t nblk = (k + BW - 1) / BW;
+    if ((fe && atoi(fe) == 0) || !fused_on || !blk_on || m < fused_min_rows || k < BW || k % BW != 0 || k > 448 || nblk > 31 || lda < m ||
+        (4 * lda + m) >= ((int64_t)1 << 28))
+        return 1;
+    *info_host = 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
+    T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
+    int* words = ws_alloc<int>(c, 40);                            // [0] potrf info, [1 .. nblk] guard verdicts
+    T* Uneg = ws_alloc<T>(c, (size_t)k * k);
+    T* fdump = ws_alloc<T>(c, 512 + 64);
+    if (!Upk_all || !Dinv_all || !words || !Uneg || !fdump) { rlhip_ws_release(c, mark); return 1; }
+    auto fail = [&](int rc) { rlhip_ws_release(c, mark); return rc; };
+    hipError_t e0 = hipMemsetAsync(words, 0, 40 * sizeof(int), c->stream);
+    if (e0 != hipSuccess) return fail(RLHIP_ERR_HIP(e0));
+    int rc = laset<T>(c, 2, k, k, T(0), T(0), R, k);
+    if (!rc) rc = syrk<T>(c, Upper, 1, k, m, T(1), A, lda, T(0), R, k);
+    if (!rc && reduce_gram) rc = (sizeof(T) == 8) ? rlhip_allreduce_sum_f64(c, (double*)R, k * k) : rlhip_allreduce_sum_f32(c, (float*)R, k * k);
+    if (!rc) rc = potrf_upper_enqueue<T>(c, k, R, k, words);
+    if (rc) return fail(rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown));
+    hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, k, (int)NonUnit, R, k, Upk_all, Dinv_all, words + 1, 1.0e6);
+    hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(k / 32), (unsigned)(k / 32)), dim3(256), 0, c->stream, k, k, R, k, Uneg);
+    {
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(RLHIP_ERR_HIP(le));
+    }
+    rc = tf_launch<T, false>(c, m, k, k, T(1), Uneg, Dinv_all, A, lda, 0, (int)nblk, 0, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0, words, 1 + (int)nblk);
+    if (rc) return fail(rc);
+    hipError_t e1 = hipMemcpyAsync(c->h_mail + 44, words, 40 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e1 == hipSuccess) e1 = rlhip_stream_sync(c);
+    rlhip_ws_release(c, mark);
+    if (e1 != hipSuccess) return RLHIP_ERR_HIP(e1);
+    const int* w = (const int*)(c->h_mail + 44);
+    *info_host = w[0];
+    if (w[0] != 0) return 0;                                      // not positive definite: A untouched, R partially factored (as dpotrf leaves it)
+    bool guard = false;
+    for (int64_t b = 0; b < nblk; ++b) guard = guard || (w[1 + b] != 0);
+    if (guard) return trsm_right_upper<T>(c, NonUnit, m, k, T(1), R, k, A, lda);
+    c->path_count[2]++;
+    c->path_count[11]++;
+    return 0;
+}
+template int cholqrq<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*, int, int*);
+template int cholqrq<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*, int, int*);
 
 template int trsm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trsm_right_upper_oop<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, const int64_t*, double*, int64_t);

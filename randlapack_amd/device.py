@@ -216,14 +216,34 @@ def _state_arr(ctr, key):
     return (C.c_uint32 * 6)(*[int(v) & 0xFFFFFFFF for v in list(ctr) + list(key)])
 
 
+class _Owned:
+    """a callee-allocated device block (rlhip_malloc) exposed through __cuda_array_interface__; returned to the library's pool when the
+    last tensor viewing it goes away (the reference's caller free()s these arrays: rl_rsvd.hh:139-143)"""
+
+    def __init__(self, ctx: "Context", ptr: int, shape, typestr: str):
+        self._ctx, self._ptr = ctx, ptr
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if self._ptr and getattr(self._ctx, "h", None):
+                self._ctx.lib.rlhip_free(self._ctx.h, C.c_void_p(self._ptr))
+        except Exception:
+            pass
+        self._ptr = 0
+
+
 def _adopt(ctx: "Context", ptr: C.c_void_p, rows: int, cols: int, dtype=None):
-    """copy a callee-allocated column-major device block into a torch tensor (cols, rows) and free it"""
+    """a callee-allocated column-major device block as a torch tensor of shape (cols, rows) WITHOUT a copy: the tensor views the block and
+    the block goes back to the library's pool when the tensor dies"""
     torch = _torch()
-    t = torch.empty((cols, rows), dtype=dtype or torch.float64, device=f"cuda:{ctx.device}")
-    if rows * cols > 0:
-        _lib.check(ctx.lib.rlhip_memcpy_d2d(ctx.h, t.data_ptr(), ptr, rows * cols * t.element_size()), "memcpy_d2d")
-    _lib.check(ctx.lib.rlhip_free(ctx.h, ptr), "rlhip_free")
-    return t
+    dtype = dtype or torch.float64
+    if rows * cols <= 0 or not ptr.value:
+        if ptr.value:
+            _lib.check(ctx.lib.rlhip_free(ctx.h, ptr), "rlhip_free")
+        return torch.empty((cols, rows), dtype=dtype, device=f"cuda:{ctx.device}")
+    owner = _Owned(ctx, int(ptr.value), (cols, rows), "<f8" if dtype == torch.float64 else "<f4")
+    return torch.as_tensor(owner, device=f"cuda:{ctx.device}")
 
 
 def _drv_check(ctx, rc, what):

@@ -38,6 +38,45 @@ def test_cholqrq_vs_oracle(ctx, orc):
     assert np.linalg.norm(Q2.T @ Q2 - np.eye(200)) <= EPS**0.625
 
 
+@pytest.mark.parametrize("m,k,dtype", [(40000, 256, "f64"), (20000, 256, "f32"), (17000, 256, "f64")])
+def test_cholqrq_one_stream_equals_three_calls(ctx, orc, monkeypatch, m, k, dtype):
+    """CholQRQ on a tall 256-column input runs as ONE stream of kernels with one host read (rlhip_cholqrq: syrk, device-side potrf info,
+    conditioning guard and gated fused solve; path counter 11) -- the same kernels as the three separate calls, so Q is BITWISE the same;
+    checked against the oracle too.  A rank-deficient input reports the reference's failure (rl_orth.hh:81-85) and leaves A untouched."""
+    import torch
+
+    d = _d()
+    rng = np.random.default_rng(m + k)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    Y = rng.standard_normal((m, k)) @ (np.eye(k) + 0.01 * rng.standard_normal((k, k)))
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("RLHIP_CHOLQRQ_FUSED", fused)
+        Yd = d.cm_from_numpy(Y).to(tdt)
+        before = ctx.path_count(11)
+        rc, fail = d.drv_stab(ctx, 0, Yd, m, k)
+        assert rc == 0 and not fail
+        assert ctx.path_count(11) - before == (1 if fused == "1" else 0)
+        out[fused] = d.cm_to_numpy(Yd)
+    assert np.array_equal(out["1"], out["0"])
+    Q = out["1"].astype(np.float64)
+    eps = np.finfo(np.float64 if dtype == "f64" else np.float32).eps
+    assert np.linalg.norm(Q.T @ Q - np.eye(k)) <= 50 * eps * k
+    if dtype == "f64":
+        rc_o, Qo = orc.stab(0, Y)
+        assert rc_o == 0
+        np.testing.assert_allclose(Q, Qo, atol=1e-11)
+    # failure: a zero column -> a zero pivot; the reference returns 1 before its trsm, A keeps its values
+    monkeypatch.setenv("RLHIP_CHOLQRQ_FUSED", "1")
+    Yb = Y.copy()
+    Yb[:, 17] = 0.0
+    Ybd = d.cm_from_numpy(Yb).to(tdt)
+    keep = Ybd.clone()
+    rc, fail = d.drv_stab(ctx, 0, Ybd, m, k)
+    assert rc == 1 and fail
+    assert torch.equal(Ybd, keep)
+
+
 def test_cholqrq_failure_code(ctx, orc):
     d = _d()
     A = np.ones((50, 4))

@@ -824,6 +824,33 @@ def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n
     assert np.linalg.norm(U1.T @ U1 - np.eye(n)) <= 1e-11 * np.sqrt(n)
 
 
+@pytest.mark.parametrize("m,n,dtype", [(131072, 1024, "f64"), (65536, 512, "f32"), (20000, 256, "f64")])
+def test_trsm_fused_asm_and_plain_loads_agree_bitwise(ctx, monkeypatch, m, n, dtype):
+    """The fused solve exists in two builds inside the library: X-operand loads issued from inline asm behind the kernel's own counted
+    waits (the default when scripts/check_trsm_asm.py has proven the build's register allocation safe) and plain C++ loads.  Same
+    arithmetic, same order: the solutions must be BITWISE equal -- a register the allocator moved before its load landed would show here."""
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(n)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    R = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2.0 * np.eye(n)
+    B = rng.standard_normal((m, n))
+    Rd = d.cm_from_numpy(R).to(tdt)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RLHIP_TRSM_XASM", mode)
+        Bd = d.cm_from_numpy(B).to(tdt)
+        before = ctx.path_count(2)
+        ctx.trsm(m, n, 1.0, Rd, n, Bd, m)
+        assert ctx.path_count(2) > before, "the fused solve did not run"
+        res[mode] = Bd.clone()
+    assert torch.equal(res["1"], res["0"])
+    X = d.cm_to_numpy(res["1"])[:4096].astype(np.float64)
+    eps = np.finfo(np.float64 if dtype == "f64" else np.float32).eps
+    assert np.linalg.norm(X @ R - B[:4096]) <= 200 * eps * np.linalg.norm(B[:4096]) * np.sqrt(n)
+
+
 @pytest.mark.parametrize("m,n,kind,gram", [(20000, 256, "flat", True), (3000, 200, "flat", True), (5000, 128, "cond5", True), (1000, 256, "flat", True), (300, 256, "flat", None),
                                            (2000, 256, "cond100", False), (4000, 96, "cond1e6", False), (1500, 64, "rank-deficient", False)])
 def test_gesdd_gram_route(ctx, monkeypatch, m, n, kind, gram):
