@@ -217,6 +217,11 @@ def main():
             "data": "synthetic iid N(0,1), generated on-device from Philox4x32-10",
             "config": {"workload": f"RSVD {m}x{n} fp64 rank {k}, one QB block, p=0, CholQRQ (BASELINE configs[1])",
                        "m": m, "n": n, "k": k, "parallelism": f"row-block x{world}", "collectives": transport,
+                       # what the library's communicator actually saw (a scaling line must prove it ran on N ranks over RCCL)
+                       "ranks_seen": int(ctx.lib.rlhip_comm_size(ctx.h)),
+                       "comm_kind": {0: "none", 1: "rccl communicator of librlhip (ncclAllReduce on the context's stream)", 2: "hook"}[int(ctx.lib.rlhip_comm_kind(ctx.h))],
+                       "rccl_version": int(ctx.lib.rlhip_comm_rccl_version()) if world > 1 else None,
+                       "collectives_per_step": 0 if world == 1 else 2,   # Gram matrix of Y (+ ||A||_F^2 riding on it), B^T
                        "algorithmic_flops": flops, "qb_return": r["qb_rc"], "k_out": r["k"]},
             "roofline": roofline,
             "frac_of_peak_whole_job": round(value / 1e3 / (PEAK_F64_MFMA_TFLOPS * world), 4),

@@ -4,6 +4,7 @@
 // forwards to the C ABI in rlhip.h.  All pointers are device pointers.
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -58,8 +59,10 @@ public:
     // `defer`: the product does not wait for the norm; collect_norm() fetches it after the caller's next synchronisation (QB's ||B_i||_F).
     struct NormRequest { const void* ptr = nullptr; int64_t rows = 0, cols = 0, ld = 0; bool done = false; double value = 0; bool defer = false, pending = false; };
     NormRequest norm_req;
-    double collect_norm() {
-        if (norm_req.pending) { check(rlhip_norma_collect_f64(ctx_, &norm_req.value), "norma_collect"); norm_req.pending = false; }
+    // over_ranks: the matrix is row-sharded and the norm of the whole matrix is wanted (the sum rides on CholQRQ's Gram all-reduce when it can)
+    double collect_norm(bool over_ranks) {
+        if (norm_req.pending) { check(rlhip_norma_collect_f64(ctx_, over_ranks ? 1 : 0, &norm_req.value), "norma_collect"); norm_req.pending = false; }
+        else if (over_ranks && world() > 1) { double ssq = norm_req.value * norm_req.value; allreduce_sum_host(&ssq, 1); norm_req.value = std::sqrt(ssq); }
         return norm_req.value;
     }
     bool rows_sharded = false;

@@ -86,13 +86,13 @@ public:
             if (q.world() > 1) q.allreduce_sum(BT_i, n * b_sz);     // B_i^T = sum_g A_g^T Q_g : the n x b exchange
             T norm_B_i = lapack::lange(Norm::Fro, n, b_sz, BT_i, n, q);                                   // :221
             if (!have_norm) {
-                if (norm_rides) norm_A = (T)q.collect_norm();      // (the stream has just been drained by lange: no second wait)
-                q.norm_req = blas::Queue::NormRequest();
-                if (q.world() > 1) {                                   // ||A||_F^2 = sum over the row blocks
+                if (norm_rides) norm_A = (T)q.collect_norm(true);   // (the stream has just been drained by lange: no second wait; row-sharded: the global norm)
+                else if (q.world() > 1) {                              // ||A||_F^2 = sum over the row blocks
                     double ssq = (double)norm_A * (double)norm_A;
                     q.allreduce_sum_host(&ssq, 1);
                     norm_A = (T)std::sqrt(ssq);
                 }
+                q.norm_req = blas::Queue::NormRequest();
                 have_norm = true;
             }
             norm_B = std::hypot(norm_B, norm_B_i);

@@ -106,8 +106,10 @@ int rlhip_gemm_f32(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t 
 int rlhip_gemm_norma_f64(rlhip_ctx* ctx, char transa, char transb, int64_t m, int64_t n, int64_t k, double alpha,
                          const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C,
                          int64_t ldc, double* norm_a_host, int* fused_host);
-/* the norm a rlhip_gemm_norma_f64 call with a NULL result pointer left pending; -3 when there is none */
-int rlhip_norma_collect_f64(rlhip_ctx* ctx, double* norm_a_host);
+/* the norm a rlhip_gemm_norma_f64 call with a NULL result pointer left pending (-4 when there is none).  over_ranks != 0 on a row-sharded
+ * context: the norm of the WHOLE matrix (root of the sum over the ranks' sums of squares) -- the sum rides on the Gram matrix's all-reduce
+ * when a rlhip_cholqrq call came in between (the QB sequence), otherwise it takes a scalar all-reduce of its own here. */
+int rlhip_norma_collect_f64(rlhip_ctx* ctx, int over_ranks, double* norm_a_host);
 /* uplo must be 'U' (the only form the path uses); the strictly lower triangle of C is not touched. */
 int rlhip_syrk_f64(rlhip_ctx* ctx, char uplo, char trans, int64_t n, int64_t k, double alpha, const double* A,
                    int64_t lda, double beta, double* C, int64_t ldc);
@@ -335,6 +337,10 @@ typedef int (*rlhip_allreduce_hook)(void* user, void* dev_buf, int64_t count, in
  * ranks) BEFORE any of them calls rlhip_comm_init; a process that already maps an RCCL (PyTorch's) gets that copy, never a second one. */
 int rlhip_comm_can_load(void);
 const char* rlhip_comm_rccl_origin(void);   /* where the bound RCCL came from (diagnostics) */
+/* ncclGetVersion of the bound RCCL (e.g. 22203; 0: not bound); how this context's collectives travel: 1 its own RCCL communicator, 2 the
+ * caller's hook, 0 none (one rank) -- bench.py prints both next to rlhip_comm_size so that a scaling line proves what it ran on */
+int rlhip_comm_rccl_version(void);
+int rlhip_comm_kind(rlhip_ctx* ctx);
 int rlhip_comm_unique_id(unsigned char id_out[128]);                 /* rank 0: ncclGetUniqueId */
 int rlhip_comm_init(rlhip_ctx* ctx, int nranks, int rank, const unsigned char id[128]);
 int rlhip_comm_set_hook(rlhip_ctx* ctx, rlhip_allreduce_hook hook, void* user, int nranks, int rank);

@@ -98,7 +98,7 @@ SIGNATURES = {
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
     "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
-    "rlhip_norma_collect_f64": (c_int, [c_vp, C.POINTER(c_dbl)]),
+    "rlhip_norma_collect_f64": (c_int, [c_vp, c_int, C.POINTER(c_dbl)]),
     "rlhip_cholqrq_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),
     "rlhip_cholqrq_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),
     "rlhip_saso_create": (c_int, [c_vp, c_i64, c_i64, c_int, u32p, u32p, u32p, C.POINTER(c_vp)]),
@@ -115,6 +115,8 @@ HOOK = C.CFUNCTYPE(c_int, c_vp, c_vp, c_i64, c_int)
 SIGNATURES.update({
     "rlhip_comm_can_load": (c_int, []),
     "rlhip_comm_rccl_origin": (C.c_char_p, []),
+    "rlhip_comm_rccl_version": (c_int, []),
+    "rlhip_comm_kind": (c_int, [c_vp]),
     "rlhip_comm_unique_id": (c_int, [c_vp]),
     "rlhip_comm_init": (c_int, [c_vp, c_int, c_int, c_vp]),
     "rlhip_comm_set_hook": (c_int, [c_vp, HOOK, c_vp, c_int, c_int]),

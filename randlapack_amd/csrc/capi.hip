@@ -527,6 +527,7 @@ int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, i
     if (fused_host) *fused_host = done ? 1 : 0;
     const int64_t arows = fa ? k : m, acols = fa ? m : k;
     c->norma_state = 0;
+    c->norma_reduced = 0;
     if (done == 2 && norm_a_host == nullptr) {
         // deferred: the sum of squares travels to the pinned mailbox behind the stream; rlhip_norma_collect_f64 picks it up after whatever
         // synchronisation comes next (QB reads ||A||_F and ||B_i||_F with ONE host round trip this way)
@@ -557,17 +558,26 @@ int rlhip_gemm_norma_f64(rlhip_ctx* c, char ta, char tb, int64_t m, int64_t n, i
     return 0;
 }
 
-int rlhip_norma_collect_f64(rlhip_ctx* c, double* norm_a_host) {
-    if (!norm_a_host) return -2;
+int rlhip_norma_collect_f64(rlhip_ctx* c, int over_ranks, double* norm_a_host) {
+    if (!norm_a_host) return -3;
+    double ssq = 0;
+    bool global = false;
     if (c->norma_state == 1) {
         if (c->sync_epoch == c->norma_epoch) RLHIP_CHECK(rlhip_stream_sync(c));      // (normally a later call has already waited on the stream: no second round trip)
-        *norm_a_host = sqrt(*(double*)(c->h_mail + 40));
+        if (over_ranks && c->norma_reduced) { ssq = *(double*)(c->h_mail + 41); global = true; }
+        else ssq = *(double*)(c->h_mail + 40);
     } else if (c->norma_state == 2) {
-        *norm_a_host = c->norma_value;
+        ssq = c->norma_value * c->norma_value;
     } else {
-        return -3;                                               // nothing pending
+        return -4;                                               // nothing pending
     }
     c->norma_state = 0;
+    c->norma_reduced = 0;
+    if (over_ranks && !global && rlhip_comm_size(c) > 1) {       // no all-reduce has carried it yet: one of its own
+        const int rc = rlhip_allreduce_sum_host_f64(c, &ssq, 1);
+        if (rc) return rc;
+    }
+    *norm_a_host = sqrt(ssq);
     return 0;
 }
 

@@ -99,6 +99,21 @@ extern "C" {
  * any of them calls rlhip_comm_init).  rlhip_comm_rccl_origin: where the bound copy came from (diagnostics). */
 int rlhip_comm_can_load(void) { return load_rccl() == 0 ? 1 : 0; }
 const char* rlhip_comm_rccl_origin(void) { return g_rccl_origin; }
+/* ncclGetVersion of the bound RCCL (e.g. 22203), 0 when RCCL cannot be bound or has no such entry point */
+int rlhip_comm_rccl_version(void) {
+    if (load_rccl()) return 0;
+    typedef int (*fn_version)(int*);
+    fn_version f = (fn_version)dlsym(g_rccl.h, "ncclGetVersion");
+    int v = 0;
+    if (!f || f(&v)) return 0;
+    return v;
+}
+/* 1 when this context's collectives run through its own RCCL communicator, 2 through the caller's hook, 0 when it has neither (one rank) */
+int rlhip_comm_kind(rlhip_ctx* c) {
+    if (!c->comm) return 0;
+    rlhip_comm* cm = (rlhip_comm*)c->comm;
+    return cm->hook ? 2 : (cm->comm ? 1 : 0);
+}
 
 int rlhip_comm_unique_id(unsigned char id_out[128]) {
     if (load_rccl()) return -1001;

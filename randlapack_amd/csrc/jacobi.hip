@@ -190,6 +190,21 @@ __device__ __forceinline__ double row16_allsum(double v) {
     return dpp_ror_add(v, 1);
 }
 
+// every lane of a 32-lane half wave ends up with the half's sum: the 16-lane all-reduce, then v_permlane16_swap (gfx950) trades row 1 of one copy
+// for row 0 of the other (rows 3 / 2 likewise), so copy a holds the even row's sum in both rows, copy b the odd row's
+__device__ __forceinline__ double half32_allsum(double v) {
+    v = row16_allsum(v);
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+template <int QW>
+__device__ __forceinline__ double pair_allsum(double v) {
+    if constexpr (QW == 16) return row16_allsum(v);
+    else return half32_allsum(v);
+}
+
 // The rotation rounds of ONE block pair held in LDS (Xs: [2 JB][JMT] column-major, Js: the 2 JB x 2 JB rotation accumulator, only touched
 // when want_v).  Shared by the per-launch kernel and the persistent kernel below, so both execute the same arithmetic in the same order.
 //   intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
@@ -201,20 +216,23 @@ __device__ __forceinline__ double row16_allsum(double v) {
 // is that of 16 updates.  Only the inner product of the pair is reduced in a round: one dot product and one 16-lane all-reduce instead
 // of three of each (a third of a round's instructions).  my_cos2 is a FLAG (1: some pair met a cosine above 1e-9), my_nmax / my_nmin the
 // largest / smallest non-zero fresh squared norm seen (the persistent kernel's condition monitor).
-template <typename T, int JB, int JMT>
+// QW = lanes per column pair: 16 (a quarter wave, 16 rows per lane, four pairs per wavefront, 4 rotating waves at JB = 16) or 32 (a half wave,
+// 8 rows per lane, two pairs per wavefront, 8 rotating waves: two per SIMD, so one wave's dependent chain -- reduce, rotation
+// parameters, update, LDS round trip -- runs behind the other's).
+template <typename T, int JB, int JMT, int QW>
 __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __restrict__ Js, const bool want_v, const int intra, const double tol2,
                                                    unsigned& my_rot, float& my_cos2, double* __restrict__ Ns, float& my_nmax, float& my_nmin) {
     constexpr int JP = 2 * JB;
-    constexpr int NROT = 16 * JB;
+    constexpr int NROT = QW * JB;
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ql = lane & 15;
+    const int ql = lane & (QW - 1);
     // intra = 1: the 2 x JB(JB-1)/2 pairs INSIDE the two blocks (JB-1 rounds, JB/2 pairs per block per round)
     // intra = 0: the JB x JB CROSS pairs between the blocks (JB rounds of JB pairs): every column pair of the
     //            matrix is then visited exactly once per outer sweep (NB-1 cross launches + 1 intra launch)
     const int nrounds = intra ? (JB - 1) : JB;
-    const int sl = tid >> 4;                           // pair slot of this quarter wave: 0 .. JB-1
-    constexpr int RL = JMT / 32;                       // 16-byte row pairs per lane
+    const int sl = tid / QW;                           // pair slot of this quarter / half wave: 0 .. JB-1
+    constexpr int RL = JMT / (2 * QW);                 // 16-byte row pairs per lane
     constexpr bool MAINT = (JB == 16);                  // (the 32-wide panels of tiny problems fill the whole LDS: no room for Ns, norms recomputed)
     d2_t x[RL], y[RL];
     double aa = 0;                                      // squared norm of the quarter's own column (cross rounds: carried from round to round)
@@ -240,10 +258,10 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
         const bool fresh = !MAINT || intra || round == 0;
         if (fresh) {
 #pragma unroll
-            for (int r = 0; r < RL; ++r) x[r] = xp[16 * r];
+            for (int r = 0; r < RL; ++r) x[r] = xp[QW * r];
         }
 #pragma unroll
-        for (int r = 0; r < RL; ++r) y[r] = xq[16 * r];
+        for (int r = 0; r < RL; ++r) y[r] = xq[QW * r];
         if (fresh) {
             aa = 0;
 #pragma unroll
@@ -252,9 +270,9 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
                 bb = fma(y[r].x, y[r].x, bb); bb = fma(y[r].y, y[r].y, bb);
                 ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab);
             }
-            aa = row16_allsum(aa);
-            bb = row16_allsum(bb);
-            ab = row16_allsum(ab);
+            aa = pair_allsum<QW>(aa);
+            bb = pair_allsum<QW>(bb);
+            ab = pair_allsum<QW>(ab);
             const float fa = (float)aa, fb = (float)bb;
             my_nmax = fmaxf(my_nmax, fmaxf(fa, fb));
             if (fa > 0.f) my_nmin = fminf(my_nmin, fa);
@@ -263,7 +281,7 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
             if constexpr (MAINT) bb = Ns[q];                                // the partner's norm travels with it
 #pragma unroll
             for (int r = 0; r < RL; ++r) { ab = fma(x[r].x, y[r].x, ab); ab = fma(x[r].y, y[r].y, ab); }
-            ab = row16_allsum(ab);
+            ab = pair_allsum<QW>(ab);
         }
         const double nn = aa * bb, ab2 = ab * ab;
         const bool live = (aa > 0.0) && (bb > 0.0);
@@ -290,16 +308,19 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
                 d2_t xn, yn;
                 xn.x = cs * x[r].x - sn * y[r].x; xn.y = cs * x[r].y - sn * y[r].y;
                 yn.x = sn * x[r].x + cs * y[r].x; yn.y = sn * x[r].y + cs * y[r].y;
-                if (intra) xp[16 * r] = xn;
+                if (intra) xp[QW * r] = xn;
                 x[r] = xn;
-                xq[16 * r] = yn;
+                xq[QW * r] = yn;
             }
             if (want_v) {                // the rotation accumulator is only needed when V is wanted
 #pragma unroll
-                for (int r = 0; r < JP / 16; ++r) {
-                    const double jp = Js[ql + 16 * r + p * JP], jq = Js[ql + 16 * r + q * JP];
-                    Js[ql + 16 * r + p * JP] = cs * jp - sn * jq;
-                    Js[ql + 16 * r + q * JP] = sn * jp + cs * jq;
+                for (int r = 0; r < (JP + QW - 1) / QW; ++r) {
+                    const int jr = ql + QW * r;
+                    if (jr < JP) {
+                        const double jp = Js[jr + p * JP], jq = Js[jr + q * JP];
+                        Js[jr + p * JP] = cs * jp - sn * jq;
+                        Js[jr + q * JP] = sn * jp + cs * jq;
+                    }
                 }
             }
         }
@@ -309,13 +330,13 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
     if (!intra && tid < NROT) {                        // the register-resident column goes back once
         d2_t* xp = reinterpret_cast<d2_t*>(Xs + sl * JMT) + ql;
 #pragma unroll
-        for (int r = 0; r < RL; ++r) xp[16 * r] = x[r];
+        for (int r = 0; r < RL; ++r) xp[QW * r] = x[r];
     }
     __syncthreads();
 }
 
 // JMT = panel rows held in LDS: 256 (1024 threads) or 512 (512 threads: the rotating lanes then carry 32 rows of two columns = 128 VGPRs)
-template <typename T, int JB, int JMT>
+template <typename T, int JB, int JMT, int QW>
 __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
                                                                int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
                                                                unsigned* __restrict__ nrot) {
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
     float my_cos2 = 0.f;                               // 1: a cosine above 1e-9 was met before rotating (convergence shortcut)
     float my_nmax = 0.f, my_nmin = 3e38f;
     __shared__ double Ns[JB == 16 ? JP : 1];
-    jacobi_pair_rounds<T, JB, JMT>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2, Ns, my_nmax, my_nmin);
+    jacobi_pair_rounds<T, JB, JMT, QW>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2, Ns, my_nmax, my_nmin);
     // one atomic pair per wavefront
     {
         unsigned r = my_rot;
@@ -482,7 +503,7 @@ __device__ __forceinline__ bool jp_wait(const unsigned long long* w, unsigned ta
     return false;
 }
 
-template <typename T, int JB, int JMT>
+template <typename T, int JB, int JMT, int QW>
 __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     static_assert(sizeof(T) == 8, "fp64 only");
     constexpr int JP = 2 * JB, NT = 1024;
@@ -559,7 +580,7 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     for (; sweep < g.max_sweeps && !lost; ++sweep) {
         unsigned my_rot = 0;
         float my_cos2 = 0.f, my_nmax = 0.f, my_nmin = 3e38f;
-        jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 1, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);          // pairs inside whichever two blocks are here
+        jacobi_pair_rounds<T, JB, JMT, QW>(Xs, nullptr, false, 1, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);          // pairs inside whichever two blocks are here
         for (int oround = 0; oround < g.NB - 1; ++oround) {
             int P, Q;
             if (w == 0) { P = g.NB - 1; Q = oround % (g.NB - 1); }
@@ -586,7 +607,7 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
             fetch2(out0, want[0], out1, want[1]);
             held[0] = want[0]; held[1] = want[1];
             __syncthreads();
-            jacobi_pair_rounds<T, JB, JMT>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);
+            jacobi_pair_rounds<T, JB, JMT, QW>(Xs, nullptr, false, 0, tol2, my_rot, my_cos2, Ns, my_nmax, my_nmin);
         }
         if (lost) break;
         // ---- end of the sweep: everybody learns the sweep's rotation count, whether a cosine above 1e-9 was met, and the range of the column norms
@@ -760,9 +781,17 @@ static const JpHold& jp_hold() {
     return h;
 }
 
+// lanes per column pair in the rotation rounds (RLHIP_JACOBI_QW = 16 (default) | 32, read once): see jacobi_pair_rounds
+static int jacobi_qw() {
+    static int qw = 0;
+    // measured at k = 256: 16 -> 10.88 ms per 1/8-shard RSVD step, 32 -> 10.98
+    if (!qw) { const char* e = getenv("RLHIP_JACOBI_QW"); qw = (e && atoi(e) == 32) ? 32 : 16; }
+    return qw;
+}
+
 // clears the flag words and enqueues ONE persistent launch; g.A / lda / trans_upper / skip / sweep0 / max_sweeps / tol / out are the caller's
-template <typename T>
-int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NBk) {
+template <typename T, int QW>
+int jp_launch_qw(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NBk) {
     constexpr int JB = 16, JMT = JM;
     const int NW = NBk / 2;
     const size_t xwords = (size_t)NBk * JB * m;
@@ -773,17 +802,22 @@ int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NB
     if (e1 == hipSuccess) e1 = hipMemsetAsync(g.out, 0, 16 * sizeof(int), c->stream)     /* (out has >= 16 ints: the Gram route keeps its defect word behind the 8 of this launch) */;
     if (e1 != hipSuccess) return RLHIP_ERR_HIP(e1);
     constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
-    RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT>), smem);
+    RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT, QW>), smem);
     void* kargs[] = {(void*)&g};
     // the whole device when the clock holders are wanted and fit (one 1024-thread workgroup per CU), else the workers alone
     const unsigned grid_hold = (h.mode && c->num_cu > NW) ? (unsigned)(NW + (h.wgs < c->num_cu - NW ? h.wgs : c->num_cu - NW)) : (unsigned)NW;
-    hipError_t le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3(grid_hold), dim3(1024), kargs, (unsigned)smem, c->stream);
+    hipError_t le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT, QW>, dim3(grid_hold), dim3(1024), kargs, (unsigned)smem, c->stream);
     if (le != hipSuccess && grid_hold != (unsigned)NW) {
         (void)hipGetLastError();
-        le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream);
+        le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT, QW>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream);
     }
     if (le != hipSuccess) { (void)hipGetLastError(); return 1; }
     return 0;
+}
+
+template <typename T>
+int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NBk) {
+    return jacobi_qw() == 16 ? jp_launch_qw<T, 16>(c, g, buf, m, NBk) : jp_launch_qw<T, 32>(c, g, buf, m, NBk);
 }
 
 // Sweeps of the persistent kernel (V not accumulated).  Returns 0 and the number of sweeps when it ran to a verdict, 1 when the path is
@@ -838,22 +872,22 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
     return 0;
 }
 
-template <typename T, int JB, int JMT>
-int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
+template <typename T, int JB, int JMT, int QW>
+int block_jacobi_sweeps_qw(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
     constexpr int JP = 2 * JB;
     int NBk = (n + JB - 1) / JB;
     if (NBk < 2) NBk = 2;
     if (NBk % 2) ++NBk;
     constexpr int smem = (JP * JMT + JP * JP) * (int)sizeof(T);
     constexpr int NT = (JMT == 256) ? 1024 : 512;
-    RLHIP_FUNC_LDS(c, (jacobi_block_kernel<T, JB, JMT>), smem);
+    RLHIP_FUNC_LDS(c, (jacobi_block_kernel<T, JB, JMT, QW>), smem);
     int sweep = *sweeps_out;                           // sweeps already done by the persistent kernel (0 otherwise)
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
-        hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
+        hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT, QW>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
                            (int64_t)n, tol, d_nrot);
         for (int oround = 0; oround < NBk - 1; ++oround)
-            hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, oround, 0, A, lda,
+            hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT, QW>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, oround, 0, A, lda,
                                V, (int64_t)n, tol, d_nrot);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
@@ -874,6 +908,13 @@ int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T t
     }
     *sweeps_out = sweep;
     return 0;
+}
+
+template <typename T, int JB, int JMT>
+int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
+    // (32-wide blocks with 32 lanes per pair would need 1024 rotating threads AND leave no wave to spare: they keep the quarter-wave layout)
+    if (JB == 16 && jacobi_qw() == 32) return block_jacobi_sweeps_qw<T, JB, JMT, (JB == 16 ? 32 : 16)>(c, m, n, A, lda, V, tol, d_nrot, max_sweeps, sweeps_out);
+    return block_jacobi_sweeps_qw<T, JB, JMT, 16>(c, m, n, A, lda, V, tol, d_nrot, max_sweeps, sweeps_out);
 }
 
 }  // namespace

@@ -81,6 +81,7 @@ struct rlhip_ctx {
     // is on its way to h_mail[40] behind the stream, 2 norma_value holds the norm
     int norma_state = 0;
     double norma_value = 0;
+    int norma_reduced = 0;           // 1: the sum over the row shards is on its way to h_mail[41] as well (rode on the Gram matrix's all-reduce, tri.hip::cholqrq)
     unsigned long norma_epoch = 0;   // sync_epoch when the deferred copy was enqueued
     unsigned long sync_epoch = 0;    // completed host waits on the stream (rlhip_stream_sync): anything enqueued before the last one has landed
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)

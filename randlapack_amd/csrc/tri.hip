@@ -1009,7 +1009,26 @@ int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int red
     if (e0 != hipSuccess) return fail(RLHIP_ERR_HIP(e0));
     int rc = laset<T>(c, 2, k, k, T(0), T(0), R, k);
     if (!rc) rc = syrk<T>(c, Upper, 1, k, m, T(1), A, lda, T(0), R, k);
-    if (!rc && reduce_gram) rc = (sizeof(T) == 8) ? rlhip_allreduce_sum_f64(c, (double*)R, k * k) : rlhip_allreduce_sum_f32(c, (float*)R, k * k);
+    if (!rc && reduce_gram) {
+        if (sizeof(T) == 8 && c->norma_state == 1 && !c->norma_reduced) {
+            // a deferred ||A||_F^2 is waiting (QB: rl_qb.hh:168): its sum over the ranks rides on THIS all-reduce as word k*k of the buffer instead
+            // of taking a scalar collective (and a host round trip) of its own
+            double* G2 = ws_alloc<double>(c, (size_t)k * k + 1);
+            if (!G2) return fail(RLHIP_ERR_HIP(hipErrorOutOfMemory));
+            hipError_t e = hipMemcpyAsync(G2, R, (size_t)k * k * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(G2 + (size_t)k * k, (double*)(c->d_mail + 40), sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) return fail(RLHIP_ERR_HIP(e));
+            rc = rlhip_allreduce_sum_f64(c, G2, k * k + 1);
+            if (!rc) {
+                e = hipMemcpyAsync(R, G2, (size_t)k * k * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(c->h_mail + 41, G2 + (size_t)k * k, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+                if (e != hipSuccess) return fail(RLHIP_ERR_HIP(e));
+                c->norma_reduced = 1;
+            }
+        } else {
+            rc = (sizeof(T) == 8) ? rlhip_allreduce_sum_f64(c, (double*)R, k * k) : rlhip_allreduce_sum_f32(c, (float*)R, k * k);
+        }
+    }
     if (!rc) rc = potrf_upper_enqueue<T>(c, k, R, k, words);
     if (rc) return fail(rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown));
     hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, k, (int)NonUnit, R, k, Upk_all, Dinv_all, words + 1, 1.0e6);

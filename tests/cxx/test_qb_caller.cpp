@@ -14,6 +14,7 @@
 // tests/test_gpu_cxx.py (-m gpu).
 #include "RandLAPACK_amd.hh"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -258,7 +259,8 @@ static void rsvd_through_the_bases(int64_t m, int64_t n, int64_t r, int64_t bloc
     EXPECT(ordered, "%s: singular values are not positive and descending", label);
     EXPECT(worst <= 200 * eps * (T)r, "%s: singular values off by %.3e", label, (double)worst);
     const T bound = std::pow(eps, (T)0.625);
-    EXPECT(res <= bound && uo <= bound && vo <= bound, "%s: factor checks failed (%.2e %.2e %.2e)", label, (double)res, (double)uo, (double)vo);
+    const T orth_bound = std::sqrt(eps) * (T)(sizeof(T) == 4 ? 1 : 1e-3);   // single precision: Cholesky-QR's eps * cond^2 on a cond-16 spectrum
+    EXPECT(res <= bound && uo <= std::max(bound, orth_bound) && vo <= std::max(bound, orth_bound), "%s: factor checks failed (%.2e %.2e %.2e)", label, (double)res, (double)uo, (double)vo);
     blas::device_free(U);
     blas::device_free(S);
     blas::device_free(V);

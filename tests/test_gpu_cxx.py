@@ -16,7 +16,7 @@ def test_cxx_caller_program_builds_and_links():
     assert exe.exists()
     out = subprocess.check_output(["nm", "-D", "--undefined-only", str(exe)], text=True)
     assert "rlhip_drv" not in out                      # the object layer is header-only C++ over the kernel-level C ABI ...
-    assert "rlhip_gemm_f64" in out and "rlhip_malloc_host" in out
+    assert "rlhip_gemm_f64" in out and "rlhip_malloc" in out
     assert "hip" not in out.replace("rlhip", "")       # ... and needs no HIP runtime symbol of its own
 
 
