@@ -249,7 +249,8 @@ __global__ __launch_bounds__(NT) void qr_blk_kernel(QbArgs<T> g) {
             const T alpha = s_bc[par][cc];
             T beta = alpha, tcc = T(0), scale = T(0);
             if (ds[cc] != T(0)) {
-                // (ds[cc] is a plain sum of squares already: the scaled hypot of larfg / lapy2 would protect nothing here)
+                // (ds[cc] is a plain sum of squares already: the scaled hypot of larfg / lapy2 would protect nothing here; the exponent range
+                // is the business of rlhip::geqrf, which hands this kernel a matrix whose largest entry lies in [1, 2))
                 const T nrm = sqrt(alpha * alpha + ds[cc]);
                 beta = (alpha >= T(0)) ? -nrm : nrm;
                 tcc = (beta - alpha) / beta;
@@ -468,7 +469,10 @@ int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev)
     g.Tx = ws_alloc<T>(c, (size_t)G * 64);
     g.flag = ws_alloc<unsigned>(c, (size_t)G + 4);
     if (!g.Tx || !g.flag) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    RLHIP_CHECK(hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream));
+    {
+        const hipError_t me = hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream);
+        if (me != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(me); }
+    }
 #ifdef RLHIP_QB_PROF
     g.prof = (unsigned long long*)ws_alloc<double>(c, 4);
     RLHIP_CHECK(hipMemsetAsync(g.prof, 0, 4 * sizeof(double), c->stream));
@@ -512,7 +516,10 @@ int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
     g.n = n; g.A = A; g.lda = lda; g.D = D;
     g.flag = ws_alloc<unsigned>(c, (size_t)G + 4);
     if (!g.flag) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    RLHIP_CHECK(hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream));
+    {
+        const hipError_t me = hipMemsetAsync(g.flag, 0, (size_t)G * sizeof(unsigned), c->stream);
+        if (me != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(me); }
+    }
     void* kargs[] = {(void*)&g};
     if (hipLaunchCooperativeKernel((const void*)lunp_blk_kernel<T, NT, RPT>, dim3((unsigned)G), dim3(NT), kargs, 0, c->stream) != hipSuccess) {
         (void)hipGetLastError();

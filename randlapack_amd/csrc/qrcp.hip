@@ -925,8 +925,83 @@ template int qrp_partial<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, i
 // lapack::geqrf: Householder QR without pivoting.  Wide input (n > m, BQRRP's permuted sketch rl_bqrrp.hh:356): only the
 // leading m x m block goes through the step-synchronous kernel; the remaining columns get Q^T applied as ONE compact-WY
 // block (larft + gemqrt on the MFMA path).
+// ---- exponent-range guard of geqrf.  The Householder kernels of this library form column norms as plain sums of squares (one reduction
+// round gives the norm, the reflector's action and the larft entries at once) where LAPACK's larfg / nrm2 scale; entries above ~1e19 / below
+// ~1e-19 in fp32 (1e154 / 1e-154 in fp64) would turn into inf, NaN or a zero tau.  So every geqrf call measures max |a_ij| (one pass, the
+// result stays on the device), factors s A with s the power of two that brings it into [1, 2) when it lies outside the safe window --
+// exact: the reflectors and tau do not depend on the scale -- and gives R its scale back.  No host read; inside the window (always, on
+// this path's sketches) the two rescale launches find s = 1 and write nothing.  What is NOT protected: a column more than half the
+// exponent range below the matrix's largest entry loses its norm to underflow.
+// w[0] = max |a_ij| as a bit pattern (non-negative IEEE values order like unsigned integers)
+template <typename T>
+__global__ __launch_bounds__(256) void geqrf_absmax_kernel(int64_t m, int64_t n, const T* __restrict__ A, int64_t lda, unsigned long long* __restrict__ w) {
+    unsigned long long best = 0;
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+            const double v = fabs((double)A[i + j * lda]);
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            best = b > best ? b : best;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(best, off, 64); best = o > best ? o : best; }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(w, best);
+}
+// the scale this matrix needs (1 inside the safe window, and for zero / non-finite matrices)
+template <typename T>
+__device__ __forceinline__ double geqrf_scale_of(const unsigned long long* w) {
+    const double mx = __longlong_as_double((long long)w[0]);
+    const double hi = (sizeof(T) == 8) ? 1e149 : 2.8e14, lo = (sizeof(T) == 8) ? 1e-149 : 7e-15;
+    if (!(mx > 0.0) || !(mx < 1.7e308) || (mx < hi && mx > lo)) return 1.0;
+    int ex = 0;
+    (void)frexp(mx, &ex);
+    return ldexp(1.0, 1 - ex);
+}
+// A *= s (back = 0: the whole matrix) or A(i <= j) /= s (back = 1: the R part of the result)
+template <typename T>
+__global__ __launch_bounds__(256) void geqrf_rescale_kernel(int64_t m, int64_t n, T* __restrict__ A, int64_t lda, const unsigned long long* __restrict__ w, int back) {
+    const double s = geqrf_scale_of<T>(w);
+    if (s == 1.0) return;
+    const double f = back ? 1.0 / s : s;               // (a power of two: exact both ways)
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256)
+            if (!back || i <= j) A[i + j * lda] = (T)((double)A[i + j * lda] * f);
+}
+
+template <typename T>
+int geqrf_core(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev);
+
 template <typename T>
 int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
+    if (m < 0) return -2;
+    if (n < 0) return -3;
+    if (lda < (m > 1 ? m : 1)) return -5;
+    if (m == 0 || n == 0) return 0;
+    static int guard = -1;
+    if (guard < 0) { const char* e = getenv("RLHIP_GEQRF_SCALE_GUARD"); guard = (e && atoi(e) == 0) ? 0 : 1; }
+    if (!guard) return geqrf_core<T>(c, m, n, A, lda, tau_dev);
+    size_t mark = rlhip_ws_mark(c);
+    unsigned long long* w = ws_alloc<unsigned long long>(c, 4);
+    if (!w) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    int64_t bx = (m + 1023) / 1024, by = n;            // a thread walks ~4 rows of a column: coalesced, no index divisions
+    if (bx > 64) bx = 64;
+    if (by > 4096 / bx) by = 4096 / bx;
+    const dim3 blocks((unsigned)bx, (unsigned)(by < 1 ? 1 : by));
+    hipError_t e = hipMemsetAsync(w, 0, sizeof(unsigned long long), c->stream);
+    if (e != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(e); }
+    hipLaunchKernelGGL(geqrf_absmax_kernel<T>, blocks, dim3(256), 0, c->stream, m, n, A, lda, w);
+    hipLaunchKernelGGL(geqrf_rescale_kernel<T>, blocks, dim3(256), 0, c->stream, m, n, A, lda, w, 0);
+    int rc = geqrf_core<T>(c, m, n, A, lda, tau_dev);
+    if (!rc) {
+        hipLaunchKernelGGL(geqrf_rescale_kernel<T>, blocks, dim3(256), 0, c->stream, m, n, A, lda, w, 1);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = RLHIP_ERR_HIP(e);
+    }
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+
+template <typename T>
+int geqrf_core(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     if (m < 0) return -2;
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
@@ -1136,16 +1211,26 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
             const size_t words = 2 * qt_words<T>(m, Gt);
             t.tw = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
             t.info = (int*)ws_alloc<int>(c, 32);
-            if (!t.tw || !t.info || !t.Aout || !t.jpvt) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+            // (the scratch copy of the output is this path's own need: when it cannot be had, the rendezvous kernel below -- which works in
+            // place -- takes the problem instead of an out-of-memory error; every error exit releases the arena mark)
+            const bool have = t.tw && t.info && t.Aout && t.jpvt;
             t.tol3z = std::sqrt(std::numeric_limits<T>::epsilon() / 2);
             t.max_steps = max_steps; t.hq_formula = hq_formula;
-            RLHIP_CHECK(hipMemsetAsync(t.tw, 0, words * sizeof(unsigned long long), c->stream));
-            RLHIP_CHECK(hipMemsetAsync(t.info, 0, sizeof(int), c->stream));
+            hipError_t te = hipSuccess;
+            if (have) te = hipMemsetAsync(t.tw, 0, words * sizeof(unsigned long long), c->stream);
+            if (have && te == hipSuccess) te = hipMemsetAsync(t.info, 0, sizeof(int), c->stream);
             const double kq = (double)((max_steps >= 0 && max_steps < (m < n ? m : n)) ? max_steps : (m < n ? m : n)); (void)kq;
             void* kargs[] = {(void*)&t};
-            RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qrcp_tag_kernel<T>, dim3((unsigned)Gt), dim3(256), kargs, (unsigned)dyn, c->stream));
-            RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 56, t.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            RLHIP_CHECK(rlhip_stream_sync(c));
+            bool launched = false;
+            if (have && te == hipSuccess) {
+                if (hipLaunchCooperativeKernel((const void*)qrcp_tag_kernel<T>, dim3((unsigned)Gt), dim3(256), kargs, (unsigned)dyn, c->stream) == hipSuccess) launched = true;
+                else (void)hipGetLastError();                          // not resident here: the rendezvous kernel decides for itself
+            }
+            if (launched) {
+                te = hipMemcpyAsync(c->h_mail + 56, t.info, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (te == hipSuccess) te = rlhip_stream_sync(c);
+            }
+            if (te != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(te); }
 #ifdef RLHIP_QT_PROF
             {
                 long long pf[6];
@@ -1154,14 +1239,14 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
                         pf[0] / 100.0 / kq, pf[1] / 100.0 / kq, pf[2] / 100.0 / kq, pf[3] / 100.0 / kq, pf[4] / 100.0 / kq, pf[5] / 100.0 / kq);
             }
 #endif
-            if (*(int*)(c->h_mail + 56) == 0) {
+            if (launched && *(int*)(c->h_mail + 56) == 0) {
                 // the kernel only read A: its results are taken over now (10 MB at 1280 x 1024: microseconds)
-                RLHIP_CHECK(hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), t.Aout, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-                RLHIP_CHECK(hipMemcpyAsync(jpvt_dev, t.jpvt, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+                te = hipMemcpy2DAsync(A, (size_t)lda * sizeof(T), t.Aout, (size_t)m * sizeof(T), (size_t)m * sizeof(T), (size_t)n, hipMemcpyDeviceToDevice, c->stream);
+                if (te == hipSuccess) te = hipMemcpyAsync(jpvt_dev, t.jpvt, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream);
                 rlhip_ws_release(c, mark);
-                return 0;
+                return te == hipSuccess ? 0 : RLHIP_ERR_HIP(te);
             }
-            // a published word never arrived (bounded spins).  A and jpvt are untouched: fall through to the rendezvous kernel below.
+            // no scratch, no residency, or a published word never arrived (bounded spins).  A and jpvt are untouched: the rendezvous kernel below.
             rlhip_ws_release(c, mark);
         }
     }

@@ -87,3 +87,15 @@ int main(){return 0;}
 """
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", str(ROOT / "include"), "-x", "c++", "-"], input=src,
                    text=True, check=True)
+
+
+def test_trsm_asm_proof_ran_and_passed_for_this_build():
+    """the build replays the fused solve's assembly against a vector-memory counter model (scripts/check_trsm_asm.py, run by the Makefile
+    before tri.o is compiled): its log must exist and report zero violations -- otherwise the library was built with the plain-load kernel
+    as its default, which the log says too"""
+    log = ROOT / "randlapack_amd" / "csrc" / "tri.xasm_check.log"
+    assert log.exists(), "tri.o was not built through the Makefile rule that runs scripts/check_trsm_asm.py"
+    txt = log.read_text()
+    counts = re.findall(r"(\d+) asm-issued loads, (\d+) violations", txt)
+    assert len(counts) == 4, txt                       # {double, float} x {in place, out of place}
+    assert all(int(n) > 0 and int(v) == 0 for n, v in counts), txt

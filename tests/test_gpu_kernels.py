@@ -679,6 +679,33 @@ def test_geqrf_block_pipelined_matches_lapack(ctx, m, n, dt):
     assert np.linalg.norm(A.astype(np.float64) - Qref.astype(np.float64) @ R.astype(np.float64)) <= 30 * eps * np.linalg.norm(A) * np.sqrt(k)
 
 
+@pytest.mark.parametrize("m,n", [(1024, 1024), (1024, 512), (20000, 64)])
+@pytest.mark.parametrize("scale,dt", [(1e19, "f32"), (1e-21, "f32"), (1e160, "f64"), (1e-170, "f64")])
+def test_geqrf_badly_scaled_input_is_rescaled(ctx, scale, dt, m, n):
+    """The Householder kernels form column norms as plain sums of squares; an input whose squares leave the exponent range is
+    found by a max-abs pass that stays on the device and factored as s A with s a power of two (same reflectors, same tau, R scaled
+    back): LAPACK's result, on the block-pipelined, the flag-pipelined and the Cholesky-QR panel routes alike."""
+    import scipy.linalg.lapack as ll
+    import torch
+
+    d = _dev()
+    f64 = dt == "f64"
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    rng = np.random.default_rng(11)
+    A = (rng.standard_normal((m, n)) * scale).astype(npdt)
+    Ad = d.cm_from_numpy(A)
+    tau = torch.zeros(n, dtype=tdt, device="cuda")
+    fn = ctx.lib.rlhip_geqrf_f64 if f64 else ctx.lib.rlhip_geqrf_f32
+    assert fn(ctx.h, m, n, Ad.data_ptr(), m, tau.data_ptr()) == 0
+    ctx.sync()
+    qr_ref, tau_ref, _, _ = (ll.dgeqrf if f64 else ll.sgeqrf)(A)
+    got = d.cm_to_numpy(Ad)
+    assert np.all(np.isfinite(got)) and np.all(np.isfinite(tau.cpu().numpy()))
+    np.testing.assert_allclose(np.abs(np.diag(got[:n])), np.abs(np.diag(qr_ref[:n])), rtol=(1e-10 if f64 else 2e-3))
+    np.testing.assert_allclose(tau.cpu().numpy(), tau_ref, atol=(1e-11 if f64 else 2e-4), rtol=0)
+    np.testing.assert_allclose(np.tril(got, -1), np.tril(qr_ref, -1), atol=(1e-10 if f64 else 3e-3), rtol=0)      # the reflectors do not scale
+
+
 @pytest.mark.parametrize("m,n,nb", [(60, 12, 12), (500, 64, 32), (2000, 256, 256), (300, 100, 40), (2500, 2048, 2048), (1500, 1003, 1003)])
 def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
     import torch
