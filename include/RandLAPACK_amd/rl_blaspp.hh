@@ -50,8 +50,11 @@ public:
     void sync() { check(rlhip_sync(ctx_), "rlhip_sync"); }
 
     // ---- row-block sharding (one process per GPU).  world() == 1 -> everything below is a no-op.
-    int world() const { return rlhip_comm_size(ctx_); }
-    int rank() const { return rlhip_comm_rank(ctx_); }
+    int world() const { return local_only ? 1 : rlhip_comm_size(ctx_); }
+    int rank() const { return local_only ? 0 : rlhip_comm_rank(ctx_); }
+    // > 0: the queue answers as a single rank (LocalOnly below): replicated sub-problems of a sharded driver -- the QRCP of CQRRPT's
+    // sketch -- run the ordinary single-device code on every rank and arrive at identical results without an exchange
+    int local_only = 0;
     // Drivers mark, around each call that reduces over the row index, whether the operand's rows are the
     // sharded dimension (m-long objects: A, Y, Q, Omega_1) or replicated (n- or k-long objects: Omega, B^T, R).
     // Fused-norm request (QB): the next blas::gemm whose A operand is exactly this matrix also returns ||A||_F
@@ -125,6 +128,14 @@ class RowsSharded {
 public:
     RowsSharded(Queue& q, bool on) : q_(q), prev_(q.rows_sharded) { q.rows_sharded = on; }
     ~RowsSharded() { q_.rows_sharded = prev_; }
+};
+
+// RAII: inside the scope the queue answers as ONE rank (no collectives, nothing sharded)
+class LocalOnly {
+    Queue& q_;
+public:
+    explicit LocalOnly(Queue& q) : q_(q) { ++q.local_only; }
+    ~LocalOnly() { --q_.local_only; }
 };
 
 // RAII scope over the queue's stream-ordered scratch arena

@@ -105,13 +105,13 @@ public:
         auto t1 = stamp();
         // ---- QRCP of the sketch (:247)
         if (qrcp == Subroutines::QRCP::hqrrp) {                                                             // :230-231
-            randlapack_require(q.world() == 1) << "CQRRPT with qrcp = hqrrp / bqrrp on a row-sharded queue: the inner QRCP would treat the replicated sketch as sharded; use geqp3";
+            blas::LocalOnly replicated(q);    // the sketch is replicated: every rank runs the single-device QRCP and gets the same pivots
             hqrrp(d, n, A_hat, d, J, tau, nb_alg, oversampling, panel_pivoting, use_cholqr, state, q);
         } else if (qrcp == Subroutines::QRCP::bqrrp) {                                                      // :232-245
             if (n <= 2000) bqrrp_block_ratio = 1.0;
             else if (n <= 8000) bqrrp_block_ratio = 0.5;
             else bqrrp_block_ratio = (T)1 / (T)32;
-            randlapack_require(q.world() == 1) << "CQRRPT with qrcp = bqrrp on a row-sharded queue is not supported (the sketch is replicated); use geqp3";
+            blas::LocalOnly replicated(q);    // (as for hqrrp: a replicated sub-problem)
             RandLAPACK::BQRRP<T, RNG> bq(q, false, (int64_t)(n * bqrrp_block_ratio));
             bq.qrcp_wide = BQRRPSubroutines::QRCPWide::luqr;      // the reference object's defaults (rl_bqrrp.hh:101-103)
             bq.qr_tall = BQRRPSubroutines::QRTall::geqrf;
@@ -229,20 +229,33 @@ public:
             // complete the orthonormal set: Gaussian trailing columns, projected against Q, Householder-orthogonalised.
             // (the reference passes &A[new_rank*lda] to fill_dense as an m x cols buffer with ld m and DISCARDS the returned
             //  state, :351-352 -- both kept: the fill goes through a packed scratch and `state` is left alone)
-            randlapack_require(q.world() == 1) << "CQRRPT orthogonalization mode is not row-sharded";
             const int64_t cols_to_fill = n - new_rank;
             blas::Scratch w2(q);
             T* Gs = w2.alloc<T>(m * cols_to_fill);
             T* temp = w2.alloc<T>(new_rank * cols_to_fill);
             T* tau_orth = w2.alloc<T>(cols_to_fill);
-            RandBLAS::DenseDist Dg(m, cols_to_fill);
-            (void)RandBLAS::fill_dense(Dg, Gs, state, q);
             T* Gc = &A[new_rank * lda];
-            lapack::lacpy(MatrixType::General, m, cols_to_fill, Gs, m, Gc, lda, q);
-            blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, new_rank, cols_to_fill, m, (T)1.0, A, lda, Gc, lda, (T)0.0, temp, new_rank, q);
-            blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, cols_to_fill, new_rank, (T)-1.0, A, lda, temp, new_rank, (T)1.0, Gc, lda, q);
-            lapack::geqrf(m, cols_to_fill, Gc, lda, tau_orth, q);
-            lapack::ungqr(m, cols_to_fill, cols_to_fill, Gc, lda, tau_orth, q);
+            if (q.world() > 1) {
+                // row-sharded: every rank draws ITS rows of the one global Gaussian block, the projection coefficients Q^T G sum over the
+                // ranks, and the Householder step is the one-exchange TSQR of rl_orth.hh
+                int64_t m_glob = m, row0 = 0;
+                q.shard_extent(m, m_glob, row0);
+                RandBLAS::DenseDist Dg(m_glob, cols_to_fill);
+                (void)RandBLAS::fill_dense_rows(Dg, row0, m, Gs, state, q);
+                lapack::lacpy(MatrixType::General, m, cols_to_fill, Gs, m, Gc, lda, q);
+                blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, new_rank, cols_to_fill, m, (T)1.0, A, lda, Gc, lda, (T)0.0, temp, new_rank, q);
+                q.allreduce_sum(temp, new_rank * cols_to_fill);
+                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, cols_to_fill, new_rank, (T)-1.0, A, lda, temp, new_rank, (T)1.0, Gc, lda, q);
+                detail::tsqr_q(q, m, cols_to_fill, Gc, lda);
+            } else {
+                RandBLAS::DenseDist Dg(m, cols_to_fill);
+                (void)RandBLAS::fill_dense(Dg, Gs, state, q);
+                lapack::lacpy(MatrixType::General, m, cols_to_fill, Gs, m, Gc, lda, q);
+                blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, new_rank, cols_to_fill, m, (T)1.0, A, lda, Gc, lda, (T)0.0, temp, new_rank, q);
+                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m, cols_to_fill, new_rank, (T)-1.0, A, lda, temp, new_rank, (T)1.0, Gc, lda, q);
+                lapack::geqrf(m, cols_to_fill, Gc, lda, tau_orth, q);
+                lapack::ungqr(m, cols_to_fill, cols_to_fill, Gc, lda, tau_orth, q);
+            }
         }
         if (timing) {                                                                                        // :370-384
             auto t7 = stamp();

@@ -181,6 +181,7 @@ int rlhip_drv_stab_f64(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int6
     return guarded([&] {
         blas::Queue q(ctx);
         auto st = make_stab<double>(q, kind, cond_check != 0);
+        blas::RowsSharded sh(q, true);                     // (a context with a communicator holds a row block of the tall matrix)
         int rc = st->call(m, k, A);
         if (chol_fail) {
             auto* c = dynamic_cast<RandLAPACK::CholQRQ<double>*>(st.get());
@@ -444,6 +445,7 @@ int rlhip_drv_stab_f32(rlhip_ctx* ctx, int kind, int cond_check, int64_t m, int6
     return guarded([&] {
         blas::Queue q(ctx);
         auto st = make_stab<float>(q, kind, cond_check != 0);
+        blas::RowsSharded sh(q, true);                     // (a context with a communicator holds a row block of the tall matrix)
         int rc = st->call(m, k, A);
         if (chol_fail) {
             auto* c = dynamic_cast<RandLAPACK::CholQRQ<float>*>(st.get());

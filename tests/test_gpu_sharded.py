@@ -56,6 +56,37 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     assert out["ab_S_vs_single"] <= 1e-9 and out["ab_orthU"] <= 1e-9 and out["ab_res"] <= 1e-9
 
 
+@pytest.mark.parametrize("world,m,n,k,p", [(2, 3000, 400, 32, 2), (3, 2400, 300, 40, 2), (3, 5000, 256, 64, 3)])
+def test_rowsharded_stabilisers_power_scheme_and_replicated_qrcp(world, m, n, k, p):
+    """Row-sharded PLUL (tournament-pivoted LU, one exchange) and HQRQ (TSQR, one exchange) -- the stabilisers the reference's own RSVD / QB
+    object graphs put inside the power scheme (test/drivers/test_rsvd.cc:70, test/comps/test_qb.cc:59) -- at world 2 and 3 with p >= 2:
+    valid bases of the same column space, and the RSVD they feed delivers the single-device singular values to 1e-10.  Also: CQRRPT with
+    the hqrrp / bqrrp QRCP (replicated on every rank: identical pivots) and with the orthonormal completion, on a sharded queue."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_sharded_stab_worker.py"), str(m), str(n), str(k), str(p)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("STAB_RESULT ")]
+    assert res.returncode == 0 and line, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads(line[-1][len("STAB_RESULT "):])
+    assert out["hqrq_rc"] == 0 and out["plul_rc"] == 0
+    assert out["hqrq_orth"] <= 1e-12 and out["hqrq_span"] <= 1e-11              # orthonormal basis of span(Y)
+    assert out["plul_span"] <= 1e-10 and out["plul_unit_rows"] == k              # same span; the k pivot rows form a unit lower triangle
+    assert out["plul_max"] <= 50.0 and out["plul_cond"] <= 1e4                   # tournament pivoting: bounded multipliers, a well-conditioned basis
+    for name in ("cholqrq", "hqrq", "plul"):
+        r = out[f"rsvd_{name}"]
+        assert r["k"] == k, (name, r)
+        assert r["S_vs_single"] <= 1e-10 and r["S_vs_exact"] <= 1e-9, (name, r)
+        assert r["orthU"] <= 1e-9 and r["recon"] <= 2e-7, (name, r)          # (the 1e-9 noise floor of the test matrix)
+    for name in ("hqrrp", "bqrrp"):
+        c = out[f"cq_{name}"]
+        assert c["rank"][0] == c["rank"][1] and c["J_equal"], (name, c)
+        assert c["R"] <= 1e-10 and c["resid"] <= 1e-12 and c["orth"] <= 1e-11, (name, c)
+    co = out["cq_orth"]
+    assert co["rank"] < co["ncols"] and co["orth_all"] <= 1e-10 and co["resid"] <= 1e-11, co
+
+
 def test_bench_multi_rank_code_path_on_one_gpu():
     """bench.py --gpus 2 end to end (row sharding, barrier + max-over-ranks timing, JSON line) with two ranks sharing the GPU and
     gloo as the process group; the driver's real runs differ only in the transport (RCCL)."""
