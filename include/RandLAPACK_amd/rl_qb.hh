@@ -43,8 +43,8 @@ public:
         const int64_t k_in = k;
         Q = blas::device_malloc<T>(m * k_in, q);
         BT = blas::device_malloc<T>(n * k_in, q);
-        blas::device_memset(Q, 0, m * k_in, q);
-        blas::device_memset(BT, 0, n * k_in, q);
+        // (the reference callocs: here every column a block writes is written in full, and the columns NOT reached -- an early exit --
+        //  are zeroed on the way out: `done` below; a 51 + 41 MB memset per call otherwise, 22 us of an 11 ms shard step)
         blas::Scratch ws(q);
         T* QtQi = ws.alloc<T>(k_in * std::max<int64_t>(1, std::min(b_sz, k_in)));
         const bool single_block = (b_sz >= k_in);
@@ -65,7 +65,16 @@ public:
             q.norm_req.defer = true;                               // read together with ||B_1||_F below: one host round trip for both
         }
         blas::RowsSharded sh(q, true);                             // Q_i, Q: rows sharded
-        auto done = [&](int code) { q.norm_req = blas::Queue::NormRequest(); if (A_own) blas::device_free(A_own, q); return code; };
+        auto done = [&](int code) {
+            q.norm_req = blas::Queue::NormRequest();
+            if (A_own) blas::device_free(A_own, q);
+            const int64_t kept = std::max<int64_t>(std::min(k, k_in), 0);      // columns [kept, k_in) hold nothing the caller may read: zero, as calloc would leave them
+            if (kept < k_in) {
+                blas::device_memset(Q + m * kept, 0, m * (k_in - kept), q);
+                blas::device_memset(BT + n * kept, 0, n * (k_in - kept), q);
+            }
+            return code;
+        };
 
         while (curr_sz < k) {
             b_sz = std::min(b_sz, k - curr_sz);                                                           // :175

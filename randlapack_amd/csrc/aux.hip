@@ -80,9 +80,11 @@ __global__ __launch_bounds__(256) void ssq_scaled_partial_kernel(int64_t m, int6
 __global__ __launch_bounds__(256) void ssq_final_kernel(int np, const double* __restrict__ partial,
                                                         double* __restrict__ out) {
     __shared__ double sm[4];
-    double acc = 0;
-    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
-    double s = block_sum<double, 256>(acc, sm);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;             // four loads in flight per thread (fixed order: deterministic)
+    int i = threadIdx.x;
+    for (; i + 768 < np; i += 1024) { a0 += partial[i]; a1 += partial[i + 256]; a2 += partial[i + 512]; a3 += partial[i + 768]; }
+    for (; i < np; i += 256) a0 += partial[i];
+    double s = block_sum<double, 256>((a0 + a1) + (a2 + a3), sm);
     if (threadIdx.x == 0) out[0] = s;
 }
 
@@ -136,6 +138,9 @@ int lange_fro(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* re
     if (n < 0) return -3;
     if (m == 0 || n == 0) { *result_host = T(0); return 0; }
     dim3 grid = grid2d(m, n);
+    // at most ~2048 partial sums: the one-workgroup second stage walked 16384 of them one dependent load at a time (17 us of a 30 us norm
+    // of the 20000 x 256 factor B^T of the RSVD tail)
+    if ((int64_t)grid.x * grid.y > 2048) grid.y = (unsigned)(2048 / grid.x < 1 ? 1 : 2048 / grid.x);
     int np = (int)(grid.x * grid.y);
     size_t mark = rlhip_ws_mark(c);
     double* partial = ws_alloc<double>(c, np);

@@ -328,17 +328,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(
     }
 }
 
-// sums split-K slabs in fixed z order: C = alpha * sum_z slab[z] + beta * C
+// sums split-K slabs in a fixed order: C = alpha * sum_z slab[z] + beta * C.  Four lanes share an output entry (lane q takes the slices
+// z = q mod 4, eight loads in flight each, then a fixed two-step butterfly): with one thread per entry walking all slices the reduction of
+// the 170 slabs of a tall-skinny Gram matrix took half as long as the product itself.
 template <typename T>
-__global__ void splitk_reduce_kernel(int64_t M, int64_t N, int nz, const T* __restrict__ slab, T alpha, T beta,
-                                     T* __restrict__ C, int64_t ldc, int tri, int tile) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = M * N;
-    for (; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = idx % M, j = idx / M;
-        if (tri && i > j) continue;   // LAPACK uplo contract: the strictly lower triangle is never written
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int nz, const T* __restrict__ slab, T alpha, T beta,
+                                                            T* __restrict__ C, int64_t ldc, int tri, int tile) {
+    const int64_t total = M * N;
+    const int q = threadIdx.x & 3;
+    for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; idx < ((total + 63) / 64) * 64; idx += ((int64_t)gridDim.x * blockDim.x) >> 2) {
+        const int64_t e = idx < total ? idx : total - 1;             // (whole wavefronts stay in the loop for the shuffles)
         T s = 0;
-        for (int z = 0; z < nz; ++z) s += slab[(int64_t)z * total + idx];
+        int z = q;
+        for (; z + 28 < nz; z += 32) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(z + 4 * u) * total + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < nz; z += 4) s += slab[(int64_t)z * total + e];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        const int64_t i = e % M, j = e / M;
+        if (q != 0 || idx >= total || (tri && i > j)) continue;      // LAPACK uplo contract: the strictly lower triangle is never written
         T v = alpha * s;
         if (beta != T(0)) v += beta * C[i + j * ldc];
         C[i + j * ldc] = v;
@@ -468,7 +481,9 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
         const double flops_cu = 78.6e12 / slots * (sizeof(T) == 4 ? 2.0 : 1.0);
         const double t_tile_k = 2.0 * bm * bn * BK / flops_cu;  // seconds per K-tile per workgroup
         const double slab_bw = 4.0e12;
-        int64_t maxs = ktiles / 32;
+        // slices of >= 32 K-tiles, except for the Gram matrices of tall-skinny factors (k x k outputs: <= 8 tiles, 1500+ K-tiles): there 48
+        // slices x 3 tiles left 112 of 256 CUs without a workgroup (91 us for the 25000 x 256 Gram matrix of a shard), so slices go down to 8
+        int64_t maxs = ktiles / ((tiles <= 8) ? 8 : 32);
         if (maxs > 256) maxs = 256;
         double best = 1e300;
         for (int64_t s = 1; s <= (maxs < 1 ? 1 : maxs); ++s) {
@@ -516,8 +531,8 @@ int gemm_dispatch(rlhip_ctx* c, GemmArgs<T> g, int tri) {
 
     if (splitk > 1) {
         int64_t total = M * N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = (int)((4 * total + 255) / 256);                 // four lanes per entry
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, M, N, (int)splitk,
                            g.slab, alpha, beta, g.C, g.ldc, tri, (int)bm);
         RLHIP_LAUNCH_CHECK();
