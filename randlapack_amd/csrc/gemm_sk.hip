@@ -78,6 +78,7 @@ struct SkArgs {
     int tri;                  // 1: syrk-upper -- only tiles touching i <= j are computed, only i <= j is written
     int64_t ntiles;           // number of active tiles
     int gs;                   // workgroups per lockstep group (see sk_group below); 1 = every workgroup on its own
+    int stag;                 // K-tile stagger between the members of a lockstep group (transposed product only; 0 = walk in phase)
     unsigned long long* clk;  // nullptr, or 4 words: workgroup 0's shader-clock and 100 MHz timestamps at entry and exit (RLHIP_SK_CLOCK=1: effective clock)
 };
 
@@ -247,8 +248,16 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         const T* Bg = g.B + k0 + td.nA0 * g.ldb;              // columns 0 .. 127 of the tile
         const T* Bg1 = g.B + k0 + td.nB0 * g.ldb;             // columns 128 .. 255 (the same block row for ordinary tiles)
 
+        // Staggered lockstep (transposed product): the members of a group walk the SAME K range, but member j starts `stag * j` K-tiles into it
+        // and wraps around.  In phase, the eight members fetch the same 16 rows of eight neighbouring column blocks of A -- addresses a multiple
+        // of 128 * lda * sizeof(T) apart, which land on a handful of memory channels (31.2 ms against 30.0 ungrouped at C2); a few tiles apart
+        // they hit different channels while the rows of the shared operand Q stay within a ~1 MiB window of L2.  The sum over a segment is taken
+        // in the rotated order: fixed per (shape, grid), so results stay reproducible.
+        const int64_t rot = (A_KC && GS > 1 && g.stag > 0) ? ((int64_t)who.member * g.stag) % nk : 0;
         auto issue = [&](int64_t t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
             unsigned char* st = smem + stage * STAGE;
+            t += rot;
+            if (t >= nk) t -= nk;
             const T* Ap = Ag + t * a_step;
             const T* Bp = Bg + t * BK;
             const T* Bp1 = Bg1 + t * BK;
@@ -561,21 +570,24 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     g.tri = tri; g.ntiles = ntiles;
     int64_t P = num_cu;
     // experiments only (scripts/shard_gemm_ab.py): RLHIP_SK_TUNE="gs_nn,gs_tn,workgroups", 0 keeps the default
-    static int tune[3] = {-1, 0, 0};
+    static int tune[4] = {-1, 0, 0, -1};
     if (tune[0] < 0) {
         tune[0] = 0;
-        if (const char* e = getenv("RLHIP_SK_TUNE")) sscanf(e, "%d,%d,%d", &tune[0], &tune[1], &tune[2]);
+        if (const char* e = getenv("RLHIP_SK_TUNE")) sscanf(e, "%d,%d,%d,%d", &tune[0], &tune[1], &tune[2], &tune[3]);    // gs_nn, gs_tn, workgroups, stagger
     }
     if (tune[2] > 0 && tune[2] <= num_cu) P = tune[2];
     // Lockstep group size (sk_group).  Measured at C2 (200000 x 20000 x 256 fp64, kernel ms / FETCH_SIZE GB against 32.5 GB algorithmic):
     //   Y = A Omega (NN):   1: 29.8 / 72.8   2: 29.9 / 68.8   4: 29.9 / 52.1   8: 30.0 / 34.4   (16, 32: as 8)
     //   B^T = A^T Q (TN):   1: 30.1 / 63.0   2: 30.0 / 58.8   4: 30.6 / 58.7   8: 31.2 / 34.9
-    // NN takes 8 (fabric traffic 2.27x -> 1.08x of the algorithmic bytes for 0.5 % of kernel time).  TN loses 4 % at 8 -- its members read
-    // the SAME k-rows of neighbouring column blocks of A, 1.6 MB apart, at the same instant, which camps on memory channels -- and stays
-    // at 2.  The triangular map has too few tiles for whole units (18 at n = 1024) and runs ungrouped.
-    int gs_want = tri ? 1 : (transA ? 2 : 8);
+    // NN takes 8 (fabric traffic 2.27x -> 1.08x of the algorithmic bytes for 0.5 % of kernel time).  TN loses 4 % at 8 IN PHASE -- its members
+    // read the SAME k-rows of neighbouring column blocks of A, 1.6 MB apart, at the same instant, which camps on memory channels -- so its
+    // groups of 8 walk staggered (round 4, below).  The triangular map has too few tiles for whole units (18 at n = 1024) and runs ungrouped.
+    int gs_want = tri ? 1 : 8;
     if (!tri && tune[transA ? 1 : 0] > 0) gs_want = tune[transA ? 1 : 0];
     g.gs = (gs_want > 1 && P % (8 * gs_want) == 0 && ntiles >= 4 * (int64_t)gs_want) ? gs_want : 1;
+    // transposed product: groups of 8 walk their K range 16 tiles apart (see `rot` in the kernel).  Interleaved A/B at C2, best of 4 / median,
+    // ms: groups of 2 in phase (round 3) 31.64 / 33.1;  8 in phase 32.1;  8 staggered by 16: 30.87 / 31.6;  4 by 8: 30.85 / 31.6;  8 by 64: 32.2
+    g.stag = (transA && g.gs > 1) ? (tune[3] >= 0 ? tune[3] : 16) : 0;
     size_t mark = rlhip_ws_mark(c);
     g.slab = ws_alloc<T>(c, (size_t)2 * P * SLAB_ELEMS);
     if (!g.slab) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
