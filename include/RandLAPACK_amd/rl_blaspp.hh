@@ -44,6 +44,15 @@ public:
     }
     // adopt an existing context (e.g. one bound to PyTorch's stream)
     explicit Queue(rlhip_ctx* ctx) : ctx_(ctx), owned_(false) {}
+    // a SIDE queue of `parent`: same device, its own high-priority stream and scratch arena, for work that runs beside the parent's
+    // stream (BQRRP's look-ahead).  No communicator: it answers as one rank.  Order the two with wait_for().
+    struct Side {};
+    Queue(Queue& parent, Side) {
+        check(rlhip_create_side(parent.ctx_, &ctx_), "rlhip_create_side");
+        owned_ = true;
+    }
+    // what this queue enqueues from now on starts after what `other` has enqueued so far (device-side ordering, the host does not wait)
+    void wait_for(Queue& other) { check(rlhip_order_after(ctx_, other.ctx_), "rlhip_order_after"); }
     Queue(Queue const&) = delete;
     Queue& operator=(Queue const&) = delete;
     ~Queue() { if (owned_ && ctx_) rlhip_destroy(ctx_); }

@@ -11,6 +11,8 @@
 // `use_fast_subroutines()` selects {luqr, cholqr, gemqrt}, the BLAS-3 triple.  The blocked loop itself lives in
 // detail::bqrrp_factor and is shared with BQRRP_GPU (rl_bqrrp_gpu.hh), which differs only in taking the sketch from its caller.
 #pragma once
+#include <cstdlib>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -65,6 +67,7 @@ struct BqrrpOpts {
     bool cholqr_fallback;
     T cholqr_cond_limit_inv;
     bool timing;
+    bool lookahead = true;     // run the sketch down-date and the next QRCP of the sketch BESIDE the trailing update (see bqrrp_factor)
 };
 
 /// The blocked loop of BQRRP (rl_bqrrp.hh:318-661) and of BQRRP_GPU (rl_bqrrp_gpu.hh:336-934) on one device: both classes run
@@ -102,28 +105,47 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
     T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;                                                       // :262-266
     int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
     std::vector<T> diag(b_sz_const);
-    auto transpose_call = [&](int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
-        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
-        else return rlhip_transpose_f32(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+    auto transpose_call = [&](blas::Queue& qq, int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
+        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(qq.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+        else return rlhip_transpose_f32(qq.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
     };
+    // ---- look-ahead.  The block row R12 of the trailing matrix is final after the HEAD of the compact-WY apply (W2 = T^T V^T C, C1 -= V1 W2);
+    // the TAIL (C2 -= V2 W2, half of the apply's flops) is read by nothing on the way to the next panel's pivots.  So the sketch down-date and
+    // the next QRCP of the sketch -- latency-bound kernels that leave most CUs idle (a quarter busy in the LU panels of C4) -- are enqueued
+    // on a SIDE queue (own high-priority stream) right behind the head and run beside the tail; the main stream joins it before it touches
+    // A again.  The same operations on the same data in the same order (the tail goes through the tiled GEMM kernel instead of the persistent
+    // one, whose workgroups would hold every CU: different rounding of that one product, nothing else).  Off when the subroutines are timed
+    // (every lap drains the streams) and for small problems (a side queue costs a scratch arena).
+    // What it buys is limited by how badly the latency-bound panel kernels run BESIDE a GEMM that saturates the memory system: at C4 the LU of
+    // the sketch takes 55 ms beside the tail against 15 ms alone, and the cooperative sketch QR waits for the tail's last workgroups
+    // (rocprofv3 trace): 4.39 -> 4.27 s.
+    static const bool la_env = [] { const char* e = std::getenv("RLHIP_BQRRP_LOOKAHEAD"); return !(e && std::atoi(e) == 0); }();
+    const bool la_ok = P.lookahead && la_env && !P.timing && (double)m * (double)n >= 2.5e8 && b_sz_const >= 256;   // (16384^2: -1.4 %, 65536^2: -2.5 %; 8192^2: +1 %)
+    std::unique_ptr<blas::Queue> side;
+    T* W2_la = la_ok ? ws.try_alloc<T>(b_sz_const * n) : nullptr;
+    bool pre_on_side = false;          // this iteration's sketch (down-dated) lives on the side stream: its QRCP goes there too
 
     for (int64_t iter = 0; iter < maxiter; ++iter) {
         b_sz = std::min(b_sz, mn - curr_sz);                                                                // :322-324
         inb = std::min(inb, b_sz);
         block_rank = b_sz;
         auto ta = stamp();
-        if (!lu) {
-            lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);                           // :336
-            lap(L.qrcp_main, ta);
-        } else {                                                                                            // :337-357
-            blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
-            lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
-            lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
-            lap(L.qrcp_main, ta);
-            util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
-            lap(L.qrcp_piv, ta);
-            lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
-            lap(L.qrcp_main, ta);
+        {
+            blas::Queue& qq = pre_on_side ? *side : q;
+            if (!lu) {
+                lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, qq);                      // :336
+                lap(L.qrcp_main, ta);
+            } else {                                                                                        // :337-357
+                blas::check(transpose_call(qq, sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
+                lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, qq);   // only J_buffer_lu is read below
+                lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, qq);
+                lap(L.qrcp_main, ta);
+                util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, qq);
+                lap(L.qrcp_piv, ta);
+                lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, qq);
+                lap(L.qrcp_main, ta);
+            }
+            if (pre_on_side) { q.wait_for(*side); pre_on_side = false; }     // the main stream continues behind the pivots and behind its own tail
         }
         util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);                                 // :369
         bool block_zero = !lapack::any_abs_gt(rows, A_work, std::numeric_limits<T>::epsilon(), q);         // :373-379
@@ -197,8 +219,21 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
         }
         // ---- apply Q^T to the trailing columns (:535-547)
         const int64_t q_rows = (block_rank != b_sz_const) ? block_rank : rows;
+        const bool more = (curr_sz + b_sz < mn) && (block_rank == b_sz_const);           // another panel follows (:576-618)
+        const bool use_t = (P.apply_trans_q == Sub::ApplyTransQ::gemqrt && have_T);
+        bool la = false;
         if (cols - b_sz > 0 && block_rank > 0) {
-            if (P.apply_trans_q == Sub::ApplyTransQ::gemqrt && have_T)                                      // :535-547
+            // one compact-WY block and a next panel to prepare: head on the main stream, the side queue starts behind it, tail on the main stream
+            la = la_ok && W2_la && more && (!use_t || inb >= block_rank) && q_rows > block_rank;
+            if (la) {
+                if (!side) side = std::make_unique<blas::Queue>(q, typename blas::Queue::Side{});
+                const T* Tptr = T_dat;
+                int64_t ldt = b_sz_const;
+                if (!use_t) { lapack::larft(q_rows, block_rank, A_work, lda, tau_sub, T_ormqr, block_rank, q); Tptr = T_ormqr; ldt = block_rank; }
+                lapack::gemqrt_head(q_rows, cols - b_sz, block_rank, A_work, lda, Tptr, ldt, Work1, lda, W2_la, q);
+                side->wait_for(q);                                                        // R11, R12, R_sk are final from here on
+                lapack::gemqrt_tail(q_rows, cols - b_sz, block_rank, A_work, lda, W2_la, Work1, lda, q);
+            } else if (use_t)                                                                                // :535-547
                 lapack::gemqrt(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work1, lda, q);
             else   // ormqr: the same reflectors applied from (V, tau); T_dat is free to hold the k x k block when T is not needed again
                 lapack::ormqr(Side::Left, Op::Trans, q_rows, cols - b_sz, block_rank, A_work, lda, tau_sub, Work1, lda, T_ormqr, q);
@@ -208,14 +243,16 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
         curr_sz += b_sz;
         if (curr_sz >= mn || block_rank != b_sz_const) { rank = curr_sz; return 0; }                        // :576-618
         A_work = &Work1[b_sz];                                                                               // :624
-        // sketch down-date (:633-651)
-        if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);         // get_U(b, b, R_sk, d)
-        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R11, lda, R_sk, d, q);
-        blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, cols - b_sz, b_sz, (T)-1.0, R_sk, d, R12, lda, (T)1.0, &R_sk[d * b_sz], d, q);
+        // sketch down-date (:633-651) -- beside the tail of the apply when the look-ahead is on
+        blas::Queue& qd = la ? *side : q;
+        if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, qd);        // get_U(b, b, R_sk, d)
+        blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R11, lda, R_sk, d, qd);
+        blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, cols - b_sz, b_sz, (T)-1.0, R_sk, d, R12, lda, (T)1.0, &R_sk[d * b_sz], d, qd);
         sampling_dimension = std::min(sampling_dimension, cols);
         if (sampling_dimension - b_sz > 1)
             lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0,
-                          &R_sk[(d + 1) * b_sz] + 1, d, q);
+                          &R_sk[(d + 1) * b_sz] + 1, d, qd);
+        pre_on_side = la;
         A_sk = &A_sk[d * b_sz];
         rows -= b_sz;
         cols -= b_sz;

@@ -76,6 +76,11 @@ inline void orhr_col(int64_t m, int64_t n, int64_t nb, double* A, int64_t lda, d
 inline void orhr_col(int64_t m, int64_t n, int64_t nb, float* A, int64_t lda, float* T, int64_t ldt, float* D, Queue& q = blas::default_queue()) { blas::check(rlhip_orhr_col_f32(q.ctx(), m, n, nb, A, lda, T, ldt, D), "orhr_col"); }
 inline void gemqrt(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, int64_t nb, double const* V, int64_t ldv, double const* T, int64_t ldt, double* C, int64_t ldc, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_f64(q.ctx(), (char)s, (char)t, m, n, k, nb, V, ldv, T, ldt, C, ldc), "gemqrt"); }
 inline void gemqrt(blas::Side s, blas::Op t, int64_t m, int64_t n, int64_t k, int64_t nb, float const* V, int64_t ldv, float const* T, int64_t ldt, float* C, int64_t ldc, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_f32(q.ctx(), (char)s, (char)t, m, n, k, nb, V, ldv, T, ldt, C, ldc), "gemqrt"); }
+// gemqrt(Left, Trans) of one compact-WY block in two calls (rlhip_gemqrt_head / _tail): after `head` the first k rows of C are final
+inline void gemqrt_head(int64_t m, int64_t n, int64_t k, double const* V, int64_t ldv, double const* T, int64_t ldt, double* C, int64_t ldc, double* W2, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_head_f64(q.ctx(), m, n, k, V, ldv, T, ldt, C, ldc, W2), "gemqrt_head"); }
+inline void gemqrt_head(int64_t m, int64_t n, int64_t k, float const* V, int64_t ldv, float const* T, int64_t ldt, float* C, int64_t ldc, float* W2, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_head_f32(q.ctx(), m, n, k, V, ldv, T, ldt, C, ldc, W2), "gemqrt_head"); }
+inline void gemqrt_tail(int64_t m, int64_t n, int64_t k, double const* V, int64_t ldv, double const* W2, double* C, int64_t ldc, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_tail_f64(q.ctx(), m, n, k, V, ldv, W2, C, ldc), "gemqrt_tail"); }
+inline void gemqrt_tail(int64_t m, int64_t n, int64_t k, float const* V, int64_t ldv, float const* W2, float* C, int64_t ldc, Queue& q = blas::default_queue()) { blas::check(rlhip_gemqrt_tail_f32(q.ctx(), m, n, k, V, ldv, W2, C, ldc), "gemqrt_tail"); }
 inline void larft(int64_t m, int64_t k, double const* V, int64_t ldv, double const* tau, double* T, int64_t ldt, Queue& q = blas::default_queue()) { blas::check(rlhip_larft_f64(q.ctx(), m, k, V, ldv, tau, T, ldt), "larft"); }
 inline void larft(int64_t m, int64_t k, float const* V, int64_t ldv, float const* tau, float* T, int64_t ldt, Queue& q = blas::default_queue()) { blas::check(rlhip_larft_f32(q.ctx(), m, k, V, ldv, tau, T, ldt), "larft"); }
 inline void row_sign(int64_t n, double* R, int64_t ldr, double const* D, Queue& q = blas::default_queue()) { blas::check(rlhip_row_sign_f64(q.ctx(), n, R, ldr, D), "row_sign"); }

@@ -35,6 +35,11 @@ typedef struct rlhip_ctx rlhip_ctx;
  * own_stream == 0: enqueue on hip_stream (a hipStream_t; NULL = the device's default stream, which is what
  * PyTorch-ROCm uses unless told otherwise). */
 int rlhip_create(rlhip_ctx** ctx, int device, void* hip_stream, int own_stream);
+/* a second context on the parent's device: own high-priority stream, own scratch arena -- for work that runs beside the parent's stream
+ * (BQRRP's look-ahead); destroyed with rlhip_destroy.  rlhip_order_after: what `waiter` enqueues from now on starts after what `signaler`
+ * has enqueued so far (an event, no host wait). */
+int rlhip_create_side(rlhip_ctx* parent, rlhip_ctx** out);
+int rlhip_order_after(rlhip_ctx* waiter, rlhip_ctx* signaler);
 int rlhip_destroy(rlhip_ctx* ctx);
 int rlhip_sync(rlhip_ctx* ctx);
 void* rlhip_stream(rlhip_ctx* ctx);
@@ -266,6 +271,13 @@ int rlhip_gemqrt_f64(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n
                      int64_t ldv, const double* T, int64_t ldt, double* C, int64_t ldc);
 int rlhip_gemqrt_f32(rlhip_ctx* ctx, char side, char trans, int64_t m, int64_t n, int64_t k, int64_t nb, const float* V,
                      int64_t ldv, const float* T, int64_t ldt, float* C, int64_t ldc);
+/* The left / transposed apply of ONE compact-WY block (k reflectors, nb >= k) in two calls, cut where the first k rows of C -- BQRRP's block
+ * row R12 (rl_bqrrp.hh:547) -- are final: head computes W2 = T^T V^T C (k x n, ld k, the caller's buffer) and updates rows 0..k-1 of C;
+ * tail updates rows k..m-1 (C2 -= V2 W2).  head + tail == rlhip_gemqrt_*('L', 'T', ..., nb = k) bit for bit. */
+int rlhip_gemqrt_head_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* V, int64_t ldv, const double* T, int64_t ldt, double* C, int64_t ldc, double* W2);
+int rlhip_gemqrt_head_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, const float* V, int64_t ldv, const float* T, int64_t ldt, float* C, int64_t ldc, float* W2);
+int rlhip_gemqrt_tail_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* V, int64_t ldv, const double* W2, double* C, int64_t ldc);
+int rlhip_gemqrt_tail_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, const float* V, int64_t ldv, const float* W2, float* C, int64_t ldc);
 /* (side = 'R', trans = 'N', nb >= k): C (m x n) <- C (I - V T V^T), V n x k -- lapack::larfb(Right, NoTrans, Forward, Columnwise) as
  * used by HQRRP to carry the sketching matrix along (NoFLA_Apply_Q_WY_rnfc_blk_var4, rl_hqrrp.hh:178-206).
  * rlhip_qrp_partial_*: pivoted Householder QR of the first `steps` columns only, HQRRP's norm down-date form

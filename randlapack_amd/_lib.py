@@ -98,6 +98,12 @@ SIGNATURES = {
     "rlhip_philox4x32_10": (c_int, [c_vp, c_i64, c_vp, u32p, u32p]),
     "rlhip_gemm_norma_f64": (c_int, [c_vp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_vp, c_i64, c_dbl,
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
+    "rlhip_create_side": (c_int, [c_vp, C.POINTER(c_vp)]),
+    "rlhip_order_after": (c_int, [c_vp, c_vp]),
+    "rlhip_gemqrt_head_f64": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "rlhip_gemqrt_head_f32": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "rlhip_gemqrt_tail_f64": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64]),
+    "rlhip_gemqrt_tail_f32": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64]),
     "rlhip_norma_collect_f64": (c_int, [c_vp, c_int, C.POINTER(c_dbl)]),
     "rlhip_cholqrq_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),
     "rlhip_cholqrq_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_int, C.POINTER(c_int)]),

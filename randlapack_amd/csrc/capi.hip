@@ -22,6 +22,8 @@ int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* 
 template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
 template <typename T> int orhr_col(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);
 template <typename T> int gemqrt_lt(rlhip_ctx*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
+template <typename T> int gemqrt_lt_head(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t, T*);
+template <typename T> int gemqrt_lt_tail(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);
 template <typename T> int larft_gram(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);
 template <typename T> int row_sign(rlhip_ctx*, int64_t, T*, int64_t, const T*);
 template <typename T> int tau_from_t(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, T*);
@@ -165,6 +167,35 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
     }
     *out = c;
     return 0;
+}
+
+// A second context on the parent's device with its own HIGH-PRIORITY stream and its own scratch arena: work that should run BESIDE the
+// parent's stream and get CUs as soon as they free up (BQRRP's look-ahead: the latency-bound pivoting of the next panel beside the
+// trailing update).  Ordering between the two streams is explicit: rlhip_order_after.
+int rlhip_create_side(rlhip_ctx* parent, rlhip_ctx** out) {
+    if (!parent || !out) return -1;
+    RLHIP_CHECK(hipSetDevice(parent->device));
+    int lo = 0, hi = 0;
+    RLHIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));             // (numerically lower = higher priority)
+    hipStream_t st = nullptr;
+    RLHIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    const int rc = rlhip_create(out, parent->device, (void*)st, 0);
+    if (rc) { hipStreamDestroy(st); return rc; }
+    (*out)->owns_stream = true;
+    (*out)->avoid_persistent = 1;        // a side context shares the device by definition: no kernel of its own may wait for every CU to be free
+    return 0;
+}
+
+// everything enqueued on `waiter`'s stream from now on starts after everything enqueued on `signaler`'s stream so far (no host wait)
+int rlhip_order_after(rlhip_ctx* waiter, rlhip_ctx* signaler) {
+    if (!waiter || !signaler) return -1;
+    if (waiter->stream == signaler->stream) return 0;
+    hipEvent_t ev = nullptr;
+    RLHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, signaler->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter->stream, ev, 0);
+    hipEventDestroy(ev);                                                 // (released once the wait has been consumed)
+    return e == hipSuccess ? 0 : RLHIP_ERR_HIP(e);
 }
 
 int rlhip_destroy(rlhip_ctx* c) {
@@ -454,6 +485,12 @@ static inline int op_flag(char t, int* out) {
             return rlhip::gemqrt_rn<T>(c, m, n, k, V, ldv, Tm, ldt, C, ldc);                                    \
         }                                                                                                       \
         return left ? -3 : -2;                                                                                  \
+    }                                                                                                           \
+    int rlhip_gemqrt_head_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc, T* W2) { \
+        return rlhip::gemqrt_lt_head<T>(c, m, n, k, V, ldv, Tm, ldt, C, ldc, W2);                               \
+    }                                                                                                           \
+    int rlhip_gemqrt_tail_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* W2, T* C, int64_t ldc) { \
+        return rlhip::gemqrt_lt_tail<T>(c, m, n, k, V, ldv, W2, C, ldc);                                        \
     }                                                                                                           \
     int rlhip_vrows_explicit_##SUF(rlhip_ctx* c, int64_t br, int64_t toff, int64_t tcnt, const T* Vtop, int64_t ldv, T* out, int64_t ldo) { \
         return rlhip::vrows_explicit<T>(c, br, toff, tcnt, Vtop, ldv, out, ldo);                                \

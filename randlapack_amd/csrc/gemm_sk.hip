@@ -545,7 +545,7 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
         enabled_f32 = f ? atoi(f) : 1;
     }
     const int num_cu = c->num_cu;
-    if (!enabled || transB || (sizeof(T) == 4 && !enabled_f32)) return 0;
+    if (!enabled || transB || (sizeof(T) == 4 && !enabled_f32) || c->avoid_persistent) return 0;
     // fp32: the kernel carries ONE fma chain per output entry through the whole K of a tile.  Beyond ~16k products the rounding of the
     // growing partial sum (eps * K / sqrt 2) is 2-3x that of a cache-blocked host sgemm or of the split-K generic kernel (measured on
     // BQRRP 65536^2: residual per column 4e-5 -> 7.5e-5; a second accumulator level costs more registers than the kernel has: 137 ->

@@ -256,6 +256,51 @@ int gemqrt_lt(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, int64_t nb, const T
     return rc;
 }
 
+// The same apply for ONE compact-WY block (k reflectors), cut where the first k rows of C are final:
+//   head:  W2 = T^T (V1^T C1 + V2^T C2),  C1 -= V1 W2     -- after it the block row C1 (BQRRP's R12, rl_bqrrp.hh:547) does not change any more
+//   tail:  C2 -= V2 W2                                     -- the big product; nothing on the path to the NEXT panel's pivots reads C2
+// BQRRP's look-ahead (rl_bqrrp.hh, detail::bqrrp_factor) runs the sketch down-date and the next QRCP of the sketch beside the tail.
+// W2 is the caller's k x n buffer (ld k).  Same kernels, same order of operations as gemqrt_lt with nb >= k: bitwise the same C.
+template <typename T>
+int gemqrt_lt_head(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* Tm, int64_t ldt, T* C, int64_t ldc, T* W2) {
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0 || k > m) return -5;
+    if (k == 0 || n == 0 || m == 0) return 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* V1 = ws_alloc<T>(c, (size_t)k * k);
+    T* W = ws_alloc<T>(c, (size_t)k * n);
+    if (!V1 || !W) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    const int64_t mr = m - k;
+    hipLaunchKernelGGL(unit_lower_copy_kernel<T>, dim3((unsigned)((k * k + 255) / 256)), dim3(256), 0, c->stream, k, V, ldv, V1, 0);
+    int rc = 0;
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = RLHIP_ERR_HIP(le);
+    }
+    if (!rc) rc = gemm<T>(c, 1, 0, k, n, k, T(1), V1, k, C, ldc, T(0), W, k);
+    if (!rc && mr > 0) rc = gemm<T>(c, 1, 0, k, n, mr, T(1), V + k, ldv, C + k, ldc, T(1), W, k);
+    if (!rc) rc = gemm<T>(c, 1, 0, k, n, k, T(1), Tm, ldt, W, k, T(0), W2, k);
+    if (!rc) rc = gemm<T>(c, 0, 0, k, n, k, T(-1), V1, k, W2, k, T(1), C, ldc);
+    rlhip_ws_release(c, mark);
+    return rc;
+}
+template <typename T>
+int gemqrt_lt_tail(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* W2, T* C, int64_t ldc) {
+    if (m < 0) return -3;
+    if (n < 0) return -4;
+    if (k < 0 || k > m) return -5;
+    const int64_t mr = m - k;
+    if (k == 0 || n == 0 || mr <= 0) return 0;
+    // the tiled kernel: its workgroups retire continuously, so the look-ahead's kernels on the side stream find CUs (the persistent kernel
+    // would hold all of them until the product is done); same rate for this NN shape (132 TFLOP/s fp32 either way)
+    const int keep = c->avoid_persistent;
+    c->avoid_persistent = 1;
+    const int rc = gemm<T>(c, 0, 0, mr, n, k, T(-1), V + k, ldv, W2, k, T(1), C + k, ldc);
+    c->avoid_persistent = keep;
+    return rc;
+}
+
 // C (m x n) <- C Q,  Q = I - V T V^T one compact-WY block (V: n x k unit lower trapezoidal, T: k x k upper).  Side::Right,
 // Op::NoTrans: HQRRP's update of the sketching matrix G (NoFLA_Apply_Q_WY_rnfc_blk_var4, rl_hqrrp.hh:178-206).
 template <typename T>
@@ -336,6 +381,8 @@ int any_abs_gt(rlhip_ctx* c, int64_t n, const T* x, T thr, int* any_host) {
 #define INST(T)                                                                                                          \
     template int orhr_col<T>(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);                       \
     template int gemqrt_lt<T>(rlhip_ctx*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t); \
+    template int gemqrt_lt_head<T>(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t, T*); \
+    template int gemqrt_lt_tail<T>(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t); \
     template int larft_gram<T>(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);                  \
     template int row_sign<T>(rlhip_ctx*, int64_t, T*, int64_t, const T*);                                                \
     template int tau_from_t<T>(rlhip_ctx*, int64_t, int64_t, const T*, int64_t, T*);                                     \

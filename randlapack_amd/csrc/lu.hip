@@ -46,6 +46,7 @@ __device__ __forceinline__ void lu_barrier(unsigned* bar, unsigned target) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void getrf_panel_kernel(LuArgs<T> g) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
     T* P = reinterpret_cast<T*>(lu_smem);                 // [pb][rpw] : local rows of the panel, column-major
     __shared__ T s_val[256];
@@ -421,6 +422,7 @@ __device__ __forceinline__ void lu_reg_steps(const LuArgs<T>& g, LuRegState<T, R
 }
 template <typename T, int RPT, bool TAG>
 __global__ __launch_bounds__(256, (sizeof(T) == 8) ? 2 : 1) void getrf_panel_reg_kernel(LuArgs<T> g) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ T s_wv[4];
     __shared__ int64_t s_wr[4];
     __shared__ int s_ww[4];
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(256) void getf2_update_kernel(int64_t m, int64_t j0
 template <typename T, bool SOLVE>
 __global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, int64_t j0, int pb, T* A, int64_t lda,
                                                    const int64_t* __restrict__ ipiv) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ int64_t s_pos[2 * PB], s_src[2 * PB];
     __shared__ int s_n;
     __shared__ T sL[SOLVE ? PB : 1][PB + 1];
@@ -677,6 +680,7 @@ __global__ void luqrcp_piv_kernel(int64_t sd, int64_t cols, const int64_t* __res
 // (open addressing, 2 * LQ_MAX slots); one thread walks the swaps in ~20 ns a step, the workgroup writes the touched entries back.
 constexpr int LQ_MAX = 2048;
 __global__ __launch_bounds__(256) void luqrcp_piv_lds_kernel(int64_t sd, int64_t cols, const int64_t* __restrict__ ipiv, int64_t* __restrict__ J) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ int s_low[LQ_MAX];                 // J[i] - 1 for i < lim
     __shared__ int s_piv[LQ_MAX];                 // ipiv[i] - 1
     __shared__ int s_key[2 * LQ_MAX], s_val[2 * LQ_MAX];

@@ -167,6 +167,7 @@ __device__ __forceinline__ void lu_f32_steps(const LuArgs<float>& g, LuRegState<
     }
 }
 __global__ __launch_bounds__(256) void getrf_panel_f32_kernel(LuArgs<float> g) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ LuF32Shared sh;
     const int tid = threadIdx.x;
     const int64_t me = blockIdx.x;

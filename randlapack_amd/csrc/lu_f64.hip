@@ -186,6 +186,7 @@ __device__ __forceinline__ void lu_f64_steps(const LuArgs<double>& g, LuRegState
     }
 }
 __global__ __launch_bounds__(256) void getrf_panel_f64_kernel(LuArgs<double> g) {
+    __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ LuF64Shared sh;
     const int tid = threadIdx.x;
     const int64_t me = blockIdx.x;

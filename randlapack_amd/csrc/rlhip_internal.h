@@ -84,6 +84,9 @@ struct rlhip_ctx {
     int norma_reduced = 0;           // 1: the sum over the row shards is on its way to h_mail[41] as well (rode on the Gram matrix's all-reduce, tri.hip::cholqrq)
     unsigned long norma_epoch = 0;   // sync_epoch when the deferred copy was enqueued
     unsigned long sync_epoch = 0;    // completed host waits on the stream (rlhip_stream_sync): anything enqueued before the last one has landed
+    // != 0: products take the tiled kernel whose workgroups come and go, not the persistent stream-K kernel that holds every CU for its whole
+    // duration (set around a product that is meant to share the device with another stream: house.hip::gemqrt_lt_tail)
+    int avoid_persistent = 0;
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU
     void* comm = nullptr;
