@@ -564,6 +564,9 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     }
     const int64_t W = ntiles * ktiles;
     if (W < (int64_t)num_cu * 64) return 0;   // too little work to amortise the persistent launch
+    // a k x k Gram matrix with k = 256 is TWO tiles: every one of the 256 workgroups would write a partial slab (64 MB) for the fix-up to
+    // sum -- 453 + 69 us at 200000 x 256 against ~300 for the tiled kernel with split-K slabs of its 3 upper 128-blocks
+    if (tri && ntiles < 8) return 0;
     SkArgs<T> g;
     g.M = m; g.N = n; g.K = k; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles_m = tiles_m; g.tiles_n = tiles_n; g.ktiles = ktiles;

@@ -82,13 +82,34 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
     apply_us = r["times_us"][5]
     ach = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
     pk = PEAK[dtype]
+    # the headline time is taken WITHOUT subroutine timers (they drain the streams at every lap, which also switches the look-ahead off)
+    best_timed = best
+    for it in range(2):
+        ctx.fill_dense(A, m, n, key=(4, 0)); ctx.sync()
+        t0 = time.perf_counter(); r2 = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=False, qrcp_wide=0, qr_tall=1, apply_trans_q=1); ctx.sync(); dt = time.perf_counter() - t0
+        best = min(best, dt)
+    # CPU baseline: the oracle's BQRRP restatement (same precision, same subroutine triple) on a bounded square sample with the SAME block size
+    cpu = None
+    try:
+        import oracle
+        oracle.load(); oracle.set_threads(os.cpu_count() or 1)
+        ms_ = 4 * b if m >= 4 * b else m
+        rng = np.random.default_rng(0)
+        As = rng.standard_normal((ms_, ms_)).astype(np.float32 if dtype == torch.float32 else np.float64)
+        t0 = time.perf_counter(); o = oracle.bqrrp(As, b, 1.0, qrcp_wide=0, qr_tall=1, apply_trans_q=1); tc = time.perf_counter() - t0
+        fl_s = 2.0 * b * ms_ * ms_ + 2.0 * ms_**3 - 2.0 / 3 * ms_**3
+        cpu = {"value": round(fl_s / tc / 1e9, 1), "unit": "GFLOP/s", "cores": oracle.get_threads(), "kind": "port",
+               "sample": f"oracle BQRRP {{luqr, cholqr, gemqrt}} on {ms_} x {ms_} {'fp32' if dtype == torch.float32 else 'fp64'} Gaussian, b = {b}, rank {o['rank']}, {tc:.2f} s"}
+    except Exception as e:  # noqa: BLE001
+        cpu = {"error": repr(e)}
     print(json.dumps({"metric": f"GFLOP/s BQRRP {m} x {n} {'fp32' if dtype == torch.float32 else 'fp64'}, b={b} ({'BASELINE configs[3] on one GPU' if m == 65536 else 'single-GPU cut of BASELINE configs[3]'})",
                       "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 1), "best_of": steps,
                       "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic iid N(0,1), generated on-device",
-                      "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"]},
+                      "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"],
+                                 "ms_with_subroutine_timers": round(best_timed * 1e3, 1), "frac_of_peak_whole_job": round(flops / best / 1e12 / pk, 4)},
                       "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": None,
-                                   "kernel": "compact-WY apply (gemqrt: generic MFMA GEMMs), wall time of the apply phase over all iterations"},
-                      "cpu_baseline": None}))
+                                   "kernel": "compact-WY apply (gemqrt: generic MFMA GEMMs), wall time of the apply phase over all iterations (timed run)"},
+                      "cpu_baseline": cpu}))
 
 
 def rsvd_p2(steps):
@@ -179,6 +200,19 @@ def abrik(steps):
         t0 = time.perf_counter(); rd_ = d.drv_abrik(ctx, A, md, nd, k, eps, iters, key=(2, 0)); ctx.sync(); dt = time.perf_counter() - t0
         bd = dt if bd is None else min(bd, dt)
     fl_dense = 2.0 * md * nd * k * rd_["iters"]
+    # CPU baseline: the oracle's ABRIK restatement (dense operator, geqrf_ungqr panels) on a row sample of the dense operator of the same rank
+    cpu = None
+    try:
+        import oracle
+        oracle.load(); oracle.set_threads(os.cpu_count() or 1)
+        ms_ = 24576
+        As = np.asfortranarray(np.random.default_rng(0).standard_normal((ms_, nd)))
+        t0 = time.perf_counter(); o = oracle.abrik(As, k, eps, iters); tc = time.perf_counter() - t0
+        cpu = {"value": round(tc * 1e3, 1), "unit": "ms (on the sample)", "cores": oracle.get_threads(), "kind": "port",
+               "sample": f"oracle ABRIK (block {k}, {o['iters']} Krylov iterations) on a dense {ms_} x {nd} fp64 Gaussian operator: {tc:.2f} s = "
+                         f"{2.0 * ms_ * nd * k * o['iters'] / tc / 1e9:.0f} GFLOP/s in the operator products (the device line's dense variant: {fl_dense / bd / 1e9:.0f})"}
+    except Exception as e:  # noqa: BLE001
+        cpu = {"error": repr(e)}
     print(json.dumps({"metric": "ms per ABRIK::call, 200000 x 200000 implicit (CSR) operator, block 32, 8 Krylov iterations (BASELINE configs[4] on one GPU)",
                       "value": round(best * 1e3, 2), "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 2), "best_of": steps,
                       "dtype": "f64", "data": "synthetic banded Gaussian CSR operator (10 nonzeros per row) with graded diagonal scalings, built on the host, resident in HBM",
@@ -187,7 +221,7 @@ def abrik(steps):
                                  "dense_200000x20000_same_rank": {"ms": round(bd * 1e3, 1), "iters": rd_["iters"], "TFLOP/s of the operator products": round(fl_dense / bd / 1e12, 1)}},
                       "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                                    "kernel": "csr_spmm_rm_kernel (A * X, 32 columns): algorithmic bytes (nnz b + rows b) 8 + 16 nnz", "launch_ms": round(kms, 4)},
-                      "cpu_baseline": None}))
+                      "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

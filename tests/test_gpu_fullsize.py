@@ -668,10 +668,12 @@ def test_streamk_gemm_f32_entrywise(ctx, m, n, k, ta):
 
 @pytest.mark.parametrize("n,k", [(1024, 32768), (512, 131072), (768, 49152), (2048, 16384)])
 def test_streamk_syrk_f32_upper_tiles(ctx, n, k):
+    """fp32 Gram matrices through whatever route syrk takes BY DEFAULT: the persistent kernel's triangular tile map for contractions up to
+    16384 (one fp32 fma chain per entry is only accurate that far), the split-K kernel with lower-triangle tiles skipped
+    beyond -- the same contract either way: upper triangle to 4 eps sqrt(k), strictly lower triangle untouched."""
     import os
 
-    if k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2":
-        pytest.skip("see test_streamk_gemm_f32_entrywise")
+    single_launch = k <= 16384 or os.environ.get("RLHIP_STREAMK_F32") == "2"
     d = _d()
     rng = np.random.default_rng(n + k + 7)
     A = rng.standard_normal((k, n)).astype(np.float32)
@@ -679,7 +681,7 @@ def test_streamk_syrk_f32_upper_tiles(ctx, n, k):
     Cd = d.cm_from_numpy(C0)
     before = ctx.path_count(1)
     ctx.syrk("U", "T", n, k, 2.0, d.cm_from_numpy(A), k, 0.25, Cd, n)
-    assert ctx.path_count(1) == before + 1
+    assert ctx.path_count(1) == before + (1 if single_launch else 0), "unexpected route for this contraction length"
     got = d.cm_to_numpy(Cd)
     ref = 2.0 * (A.astype(np.float64).T @ A.astype(np.float64)) + 0.25 * C0
     iu = np.triu_indices(n)
