@@ -61,7 +61,7 @@ def median_of(disp, key):
 def main():
     from pmc_workloads import WORKLOADS
 
-    tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "round4"
     names = sys.argv[2:] or list(WORKLOADS)
     out_root = os.path.join(ROOT, "gpurun_out", "pmc")
     os.makedirs(out_root, exist_ok=True)

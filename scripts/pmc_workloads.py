@@ -47,11 +47,19 @@ def gemm_sk_tn():
 
 def gemm_sk_tri():
     d, ctx = _ctx()
+    import torch
+
     m, n = 1048576, 1024
-    A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(3, 0))
+    ldw = m + 32                          # the padded leading dimension CQRRPT gives its scratch matrix (a power-of-two column stride camps on channels)
+    A = torch.empty((n, ldw), dtype=torch.float64, device="cuda")
+    T0 = d.cm_empty(m, 1)
+    for j in range(0, n, 64):             # (fill through a packed block: fill_dense writes ld = rows)
+        blk = d.cm_empty(m, 64); ctx.fill_dense(blk, m, 64, key=(3, j)); ctx.sync()
+        A[j:j + 64, :m] = blk
+    del T0
     G = d.cm_zeros(n, n)
     for _ in range(REPS):
-        ctx.syrk("U", "T", n, m, 1.0, A, m, 0.0, G, n)
+        ctx.syrk("U", "T", n, m, 1.0, A, ldw, 0.0, G, n)
     ctx.sync()
 
 
@@ -171,11 +179,11 @@ WORKLOADS = {
                    8.0 * (200000 * 20000 + 20000 * 256 + 200000 * 256), 2.0 * 200000 * 20000 * 256, "mfma"),
     "gemm_sk_tn": (gemm_sk_tn, "gemm_sk_kernel<double, true>", "B^T = A^T*Q, 20000 x 256 x 200000 fp64 (C2 pass 2)",
                    8.0 * (200000 * 20000 + 20000 * 256 + 200000 * 256), 2.0 * 200000 * 20000 * 256, "mfma"),
-    "gemm_sk_tri": (gemm_sk_tri, "gemm_sk_kernel<double, true>", "Gram matrix A^T A (upper 128-blocks), 1048576 x 1024 fp64 (C3)",
+    "gemm_sk_tri": (gemm_sk_tri, "gemm_sk_kernel<double, true>", "Gram matrix A^T A (upper 128-blocks), 1048576 x 1024 fp64 with CQRRPT's padded leading dimension m + 32 (C3)",
                     8.0 * (1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
-    "trsm_fused": (trsm_fused, "trsm_fused_kernel<double, 8, 16, false>", "X U = B in place, 1048576 x 1024 fp64 (C3 second solve, reference order)",
+    "trsm_fused": (trsm_fused, "trsm_fused_kernel<double, 8, 16, false", "X U = B in place, 1048576 x 1024 fp64 (C3 second solve, reference order)",
                    8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
-    "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 16, true>", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
+    "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 16, true", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
                        8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
     "saso_apply": (saso_apply, "saso_apply_kernel<double", "A_hat = S*A, S 1280 x 1048576 with 4 nonzeros per column, A 1048576 x 1024 fp64 (C3)",
                    8.0 * 1048576 * 1024 + 8.0 * 1280 * 1024, 2.0 * 4 * 1048576 * 1024, "hbm"),

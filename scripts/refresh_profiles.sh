@@ -4,7 +4,7 @@
 # other scripts kept here: stress_matrix_types.py, hqrrp_tall_check.py, trsm_bench.py, saso_time.py, linops_time.py, sk_group_ab.py
 #   qrcp_wide_parts.py + lu_only.py (per-part timing of BQRRP's qrcp_wide step / the LU alone: DESIGN 4.10), ld_ab.py (leading-dimension A/B at C3's shape: DESIGN 4.10)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-round3}
+TAG=${1:-round4}
 export PYTHONPATH=$R
 O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
@@ -15,7 +15,7 @@ timeout 300 python scripts/bench_other.py bqrrp64 --steps 3 < /dev/null > $O/${T
 timeout 300 python scripts/bench_other.py bqrrp_full --steps 2 < /dev/null > $O/${TAG}_c4_bqrrp_f32_65536_line.json 2> $O/c4.err
 timeout 300 python scripts/bench_other.py abrik --steps 2 < /dev/null > $O/${TAG}_c5_abrik_line.json 2> $O/c5.err
 timeout 400 python scripts/bench_other.py rsvd_p2 --steps 2 < /dev/null > $O/${TAG}_c2_p2_planted_line.json 2> $O/c2p2.err
-timeout 300 python bench.py --m 25000 --steps 8 --warmup 2 --no-cpu-baseline < /dev/null > $O/${TAG}_rank_of_8_line.json 2> $O/r8.err
+timeout 300 python bench.py --m 25000 --steps 8 --warmup 3 --no-cpu-baseline < /dev/null > $O/${TAG}_rank_of_8_line.json 2> $O/r8.err
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, command...
     local name=$1; shift
@@ -26,11 +26,14 @@ prof() {   # name, command...
 }
 prof bench python $R/bench.py --no-cpu-baseline
 prof c3_cqrrpt python $R/scripts/bench_other.py cqrrpt --steps 3
-prof rank_of_8 python $R/bench.py --m 25000 --steps 5 --warmup 2 --no-cpu-baseline
+prof rank_of_8 python $R/bench.py --m 25000 --steps 5 --warmup 3 --no-cpu-baseline
 prof c4_bqrrp_f32_65536 python $R/scripts/bq_prof.py 65536 2048 f32
 # counter evidence for every kernel with a roofline claim (three rocprofv3 --pmc passes each; cooperative kernels are skipped by rocprofv3)
 ( cd $R && timeout 1500 python scripts/pmc_all.py $TAG > $O/pmc.log 2>&1; cp gpurun_out/pmc/${TAG}_pmc_*.json $O/ 2>/dev/null )
 # kernel timeline of one step of the 1/8 row shard (start, duration, gap before each kernel)
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --m 25000 --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-python $R/scripts/timeline.py $O/tl 3 > $O/${TAG}_rank_of_8_timeline.txt 2>&1; rm -rf $O/tl
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/bench.py --m 25000 --steps 6 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+python $R/scripts/timeline.py $O/tl 5 > $O/${TAG}_rank_of_8_timeline.txt 2>&1; rm -rf $O/tl
+# the DVFS map behind the clock holders and the look-ahead A/B of BQRRP
+timeout 300 python $R/scripts/dvfs_probe.py > /dev/null 2> $O/${TAG}_dvfs_probe.txt
+for la in 0 1; do RLHIP_BQRRP_LOOKAHEAD=$la timeout 400 python $R/scripts/bqrrp_lookahead_ab.py 65536 2048 f32 2; done > $O/${TAG}_c4_lookahead_ab.txt 2>&1
 for j in $O/${TAG}_*line.json; do echo "$(basename $j): $(cut -c1-240 $j)"; done

@@ -97,6 +97,20 @@ BATTERY = textwrap.dedent("""
     assert sorted(Jh.tolist()) == list(range(1, nn + 1))
     qfull, _, info = ll.dorgqr(np.asfortranarray(Ho[:, :nn].copy()), th)
     assert np.linalg.norm(H0[:, Jh - 1] - qfull @ np.triu(Ho)[:nn]) <= EPS**0.75 * np.linalg.norm(H0)
+    # 9. Cholesky-QR of a tall 256-column block (one-stream route when it is on) and the small-product kernel (256^3, all transpositions)
+    Y0 = rng.standard_normal((20000, 256)) @ (np.eye(256) + 0.01 * rng.standard_normal((256, 256)))
+    Yd = d.cm_from_numpy(Y0)
+    rc, fail = d.drv_stab(ctx, 0, Yd, 20000, 256)
+    Qy = d.cm_to_numpy(Yd)
+    assert rc == 0 and not fail and np.linalg.norm(Qy.T @ Qy - np.eye(256)) <= 1e-12 * 256, "cholqrq"
+    assert np.linalg.norm(Y0 - Qy @ (Qy.T @ Y0)) <= 1e-12 * np.linalg.norm(Y0)
+    for ta in "NT":
+        for tb in "NT":
+            P0, P1 = rng.standard_normal((256, 256)), rng.standard_normal((256, 256))
+            Cd = d.cm_zeros(256, 256)
+            ctx.gemm(ta, tb, 256, 256, 256, 1.0, d.cm_from_numpy(P0), 256, d.cm_from_numpy(P1), 256, 0.0, Cd, 256)
+            ref = (P0 if ta == "N" else P0.T) @ (P1 if tb == "N" else P1.T)
+            assert np.abs(d.cm_to_numpy(Cd) - ref).max() <= 1e-13 * 16 * np.abs(ref).max(), ("small gemm", ta, tb)
     print("BATTERY OK")
 """)
 
@@ -104,7 +118,10 @@ BATTERY = textwrap.dedent("""
 ALTERNATES = [("RLHIP_TRSM_FUSED", "0"), ("RLHIP_TRSM_BLK", "0"), ("RLHIP_STREAMK", "0"), ("RLHIP_STREAMK_F32", "0"), ("RLHIP_STREAMK_F32", "2"),
               ("RLHIP_STREAMK_F32_CHUNK", "0"), ("RLHIP_RECOVER_V", "0"), ("RLHIP_CHOLQR2_SKIP", "0"), ("RLHIP_JACOBI_PERSIST", "0"),
               ("RLHIP_QR_PIPE", "0"), ("RLHIP_QR_BLK", "0"), ("RLHIP_QRCP_TAG", "0"), ("RLHIP_LU_TAG", "0"), ("RLHIP_LU_REG_PANEL", "0"), ("RLHIP_LU_F64_FAST", "0"),
-              ("RLHIP_LU_F32_FAST", "0"), ("RLHIP_HQRRP_TALL_PANEL", "0"), ("RLHIP_GEQRF_PRECOND", "0"), ("RLHIP_TRSM_FUSED_MIN_ROWS", "1000")]
+              ("RLHIP_LU_F32_FAST", "0"), ("RLHIP_HQRRP_TALL_PANEL", "0"), ("RLHIP_GEQRF_PRECOND", "0"), ("RLHIP_TRSM_FUSED_MIN_ROWS", "1000"),
+              # round 4
+              ("RLHIP_GESDD_GRAM", "0"), ("RLHIP_JACOBI_HOLD", "0"), ("RLHIP_JACOBI_QW", "32"), ("RLHIP_CHOLQRQ_FUSED", "0"), ("RLHIP_TRSM_XASM", "0"),
+              ("RLHIP_GEMM_SMALL", "0"), ("RLHIP_GEQRF_SCALE_GUARD", "0")]
 
 
 @pytest.mark.parametrize("knob,value", [("(defaults)", "")] + ALTERNATES)
