@@ -12,6 +12,7 @@
 //
 // HBM-bound: algorithmic bytes = nnz * ncols * sizeof(T) (gather) + rows * ncols * sizeof(T) (store).
 #include "rlhip_internal.h"
+#include <cstdlib>
 #include "../../include/rlhip.h"
 
 namespace rlhip {
@@ -82,11 +83,56 @@ __global__ __launch_bounds__(256) void csr_spmm_rm_kernel(int64_t nrows, int64_t
     }
 }
 
+// Narrow right-hand sides (nc <= 32: ABRIK's Krylov blocks, rl_abrik.hh:311): a wavefront per CSR row would leave half (nc = 32) or three
+// quarters (nc = 16) of its lanes clamped and masked.  Here W = 32 or 16 lanes own a row and a wavefront takes 64 / W rows at once; every
+// lane group walks its own row (the (column, value) pair of an entry is ONE address for the whole group: the memory pipeline broadcasts
+// it), two entries in flight, and every nonzero still pulls one contiguous row segment of the row-major operand.  Same summation order
+// as the wide kernel (entry by entry along the row): bitwise the same products.
+template <typename T, int W>
+__global__ __launch_bounds__(256) void csr_spmm_rm_narrow_kernel(int64_t nrows, int64_t nc, const int64_t* __restrict__ rowptr,
+                                                                 const int64_t* __restrict__ colidx, const T* __restrict__ vals, T alpha,
+                                                                 const T* __restrict__ B, int64_t ldb, T beta, T* __restrict__ C, int64_t ldc) {
+    constexpr int RPW = 64 / W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % W, sr = lane / W;
+    const int64_t j = sub < nc ? sub : nc - 1;          // clamp; masked at the store
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; row0 < nrows; row0 += (int64_t)gridDim.x * 4 * RPW) {
+        const int64_t row = row0 + sr;
+        const bool valid = row < nrows;
+        const int64_t rl = valid ? row : nrows - 1;
+        const int64_t p0 = rowptr[rl], p1 = valid ? rowptr[rl + 1] : p0;
+        T acc = (T)0;
+        int64_t p = p0;
+        for (; p + 1 < p1; p += 2) {
+            const int64_t c0 = colidx[p], c1 = colidx[p + 1];
+            const T v0 = vals[p], v1 = vals[p + 1];
+            const T x0 = B[c0 * ldb + j], x1 = B[c1 * ldb + j];
+            acc += v0 * x0;
+            acc += v1 * x1;
+        }
+        if (p < p1) acc += vals[p] * B[colidx[p] * ldb + j];
+        if (valid && sub < nc) {
+            T* cr = C + row * ldc + sub;
+            *cr = (beta == (T)0) ? alpha * acc : alpha * acc + beta * *cr;
+        }
+    }
+}
+
 template <typename T>
 int csr_spmm_rowmajor(rlhip_ctx* c, int64_t nrows, int64_t nc, const int64_t* rowptr, const int64_t* colidx, const T* vals, T alpha,
                       const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
     if (nrows <= 0 || nc <= 0) return 0;
     const int64_t gx = std::min<int64_t>((nrows + 3) / 4, 256 * 64);
+    static int narrow_on = -1;
+    if (narrow_on < 0) { const char* e = getenv("RLHIP_SPMM_NARROW"); narrow_on = (e && atoi(e) == 0) ? 0 : 1; }
+    if (narrow_on && nc <= 32) {
+        const int rpw = nc <= 16 ? 4 : 2;
+        dim3 grid((unsigned)std::min<int64_t>((nrows + 4 * rpw - 1) / (4 * rpw), 256 * 64), 1);
+        if (nc <= 16) hipLaunchKernelGGL((csr_spmm_rm_narrow_kernel<T, 16>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);
+        else hipLaunchKernelGGL((csr_spmm_rm_narrow_kernel<T, 32>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);
+        RLHIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (nc > 128) {
         dim3 grid((unsigned)gx, (unsigned)((nc + 255) / 256));
         hipLaunchKernelGGL((csr_spmm_rm_kernel<T, 4>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);

@@ -111,6 +111,16 @@ BATTERY = textwrap.dedent("""
             ctx.gemm(ta, tb, 256, 256, 256, 1.0, d.cm_from_numpy(P0), 256, d.cm_from_numpy(P1), 256, 0.0, Cd, 256)
             ref = (P0 if ta == "N" else P0.T) @ (P1 if tb == "N" else P1.T)
             assert np.abs(d.cm_to_numpy(Cd) - ref).max() <= 1e-13 * 16 * np.abs(ref).max(), ("small gemm", ta, tb)
+    # 10. sparse operator products with narrow, medium and wide right-hand sides, both directions
+    import scipy.sparse as sp
+    Ssp = sp.random(3000, 1700, 0.01, random_state=np.random.default_rng(3), format="csr", data_rvs=np.random.default_rng(4).standard_normal).tocsr()
+    op = d.CsrOperator.from_scipy(Ssp)
+    for nb_ in (7, 16, 32, 100, 200):
+        X = rng.standard_normal((1700, nb_)); Z = rng.standard_normal((3000, nb_))
+        Y = d.cm_to_numpy(d.linop_apply(ctx, op, "L", "N", d.cm_from_numpy(X), 3000, nb_, 1700))
+        assert np.abs(Y - Ssp @ X).max() <= 1e-13 * np.abs(Ssp @ X).max() * 10, ("spmm", nb_)
+        Yt = d.cm_to_numpy(d.linop_apply(ctx, op, "L", "T", d.cm_from_numpy(Z), 1700, nb_, 3000))
+        assert np.abs(Yt - Ssp.T @ Z).max() <= 1e-13 * np.abs(Ssp.T @ Z).max() * 10, ("spmm^T", nb_)
     print("BATTERY OK")
 """)
 
@@ -121,7 +131,7 @@ ALTERNATES = [("RLHIP_TRSM_FUSED", "0"), ("RLHIP_TRSM_BLK", "0"), ("RLHIP_STREAM
               ("RLHIP_LU_F32_FAST", "0"), ("RLHIP_HQRRP_TALL_PANEL", "0"), ("RLHIP_GEQRF_PRECOND", "0"), ("RLHIP_TRSM_FUSED_MIN_ROWS", "1000"),
               # round 4
               ("RLHIP_GESDD_GRAM", "0"), ("RLHIP_JACOBI_HOLD", "0"), ("RLHIP_JACOBI_QW", "32"), ("RLHIP_CHOLQRQ_FUSED", "0"), ("RLHIP_TRSM_XASM", "0"),
-              ("RLHIP_GEMM_SMALL", "0"), ("RLHIP_GEQRF_SCALE_GUARD", "0")]
+              ("RLHIP_GEMM_SMALL", "0"), ("RLHIP_GEQRF_SCALE_GUARD", "0"), ("RLHIP_SPMM_NARROW", "0")]
 
 
 @pytest.mark.parametrize("knob,value", [("(defaults)", "")] + ALTERNATES)
