@@ -118,6 +118,61 @@ __global__ __launch_bounds__(256) void csr_spmm_rm_narrow_kernel(int64_t nrows, 
     }
 }
 
+// The same product for a COLUMN-major C (the layout every caller above the C entry uses): a workgroup takes 64 consecutive rows, its four
+// wavefronts walk them 64 / W at a time exactly as above, and the 64 x nc block of results crosses LDS once so that every column leaves
+// as one 512-byte run -- the separate transpose pass of C (a read and a write of the whole block) is gone.  Same sums, same order.
+template <typename T, int W>
+__global__ __launch_bounds__(256) void csr_spmm_cmout_narrow_kernel(int64_t nrows, int64_t nc, const int64_t* __restrict__ rowptr,
+                                                                    const int64_t* __restrict__ colidx, const T* __restrict__ vals, T alpha,
+                                                                    const T* __restrict__ B, int64_t ldb, T beta, T* __restrict__ C, int64_t ldc) {
+    constexpr int RPW = 64 / W, RB = 64;
+    __shared__ T tile[W][RB + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % W, sr = lane / W;
+    const int64_t j = sub < nc ? sub : nc - 1;
+    for (int64_t blk = blockIdx.x; blk * RB < nrows; blk += gridDim.x) {
+        const int64_t r0 = blk * RB;
+#pragma unroll 2
+        for (int pass = 0; pass < RB / (4 * RPW); ++pass) {
+            const int rl = (pass * 4 + wave) * RPW + sr;
+            const int64_t row = r0 + rl;
+            const bool valid = row < nrows;
+            const int64_t rr = valid ? row : nrows - 1;
+            const int64_t p0 = rowptr[rr], p1 = valid ? rowptr[rr + 1] : p0;
+            T acc = (T)0;
+            int64_t p = p0;
+            for (; p + 3 < p1; p += 4) {                 // four entries in flight: the chain is index -> operand row, twice the depth of the kernel above
+                const int64_t c0 = colidx[p], c1 = colidx[p + 1], c2 = colidx[p + 2], c3 = colidx[p + 3];
+                const T v0 = vals[p], v1 = vals[p + 1], v2 = vals[p + 2], v3 = vals[p + 3];
+                const T x0 = B[c0 * ldb + j], x1 = B[c1 * ldb + j], x2 = B[c2 * ldb + j], x3 = B[c3 * ldb + j];
+                acc += v0 * x0;
+                acc += v1 * x1;
+                acc += v2 * x2;
+                acc += v3 * x3;
+            }
+            for (; p + 1 < p1; p += 2) {
+                const int64_t c0 = colidx[p], c1 = colidx[p + 1];
+                const T v0 = vals[p], v1 = vals[p + 1];
+                const T x0 = B[c0 * ldb + j], x1 = B[c1 * ldb + j];
+                acc += v0 * x0;
+                acc += v1 * x1;
+            }
+            if (p < p1) acc += vals[p] * B[colidx[p] * ldb + j];
+            tile[sub][rl] = acc;
+        }
+        __syncthreads();
+        const int rl = threadIdx.x & 63;
+        if (r0 + rl < nrows) {
+            for (int col = threadIdx.x >> 6; col < nc; col += 4) {
+                T* cp = C + (r0 + rl) + (int64_t)col * ldc;
+                const T a = alpha * tile[col][rl];
+                *cp = (beta == (T)0) ? a : a + beta * *cp;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 int csr_spmm_rowmajor(rlhip_ctx* c, int64_t nrows, int64_t nc, const int64_t* rowptr, const int64_t* colidx, const T* vals, T alpha,
                       const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
@@ -154,6 +209,26 @@ int csr_spmm(rlhip_ctx* c, int layout_rowmajor, int64_t nrows, int64_t k, int64_
     if (nrows <= 0 || nc <= 0) return 0;
     if (layout_rowmajor) return csr_spmm_rowmajor<T>(c, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);
     const size_t mark = rlhip_ws_mark(c);
+    static int cmout_on = -1;
+    if (cmout_on < 0) {
+        const char* e = getenv("RLHIP_SPMM_NARROW"); const char* e2 = getenv("RLHIP_SPMM_CMOUT");
+        cmout_on = ((e && atoi(e) == 0) || (e2 && atoi(e2) == 0)) ? 0 : 1;
+    }
+    if (cmout_on && nc <= 32) {
+        T* Bt = ws_alloc<T>(c, (size_t)std::max<int64_t>(k, 1) * nc);
+        if (!Bt) { rlhip_ws_release(c, mark); return -3; }
+        int rc = 0;
+        if (k > 0) rc = transpose<T>(c, k, nc, B, ldb, Bt, nc, 0);
+        if (!rc) {
+            dim3 grid((unsigned)std::min<int64_t>((nrows + 63) / 64, 256 * 64), 1);
+            if (nc <= 16) hipLaunchKernelGGL((csr_spmm_cmout_narrow_kernel<T, 16>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, Bt, nc, beta, C, ldc);
+            else hipLaunchKernelGGL((csr_spmm_cmout_narrow_kernel<T, 32>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, Bt, nc, beta, C, ldc);
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) rc = RLHIP_ERR_HIP(le);
+        }
+        rlhip_ws_release(c, mark);
+        return rc;
+    }
     T* Bt = ws_alloc<T>(c, (size_t)std::max<int64_t>(k, 1) * nc);
     T* Ct = ws_alloc<T>(c, (size_t)nrows * nc);
     if (!Bt || !Ct) { rlhip_ws_release(c, mark); return -3; }

@@ -220,7 +220,7 @@ def abrik(steps):
                                  "times_us": dict(zip(d.ABRIK_TIMES, r.get("times_us", []))),
                                  "dense_200000x20000_same_rank": {"ms": round(bd * 1e3, 1), "iters": rd_["iters"], "TFLOP/s of the operator products": round(fl_dense / bd / 1e12, 1)}},
                       "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
-                                   "kernel": "csr_spmm_rm_kernel (A * X, 32 columns): algorithmic bytes (nnz b + rows b) 8 + 16 nnz", "launch_ms": round(kms, 4)},
+                                   "kernel": "rlhip_linop_apply on the CSR operator (A * X, 32 column-major columns) = transpose of X + csr_spmm_cmout_narrow_kernel: algorithmic bytes (nnz b + rows b) 8 + 16 nnz", "launch_ms": round(kms, 4)},
                       "cpu_baseline": cpu}))
 
 

@@ -131,7 +131,7 @@ ALTERNATES = [("RLHIP_TRSM_FUSED", "0"), ("RLHIP_TRSM_BLK", "0"), ("RLHIP_STREAM
               ("RLHIP_LU_F32_FAST", "0"), ("RLHIP_HQRRP_TALL_PANEL", "0"), ("RLHIP_GEQRF_PRECOND", "0"), ("RLHIP_TRSM_FUSED_MIN_ROWS", "1000"),
               # round 4
               ("RLHIP_GESDD_GRAM", "0"), ("RLHIP_JACOBI_HOLD", "0"), ("RLHIP_JACOBI_QW", "32"), ("RLHIP_CHOLQRQ_FUSED", "0"), ("RLHIP_TRSM_XASM", "0"),
-              ("RLHIP_GEMM_SMALL", "0"), ("RLHIP_GEQRF_SCALE_GUARD", "0"), ("RLHIP_SPMM_NARROW", "0")]
+              ("RLHIP_GEMM_SMALL", "0"), ("RLHIP_GEQRF_SCALE_GUARD", "0"), ("RLHIP_SPMM_NARROW", "0"), ("RLHIP_SPMM_CMOUT", "0")]
 
 
 @pytest.mark.parametrize("knob,value", [("(defaults)", "")] + ALTERNATES)

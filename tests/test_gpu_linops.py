@@ -53,7 +53,7 @@ def _verify_qr(A, Q, R):
 
 
 # ------------------------------------------------------------------------------------------------ kernels
-@pytest.mark.parametrize("nc", [1, 7, 63, 64, 65, 130, 257, 600])
+@pytest.mark.parametrize("nc", [1, 7, 16, 17, 32, 63, 64, 65, 130, 257, 600])
 @pytest.mark.parametrize("layout", ["C", "R"])
 def test_csr_spmm_matches_scipy(ctx, nc, layout):
     d = _d()
