@@ -91,7 +91,9 @@ __device__ __forceinline__ T wave_sum_fast(T x) {
     return (T)r;
 }
 
-template <typename T>
+// (USE_LDS / V_IN_LDS are template parameters for the reason given at qr_pipe_kernel: a run-time choice between an LDS and a global pointer
+//  is a generic pointer, and every access through it a flat_ instruction)
+template <typename T, bool USE_LDS, bool V_IN_LDS>
 __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t G = gridDim.x, me = blockIdx.x;
@@ -105,13 +107,16 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
     T* l_vn1 = reinterpret_cast<T*>(qr_smem);            // partial norms of the owned positions (local to the owner)
     T* l_vn2 = l_vn1 + cpw;
     T* l_v = l_vn2 + cpw;                                // the step's finished pivot column (m)
-    T* lds_cols = l_v + (g.v_in_lds ? m : 0);
+    T* lds_cols = l_v + (V_IN_LDS ? m : 0);
     __shared__ T s_cval[256];
     __shared__ int64_t s_cpos[256];
     __shared__ int s_cw[256];
-    // column position j -> storage (generic pointer: LDS slot j/G of the owner, or the matrix itself)
-    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + (j / G) * m) : (g.A + j * g.lda); };
-    if (g.use_lds) {
+    // column position j -> storage (LDS slot j/G of the owner, or the matrix itself)
+    auto colptr = [&](int64_t j) {
+        if constexpr (USE_LDS) return lds_cols + (j / G) * m;
+        else return g.A + j * g.lda;
+    };
+    if constexpr (USE_LDS) {
         for (int64_t j = me; j < n; j += G) {
             T* dst = lds_cols + (j / G) * m;
             const T* src = g.A + j * g.lda;
@@ -212,11 +217,15 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
         const T tauk = g.cand_tau[par * G + wstar];
         const T* vcol = g.slot + ((int64_t)par * G + wstar) * m;    // finished column: R above k, beta at k, v below
         // ---- C. install the moved columns, swap bookkeeping
-        if (g.v_in_lds) {
+        if constexpr (V_IN_LDS) {
             for (int64_t i = tid; i < m; i += 256) l_v[i] = vcol[i];
             __syncthreads();
         }
-        const T* vv = g.v_in_lds ? l_v : vcol;       // tall inputs: straight from the published slot (L2)
+        auto vv_of = [&]() {                          // tall inputs: straight from the published slot (L2)
+            if constexpr (V_IN_LDS) return (const T*)l_v;
+            else return vcol;
+        };
+        const auto vv = vv_of();
         if (me == own_k) {
             T* col = colptr(k);
             for (int64_t i = tid; i < m; i += 256) col[i] = vv[i];
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
         }
         __syncthreads();
     }
-    if (g.use_lds) {
+    if constexpr (USE_LDS) {
         __syncthreads();
         for (int64_t j = me; j < n; j += G) {
             const T* src = lds_cols + (j / G) * m;
@@ -721,7 +730,10 @@ struct QrPipeArgs {
     int chunk;                // columns are dealt to the workgroups in chunks of this many consecutive columns (block-cyclic)
 };
 
-template <typename T>
+// USE_LDS / V_IN_LDS (= USE_LDS / V_IN_LDS) are template parameters, not run-time flags: `flag ? lds_pointer : global_pointer` is a GENERIC
+// pointer to hipcc, every access through it a flat_ instruction (218 of them in this kernel before) that is slower on LDS data and, because a flat
+// access may land on either side, is waited for with vmcnt(0) AND lgkmcnt(0).
+template <typename T, bool USE_LDS, bool V_IN_LDS>
 __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t G = gridDim.x, me = blockIdx.x;
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
     const int64_t kmax = m < n ? m : n;
     extern __shared__ __attribute__((aligned(16))) unsigned char qp_smem[];
     T* l_v = reinterpret_cast<T*>(qp_smem);              // current reflector (m), when it fits
-    T* lds_cols = l_v + (g.v_in_lds ? m : 0);
+    T* lds_cols = l_v + (V_IN_LDS ? m : 0);
     __shared__ T s_val[4];
     __shared__ T s_tau;
     // Block-cyclic column ownership: chunks of CH consecutive columns go round the workgroups.  Inside a chunk consecutive steps
@@ -740,8 +752,11 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
     auto owner = [&](int64_t j) -> int64_t { return (j / CH) % G; };
     auto slot = [&](int64_t j) -> int64_t { return (j / (CH * G)) * CH + (j % CH); };
     auto col_of = [&](int64_t c) -> int64_t { return ((c / CH) * G + me) * CH + (c % CH); };   // increasing in c
-    auto colptr = [&](int64_t j) -> T* { return g.use_lds ? (lds_cols + slot(j) * m) : (g.A + j * g.lda); };
-    if (g.use_lds) {
+    auto colptr = [&](int64_t j) {
+        if constexpr (USE_LDS) return lds_cols + slot(j) * m;
+        else return g.A + j * g.lda;
+    };
+    if constexpr (USE_LDS) {
         for (int64_t c = 0; c < cpw; ++c) {
             const int64_t j = col_of(c);
             if (j >= n) break;
@@ -751,6 +766,10 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
         }
         __syncthreads();
     }
+    auto vread = [](const T* lv, const T* gv, int64_t i) -> T {
+        if constexpr (V_IN_LDS) return lv[i];
+        else return gv[i];
+    };
     // compute H_k from (already updated) column k, publish it, leave v in l_v and tau in s_tau
     auto make_reflector = [&](int64_t k) {
         T* col = colptr(k);
@@ -774,8 +793,8 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
         for (int64_t i = tid; i < m; i += 256) {
             T v = col[i];
             if (i == k) v = beta; else if (i > k) v *= scale;
-            if (g.v_in_lds) l_v[i] = v;
-            if (g.use_lds) col[i] = v;
+            if constexpr (V_IN_LDS) l_v[i] = v;
+            if constexpr (USE_LDS) col[i] = v;
             pub_store(gcol + i, v);                       // final content of column k of A (R above, beta, v below)
         }
         if (tid == 0) { pub_store(g.tau + k, tk); s_tau = tk; }
@@ -784,32 +803,32 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
         if (tid == 0) {
             __hip_atomic_store(g.flag + k, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             // tall matrices read v back from its column of A with ordinary loads: drop this CU's stale L1 lines of that column
-            if (!g.v_in_lds) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!V_IN_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        if (!g.v_in_lds) __syncthreads();
+        if (!V_IN_LDS) __syncthreads();
     };
     // apply H (v in l_v, tau = tk, pivot row k) to column j
     auto apply_one = [&](int64_t k, T tk, T* col) {       // one wave per column
         const T* gv = g.A + k * g.lda;                    // (tall matrices: v straight from its published column)
         T w = 0;
 #pragma unroll 4
-        for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i])) * col[i];
+        for (int64_t i = k + lane; i < m; i += 64) w += ((i == k) ? T(1) : vread(l_v, gv, i)) * col[i];
         w = wave_sum(w) * tk;
 #pragma unroll 4
-        for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i]));
+        for (int64_t i = k + lane; i < m; i += 64) col[i] -= w * ((i == k) ? T(1) : vread(l_v, gv, i));
     };
     auto apply_wg = [&](int64_t k, T tk, T* col) {        // whole workgroup on one (long) column
         const T* gv = g.A + k * g.lda;
         T w = 0;
 #pragma unroll 8
-        for (int64_t i = k + tid; i < m; i += 256) w += ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i])) * col[i];
+        for (int64_t i = k + tid; i < m; i += 256) w += ((i == k) ? T(1) : vread(l_v, gv, i)) * col[i];
         w = wave_sum(w);
         __syncthreads();
         if (lane == 0) s_val[wid] = w;
         __syncthreads();
         w = (s_val[0] + s_val[1] + s_val[2] + s_val[3]) * tk;
 #pragma unroll 8
-        for (int64_t i = k + tid; i < m; i += 256) col[i] -= w * ((i == k) ? T(1) : (g.v_in_lds ? l_v[i] : gv[i]));
+        for (int64_t i = k + tid; i < m; i += 256) col[i] -= w * ((i == k) ? T(1) : vread(l_v, gv, i));
     };
     bool have_next = false;                               // reflector k already made by the look-ahead of step k-1
     for (int64_t k = 0; k < kmax; ++k) {
@@ -825,7 +844,7 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
             }
             __syncthreads();
             const T* gcol = g.A + k * g.lda;
-            if (g.v_in_lds)
+            if constexpr (V_IN_LDS)
                 for (int64_t i = k + tid; i < m; i += 256) l_v[i] = gcol[i];
             if (tid == 0) s_tau = g.tau[k];
             __syncthreads();
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
         }
     }
     // columns that never became a pivot (n > m) or global-path bookkeeping: write back what lives only in LDS
-    if (g.use_lds) {
+    if constexpr (USE_LDS) {
         __syncthreads();
         for (int64_t c = 0; c < cpw; ++c) {
             const int64_t j = col_of(c);
@@ -906,6 +925,19 @@ int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev)
 template <typename T>
 static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev, int64_t max_steps = -1,
                    int hq_formula = 0);
+
+// dynamic-LDS limit (150 KiB) of one instantiation of the cooperative QR kernels, raised once per (device, kernel address)
+static hipError_t qr_kernel_lds_limit(rlhip_ctx* c, const void* kern) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, const void*>> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    const std::pair<int, const void*> key(c->device, kern);
+    for (auto const& e : seen) if (e == key) return hipSuccess;
+    hipError_t le = hipSetDevice(c->device);
+    if (le == hipSuccess) le = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (le == hipSuccess) seen.push_back(key);
+    return le;
+}
 
 template <typename T>
 int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
@@ -1154,8 +1186,6 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         if ((size_t)(cpw2 + 1) * m * sizeof(T) <= 140 * 1024) { G = G2; lds_bytes = (size_t)cpw2 * m * sizeof(T); use_lds = 1; }
         else lds_bytes = 0;
     }
-    RLHIP_FUNC_LDS(c, qrcp_kernel<T>, 150 * 1024);
-    RLHIP_FUNC_LDS(c, qr_pipe_kernel<T>, 150 * 1024);
     static int pipe_on = -1;
     if (pipe_on < 0) { const char* e = getenv("RLHIP_QR_PIPE"); pipe_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (!pivot && max_steps < 0 && pipe_on) {
@@ -1185,7 +1215,11 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         // or with busy CUs cannot strand part of the grid.
         {
             void* kargs[] = {(void*)&pa};
-            RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qr_pipe_kernel<T>, dim3((unsigned)Gp), dim3(256), kargs, (unsigned)dyn2, c->stream));
+            const void* kern = use_lds ? (const void*)qr_pipe_kernel<T, true, true>            // (columns in LDS implies the reflector in LDS)
+                                       : (pa.v_in_lds ? (const void*)qr_pipe_kernel<T, false, true> : (const void*)qr_pipe_kernel<T, false, false>);
+            hipError_t le = qr_kernel_lds_limit(c, kern);
+            if (le == hipSuccess) le = hipLaunchCooperativeKernel(kern, dim3((unsigned)Gp), dim3(256), kargs, (unsigned)dyn2, c->stream);
+            if (le != hipSuccess) { rlhip_ws_release(c, mark2); return RLHIP_ERR_HIP(le); }
         }
         rlhip_ws_release(c, mark2);
         return 0;
@@ -1269,7 +1303,11 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     if (dyn > 150 * 1024) { rlhip_ws_release(c, mark); return -2; }   // only the per-column norms left: n / G > ~9000 columns per workgroup
     {   // grid barrier inside: cooperative launch (see qr_pipe_kernel above)
         void* kargs[] = {(void*)&g};
-        RLHIP_CHECK(hipLaunchCooperativeKernel((const void*)qrcp_kernel<T>, dim3((unsigned)G), dim3(256), kargs, (unsigned)dyn, c->stream));
+        const void* kern = use_lds ? (const void*)qrcp_kernel<T, true, true>
+                                   : (g.v_in_lds ? (const void*)qrcp_kernel<T, false, true> : (const void*)qrcp_kernel<T, false, false>);
+        hipError_t le = qr_kernel_lds_limit(c, kern);
+        if (le == hipSuccess) le = hipLaunchCooperativeKernel(kern, dim3((unsigned)G), dim3(256), kargs, (unsigned)dyn, c->stream);
+        if (le != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(le); }
     }
     rlhip_ws_release(c, mark);
     return 0;
