@@ -110,7 +110,10 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     sU11[i * 33 + j] = (i <= j) ? col[i] : T(0);
-                    if (!bad && i < jb && j < jb && i <= j) A[(j0 + i) + (int64_t)(j0 + j) * lda] = col[i];
+                    // on a non-positive pivot (step bad - 1) the rows above it are final and go back, and the pivot entry holds its updated,
+                    // non-positive value -- what dpotf2 leaves behind (Chol_check.cc reads the leading block of such a factor)
+                    const bool keep = !bad || i < bad - 1 || (i == bad - 1 && j == bad - 1);
+                    if (keep && i < jb && j < jb && i <= j) A[(j0 + i) + (int64_t)(j0 + j) * lda] = col[i];
                 }
             }
         }

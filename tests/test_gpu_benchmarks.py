@@ -274,3 +274,36 @@ def test_flop_count_mains(capsys):
     assert flop_count.main(["potrf", "300", "200", "1"]) == 0
     with pytest.raises(RuntimeError):
         flop_count.main(["gesvd", "10", "10", "1"])
+
+
+def test_general_and_side_mains(tmp_path):
+    """benchmarks/general.py = benchmark/bench_general/{Chol_check, Gemm_vs_ormqr, basic_blas_speed, convert_time}.cc and
+    bench_BQRRP/{HQRRP_sanity_check, find_test_mat_spectrum}.cc at toy sizes: the checks they print hold and the files have the reference's layout."""
+    from benchmarks import general
+
+    out = general.chol_check(m=300, k=120, seeds=2)
+    for rc, nrm in out:
+        assert rc > 120                                    # the indefinite trailing part stops potrf past the Gram block ...
+        assert nrm < 1e-10                                 # ... whose factor is already final: R'R = A[:k, :k]
+    rows = general.gemm_vs_ormqr(sizes=((1024, 32), (2048, 64)), runs=3)
+    assert len(rows) == 2 and all(r[2] > 0 and r[3] > 0 for r in rows)
+    p = general.basic_blas_speed(256, 512, 2, str(tmp_path))
+    lines = open(p).read().strip().split("\n")
+    assert len(lines) == 4 and lines[0].startswith("256,") and lines[-1].startswith("512,") and all(len(ln.split(",")) == 5 for ln in lines)
+    raw = tmp_path / "embedding_combined.dat"
+    raw.write_text("1000000 2500000 10\n3 4 5\n")
+    general.convert_time(str(raw))
+    assert raw.read_text() == "\n1.000000  2.500000  0.000010  \n0.000003  0.000004  0.000005  "
+    p = general.hqrrp_sanity_check([str(tmp_path), "2", "256", "512"])
+    lines = open(p).read().split("\n")
+    assert lines[0].startswith("Description: Results from the sanity check") and lines[5].startswith("Input row sizes:256, 512, ")
+    data = [ln for ln in lines[7:] if ln.strip()]
+    assert len(data) == 4 and all(len(ln.split(",")) == 3 and int(ln.split(",")[0]) > 0 for ln in data)
+    paths = general.find_test_mat_spectrum([str(tmp_path), "300", "200"])
+    assert [pp.split("/")[-1] for pp in paths] == [f"_{t}_spectrum_num_info_lines_4.txt" for t in ("poly", "stair", "spike", "kahan")]
+    poly = open(paths[0]).read().split("\n")
+    assert poly[2].startswith("Input type:0") and poly[3] == "Input size:300 by 200"
+    sv = np.array([float(x) for x in poly[4].split(",") if x.strip()])
+    assert sv.size == 200 and abs(sv[0] - 1.0) < 1e-6 and abs(sv[-1] / 1e-10 - 1.0) < 0.05 and np.all(np.diff(sv) <= 1e-15)      # (six printed digits)
+    stair = np.array([float(x) for x in open(paths[1]).read().split("\n")[4].split(",") if x.strip()])
+    assert stair.size == 200 and abs(stair[0] / stair[-1] - 1e10) / 1e10 < 1e-3

@@ -164,6 +164,27 @@ def test_potrf_reports_first_bad_minor(ctx, orc):
     assert ctx.potrf(600, d.cm_from_numpy(Gm), 600) == 301
 
 
+@pytest.mark.parametrize("n,bad", [(300, 125), (300, 97), (1000, 505), (40, 1)])
+def test_potrf_failure_leaves_the_leading_factor(ctx, n, bad):
+    """On a non-positive pivot the rows of U above it are final, as dpotrf leaves them (benchmark/bench_general/Chol_check.cc factors an
+    indefinite matrix on purpose and reads the leading block of R): every row above the failing pivot's 32-row panel row agrees with the
+    Cholesky factor of the leading minor -- through the columns that panel reaches -- and so do the rows of its own diagonal block."""
+    d = _dev()
+    rng = np.random.default_rng(n + bad)
+    X = rng.standard_normal((2 * n, n))
+    G = X.T @ X
+    G[bad - 1, bad - 1] = -1.0                                               # minors 1 .. bad - 1 positive definite, minor `bad` not
+    Gd = d.cm_from_numpy(G)
+    assert ctx.potrf(n, Gd, n) == bad
+    got = np.triu(d.cm_to_numpy(Gd))
+    k = bad - 1
+    if k:
+        U = np.linalg.cholesky(G[:k, :k]).T
+        assert np.abs(got[:k, :k] - U).max() <= 1e-12 * np.abs(U).max()
+        assert np.abs(got[:k, :k].T @ got[:k, :k] - G[:k, :k]).max() <= 1e-12 * np.abs(G).max()
+    assert got[k, k] <= 0.0                                                  # the pivot entry holds its updated, non-positive value
+
+
 @pytest.mark.parametrize("m,n", [(1000, 256), (333, 100), (2000, 600), (70, 5), (1, 1), (513, 257)])
 def test_trsm_right_upper_matches_lapack(ctx, orc, m, n):
     import ctypes as C
