@@ -51,8 +51,16 @@ public:
         check(rlhip_create_side(parent.ctx_, &ctx_), "rlhip_create_side");
         owned_ = true;
     }
+    // the parent's cached side context, borrowed (created on first use, lives as long as the parent): for callers inside a timed path
+    struct CachedSide {};
+    Queue(Queue& parent, CachedSide) {
+        check(rlhip_side_of(parent.ctx_, &ctx_), "rlhip_side_of");
+        owned_ = false;
+    }
     // what this queue enqueues from now on starts after what `other` has enqueued so far (device-side ordering, the host does not wait)
     void wait_for(Queue& other) { check(rlhip_order_after(ctx_, other.ctx_), "rlhip_order_after"); }
+    // columns per workgroup of the tag-exchange pivoted QR on this queue (0: default); see rlhip_set_qrcp_cols
+    void set_qrcp_cols(int cols) { check(rlhip_set_qrcp_cols(ctx_, cols), "rlhip_set_qrcp_cols"); }
     Queue(Queue const&) = delete;
     Queue& operator=(Queue const&) = delete;
     ~Queue() { if (owned_ && ctx_) rlhip_destroy(ctx_); }
@@ -214,6 +222,22 @@ inline void trsm_gather(Diag d, int64_t m, int64_t n, double alpha, double const
 inline void trsm_gather(Diag d, int64_t m, int64_t n, float alpha, float const* A, int64_t lda, float const* Bsrc, int64_t ldsrc,
                         int64_t const* jpvt, float* B, int64_t ldb, Queue& q = blas::default_queue()) {
     check(rlhip_trsm_gather_f32(q.ctx(), (char)d, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb), "trsm_gather");
+}
+// (extension) columns [col0, col1) of that solve, B[:, 0 : col0) holding the leading columns already; jpvt maps into nsrc source columns.
+// false: outside the fused kernel's domain, nothing was written -- the caller runs trsm_gather on the whole matrix.  See rlhip_trsm_gather_range_f64.
+inline bool trsm_gather_range(Diag d, int64_t m, int64_t nsrc, double alpha, double const* A, int64_t lda, double const* Bsrc, int64_t ldsrc,
+                              int64_t const* jpvt, double* B, int64_t ldb, int64_t col0, int64_t col1, Queue& q = blas::default_queue()) {
+    const int rc = rlhip_trsm_gather_range_f64(q.ctx(), (char)d, m, nsrc, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb, col0, col1);
+    if (rc == 1) return false;
+    check(rc, "trsm_gather_range");
+    return true;
+}
+inline bool trsm_gather_range(Diag d, int64_t m, int64_t nsrc, float alpha, float const* A, int64_t lda, float const* Bsrc, int64_t ldsrc,
+                              int64_t const* jpvt, float* B, int64_t ldb, int64_t col0, int64_t col1, Queue& q = blas::default_queue()) {
+    const int rc = rlhip_trsm_gather_range_f32(q.ctx(), (char)d, m, nsrc, alpha, A, lda, Bsrc, ldsrc, jpvt, B, ldb, col0, col1);
+    if (rc == 1) return false;
+    check(rc, "trsm_gather_range");
+    return true;
 }
 inline void trmm(Layout, Side s, Uplo u, Op t, Diag d, int64_t m, int64_t n, double alpha, double const* A, int64_t lda,
                  double* B, int64_t ldb, Queue& q = blas::default_queue()) {

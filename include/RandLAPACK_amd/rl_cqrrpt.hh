@@ -49,6 +49,8 @@ public:
         rank = 0;
         const char* fe = std::getenv("RLHIP_CQRRPT_FOLD_PIVOTING");
         fold_pivoting = !(fe && std::atoi(fe) == 0);
+        const char* se = std::getenv("RLHIP_CQRRPT_SPLIT_QRCP");
+        split_qrcp = !(se && std::atoi(se) == 0);
     }
 
     /// A (m x n, lda, DEVICE) is overwritten by Q (first `rank` columns orthonormal), R (n x n, ldr, DEVICE) receives
@@ -70,6 +72,9 @@ public:
         auto t_total0 = stamp();
 
         int64_t k = n;
+        T* W_early = nullptr;            // split QRCP: the scratch copy of A_pre, allocated before the factorization of the sketch ...
+        bool half_solved = false;        // ... whose left half is solved beside the second half of that factorization
+        auto ldw_of = [](int64_t rows) { return (rows % 512 == 0) ? rows + 32 : rows; };
         const int64_t d = (int64_t)(d_factor * n);                                                          // :198 (truncation)
         const T eps_initial_rank_estimation = 2 * std::pow(std::numeric_limits<T>::epsilon(), (T)0.95);   // :200
         int64_t new_rank;
@@ -118,7 +123,48 @@ public:
             bq.apply_trans_q = BQRRPSubroutines::ApplyTransQ::ormqr;
             bq.call(d, n, A_hat, d, (T)1.0, tau, J, state);
         } else {
-            lapack::geqp3(d, n, A_hat, d, J, tau, q);
+            // Split QRCP (not in the reference; same factorization): after the first n / 2 steps of geqp3 the leading n / 2 rows of R_sk and
+            // the leading n / 2 pivots are final, and the left half of A_pre = (A P) R_sk^-1 depends on nothing else -- so the first solve
+            // starts on it while the second half of the sketch (geqp3 of the trailing block: a latency-bound kernel that keeps a quarter
+            // of the CUs waiting on its exchanges) is factored on a side stream, packed into fewer workgroups.  C3: DESIGN 4.13.
+            // Only where it pays and cannot change a result that tests pin bit for bit: one rank, untimed, tall inputs, geqp3.
+            const int64_t h = n / 2;
+            bool split = split_qrcp && fold_pivoting && !timing && q.world() == 1 && m >= ((int64_t)1 << 18) && n >= 512 && h % 256 == 0 && d > h;
+            if (split) {
+                W_early = ws.try_alloc<T>(ldw_of(m) * n);
+                split = W_early != nullptr;
+            }
+            if (!split) lapack::geqp3(d, n, A_hat, d, J, tau, q);
+            else {
+                // (allocated BEFORE the solve below is enqueued: that call releases its own scratch -- the packed triangle its kernel is still
+                //  reading -- when it returns, and the arena is ordered by the main stream only; the side stream writes J2 beside that kernel)
+                int64_t* J2 = ws.alloc<int64_t>(n - h);
+                lapack::geqp3_steps(d, n, h, A_hat, d, J, tau, q);
+                std::vector<T> dg(h);
+                lapack::get_diag(h, A_hat, d, dg.data(), q);
+                bool lead_ok = dg[0] != (T)0;
+                for (int64_t i = 0; lead_ok && i < h; ++i)
+                    lead_ok = dg[i] != (T)0 && std::abs(dg[i]) / std::abs(dg[0]) >= eps_initial_rank_estimation;
+                if (lead_ok) {
+                    lapack::lacpy(MatrixType::Upper, h, h, A_hat, d, R, ldr, q);
+                    half_solved = blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W_early, ldw_of(m), 0, h, q);
+                }
+                {
+                    blas::Queue side(q, blas::Queue::CachedSide{});
+                    // the second half is packed into few, full workgroups (up to 16 columns each, ~100 KiB of LDS): it leaves the other CUs to
+                    // the solve and loses little itself (768 x 512: 3.5 ms with 4 columns per workgroup, 4.9 with 16; C3: 71.3 / 70.3 / 69.6 ms
+                    // with 4 / 8 / 16).  RLHIP_CQRRPT_SPLIT_COLS overrides.
+                    int64_t cols = (100 * 1024) / ((d - h) * (int64_t)sizeof(T));
+                    cols = cols < 4 ? 4 : (cols > 16 ? 16 : cols);
+                    const char* ce = std::getenv("RLHIP_CQRRPT_SPLIT_COLS");
+                    if (ce && std::atoi(ce) > 0) cols = std::atoi(ce);
+                    side.set_qrcp_cols(half_solved ? (int)cols : 0);
+                    lapack::geqp3(d - h, n - h, A_hat + h + h * d, d, J2, tau + h, side);
+                    q.wait_for(side);
+                    util::col_swap(h, n - h, n - h, A_hat + h * d, d, J2, q);          // the finished rows follow the trailing block's pivots
+                    util::col_swap(n - h, n - h, &J[h], J2, q);                        // J[h:] <- J[h:][J2]
+                }
+            }
         }
         auto t2 = stamp();
 
@@ -141,13 +187,16 @@ public:
         // The scratch matrix has its own leading dimension: with ldw = m a column stride that is a multiple of 4 KiB (m = 2^20: 8 MiB)
         // puts the 384 column pieces a Gram tile reads per K-step on the same memory channels -- 20.7 against 18.7 ms for C3's Gram matrix.
         T* W = nullptr;
-        const int64_t ldw = (m % 512 == 0) ? m + 32 : m;
-        if (fold_pivoting && k == n && m >= 16384) W = ws.try_alloc<T>(ldw * n);   // no room for a second m x n matrix: the in-place order below
+        const int64_t ldw = ldw_of(m);
+        if (fold_pivoting && k == n && m >= 16384) W = W_early ? W_early : ws.try_alloc<T>(ldw * n);   // no room for a second m x n matrix: the in-place order below
         if (W) {
             auto t4 = stamp();
             for (int64_t i = 0; i < k; ++i)                                                                 // :296-301 diag_is_nonzero
                 if (diag[i] == (T)0) { util::col_swap(m, n, k, A, lda, J, q); return 1; }                   // (A leaves permuted, as in the reference)
-            blas::trsm_gather(Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, J, W, ldw, q);                   // :288 + :302
+            // (split QRCP: the left half of W is solved already; the right half is the same launch with other bounds.  A right half outside
+            //  the fused kernel's domain -- a badly conditioned diagonal block -- takes the whole solve again.)
+            if (!(half_solved && blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W, ldw, n / 2, n, q)))
+                blas::trsm_gather(Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, J, W, ldw, q);               // :288 + :302
             auto t5 = stamp();
             blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, W, ldw, (T)0.0, R, ldr, q);   // :310
             if (q.world() > 1) {
@@ -283,6 +332,9 @@ public:
     // (not in the reference) the column pivoting is folded into the first preconditioning solve instead of a separate pass over A;
     // false restores the reference's statement order col_swap -> trsm -> syrk -> trsm, all in place (RLHIP_CQRRPT_FOLD_PIVOTING=0)
     bool fold_pivoting;
+    // (not in the reference) geqp3 of the sketch in two halves with the left half of the first solve beside the second one; false (or
+    // RLHIP_CQRRPT_SPLIT_QRCP=0) keeps the one-piece order
+    bool split_qrcp;
     // testing hooks (not in the reference): a d x n sketch to use instead of S*A / a buffer receiving the sketch
     const T* sketch_override = nullptr;
     T* sketch_export = nullptr;

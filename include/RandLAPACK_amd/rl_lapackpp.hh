@@ -142,6 +142,9 @@ inline T lansy(Norm nt, blas::Uplo u, int64_t n, T const* A, int64_t lda, Queue&
 }
 inline void qrp_partial(int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_qrp_partial_f64(q.ctx(), m, n, steps, A, lda, jpvt, tau), "qrp_partial"); }
 inline void qrp_partial(int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_qrp_partial_f32(q.ctx(), m, n, steps, A, lda, jpvt, tau), "qrp_partial"); }
+// the first `steps` steps of geqp3 (see rlhip_geqp3_steps_f64)
+inline void geqp3_steps(int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_geqp3_steps_f64(q.ctx(), m, n, steps, A, lda, jpvt, tau), "geqp3_steps"); }
+inline void geqp3_steps(int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_geqp3_steps_f32(q.ctx(), m, n, steps, A, lda, jpvt, tau), "geqp3_steps"); }
 inline void vrows_explicit(int64_t br, int64_t toff, int64_t tcnt, double const* Vtop, int64_t ldv, double* out, int64_t ldo, Queue& q = blas::default_queue()) { blas::check(rlhip_vrows_explicit_f64(q.ctx(), br, toff, tcnt, Vtop, ldv, out, ldo), "vrows_explicit"); }
 inline void vrows_explicit(int64_t br, int64_t toff, int64_t tcnt, float const* Vtop, int64_t ldv, float* out, int64_t ldo, Queue& q = blas::default_queue()) { blas::check(rlhip_vrows_explicit_f32(q.ctx(), br, toff, tcnt, Vtop, ldv, out, ldo), "vrows_explicit"); }
 inline void luqrcp_piv(int64_t sd, int64_t cols, int64_t const* ipiv, int64_t* J, Queue& q = blas::default_queue()) { blas::check(rlhip_luqrcp_piv(q.ctx(), sd, cols, ipiv, J), "luqrcp_piv"); }

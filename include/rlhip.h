@@ -134,6 +134,14 @@ int rlhip_trsm_gather_f64(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, doubl
                           const double* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, double* B, int64_t ldb);
 int rlhip_trsm_gather_f32(rlhip_ctx* ctx, char diag, int64_t m, int64_t n, float alpha, const float* A, int64_t lda,
                           const float* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, float* B, int64_t ldb);
+/* Columns [col0, col1) (multiples of 256) of the same solve, given that B[:, 0 : col0) already holds the solution's leading columns; only the
+ * leading col1 x col1 part of A and jpvt[0 : col1) are read, and jpvt maps into nsrc >= col1 source columns (a prefix of a pivot vector).
+ * Pieces of a split solve are bitwise the whole solve.  Returns 0, 1 (not taken: outside the fused kernel's domain, nothing written --
+ * the caller takes rlhip_trsm_gather_* for the whole matrix) or an error (< 0). */
+int rlhip_trsm_gather_range_f64(rlhip_ctx* ctx, char diag, int64_t m, int64_t nsrc, double alpha, const double* A, int64_t lda,
+                                const double* Bsrc, int64_t ldsrc, const int64_t* jpvt, double* B, int64_t ldb, int64_t col0, int64_t col1);
+int rlhip_trsm_gather_range_f32(rlhip_ctx* ctx, char diag, int64_t m, int64_t nsrc, float alpha, const float* A, int64_t lda,
+                                const float* Bsrc, int64_t ldsrc, const int64_t* jpvt, float* B, int64_t ldb, int64_t col0, int64_t col1);
 /* side 'R': B <- alpha * B * A, A n x n upper triangular, B m x n (trans 'N' only);
  * side 'L': B <- alpha * op(A) * B, A m x m upper triangular (trans 'N' or 'T').  uplo 'U' only. */
 int rlhip_trmm_f64(rlhip_ctx* ctx, char side, char uplo, char trans, char diag, int64_t m, int64_t n,
@@ -285,6 +293,17 @@ int rlhip_gemqrt_tail_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, const
  * is the complete permutation produced by the swaps. */
 int rlhip_qrp_partial_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau);
 int rlhip_qrp_partial_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau);
+/* The first `steps` steps of rlhip_geqp3_* itself (LAPACK's norm down-date; lapack::geqp3 as called by rl_cqrrpt.hh:247): rows 0 .. steps-1
+ * of R final for all columns, the trailing block updated by every reflector so far, jpvt the permutation so far.  geqp3 of the trailing
+ * (m - steps) x (n - steps) block, with its pivots applied to the columns of the finished rows and composed into jpvt, completes it. */
+int rlhip_geqp3_steps_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, double* A, int64_t lda, int64_t* jpvt, double* tau);
+int rlhip_geqp3_steps_f32(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t steps, float* A, int64_t lda, int64_t* jpvt, float* tau);
+/* the context's own cached side context (see rlhip_create_side): created on first use, owned by and destroyed with `parent` -- do NOT
+ * rlhip_destroy it */
+int rlhip_side_of(rlhip_ctx* parent, rlhip_ctx** out);
+/* columns per workgroup of the tag-exchange pivoted QR on this context (0 = default): fewer, fuller workgroups for a factorization that runs
+ * beside another stream's kernel */
+int rlhip_set_qrcp_cols(rlhip_ctx* ctx, int cols);
 /* rows [toff, toff + tcnt) of the unit-lower-triangular V1 held implicitly in Vtop (br x br), written explicitly (0 above, 1 on the
  * diagonal) into out (tcnt x br): a rank's own rows of a reflector block under row sharding (BQRRP). */
 int rlhip_vrows_explicit_f64(rlhip_ctx* ctx, int64_t br, int64_t toff, int64_t tcnt, const double* Vtop, int64_t ldv, double* out, int64_t ldo);

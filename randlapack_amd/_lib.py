@@ -30,6 +30,7 @@ def _blas3(T):
         "trsm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
         "trmm": [c_vp, c_char, c_char, c_char, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64],
         "trsm_gather": [c_vp, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64],
+        "trsm_gather_range": [c_vp, c_char, c_i64, c_i64, T, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64],
         "potrf": [c_vp, c_char, c_i64, c_vp, c_i64],
         "lange_fro": [c_vp, c_i64, c_i64, c_vp, c_i64, C.POINTER(T)],
         "lacpy": [c_vp, c_char, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
@@ -50,6 +51,7 @@ def _blas3(T):
         "geqrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "vrows_explicit": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "qrp_partial": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
+        "geqp3_steps": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
         "ungqr": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp],
         "laswp": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
         "getrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
@@ -100,6 +102,8 @@ SIGNATURES = {
                                      c_vp, c_i64, C.POINTER(c_dbl), C.POINTER(c_int)]),
     "rlhip_create_side": (c_int, [c_vp, C.POINTER(c_vp)]),
     "rlhip_order_after": (c_int, [c_vp, c_vp]),
+    "rlhip_set_qrcp_cols": (c_int, [c_vp, c_int]),
+    "rlhip_side_of": (c_int, [c_vp, C.POINTER(c_vp)]),
     "rlhip_gemqrt_head_f64": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rlhip_gemqrt_head_f32": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rlhip_gemqrt_tail_f64": (c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64]),

@@ -33,6 +33,7 @@ int luqrcp_piv(rlhip_ctx*, int64_t, int64_t, const int64_t*, int64_t*);
 template <typename T> int geqrf(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*);
 template <typename T> int vrows_explicit(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int qrp_partial(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, int64_t*, T*);
+template <typename T> int geqp3_steps(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, int64_t*, T*);
 template <typename T> int gemqrt_rn(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int ungqr(rlhip_ctx*, int64_t, int64_t, T*, int64_t, const T*);
 template <typename T> int laswp(rlhip_ctx*, int64_t, T*, int64_t, int64_t, int64_t, const int64_t*);
@@ -187,6 +188,26 @@ int rlhip_create_side(rlhip_ctx* parent, rlhip_ctx** out) {
 }
 
 // everything enqueued on `waiter`'s stream from now on starts after everything enqueued on `signaler`'s stream so far (no host wait)
+// The parent's OWN side context: created on the first call, handed out again on every later one, destroyed with the parent.  For callers
+// inside a timed path (CQRRPT's split QRCP: a stream, two mailboxes and a scratch arena per call would cost more than the overlap wins).
+int rlhip_side_of(rlhip_ctx* parent, rlhip_ctx** out) {
+    if (!parent || !out) return -1;
+    if (!parent->side_ctx) {
+        const int rc = rlhip_create_side(parent, &parent->side_ctx);
+        if (rc) { parent->side_ctx = nullptr; return rc; }
+    }
+    *out = parent->side_ctx;
+    return 0;
+}
+
+// columns per workgroup of the tag-exchange pivoted QR on this context (0: the default, 4): a factorization meant to run BESIDE another
+// stream's kernel is packed into fewer workgroups, i.e. fewer CUs
+int rlhip_set_qrcp_cols(rlhip_ctx* c, int cols) {
+    if (!c || cols < 0) return -1;
+    c->qrcp_cols_per_wg = cols;
+    return 0;
+}
+
 int rlhip_order_after(rlhip_ctx* waiter, rlhip_ctx* signaler) {
     if (!waiter || !signaler) return -1;
     if (waiter->stream == signaler->stream) return 0;
@@ -210,6 +231,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->side_ctx) { rlhip_destroy(c->side_ctx); c->side_ctx = nullptr; hipSetDevice(c->device); }
     if (c->side) hipStreamDestroy(c->side);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -411,6 +433,11 @@ static inline int op_flag(char t, int* out) {
         int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
         return rlhip::trsm_right_upper_oop<T>(c, fd, m, n, alpha, A, lda, Bsrc, ldsrc, jpvt_dev, B, ldb);        \
     }                                                                                                           \
+    int rlhip_trsm_gather_range_##SUF(rlhip_ctx* c, char diag, int64_t m, int64_t nsrc, T alpha, const T* A, int64_t lda, \
+                                      const T* Bsrc, int64_t ldsrc, const int64_t* jpvt_dev, T* B, int64_t ldb, int64_t col0, int64_t col1) { \
+        int fd = (diag == 'U' || diag == 'u') ? 1 : 0;                                                          \
+        return rlhip::trsm_right_upper_oop_range<T>(c, fd, m, nsrc, alpha, A, lda, Bsrc, ldsrc, jpvt_dev, B, ldb, col0, col1); \
+    }                                                                                                           \
     int rlhip_trmm_##SUF(rlhip_ctx* c, char side, char uplo, char trans, char diag, int64_t m, int64_t n,       \
                          T alpha, const T* A, int64_t lda, T* B, int64_t ldb) {                                 \
         if (uplo != 'U' && uplo != 'u') return -3;                                                              \
@@ -497,6 +524,9 @@ static inline int op_flag(char t, int* out) {
     }                                                                                                           \
     int rlhip_qrp_partial_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt, T* tau) { \
         return rlhip::qrp_partial<T>(c, m, n, steps, A, lda, jpvt, tau);                                        \
+    }                                                                                                           \
+    int rlhip_geqp3_steps_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt, T* tau) { \
+        return rlhip::geqp3_steps<T>(c, m, n, steps, A, lda, jpvt, tau);                                        \
     }                                                                                                           \
     int rlhip_larft_##SUF(rlhip_ctx* c, int64_t m, int64_t k, const T* V, int64_t ldv, const T* tau, T* Tm, int64_t ldt) { \
         return rlhip::larft_gram<T>(c, m, k, V, ldv, tau, Tm, ldt);                                              \

@@ -951,6 +951,15 @@ template <typename T>
 int qrp_partial(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
     return qr_core<T>(c, 1, m, n, A, lda, jpvt_dev, tau_dev, steps, 1);
 }
+// The first `steps` steps of geqp3 itself (LAPACK's norm down-date form): on exit rows 0 .. steps-1 of R are final for ALL columns, the trailing
+// (m - steps) x (n - steps) block carries every reflector so far and jpvt the permutation so far -- geqp3 of that block, its pivots applied to
+// the columns of the finished rows and composed into jpvt, completes the factorization (CQRRPT's split QRCP, rl_cqrrpt.hh).
+template <typename T>
+int geqp3_steps(rlhip_ctx* c, int64_t m, int64_t n, int64_t steps, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev) {
+    return qr_core<T>(c, 1, m, n, A, lda, jpvt_dev, tau_dev, steps, 0);
+}
+template int geqp3_steps<double>(rlhip_ctx*, int64_t, int64_t, int64_t, double*, int64_t, int64_t*, double*);
+template int geqp3_steps<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, int64_t, int64_t*, float*);
 template int qrp_partial<double>(rlhip_ctx*, int64_t, int64_t, int64_t, double*, int64_t, int64_t*, double*);
 template int qrp_partial<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, int64_t, int64_t*, float*);
 
@@ -1227,8 +1236,12 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
     static int tag_on = -1;
     if (tag_on < 0) { const char* e = getenv("RLHIP_QRCP_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
     if (pivot && use_lds && tag_on && m < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) - 2) {
-        constexpr int64_t g_env = 4;
-        // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: g_env (4) per workgroup
+        // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: 4 per workgroup
+        // (RLHIP_QRCP_TAG_COLS, read per call, or rlhip_set_qrcp_cols: a caller that runs this factorization BESIDE another kernel asks for
+        // fewer, fuller workgroups -- 1280 x 1024: 7.7 ms with 4 columns per workgroup, 8.7 with 8; 768 x 512: 3.5 / 3.9 / 4.9 ms with 4 / 8 / 16)
+        int64_t g_env = 4;
+        { const char* e = getenv("RLHIP_QRCP_TAG_COLS"); if (e && atoi(e) > 0) g_env = atoi(e); }
+        if (c->qrcp_cols_per_wg > 0) g_env = c->qrcp_cols_per_wg;
         int64_t Gt = (n + g_env - 1) / g_env;
         if (Gt > num_cu) Gt = num_cu;
         if (Gt > 256) Gt = 256;           // the speculation bookkeeping of the kernel holds one record per thread of a 256-thread workgroup

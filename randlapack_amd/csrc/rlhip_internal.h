@@ -87,6 +87,10 @@ struct rlhip_ctx {
     // != 0: products take the tiled kernel whose workgroups come and go, not the persistent stream-K kernel that holds every CU for its whole
     // duration (set around a product that is meant to share the device with another stream: house.hip::gemqrt_lt_tail)
     int avoid_persistent = 0;
+    // > 0: columns per workgroup of the tag-exchange pivoted QR (default 4; a caller that overlaps the factorization with another kernel packs
+    // the columns into fewer workgroups so that it occupies fewer CUs)
+    int qrcp_cols_per_wg = 0;
+    rlhip_ctx* side_ctx = nullptr;   // cached side context (rlhip_side_of): created on first use, destroyed with this one
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU
     void* comm = nullptr;
@@ -145,6 +149,9 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host);
 template <typename T>
 int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda, const T* Bsrc, int64_t ldsrc,
                          const int64_t* perm_dev, T* B, int64_t ldb);
+template <typename T>
+int trsm_right_upper_oop_range(rlhip_ctx* c, int diag, int64_t m, int64_t nsrc, T alpha, const T* A, int64_t lda, const T* Bsrc, int64_t ldsrc,
+                               const int64_t* perm_dev, T* B, int64_t ldb, int64_t col0, int64_t col1);
 template <typename T>
 int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, const T* A, int64_t lda,
                      T* B, int64_t ldb);

@@ -696,10 +696,51 @@ template int saso_apply_csr<double>(rlhip_ctx*, const SasoOp*, int64_t, double, 
 template int saso_apply_csr<float>(rlhip_ctx*, const SasoOp*, int64_t, float, const int64_t*, const int64_t*, const float*, float, float*, int64_t, int64_t);
 
 // in-place forward column permutation; idx is a DEVICE array of n 1-based indices (left untouched)
+// Small matrices (sketch-sized blocks: the finished rows of R_sk in CQRRPT's split QRCP, 512 x 512): the permutation as a parallel gather into
+// scratch and a copy back, validity checked on the way (a repeated or out-of-range entry raises the flag and the copy back does nothing --
+// the matrix is left as it was, like the cycle walk below).  The serial cycle walk costs 164 us at n = 512 and its apply kernel 241 us, on
+// the critical path between the two halves of that solve; this is two launches of a few microseconds.
+template <typename T>
+__global__ __launch_bounds__(256) void colperm_gather_kernel(int64_t m, int64_t n, const T* __restrict__ A, int64_t lda, const int64_t* __restrict__ idx,
+                                                             T* __restrict__ tmp, unsigned* __restrict__ seen, int* __restrict__ bad) {
+    const int64_t cidx = blockIdx.y;
+    const int64_t sidx = idx[cidx] - 1;
+    if (sidx < 0 || sidx >= n) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicExch(bad, 1); return; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned bit = 1u << (sidx & 31);
+        if (atomicOr(seen + (sidx >> 5), bit) & bit) atomicExch(bad, 1);
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) tmp[i + cidx * m] = A[i + sidx * lda];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colperm_store_kernel(int64_t m, const T* __restrict__ tmp, T* __restrict__ A, int64_t lda, const int* __restrict__ bad) {
+    if (*bad) return;
+    const int64_t cidx = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) A[i + cidx * lda] = tmp[i + cidx * m];
+}
+
 template <typename T>
 int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, const int64_t* idx_dev) {
     if (k > n) return -3;                       // reference throws (rl_util.hh:159-160)
     if (m <= 0 || n <= 0) return 0;
+    if (n < 4096 && (size_t)m * (size_t)n * sizeof(T) <= ((size_t)32 << 20)) {
+        const size_t mk = rlhip_ws_mark(c);
+        T* tmp = ws_alloc<T>(c, (size_t)m * n);
+        unsigned* seen = ws_alloc<unsigned>(c, (size_t)n / 32 + 2);
+        if (tmp && seen) {
+            int* bad = (int*)(seen + n / 32 + 1);
+            hipError_t he = hipMemsetAsync(seen, 0, ((size_t)n / 32 + 2) * sizeof(unsigned), c->stream);
+            if (he == hipSuccess) {
+                const dim3 grid((unsigned)std::min<int64_t>((m + 255) / 256, 64), (unsigned)n);
+                hipLaunchKernelGGL(colperm_gather_kernel<T>, grid, dim3(256), 0, c->stream, m, n, A, lda, idx_dev, tmp, seen, bad);
+                hipLaunchKernelGGL(colperm_store_kernel<T>, grid, dim3(256), 0, c->stream, m, tmp, A, lda, bad);
+                he = hipGetLastError();
+            }
+            rlhip_ws_release(c, mk);
+            return he == hipSuccess ? 0 : RLHIP_ERR_HIP(he);
+        }
+        rlhip_ws_release(c, mk);                // no scratch: the in-place cycle walk
+    }
     size_t mark = rlhip_ws_mark(c);
     int64_t* moves = ws_alloc<int64_t>(c, (size_t)(2 * n + 2));
     int64_t* nmoves = ws_alloc<int64_t>(c, 1);

@@ -637,11 +637,12 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
 }
 
 // *bad = 1 unless perm[0..n) - pbase is a permutation of 0..n-1 (seen: n bits, zeroed by the caller)
-__global__ void perm_check_kernel(int64_t n, const int64_t* __restrict__ perm, int64_t pbase, unsigned* __restrict__ seen, int* __restrict__ bad) {
+// (nsrc: number of source columns the entries may name; the whole-solve callers pass n -- a permutation of 1 .. n)
+__global__ void perm_check_kernel(int64_t n, const int64_t* __restrict__ perm, int64_t pbase, unsigned* __restrict__ seen, int* __restrict__ bad, int64_t nsrc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t sidx = perm[i] - pbase;
-    if (sidx < 0 || sidx >= n) { atomicExch(bad, 1); return; }
+    if (sidx < 0 || sidx >= nsrc) { atomicExch(bad, 1); return; }
     const unsigned bit = 1u << (sidx & 31);
     if (atomicOr(seen + (sidx >> 5), bit) & bit) atomicExch(bad, 1);
 }
@@ -885,7 +886,7 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         RLHIP_LAUNCH_CHECK();
         if (perm_dev) {     // the pivot vector is validated on the device; its verdict rides on the guard's read-back (slot 32)
             RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
-            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad_dev + 32);
+            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad_dev + 32, n);
             RLHIP_LAUNCH_CHECK();
             perm_checked = true;
         }
@@ -913,7 +914,7 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         if (!seen || !bad) { rlhip_ws_release(c, mk2); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
         RLHIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad);
+        hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad, n);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(rlhip_stream_sync(c));
@@ -927,6 +928,65 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         RLHIP_LAUNCH_CHECK();
     }
     return trsm_right_upper<T>(c, diag, m, n, alpha, A, lda, B, ldb);
+}
+
+// A RANGE of 256-blocks of the same out-of-place solve: columns [col0, col1) of  B = alpha * (Bsrc * P) * inv(A)  given that B[:, 0 : col0)
+// already holds the solution's leading columns (col0 = 0: none).  Only the leading col1 x col1 part of A and perm[0 : col1) are read, and perm
+// maps into `nsrc` source columns (a PREFIX of a pivot vector is not a permutation of 1 .. col1).  This is what lets CQRRPT solve for the
+// first half of the preconditioned matrix while the second half of the sketch is still being factored (rl_cqrrpt.hh: the leading block of R
+// and the leading pivots are final after half the steps of the pivoted QR).  The fused kernel walks block columns left to right and re-reads
+// the solved blocks from B, so a range is the same launch with other bounds: the pieces of a split solve are bitwise the whole solve.
+// Returns 0 (done), 1 (not taken: sizes or conditioning outside the fused kernel's domain -- nothing written, the caller takes the whole
+// solve), or an error (< 0; -7: perm is not injective into 1 .. nsrc).
+template <typename T>
+int trsm_right_upper_oop_range(rlhip_ctx* c, int diag, int64_t m, int64_t nsrc, T alpha, const T* A, int64_t lda, const T* Bsrc, int64_t ldsrc,
+                               const int64_t* perm_dev, T* B, int64_t ldb, int64_t col0, int64_t col1) {
+    if (m < 0) return -6;
+    if (col0 < 0 || col1 <= col0 || col0 % BW || col1 % BW) return -7;
+    if (nsrc < col1) return -7;
+    if (lda < col1) return -10;
+    if (ldsrc < (m > 1 ? m : 1)) return -12;
+    if (ldb < (m > 1 ? m : 1)) return -15;
+    if (m == 0) return 0;
+    if ((const T*)B == Bsrc) return -14;
+    const char* e = getenv("RLHIP_TRSM_FUSED"); const char* b = getenv("RLHIP_TRSM_BLK"); const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS");
+    const int64_t min_rows = r ? atoi(r) : 16384;
+    const int64_t n = col1, nblk = n / BW;
+    if ((e && atoi(e) == 0) || (b && atoi(b) == 0) || m < min_rows || nblk > 32 || (4 * ldb + m) >= ((int64_t)1 << 28)) return 1;
+    size_t mark = rlhip_ws_mark(c);
+    T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
+    T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
+    int* bad_dev = ws_alloc<int>(c, 40);
+    unsigned* seen = ws_alloc<unsigned>(c, (size_t)nsrc / 32 + 2);
+    T* Uneg = ws_alloc<T>(c, (size_t)n * n);
+    T* fdump = ws_alloc<T>(c, 512);
+    if (!Upk_all || !Dinv_all || !bad_dev || !seen || !Uneg || !fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipError_t he = hipMemsetAsync(bad_dev, 0, 33 * sizeof(int), c->stream);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, n, diag, A, lda, Upk_all, Dinv_all, bad_dev, 1.0e6);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess && perm_dev) {
+        he = hipMemsetAsync(seen, 0, ((size_t)nsrc + 31) / 32 * sizeof(unsigned), c->stream);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad_dev + 32, nsrc);
+            he = hipGetLastError();
+        }
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = rlhip_stream_sync(c);
+    if (he != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(he); }
+    if (perm_dev && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }
+    bool good = true;
+    for (int64_t bb = 0; bb < nblk; ++bb) good = good && ((int*)(c->h_mail + 16))[bb] == 0;
+    if (!good) { rlhip_ws_release(c, mark); return 1; }
+    hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
+    he = hipGetLastError();
+    int lrc = (he == hipSuccess) ? 0 : RLHIP_ERR_HIP(he);
+    if (!lrc) lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, (int)(col0 / BW), (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)nullptr, 0);
+    if (!lrc) c->path_count[4]++;
+    rlhip_ws_release(c, mark);
+    return lrc;
 }
 
 template <typename T>
@@ -1059,6 +1119,8 @@ template int cholqrq<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float
 template int trsm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trsm_right_upper_oop<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, const int64_t*, double*, int64_t);
 template int trsm_right_upper_oop<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, const int64_t*, float*, int64_t);
+template int trsm_right_upper_oop_range<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, const double*, int64_t, const int64_t*, double*, int64_t, int64_t, int64_t);
+template int trsm_right_upper_oop_range<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, const float*, int64_t, const int64_t*, float*, int64_t, int64_t, int64_t);
 template int trsm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);
 template int trmm_right_upper<double>(rlhip_ctx*, int, int64_t, int64_t, double, const double*, int64_t, double*, int64_t);
 template int trmm_right_upper<float>(rlhip_ctx*, int, int64_t, int64_t, float, const float*, int64_t, float*, int64_t);

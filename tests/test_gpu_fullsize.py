@@ -691,3 +691,102 @@ def test_streamk_syrk_f32_upper_tiles(ctx, n, k):
     assert np.abs(got[iu] - ref[iu]).max() <= 4 * EPS32 * np.sqrt(k) * np.abs(ref).max()
     il = np.tril_indices(n, -1)
     assert np.array_equal(got[il], C0[il])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CQRRPT's split QRCP: geqp3 in two halves, the solve in column ranges, the driver with and without the overlap
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,h", [(1280, 1024, 512), (640, 512, 256), (700, 300, 100)])
+def test_geqp3_in_two_halves_is_geqp3(ctx, m, n, h):
+    """rlhip_geqp3_steps (the first h steps) + geqp3 of the trailing block + its pivots applied to the finished rows and composed into jpvt
+    == rlhip_geqp3: identical pivots, R and tau to rounding (the second half starts from recomputed column norms instead of down-dated ones)."""
+    import torch
+
+    d = _d()
+    rng = np.random.default_rng(m + n + h)
+    A0 = rng.standard_normal((m, n)) * np.logspace(0, -3, n)[rng.permutation(n)]
+    f64 = torch.float64
+    Af = d.cm_from_numpy(A0); Jf = torch.zeros(n, dtype=torch.int64, device="cuda"); tf = torch.zeros(n, dtype=f64, device="cuda")
+    assert ctx.lib.rlhip_geqp3_f64(ctx.h, m, n, Af.data_ptr(), m, Jf.data_ptr(), tf.data_ptr()) == 0
+    As = d.cm_from_numpy(A0); Js = torch.zeros(n, dtype=torch.int64, device="cuda"); ts = torch.zeros(n, dtype=f64, device="cuda")
+    assert ctx.lib.rlhip_geqp3_steps_f64(ctx.h, m, n, h, As.data_ptr(), m, Js.data_ptr(), ts.data_ptr()) == 0
+    part = d.cm_to_numpy(As)
+    refh = d.cm_to_numpy(Af)
+    assert np.array_equal(Js.cpu().numpy()[:h], Jf.cpu().numpy()[:h])                       # the leading pivots are final ...
+    assert np.abs(np.triu(part[:h, :h]) - np.triu(refh[:h, :h])).max() <= 1e-13 * np.abs(refh).max()      # ... and so is the leading block of R
+    J2 = torch.zeros(n - h, dtype=torch.int64, device="cuda")
+    es = 8
+    assert ctx.lib.rlhip_geqp3_f64(ctx.h, m - h, n - h, As.data_ptr() + (h + h * m) * es, m, J2.data_ptr(), ts.data_ptr() + h * es) == 0
+    assert ctx.lib.rlhip_col_swap_f64(ctx.h, h, n - h, n - h, As.data_ptr() + h * m * es, m, J2.data_ptr()) == 0
+    assert ctx.lib.rlhip_col_swap_i64(ctx.h, n - h, n - h, Js.data_ptr() + h * 8, J2.data_ptr()) == 0
+    assert np.array_equal(Js.cpu().numpy(), Jf.cpu().numpy())
+    got, ref = d.cm_to_numpy(As), d.cm_to_numpy(Af)
+    k = min(m, n)
+    assert np.abs(np.triu(got)[:k] - np.triu(ref)[:k]).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(ts.cpu().numpy()[:k] - tf.cpu().numpy()[:k]).max() <= 1e-11
+
+
+def test_trsm_gather_range_pieces_are_the_whole_solve_bitwise(ctx):
+    """rlhip_trsm_gather_range: the column ranges of a split solve are the same fused launch with other bounds -- two and three pieces give
+    the bits of the one-piece solve; a pivot PREFIX is accepted (entries name any of nsrc source columns); a repeated entry is refused (-7)
+    and a badly conditioned diagonal block returns 1, both before anything is written."""
+    import torch
+
+    d = _d()
+    m, n = 33000, 1024
+    rng = np.random.default_rng(77)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2 * np.eye(n)
+    Ud = d.cm_from_numpy(U)
+    Src = d.cm_from_numpy(rng.standard_normal((m, n)))
+    Jn = (rng.permutation(n) + 1).astype(np.int64)
+    Jd = torch.from_numpy(Jn).cuda()
+    whole = d.cm_zeros(m, n)
+    ctx.trsm_gather(m, n, 0.5, Ud, n, Src, m, Jd, whole, m)
+    fn = ctx.lib.rlhip_trsm_gather_range_f64
+
+    def pieces(cuts):
+        X = d.cm_from_numpy(np.full((m, n), np.nan))
+        for c0, c1 in zip(cuts[:-1], cuts[1:]):
+            assert fn(ctx.h, b"N", m, n, 0.5, Ud.data_ptr(), n, Src.data_ptr(), m, Jd.data_ptr(), X.data_ptr(), m, c0, c1) == 0
+        return X
+    assert torch.equal(pieces([0, 512, 1024]), whole)
+    assert torch.equal(pieces([0, 256, 768, 1024]), whole)
+    # a prefix alone: columns [0, 512) only -- the rest of the output stays as it was
+    X = d.cm_from_numpy(np.full((m, n), -7.0))
+    assert fn(ctx.h, b"N", m, n, 0.5, Ud.data_ptr(), n, Src.data_ptr(), m, Jd.data_ptr(), X.data_ptr(), m, 0, 512) == 0
+    assert torch.equal(X[:512], whole[:512]) and bool((X[512:] == -7.0).all())
+    Jbad = Jn.copy(); Jbad[300] = Jbad[20]
+    X.fill_(-7.0)
+    assert fn(ctx.h, b"N", m, n, 0.5, Ud.data_ptr(), n, Src.data_ptr(), m, torch.from_numpy(Jbad).cuda().data_ptr(), X.data_ptr(), m, 0, 512) == -7
+    assert bool((X == -7.0).all())
+    Ub = U.copy(); Ub[300:310, 300:310] = np.triu(np.ones((10, 10))) * 1e-9 + np.diag(np.full(10, 1e-9))      # block 1 fails the conditioning guard
+    assert fn(ctx.h, b"N", m, n, 0.5, d.cm_from_numpy(Ub).data_ptr(), n, Src.data_ptr(), m, Jd.data_ptr(), X.data_ptr(), m, 0, 512) == 1
+    assert bool((X == -7.0).all())
+    assert fn(ctx.h, b"N", m, n, 0.5, Ud.data_ptr(), n, Src.data_ptr(), m, Jd.data_ptr(), X.data_ptr(), m, 100, 512) == -7     # bounds: multiples of 256
+
+
+def test_cqrrpt_split_qrcp_equals_one_piece(ctx, monkeypatch):
+    """CQRRPT with geqp3 of the sketch in two halves and the left half of the first solve beside the second one (rl_cqrrpt.hh; on for tall
+    inputs on one rank) against the one-piece order (RLHIP_CQRRPT_SPLIT_QRCP=0): the same pivots and rank, R and Q to rounding, three
+    fused out-of-place solve launches instead of two."""
+    d = _d()
+    m, n = 1 << 18, 512
+    res = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(5, 0))
+        # grade the columns a little: distinct column norms, no near-ties for the pivoting
+        import torch
+        A.mul_(torch.logspace(0, -2, n, dtype=torch.float64, device="cuda")[torch.randperm(n, generator=torch.Generator().manual_seed(3)).cuda()].unsqueeze(1))
+        before = ctx.path_count(4)
+        r = d.drv_cqrrpt(ctx, A, m, n, 1.25, 4, key=(9, 0))
+        assert r["rc"] == 0 and r["rank"] == n
+        res[knob] = (r["J"].cpu().numpy(), d.cm_to_numpy(r["R"]), A.clone(), ctx.path_count(4) - before)
+    (J0, R0, Q0, l0), (J1, R1, Q1, l1) = res["0"], res["1"]
+    assert l0 == 2 and l1 == 3
+    assert np.array_equal(J0, J1)
+    assert np.abs(R0 - R1).max() <= 1e-11 * np.abs(R0).max()
+    import torch
+    assert float((Q0 - Q1).abs().max()) <= 1e-11
+    G = (Q1 @ Q1.T).cpu().numpy()
+    assert np.abs(G - np.eye(n)).max() <= 1e-13 * n
