@@ -160,6 +160,7 @@ public:
                     if (ce && std::atoi(ce) > 0) cols = std::atoi(ce);
                     side.set_qrcp_cols(half_solved ? (int)cols : 0);
                     lapack::geqp3(d - h, n - h, A_hat + h + h * d, d, J2, tau + h, side);
+                    side.set_qrcp_cols(0);                                              // (the cached side queue goes back to its default)
                     q.wait_for(side);
                     util::col_swap(h, n - h, n - h, A_hat + h * d, d, J2, q);          // the finished rows follow the trailing block's pivots
                     util::col_swap(n - h, n - h, &J[h], J2, q);                        // J[h:] <- J[h:][J2]
