@@ -27,6 +27,9 @@
 #include <vector>
 #include "rlhip_internal.h"
 
+extern "C" int rlhip_malloc(rlhip_ctx* ctx, void** dev_ptr, size_t bytes);   // the context's caching pool (capi.hip)
+extern "C" int rlhip_free(rlhip_ctx* ctx, void* dev_ptr);
+
 namespace {
 
 __device__ inline void philox4x32_10_dev(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -526,6 +529,16 @@ static int saso_default_mode() {
     return mode;
 }
 
+// the operator's index arrays come from the context's caching pool (rlhip_malloc): no hipMalloc / hipFree in steady state
+#define RLHIP_SASO_ALLOC(field, bytes)                                                    \
+    do {                                                                                  \
+        void* _p = nullptr;                                                               \
+        const int _rc = rlhip_malloc(c, &_p, (bytes));                                    \
+        if (_rc) { saso_destroy(c, op); return _rc; }                                     \
+        field = reinterpret_cast<decltype(field)>(_p);                                    \
+    } while (0)
+int saso_destroy(rlhip_ctx* c, SasoOp* op);
+
 int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2],
                uint32_t next_ctr[4], SasoOp** out) {
     if (d <= 0 || m < 0 || nnz <= 0 || nnz > d || nnz > 128 || d >= ((int64_t)1 << 31)) return -2;
@@ -541,10 +554,10 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
     op->st = st;
     uint64_t inc;
     if (mode == 0) {
-        RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (size_t)(T * nnz * d)));
-        RLHIP_CHECK(hipMalloc((void**)&op->ainv, sizeof(int64_t) * (size_t)T));
-        RLHIP_CHECK(hipMalloc((void**)&op->b, sizeof(int64_t) * (size_t)(T * nnz)));
-        RLHIP_CHECK(hipMalloc((void**)&op->afwd, sizeof(int64_t) * (size_t)T));
+        RLHIP_SASO_ALLOC(op->src, sizeof(int32_t) * (size_t)(T * nnz * d));
+        RLHIP_SASO_ALLOC(op->ainv, sizeof(int64_t) * (size_t)T);
+        RLHIP_SASO_ALLOC(op->b, sizeof(int64_t) * (size_t)(T * nnz));
+        RLHIP_SASO_ALLOC(op->afwd, sizeof(int64_t) * (size_t)T);
         if (op->T > 0) {
             hipLaunchKernelGGL(saso_params_kernel, dim3((unsigned)((op->T + 63) / 64)), dim3(64), 0, c->stream, d, op->T, nnz,
                                st, op->ainv, op->b, op->afwd);
@@ -557,10 +570,10 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
     } else {
         if (m * nnz >= ((int64_t)1 << 31)) { delete op; return -3; }      // 32-bit list positions
         const size_t nent = (size_t)(m * nnz > 0 ? m * nnz : 1), nkeys = (size_t)(T * d);
-        RLHIP_CHECK(hipMalloc((void**)&op->rows, sizeof(int32_t) * nent));
-        RLHIP_CHECK(hipMalloc((void**)&op->src, sizeof(int32_t) * (nent + 8)));        // + 8: the apply kernel reads eight entries from any list start
+        RLHIP_SASO_ALLOC(op->rows, sizeof(int32_t) * nent);
+        RLHIP_SASO_ALLOC(op->src, sizeof(int32_t) * (nent + 8));        // + 8: the apply kernel reads eight entries from any list start
         RLHIP_CHECK(hipMemsetAsync(op->src + nent, 0, sizeof(int32_t) * 8, c->stream));
-        RLHIP_CHECK(hipMalloc((void**)&op->ptr, sizeof(int32_t) * (nkeys + 1)));
+        RLHIP_SASO_ALLOC(op->ptr, sizeof(int32_t) * (nkeys + 1));
         if (op->T > 0) {
             size_t mark = rlhip_ws_mark(c);
             int32_t* cnt = ws_alloc<int32_t>(c, nkeys);
@@ -591,8 +604,10 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
 
 int saso_destroy(rlhip_ctx* c, SasoOp* op) {
     if (!op) return 0;
-    rlhip_stream_sync(c);
-    hipFree(op->src); hipFree(op->ainv); hipFree(op->b); hipFree(op->afwd); hipFree(op->rows); hipFree(op->ptr);
+    // back to the context's pool: stream-ordered reuse, no device synchronisation (with hipFree the destructor of a sketching operator
+    // made the host wait for the apply it had just enqueued -- and the device then idled while the host prepared the next launch:
+    // 0.6 ms between the sketch and its pivoted QR in CQRRPT's timeline)
+    rlhip_free(c, op->src); rlhip_free(c, op->ainv); rlhip_free(c, op->b); rlhip_free(c, op->afwd); rlhip_free(c, op->rows); rlhip_free(c, op->ptr);
     delete op;
     return 0;
 }
