@@ -790,3 +790,40 @@ def test_cqrrpt_split_qrcp_equals_one_piece(ctx, monkeypatch):
     assert float((Q0 - Q1).abs().max()) <= 1e-11
     G = (Q1 @ Q1.T).cpu().numpy()
     assert np.abs(G - np.eye(n)).max() <= 1e-13 * n
+
+
+@pytest.mark.parametrize("r", [200, 400])
+def test_cqrrpt_split_qrcp_rank_deficient_inputs_fall_back(ctx, monkeypatch, r):
+    """The split order on inputs it cannot finish: rank 200 < n / 2 (the leading block of R_sk already fails the rank criterion: no half solve is
+    started, the second half of the factorization still runs on the side queue) and rank 400 (the left half of A_pre IS solved beside the second
+    half, then the rank estimate says k < n and the reference's in-place order takes over while that solve may still be in flight).  Same rank,
+    same leading pivots' span, same factorization quality as the one-piece order."""
+    import torch
+
+    d = _d()
+    m, n = 1 << 18, 512
+    g = torch.Generator(device="cuda").manual_seed(r)
+    L = torch.randn((r, m), dtype=torch.float64, device="cuda", generator=g)          # column-major m x r
+    Rt = torch.randn((n, r), dtype=torch.float64, device="cuda", generator=g) * torch.logspace(0, -2, r, dtype=torch.float64, device="cuda")
+    A0 = Rt @ L                                                                          # (n, m) tensor = column-major m x n matrix of rank r
+    res = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        A = A0.clone()
+        before = ctx.path_count(4)
+        out = d.drv_cqrrpt(ctx, A, m, n, 1.25, 4, key=(3, 0))
+        ctx.sync()
+        res[knob] = (out["rc"], out["rank"], out["J"].cpu().numpy(), d.cm_to_numpy(out["R"]), A, ctx.path_count(4) - before)
+    (rc0, k0, J0, R0, Q0, l0), (rc1, k1, J1, R1, Q1, l1) = res["0"], res["1"]
+    assert rc0 == rc1 == 0
+    assert k0 == k1 and 0 <= k0 - r <= 8                          # (the eps criterion may count a few noise directions: the same ones either way)
+    assert l1 == l0 + (1 if r > n // 2 else 0)                     # the speculative half solve was launched only where the leading block allowed it
+    k = k0
+    # A P = Q R on the leading k columns of Q / rows of R, for both orders
+    for (J, R, Q) in ((J0, R0, Q0), (J1, R1, Q1)):
+        AP = A0[torch.from_numpy(J - 1).cuda()]                                          # rows of the (n, m) tensor = columns of A, permuted
+        QR = torch.from_numpy(np.ascontiguousarray(R[:k, :].T)).cuda() @ Q[:k]           # (n, k) @ (k, m) = (Q R)^T
+        assert float((AP - QR).norm() / A0.norm()) <= 1e-10
+        G = (Q[:r] @ Q[:r].T).cpu().numpy()
+        assert np.abs(G - np.eye(r)).max() <= 1e-9
+    assert np.array_equal(J0[:r], J1[:r])                          # the same pivots on the numerically nonzero part
