@@ -36,4 +36,8 @@ python $R/scripts/timeline.py $O/tl 5 > $O/${TAG}_rank_of_8_timeline.txt 2>&1; r
 # the DVFS map behind the clock holders and the look-ahead A/B of BQRRP
 timeout 300 python $R/scripts/dvfs_probe.py > /dev/null 2> $O/${TAG}_dvfs_probe.txt
 for la in 0 1; do RLHIP_BQRRP_LOOKAHEAD=$la timeout 400 python $R/scripts/bqrrp_lookahead_ab.py 65536 2048 f32 2; done > $O/${TAG}_c4_lookahead_ab.txt 2>&1
+# second half of round 4: C3 with and without the split QRCP + the timeline of one call, the sparse product A/B,
+# the cooperative Householder kernels before / after the address-space fix need the previous library and are not re-run here (profiles/round4_qr_addrspace_ab.txt)
+( cd $R && bash scripts/c3_split_evidence.sh > $O/c3split.log 2>&1; cp gpurun_out/c3split/${TAG}_c3_* $O/ 2>/dev/null )
+timeout 300 python $R/scripts/spmm_ab.py > $O/${TAG}_spmm_ab.txt 2>&1
 for j in $O/${TAG}_*line.json; do echo "$(basename $j): $(cut -c1-240 $j)"; done
