@@ -827,3 +827,38 @@ def test_cqrrpt_split_qrcp_rank_deficient_inputs_fall_back(ctx, monkeypatch, r):
         G = (Q[:r] @ Q[:r].T).cpu().numpy()
         assert np.abs(G - np.eye(r)).max() <= 1e-9
     assert np.array_equal(J0[:r], J1[:r])                          # the same pivots on the numerically nonzero part
+
+
+def test_cqrrpt_split_qrcp_fp32_and_ranged_solve_fp32(ctx, monkeypatch):
+    """The fp32 instantiations of the split order: ranged fused solves bitwise the whole solve, and CQRRPT fp32 split == one piece."""
+    import torch
+
+    d = _d()
+    f32 = torch.float32
+    m, n = 40000, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    U = (torch.triu(torch.randn((n, n), dtype=f32, device="cuda", generator=g)) / (n ** 0.5) + 2 * torch.eye(n, dtype=f32, device="cuda")).T.contiguous()   # column-major upper
+    Src = torch.randn((n, m), dtype=f32, device="cuda", generator=g)
+    J = (torch.randperm(n, generator=torch.Generator().manual_seed(1)) + 1).cuda()
+    whole = torch.zeros((n, m), dtype=f32, device="cuda")
+    ctx.trsm_gather(m, n, 1.0, U, n, Src, m, J, whole, m)
+    X = torch.full((n, m), float("nan"), dtype=f32, device="cuda")
+    fn = ctx.lib.rlhip_trsm_gather_range_f32
+    for c0, c1 in ((0, 256), (256, 512)):
+        assert fn(ctx.h, b"N", m, n, 1.0, U.data_ptr(), n, Src.data_ptr(), m, J.data_ptr(), X.data_ptr(), m, c0, c1) == 0
+    assert torch.equal(X, whole)
+    m = 1 << 18
+    res = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        A = d.cm_empty(m, n, dtype=f32); ctx.fill_dense(A, m, n, key=(6, 0))
+        A.mul_(torch.logspace(0, -1.5, n, dtype=f32, device="cuda")[torch.randperm(n, generator=torch.Generator().manual_seed(4)).cuda()].unsqueeze(1))
+        before = ctx.path_count(4)
+        r = d.drv_cqrrpt(ctx, A, m, n, 1.25, 4, key=(2, 0))
+        assert r["rc"] == 0 and r["rank"] == n
+        res[knob] = (r["J"].cpu().numpy(), d.cm_to_numpy(r["R"]).astype(np.float64), A.clone(), ctx.path_count(4) - before)
+    (J0, R0, Q0, l0), (J1, R1, Q1, l1) = res["0"], res["1"]
+    assert l1 == l0 + 1
+    assert np.array_equal(J0, J1)
+    assert np.abs(R0 - R1).max() <= 2e-4 * np.abs(R0).max()
+    assert float((Q0 - Q1).abs().max()) <= 2e-4
