@@ -157,6 +157,7 @@ int rlhip_create(rlhip_ctx** out, int device, void* hip_stream, int own_stream) 
     RLHIP_CHECK(hipMalloc((void**)&c->d_mail, 64 * sizeof(int64_t)));
     RLHIP_CHECK(hipEventCreate(&c->ev0));
     RLHIP_CHECK(hipEventCreate(&c->ev1));
+    RLHIP_CHECK(hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming));
     {
         char* p = nullptr;
         RLHIP_CHECK(hipMalloc((void**)&p, (size_t)64 << 20));
@@ -231,6 +232,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_flag) hipEventDestroy(c->ev_flag);
     if (c->side_ctx) { rlhip_destroy(c->side_ctx); c->side_ctx = nullptr; hipSetDevice(c->device); }
     if (c->side) hipStreamDestroy(c->side);
     if (c->owns_stream) hipStreamDestroy(c->stream);

@@ -77,6 +77,7 @@ struct rlhip_ctx {
     size_t xchg_bytes = 0;
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_flag = nullptr;   // marks a flag read-back INSIDE a stream of launches: the host waits for the flags only, the device runs on (tri.hip)
     // ||A||_F fused into a product and not yet collected (rlhip_gemm_norma_f64 with a null result pointer): 0 nothing, 1 the sum of squares
     // is on its way to h_mail[40] behind the stream, 2 norma_value holds the norm
     int norma_state = 0;

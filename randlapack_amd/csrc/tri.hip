@@ -890,17 +890,21 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
             RLHIP_LAUNCH_CHECK();
             perm_checked = true;
         }
+        // The verdict (33 words: the conditioning guard of every block, the pivot check) travels to the host while the device runs on: the
+        // packed triangle and the fused solve are enqueued right behind the read-back, GATED on the same device words (a launch that finds
+        // one of them set does nothing), and the host waits for the read-back only -- no idle device during the round trip.
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(rlhip_stream_sync(c));
+        RLHIP_CHECK(hipEventRecord(c->ev_flag, c->stream));
+        hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
+        RLHIP_LAUNCH_CHECK();
+        {
+            const int lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
+            if (lrc) { rlhip_ws_release(c, mark); return lrc; }
+        }
+        RLHIP_CHECK(hipEventSynchronize(c->ev_flag));
         if (perm_checked && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }     // jpvt is not a permutation of 1..n (as col_swap reports it)
         for (int64_t b = 0; b < nblk; ++b) fused = fused && ((int*)(c->h_mail + 16))[b] == 0;
         if (fused) {
-            hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
-            RLHIP_LAUNCH_CHECK();
-            {
-                const int lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)nullptr, 0);
-                if (lrc) { rlhip_ws_release(c, mark); return lrc; }
-            }
             c->path_count[4]++;
             rlhip_ws_release(c, mark);
             return 0;
@@ -973,17 +977,23 @@ int trsm_right_upper_oop_range(rlhip_ctx* c, int diag, int64_t m, int64_t nsrc, 
             he = hipGetLastError();
         }
     }
+    // (the verdict is read back while the device runs on: the solve is enqueued behind the read-back and gated on the same words -- see the
+    //  whole-matrix form above)
     if (he == hipSuccess) he = hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess) he = rlhip_stream_sync(c);
+    if (he == hipSuccess) he = hipEventRecord(c->ev_flag, c->stream);
     if (he != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(he); }
-    if (perm_dev && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }
-    bool good = true;
-    for (int64_t bb = 0; bb < nblk; ++bb) good = good && ((int*)(c->h_mail + 16))[bb] == 0;
-    if (!good) { rlhip_ws_release(c, mark); return 1; }
     hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
     he = hipGetLastError();
     int lrc = (he == hipSuccess) ? 0 : RLHIP_ERR_HIP(he);
-    if (!lrc) lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, (int)(col0 / BW), (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)nullptr, 0);
+    if (!lrc) lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, (int)(col0 / BW), (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
+    he = hipEventSynchronize(c->ev_flag);
+    if (!lrc && he != hipSuccess) lrc = RLHIP_ERR_HIP(he);
+    if (!lrc && perm_dev && ((int*)(c->h_mail + 16))[32] != 0) lrc = -7;
+    if (!lrc) {
+        bool good = true;
+        for (int64_t bb = 0; bb < nblk; ++bb) good = good && ((int*)(c->h_mail + 16))[bb] == 0;
+        if (!good) lrc = 1;                       // the gated launch did nothing
+    }
     if (!lrc) c->path_count[4]++;
     rlhip_ws_release(c, mark);
     return lrc;
