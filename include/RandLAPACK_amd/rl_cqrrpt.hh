@@ -74,6 +74,7 @@ public:
         int64_t k = n;
         T* W_early = nullptr;            // split QRCP: the scratch copy of A_pre, allocated before the factorization of the sketch ...
         bool half_solved = false;        // ... whose left half is solved beside the second half of that factorization
+        std::vector<T> diag_early;       // split QRCP: diag(R_sk) as read on the side queue
         auto ldw_of = [](int64_t rows) { return (rows % 512 == 0) ? rows + 32 : rows; };
         const int64_t d = (int64_t)(d_factor * n);                                                          // :198 (truncation)
         const T eps_initial_rank_estimation = 2 * std::pow(std::numeric_limits<T>::epsilon(), (T)0.95);   // :200
@@ -140,15 +141,12 @@ public:
                 //  reading -- when it returns, and the arena is ordered by the main stream only; the side stream writes J2 beside that kernel)
                 int64_t* J2 = ws.alloc<int64_t>(n - h);
                 lapack::geqp3_steps(d, n, h, A_hat, d, J, tau, q);
-                std::vector<T> dg(h);
-                lapack::get_diag(h, A_hat, d, dg.data(), q);
-                bool lead_ok = dg[0] != (T)0;
-                for (int64_t i = 0; lead_ok && i < h; ++i)
-                    lead_ok = dg[i] != (T)0 && std::abs(dg[i]) / std::abs(dg[0]) >= eps_initial_rank_estimation;
-                if (lead_ok) {
-                    lapack::lacpy(MatrixType::Upper, h, h, A_hat, d, R, ldr, q);
-                    half_solved = blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W_early, ldw_of(m), 0, h, q);
-                }
+                // The half solve is SPECULATIVE: it goes out right behind the first half of the factorization, without a look at the leading
+                // diagonal of R_sk (a host round trip with the device idle).  A leading block that is singular or graded beyond the solve's
+                // conditioning guard closes the gate of the launch (nothing is written, `half_solved` stays false); one that merely fails the
+                // rank criterion below produces a left half nobody reads -- the rank decision then takes the reference's in-place order.
+                lapack::lacpy(MatrixType::Upper, h, h, A_hat, d, R, ldr, q);
+                half_solved = blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W_early, ldw_of(m), 0, h, q);
                 {
                     blas::Queue side(q, blas::Queue::CachedSide{});
                     // the second half is packed into few, full workgroups (up to 16 columns each, ~100 KiB of LDS): it leaves the other CUs to
@@ -161,6 +159,11 @@ public:
                     side.set_qrcp_cols(half_solved ? (int)cols : 0);
                     lapack::geqp3(d - h, n - h, A_hat + h + h * d, d, J2, tau + h, side);
                     side.set_qrcp_cols(0);                                              // (the cached side queue goes back to its default)
+                    // the diagonal of R_sk is final here (the column swap below moves entries of the finished rows right of column h only):
+                    // read on the SIDE queue, the rank decision does not make the host wait for the half solve on the main stream -- whose
+                    // successors (the swaps, the second half of the solve) are then enqueued behind it while it runs
+                    diag_early.resize(n);
+                    lapack::get_diag(n < d ? n : d, A_hat, d, diag_early.data(), side);
                     q.wait_for(side);
                     util::col_swap(h, n - h, n - h, A_hat + h * d, d, J2, q);          // the finished rows follow the trailing block's pivots
                     util::col_swap(n - h, n - h, &J[h], J2, q);                        // J[h:] <- J[h:][J2]
@@ -170,7 +173,8 @@ public:
         auto t2 = stamp();
 
         std::vector<T> diag(n);
-        lapack::get_diag(n < d ? n : d, A_hat, d, diag.data(), q);
+        if (!diag_early.empty()) diag = diag_early;
+        else lapack::get_diag(n < d ? n : d, A_hat, d, diag.data(), q);
         if (!diag[0]) { rank = 0; return 0; }                                                               // :256-261
         for (int64_t i = 0; i < n; ++i) {                                                                   // :267-272
             if (std::abs(diag[i]) / std::abs(diag[0]) < eps_initial_rank_estimation) { k = i; break; }
