@@ -191,9 +191,16 @@ def main():
             tfile = sorted(cands, key=lambda f: os.path.basename(f).split("_")[0])[-1]
             with open(tfile) as fh:
                 tj = json.load(fh)
-            traffic = float(tj["traffic_bytes"])
             tfile = os.path.relpath(tfile, here)
-            traffic_source = f"{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape, scripts/pmc_all.py; not re-measured by this run)"
+            # a counter file is only quoted when it describes THIS kernel: its own launch time (taken under the counters, which costs a
+            # few per cent) must be within 5 % of the live one -- a stale file from another build reports null instead of a wrong number
+            pmc_ms = float(tj.get("launch_ms_fetch_pass", tj.get("launch_ms", 0.0)) or 0.0)
+            if pmc_ms > 0 and abs(pmc_ms - kernel_ms) <= 0.05 * kernel_ms:
+                traffic = float(tj["traffic_bytes"])
+                traffic_source = (f"{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape, scripts/pmc_all.py; launch {pmc_ms:.2f} ms "
+                                  f"under counters vs {kernel_ms:.2f} ms live: within 5 %; not re-measured by this run)")
+            else:
+                traffic_source = f"{tfile} NOT quoted: its launch time {pmc_ms:.2f} ms is not within 5 % of the live {kernel_ms:.2f} ms"
     except Exception:
         traffic, traffic_source = None, None
     roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F64_MFMA_TFLOPS, unit="TFLOP/s",

@@ -54,6 +54,7 @@ struct BqrrpLaps {
     long recon = 0;       // cholqr panels: Householder reconstruction, signs, R11 = R_chol * R_sk
     long apply = 0;       // Q^T applied to the trailing columns
     long upd_sk = 0;      // sketch down-date
+    long lookaheads = 0;  // (not a time) block iterations whose down-date + next QRCP ran on the side queue
 };
 
 template <typename T>
@@ -68,6 +69,8 @@ struct BqrrpOpts {
     T cholqr_cond_limit_inv;
     bool timing;
     bool lookahead = true;     // run the sketch down-date and the next QRCP of the sketch BESIDE the trailing update (see bqrrp_factor)
+    double lookahead_min_elems = 2.5e8;   // ... from m * n elements on (a side queue costs a scratch arena; 8192^2 measured +1 %, 16384^2 -1.4 %, 65536^2 -2.5 %)
+    int64_t lookahead_min_block = 256;    // ... and from this block size on
 };
 
 /// The blocked loop of BQRRP (rl_bqrrp.hh:318-661) and of BQRRP_GPU (rl_bqrrp_gpu.hh:336-934) on one device: both classes run
@@ -115,12 +118,12 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
     // on a SIDE queue (own high-priority stream) right behind the head and run beside the tail; the main stream joins it before it touches
     // A again.  The same operations on the same data in the same order (the tail goes through the tiled GEMM kernel instead of the persistent
     // one, whose workgroups would hold every CU: different rounding of that one product, nothing else).  Off when the subroutines are timed
-    // (every lap drains the streams) and for small problems (a side queue costs a scratch arena).
+    // (every lap drains the streams) and for small problems (a side queue costs a scratch arena): BQRRP::lookahead, ::lookahead_min_elems and
+    // ::lookahead_min_block are members, so a test forces the side-queue path at any size and compares it with the serial loop.
     // What it buys is limited by how badly the latency-bound panel kernels run BESIDE a GEMM that saturates the memory system: at C4 the LU of
     // the sketch takes 55 ms beside the tail against 15 ms alone, and the cooperative sketch QR waits for the tail's last workgroups
     // (rocprofv3 trace): 4.39 -> 4.27 s.
-    static const bool la_env = [] { const char* e = std::getenv("RLHIP_BQRRP_LOOKAHEAD"); return !(e && std::atoi(e) == 0); }();
-    const bool la_ok = P.lookahead && la_env && !P.timing && (double)m * (double)n >= 2.5e8 && b_sz_const >= 256;   // (16384^2: -1.4 %, 65536^2: -2.5 %; 8192^2: +1 %)
+    const bool la_ok = P.lookahead && !P.timing && (double)m * (double)n >= P.lookahead_min_elems && b_sz_const >= P.lookahead_min_block;
     std::unique_ptr<blas::Queue> side;
     T* W2_la = la_ok ? ws.try_alloc<T>(b_sz_const * n) : nullptr;
     bool pre_on_side = false;          // this iteration's sketch (down-dated) lives on the side stream: its QRCP goes there too
@@ -226,6 +229,8 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
             // one compact-WY block and a next panel to prepare: head on the main stream, the side queue starts behind it, tail on the main stream
             la = la_ok && W2_la && more && (!use_t || inb >= block_rank) && q_rows > block_rank;
             if (la) {
+                ++L.lookaheads;
+                rlhip_path_note(q.ctx(), 12, 1);
                 if (!side) side = std::make_unique<blas::Queue>(q, typename blas::Queue::Side{});
                 const T* Tptr = T_dat;
                 int64_t ldt = b_sz_const;
@@ -315,9 +320,11 @@ public:
         }
         if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_sk, d, sketch_export, d, q);
         const long t_skop = us(t_begin, stamp());
-        detail::BqrrpOpts<T> P{block_size, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, cholqr_fallback, cholqr_cond_limit_inv, timing};
+        detail::BqrrpOpts<T> P{block_size, internal_nb, tol, qrcp_wide, qr_tall, apply_trans_q, cholqr_fallback, cholqr_cond_limit_inv, timing,
+                               lookahead, lookahead_min_elems, lookahead_min_block};
         detail::BqrrpLaps L;
         detail::bqrrp_factor(q, P, m, n, A, lda, A_sk, d, tau, J, rank, cholqr_fallbacks, L);
+        lookaheads = L.lookaheads;
         if (timing) {                // the reference's 9 entries (:581-590); the laps of the shared loop are finer (BQRRP_GPU reports all of them)
             q.sync();
             const long total = us(t_begin, clk::now());
@@ -532,6 +539,13 @@ public:
     bool cholqr_fallback = true;      // qr_tall = cholqr: a panel whose Cholesky factorization breaks down is factored by geqrf instead
     int64_t cholqr_fallbacks = 0;     // number of panels of the last call that took that route
     T cholqr_cond_limit_inv = std::pow(std::numeric_limits<T>::epsilon(), (T)0.25);   // min/max of diag(R_chol) below this (1.2e-4 in double) = ill-conditioned panel
+    // (not in the reference) look-ahead: the sketch down-date and the next QRCP of the sketch run on a side queue beside the tail of the
+    // compact-WY apply (detail::bqrrp_factor).  Same operations on the same data in the same order; engaged for untimed calls from
+    // lookahead_min_elems = m * n elements and lookahead_min_block columns per block on.  lookaheads = iterations of the last call that took it.
+    bool lookahead = true;
+    double lookahead_min_elems = 2.5e8;
+    int64_t lookahead_min_block = 256;
+    int64_t lookaheads = 0;
     bool rows_block_cyclic = false;   // sharded queue only: rows are dealt to the ranks in blocks of block_size (see call_sharded)
     // testing hooks (not in the reference): the d x n sketch to use instead of S*A, and a buffer receiving the sketch
     const T* sketch_override = nullptr;

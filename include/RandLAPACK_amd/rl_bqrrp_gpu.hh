@@ -65,12 +65,14 @@ public:
         const auto t_begin = clk::now();
         detail::BqrrpOpts<T> P{block_size, /*internal_nb*/ block_size, tol, BQRRPSubroutines::QRCPWide::luqr,
                                qr_tall == GPUSubroutine::QRTall::cholqr ? BQRRPSubroutines::QRTall::cholqr : BQRRPSubroutines::QRTall::geqrf,
-                               BQRRPSubroutines::ApplyTransQ::gemqrt, cholqr_fallback, cholqr_cond_limit_inv, timing};
+                               BQRRPSubroutines::ApplyTransQ::gemqrt, cholqr_fallback, cholqr_cond_limit_inv, timing,
+                               lookahead, lookahead_min_elems, lookahead_min_block};
         detail::BqrrpLaps L;
         // "Preallocation" (rl_bqrrp_gpu.hh:213-334: eleven cudaMallocAsync + workspace queries): here one reservation in the
         // queue's stream-ordered arena at the top of the loop function -- nothing to time separately, the entry reads ~0.
         const long prealloc = 0;
         detail::bqrrp_factor(q, P, m, n, A, lda, A_sk, d, tau, J, rank, cholqr_fallbacks, L);
+        lookaheads = L.lookaheads;
         if (timing) {
             q.sync();
             const long total = us(t_begin, clk::now());
@@ -114,6 +116,10 @@ public:
     bool print_timing = false;        // write the timing block to stdout at the end of a timed call, as the reference always does
     bool cholqr_fallback = true;      // qr_tall = cholqr: Householder refactorization of a panel whose Cholesky QR is unsafe (see BQRRP)
     int64_t cholqr_fallbacks = 0;
+    bool lookahead = true;            // (not in the reference) see BQRRP::lookahead
+    double lookahead_min_elems = 2.5e8;
+    int64_t lookahead_min_block = 256;
+    int64_t lookaheads = 0;
     T cholqr_cond_limit_inv = std::pow(std::numeric_limits<T>::epsilon(), (T)0.25);
 };
 

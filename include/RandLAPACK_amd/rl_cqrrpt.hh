@@ -47,10 +47,9 @@ public:
         panel_pivoting = 1;
         orthogonalization = false;
         rank = 0;
-        const char* fe = std::getenv("RLHIP_CQRRPT_FOLD_PIVOTING");
-        fold_pivoting = !(fe && std::atoi(fe) == 0);
-        const char* se = std::getenv("RLHIP_CQRRPT_SPLIT_QRCP");
-        split_qrcp = !(se && std::atoi(se) == 0);
+        fold_pivoting = true;
+        split_qrcp = true;
+        split_cols = 0;
     }
 
     /// A (m x n, lda, DEVICE) is overwritten by Q (first `rank` columns orthonormal), R (n x n, ldr, DEVICE) receives
@@ -139,23 +138,31 @@ public:
             else {
                 // (allocated BEFORE the solve below is enqueued: that call releases its own scratch -- the packed triangle its kernel is still
                 //  reading -- when it returns, and the arena is ordered by the main stream only; the side stream writes J2 beside that kernel)
+                rlhip_path_note(q.ctx(), 13, 1);
                 int64_t* J2 = ws.alloc<int64_t>(n - h);
+                T* R_lead = ws.alloc<T>(h * h);                                          // the leading h x h triangle of R_sk for the speculative half solve
                 lapack::geqp3_steps(d, n, h, A_hat, d, J, tau, q);
+                // the side queue is ordered HERE, behind the first half of the factorization and its copy-back and before the half solve is
+                // enqueued: the second half (side queue) then runs beside the solve, and never beside the kernels that still write A_hat
+                // (the ordering used to rest on a host wait inside the solve's call)
+                blas::Queue side(q, blas::Queue::CachedSide{});
+                side.wait_for(q);
                 // The half solve is SPECULATIVE: it goes out right behind the first half of the factorization, without a look at the leading
                 // diagonal of R_sk (a host round trip with the device idle).  A leading block that is singular or graded beyond the solve's
                 // conditioning guard closes the gate of the launch (nothing is written, `half_solved` stays false); one that merely fails the
                 // rank criterion below produces a left half nobody reads -- the rank decision then takes the reference's in-place order.
-                lapack::lacpy(MatrixType::Upper, h, h, A_hat, d, R, ldr, q);
-                half_solved = blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W_early, ldw_of(m), 0, h, q);
+                // (the triangle is packed into SCRATCH, not into the caller's R: when the sketch turns out rank deficient below h, or all zero,
+                //  rows of R that the one-piece order and the reference leave untouched stay untouched -- ADVICE r4)
+                lapack::laset(MatrixType::General, h, h, (T)0, (T)0, R_lead, h, q);
+                lapack::lacpy(MatrixType::Upper, h, h, A_hat, d, R_lead, h, q);
+                half_solved = blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R_lead, h, A, lda, J, W_early, ldw_of(m), 0, h, q);
                 {
-                    blas::Queue side(q, blas::Queue::CachedSide{});
                     // the second half is packed into few, full workgroups (up to 16 columns each, ~100 KiB of LDS): it leaves the other CUs to
                     // the solve and loses little itself (768 x 512: 3.5 ms with 4 columns per workgroup, 4.9 with 16; C3: 71.3 / 70.3 / 69.6 ms
-                    // with 4 / 8 / 16).  RLHIP_CQRRPT_SPLIT_COLS overrides.
+                    // with 4 / 8 / 16).  split_cols > 0 overrides.
                     int64_t cols = (100 * 1024) / ((d - h) * (int64_t)sizeof(T));
                     cols = cols < 4 ? 4 : (cols > 16 ? 16 : cols);
-                    const char* ce = std::getenv("RLHIP_CQRRPT_SPLIT_COLS");
-                    if (ce && std::atoi(ce) > 0) cols = std::atoi(ce);
+                    if (split_cols > 0) cols = split_cols;
                     side.set_qrcp_cols(half_solved ? (int)cols : 0);
                     lapack::geqp3(d - h, n - h, A_hat + h + h * d, d, J2, tau + h, side);
                     side.set_qrcp_cols(0);                                              // (the cached side queue goes back to its default)
@@ -335,11 +342,12 @@ public:
     int64_t use_cholqr;
     bool orthogonalization;
     // (not in the reference) the column pivoting is folded into the first preconditioning solve instead of a separate pass over A;
-    // false restores the reference's statement order col_swap -> trsm -> syrk -> trsm, all in place (RLHIP_CQRRPT_FOLD_PIVOTING=0)
+    // false restores the reference's statement order col_swap -> trsm -> syrk -> trsm, all in place
     bool fold_pivoting;
-    // (not in the reference) geqp3 of the sketch in two halves with the left half of the first solve beside the second one; false (or
-    // RLHIP_CQRRPT_SPLIT_QRCP=0) keeps the one-piece order
+    // (not in the reference) geqp3 of the sketch in two halves with the left half of the first solve beside the second one; false keeps the
+    // one-piece order.  split_cols: columns per workgroup of the second half (0 = auto, <= 16)
     bool split_qrcp;
+    int64_t split_cols;
     // testing hooks (not in the reference): a d x n sketch to use instead of S*A / a buffer receiving the sketch
     const T* sketch_override = nullptr;
     T* sketch_export = nullptr;

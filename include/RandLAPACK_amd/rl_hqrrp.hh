@@ -120,7 +120,7 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
             // 54 ms, 88 % of hqrrp at 16384^2).  A = Q R has the same pivoted QR as its b x b factor R (equal partial column norms at every
             // step), so the pivots come from the QRCP of R -- R from the row-parallel unpivoted geqrf of a copy -- and the reflectors from
             // the unpivoted geqrf of the permuted panel: identical to the pivoted sweep up to rounding, ties aside.
-            static const bool tall_split = [] { const char* e = std::getenv("RLHIP_HQRRP_TALL_PANEL"); return !(e && std::atoi(e) == 0); }();
+            const bool tall_split = rlhip_get_option(q.ctx(), RLHIP_OPT_HQRRP_TALL_PANEL) != 0;      // (default on; 0: the reference's single pivoted sweep)
             if (tall_split && b >= 16 && m_AB1 >= 8 * b) {
                 blas::Scratch w2(q);
                 T* P = w2.alloc<T>(m_AB1 * b);

@@ -41,6 +41,29 @@ int rlhip_create(rlhip_ctx** ctx, int device, void* hip_stream, int own_stream);
 int rlhip_create_side(rlhip_ctx* parent, rlhip_ctx** out);
 int rlhip_order_after(rlhip_ctx* waiter, rlhip_ctx* signaler);
 int rlhip_destroy(rlhip_ctx* ctx);
+/* ---- per-context options: the library's supported switches (value -1 = the default; a side context inherits its parent's at creation).
+ *      Everything else about kernel selection is decided from the shapes alone -- there are no environment switches for kernels; the
+ *      environment only carries diagnostics (RLHIP_SK_CLOCK, RLHIP_JACOBI_CLOCK, RLHIP_SK_TUNE, RLHIP_GESDD_TRACE, RLHIP_POOL_TRACE) and
+ *      RLHIP_COMM_SINGLE_RANK_NCCL (build a real one-rank RCCL communicator).
+ *      The first group selects between two routes of this library that deliver the same result (tests compare them, bitwise where
+ *      stated); the RLHIP_OPT_DRV_* group holds defaults that the rlhip_drv_* entry points (rlhip_drivers.h) hand to the C++ objects
+ *      they construct -- C++ callers set the members of the same name on their own objects. */
+enum rlhip_option {
+    RLHIP_OPT_CHOLQRQ_ONE_STREAM = 0,   /* 1: rlhip_cholqrq_* serves tall 256-aligned inputs as one stream of kernels; 0: returns 1 (caller runs syrk, potrf, trsm) */
+    RLHIP_OPT_GESDD_GRAM = 1,           /* 1: device SVD of a well-conditioned tall factor, 32 < k <= 256, by Jacobi on its Gram matrix; 0: classic route always */
+    RLHIP_OPT_JACOBI_PERSIST = 2,       /* 1: all Jacobi sweeps in one cooperative launch; 0: one launch per round (what rocprofv3 --pmc can profile) */
+    RLHIP_OPT_TRSM_XASM = 3,            /* fused solve: X loads issued from inline asm (1) or plain loads (0); default = what scripts/check_trsm_asm.py proved for this build */
+    RLHIP_OPT_SASO_MODE = 4,            /* rlhip_saso_create: 1 independent columns (RandBLAS's short-axis SASO), 0 block-affine family */
+    RLHIP_OPT_HQRRP_TALL_PANEL = 5,     /* hqrrp: 1 pivots of a tall panel from the QRCP of its R factor; 0: one pivoted sweep (the reference's order) */
+    RLHIP_OPT_DRV_BQRRP_LOOKAHEAD_MIN_ELEMS = 6,   /* BQRRP::lookahead_min_elems (default 2.5e8; 0 = whenever the shapes allow, a huge value = never) */
+    RLHIP_OPT_DRV_BQRRP_CHOLQR_FALLBACK = 7,       /* BQRRP::cholqr_fallback (default 1; 0 = the reference's behaviour on a Cholesky breakdown) */
+    RLHIP_OPT_DRV_CQRRPT_FOLD_PIVOTING = 8,        /* CQRRPT::fold_pivoting (default 1) */
+    RLHIP_OPT_DRV_CQRRPT_SPLIT_QRCP = 9,           /* CQRRPT::split_qrcp (default 1) */
+    RLHIP_OPT_DRV_SPARSE_SKETCH_DENSIFY = 10,      /* linops::SparseLinOp::force_densified_sketch (default 0) */
+    RLHIP_OPT_COUNT = 11
+};
+int rlhip_set_option(rlhip_ctx* ctx, int option, int64_t value);     /* -1 (bad context / option) or 0 */
+int64_t rlhip_get_option(rlhip_ctx* ctx, int option);                /* the stored value (-1 = default), INT64_MIN for a bad option */
 int rlhip_sync(rlhip_ctx* ctx);
 void* rlhip_stream(rlhip_ctx* ctx);
 int rlhip_malloc(rlhip_ctx* ctx, void** dev_ptr, size_t bytes);
@@ -388,8 +411,13 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
  * 5 sketch-preconditioned Cholesky-QR panel inside geqrf (house.hip), 6 persistent one-launch Jacobi sweeps (jacobi.hip),
  * 7 column-at-a-time LU panel of a matrix taller than the resident register kernels hold (lu.hip), 8 register-resident block-pipelined
  * Householder QR of a sketch-sized matrix (qr_blk.hip), 9 its sign-modified LU twin inside orhr_col, 10 the Gram route of the device SVD
- * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read), 11 the one-stream Cholesky-QR (rlhip_cholqrq).  -1 for an unknown index.  Tests use it to assert that the kernel under test is the one that ran. */
+ * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read), 11 the one-stream Cholesky-QR (rlhip_cholqrq),
+ * 12 block iterations of BQRRP whose sketch down-date and next QRCP ran on the side queue (the look-ahead of rl_bqrrp.hh; noted by the C++
+ * layer through rlhip_path_note), 13 CQRRPT calls that took the split order (rl_cqrrpt.hh).  -1 for an unknown index.  Tests use it to
+ * assert that the kernel / route under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
+/* the host layers above this ABI (include/RandLAPACK_amd/) report their own route decisions into the same counters */
+int rlhip_path_note(rlhip_ctx* ctx, int which, int64_t delta);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);
 /* diagnostic: keep `blocks` workgroups busy for `usec` microseconds (mode 0 sleeping, 1 fp64 FMA chain, 2 fp64 MFMA stream), on the context's

@@ -117,6 +117,9 @@ SIGNATURES = {
     "rlhip_col_swap_i64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_luqrcp_piv": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_path_count": (c_i64, [c_vp, c_int]),
+    "rlhip_path_note": (c_int, [c_vp, c_int, c_i64]),
+    "rlhip_set_option": (c_int, [c_vp, c_int, c_i64]),
+    "rlhip_get_option": (c_i64, [c_vp, c_int]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),
     "rlhip_dvfs_burn": (c_int, [c_vp, c_int, c_int, c_int, c_int]),
     "rlhip_hbm_read_peak": (c_int, [c_vp, c_vp, c_sz, C.POINTER(c_dbl)]),

@@ -184,6 +184,7 @@ int rlhip_create_side(rlhip_ctx* parent, rlhip_ctx** out) {
     const int rc = rlhip_create(out, parent->device, (void*)st, 0);
     if (rc) { hipStreamDestroy(st); return rc; }
     (*out)->owns_stream = true;
+    for (int i = 0; i < RLHIP_OPT_COUNT; ++i) (*out)->opt[i] = parent->opt[i];
     (*out)->avoid_persistent = 1;        // a side context shares the device by definition: no kernel of its own may wait for every CU to be free
     return 0;
 }
@@ -207,6 +208,17 @@ int rlhip_set_qrcp_cols(rlhip_ctx* c, int cols) {
     if (!c || cols < 0) return -1;
     c->qrcp_cols_per_wg = cols;
     return 0;
+}
+
+int rlhip_set_option(rlhip_ctx* c, int option, int64_t value) {
+    if (!c || option < 0 || option >= RLHIP_OPT_COUNT) return -1;
+    c->opt[option] = value;
+    if (c->side_ctx) c->side_ctx->opt[option] = value;
+    return 0;
+}
+int64_t rlhip_get_option(rlhip_ctx* c, int option) {
+    if (!c || option < 0 || option >= RLHIP_OPT_COUNT) return INT64_MIN;
+    return c->opt[option];
 }
 
 int rlhip_order_after(rlhip_ctx* waiter, rlhip_ctx* signaler) {
@@ -742,7 +754,12 @@ extern "C" int rlhip_dvfs_burn(rlhip_ctx* c, int blocks, int mode, int usec, int
 }
 
 extern "C" int64_t rlhip_path_count(rlhip_ctx* c, int which) {
-    return (c && which >= 0 && which < 12) ? c->path_count[which] : -1;
+    return (c && which >= 0 && which < 16) ? c->path_count[which] : -1;
+}
+extern "C" int rlhip_path_note(rlhip_ctx* c, int which, int64_t delta) {
+    if (!c || which < 0 || which >= 16) return -1;
+    c->path_count[which] += delta;
+    return 0;
 }
 
 extern "C" int rlhip_mfma_peak(rlhip_ctx* c, int is_f64, int iters, double* tflops) {

@@ -37,6 +37,23 @@ std::unique_ptr<RandLAPACK::Stabilization<T>> make_stab(blas::Queue& q, int kind
     }
 }
 
+// Defaults that the context's options (rlhip_set_option, RLHIP_OPT_DRV_*) hand to the objects these entry points construct; -1 keeps the
+// object's own default.  C++ callers set the members themselves.
+template <typename Alg>
+void apply_bqrrp_options(rlhip_ctx* ctx, Alg& alg) {
+    const int64_t la = rlhip_get_option(ctx, RLHIP_OPT_DRV_BQRRP_LOOKAHEAD_MIN_ELEMS);
+    if (la >= 0) { alg.lookahead_min_elems = (double)la; if (la == 0) alg.lookahead_min_block = 1; }   // 0: the side-queue path whenever the dependency structure allows it
+    const int64_t fb = rlhip_get_option(ctx, RLHIP_OPT_DRV_BQRRP_CHOLQR_FALLBACK);
+    if (fb >= 0) alg.cholqr_fallback = (fb != 0);
+}
+template <typename Alg>
+void apply_cqrrpt_options(rlhip_ctx* ctx, Alg& alg) {
+    const int64_t fp = rlhip_get_option(ctx, RLHIP_OPT_DRV_CQRRPT_FOLD_PIVOTING);
+    if (fp >= 0) alg.fold_pivoting = (fp != 0);
+    const int64_t sq = rlhip_get_option(ctx, RLHIP_OPT_DRV_CQRRPT_SPLIT_QRCP);
+    if (sq >= 0) alg.split_qrcp = (sq != 0);
+}
+
 template <typename F>
 int guarded(F&& f) {
     try {
@@ -62,7 +79,7 @@ std::unique_ptr<lo::DenseLinOp<T>> make_dense(blas::Queue& q, const rlhip_linop_
 template <typename T>
 std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_linop_desc& d) {
     auto op = std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
-    if (const char* e = std::getenv("RLHIP_SPARSE_SKETCH_DENSIFY")) op->force_densified_sketch = (e[0] == '1');   // test knob: fallback path
+    op->force_densified_sketch = rlhip_get_option(q.ctx(), RLHIP_OPT_DRV_SPARSE_SKETCH_DENSIFY) == 1;              // (tests: the fallback path)
     op->row_sharded = q.world() > 1;
     return op;
 }
@@ -266,6 +283,7 @@ int rlhip_drv_cqrrpt_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::CQRRPT<double, RNG> alg(q, times_us != nullptr, eps);
+        apply_cqrrpt_options(ctx, alg);
         alg.nnz = nnz;
         if (qrcp >= 16) { alg.orthogonalization = true; qrcp -= 16; }      // +16: CQRRPT::orthogonalization = true (rl_cqrrpt.hh:347-367)
         if (qrcp >= 0) {
@@ -321,7 +339,7 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
         if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
-        if (const char* e = std::getenv("RLHIP_BQRRP_CHOLQR_FALLBACK")) alg.cholqr_fallback = (e[0] != '0');   // test knob: reference behaviour on a Cholesky breakdown
+        apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
         if (internal_nb > 0) alg.internal_nb = internal_nb;
@@ -383,6 +401,7 @@ static int drv_bqrrp_gpu(rlhip_ctx* ctx, int64_t m, int64_t n, T* A, int64_t lda
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::BQRRP_GPU<T, RNG> alg(q, times15 != nullptr, b_sz);
+        apply_bqrrp_options(ctx, alg);
         using Sub = RandLAPACK::BQRRPGPUSubroutines;
         if (qr_tall >= 0) {
             if (qr_tall > 1) throw RandLAPACK::Error("BQRRP_GPU qr_tall must be 0 (cholqr) or 1 (geqrf)");
@@ -482,6 +501,7 @@ int rlhip_drv_cqrrpt_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t
     return guarded([&] {
         blas::Queue q(ctx);
         RandLAPACK::CQRRPT<float, RNG> alg(q, times_us != nullptr, eps);
+        apply_cqrrpt_options(ctx, alg);
         alg.nnz = nnz;
         if (qrcp >= 16) { alg.orthogonalization = true; qrcp -= 16; }      // +16: CQRRPT::orthogonalization = true (rl_cqrrpt.hh:347-367)
         if (qrcp >= 0) {
@@ -522,7 +542,7 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
         if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
-        if (const char* e = std::getenv("RLHIP_BQRRP_CHOLQR_FALLBACK")) alg.cholqr_fallback = (e[0] != '0');   // test knob: reference behaviour on a Cholesky breakdown
+        apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
         if (internal_nb > 0) alg.internal_nb = internal_nb;

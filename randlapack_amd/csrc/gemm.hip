@@ -590,9 +590,7 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     // its whole K, which is only accurate up to ~16k products (gemm_sk.hip) -- so the contraction is cut into chunks of 16384 that
     // accumulate into C (beta = 1 from the second chunk on): the rounding behaviour of a 4-way split-K at the persistent kernel's rate.
     if (sizeof(T) == 4 && !tri && !transB && k > 16384 && k % SKK == 0 && m >= 128 && n % 256 == 0 && !ssqA_dev) {
-        static int chunk_on = -1;
-        if (chunk_on < 0) { const char* e = getenv("RLHIP_STREAMK_F32_CHUNK"); chunk_on = (e && atoi(e) == 0) ? 0 : 1; }
-        if (chunk_on) {
+        {
             const int64_t KC = 16384;
             for (int64_t k0 = 0; k0 < k; k0 += KC) {
                 const int64_t kc = (k - k0 < KC) ? (k - k0) : KC;
@@ -625,9 +623,7 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
         }
     }
     if (!tri && m <= 512 && n <= 512 && k <= 2048 && m * n >= 1024 && ((m + 127) / 128) * ((n + 127) / 128) <= 16) {
-        static int small_on = -1;
-        if (small_on < 0) { const char* e = getenv("RLHIP_GEMM_SMALL"); small_on = (e && atoi(e) == 0) ? 0 : 1; }
-        if (small_on) {
+        {
             // op(A)(i, kk): NoTrans A[i + kk lda], Trans A[kk + i lda];  op(B)(kk, j): NoTrans B[kk + j ldb], Trans B[j + kk ldb]
             hipLaunchKernelGGL(gemm_small_kernel<T>, dim3((unsigned)((m + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, c->stream, (int)m, (int)n, (int)k, alpha, A,
                                transA ? lda : (int64_t)1, transA ? (int64_t)1 : lda, B, transB ? ldb : (int64_t)1, transB ? (int64_t)1 : ldb, beta, C, ldc);

@@ -537,20 +537,13 @@ template <typename T>
 int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B,
                  int64_t ldb, T beta, T* C, int64_t ldc, double* ssqA_dev, int tri) {
     constexpr int BK = SkT<T>::BK, EPP = SkT<T>::EPP;
-    static int enabled = -1, enabled_f32 = -1;
-    if (enabled < 0) {
-        const char* e = getenv("RLHIP_STREAMK");
-        enabled = e ? atoi(e) : 1;
-        const char* f = getenv("RLHIP_STREAMK_F32");
-        enabled_f32 = f ? atoi(f) : 1;
-    }
     const int num_cu = c->num_cu;
-    if (!enabled || transB || (sizeof(T) == 4 && !enabled_f32) || c->avoid_persistent) return 0;
+    if (transB || c->avoid_persistent) return 0;
     // fp32: the kernel carries ONE fma chain per output entry through the whole K of a tile.  Beyond ~16k products the rounding of the
     // growing partial sum (eps * K / sqrt 2) is 2-3x that of a cache-blocked host sgemm or of the split-K generic kernel (measured on
     // BQRRP 65536^2: residual per column 4e-5 -> 7.5e-5; a second accumulator level costs more registers than the kernel has: 137 ->
-    // 123 TFLOP/s), so longer contractions stay on the generic kernel.  RLHIP_STREAMK_F32=2 lifts the cap (A/B measurements).
-    if (sizeof(T) == 4 && k > 16384 && enabled_f32 != 2) return 0;
+    // 123 TFLOP/s), so longer contractions are cut into accumulating chunks of 16384 by the caller (gemm.hip).
+    if (sizeof(T) == 4 && k > 16384) return 0;
     if (n % BN || k % BK || m < BM || n <= 0 || k <= 0) return 0;
     if (m % BM && (tri || (m % BM) % EPP)) return 0;          // a partial last tile row: whole 16-byte pieces only, never in the tri map
     if (((uintptr_t)A | (uintptr_t)B) % 16 || lda % EPP || ldb % EPP) return 0;    // 16-byte aligned DMA pieces

@@ -469,9 +469,7 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
     // one more BLAS-3 attempt in the manner of CQRRT (rl_cqrrt.hh:124-200): a sparse sketch S A (2n rows), its small QR, and
     // A R_sk^-1 has condition O(1) whatever A's was (short of numerical rank deficiency), so Cholesky-QR twice goes through and
     // R = R_chol R_sk.  The sketch uses a fixed counter: the factorization stays a deterministic function of A.
-    static int precond_on = -1;
-    if (precond_on < 0) { const char* e = getenv("RLHIP_GEQRF_PRECOND"); precond_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!good && precond_on && m >= 8 * n && n >= 2) {
+    if (!good && m >= 8 * n && n >= 2) {
         const int64_t d = 2 * n > n + 32 ? 2 * n : n + 32;
         T* Acopy = ws_alloc<T>(c, (size_t)m * n);
         T* Ask = ws_alloc<T>(c, (size_t)d * n);

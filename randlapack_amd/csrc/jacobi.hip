@@ -770,23 +770,12 @@ int jacobi_verify_converged(rlhip_ctx* c, int m, int n, const T* A, int64_t lda,
     return 0;
 }
 
-struct JpHold { int mode = 1, nap = 4, delay = 0, wgs = 1 << 20; };
-static const JpHold& jp_hold() {
-    static JpHold h;
-    static bool read = false;
-    if (!read) {
-        read = true;
-        if (const char* e = getenv("RLHIP_JACOBI_HOLD")) sscanf(e, "%d,%d,%d,%d", &h.mode, &h.nap, &h.delay, &h.wgs);   // mode (0 off), naps per burst, delay (us), holder workgroups
-    }
-    return h;
-}
-
-// lanes per column pair in the rotation rounds (RLHIP_JACOBI_QW = 16 (default) | 32, read once): see jacobi_pair_rounds
-static int jacobi_qw() {
-    static int qw = 0;
-    // measured at k = 256: 16 -> 10.88 ms per 1/8-shard RSVD step, 32 -> 10.98
-    if (!qw) { const char* e = getenv("RLHIP_JACOBI_QW"); qw = (e && atoi(e) == 32) ? 32 : 16; }
-    return qw;
+// Clock holders: bursts of FMAs with 4 naps between on every CU the workers leave idle.  A context that SHARES the device with
+// another stream (a side context, or one that adopted a caller's stream: avoid_persistent) launches the workers alone -- holders would
+// take CUs from the other stream's kernels and make this launch wait for the whole device.
+struct JpHold { int mode, nap, delay, wgs; };
+static JpHold jp_hold(const rlhip_ctx* c) {
+    return c->avoid_persistent ? JpHold{0, 4, 0, 0} : JpHold{1, 4, 0, 1 << 20};
 }
 
 // clears the flag words and enqueues ONE persistent launch; g.A / lda / trans_upper / skip / sweep0 / max_sweeps / tol / out are the caller's
@@ -795,7 +784,7 @@ int jp_launch_qw(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int
     constexpr int JB = 16, JMT = JM;
     const int NW = NBk / 2;
     const size_t xwords = (size_t)NBk * JB * m;
-    const JpHold& h = jp_hold();
+    const JpHold h = jp_hold(c);
     g.m = m; g.NB = NBk; g.X = buf; g.bflag = buf + xwords; g.sflag = g.bflag + NBk; g.done = g.sflag + 8 * (size_t)NW;
     g.hold_mode = h.mode; g.hold_nap = h.nap; g.hold_delay_us = h.delay;
     hipError_t e1 = hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 8 * (size_t)NW + 1) * sizeof(unsigned long long), c->stream);
@@ -817,7 +806,7 @@ int jp_launch_qw(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int
 
 template <typename T>
 int jp_launch(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int NBk) {
-    return jacobi_qw() == 16 ? jp_launch_qw<T, 16>(c, g, buf, m, NBk) : jp_launch_qw<T, 32>(c, g, buf, m, NBk);
+    return jp_launch_qw<T, 16>(c, g, buf, m, NBk);     // a quarter wave per column pair (a half wave was measured slower: 10.98 against 10.88 ms per shard step)
 }
 
 // Sweeps of the persistent kernel (V not accumulated).  Returns 0 and the number of sweeps when it ran to a verdict, 1 when the path is
@@ -833,7 +822,7 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
     const int NW = NBk / 2;
     if (NW > c->num_cu || NW > 512) return 1;
     const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1;
-    const int hold = jp_hold().mode;
+    const int hold = jp_hold(c).mode;
     unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
     size_t mark = rlhip_ws_mark(c);
     int* out = ws_alloc<int>(c, 32);
@@ -913,7 +902,6 @@ int block_jacobi_sweeps_qw(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, 
 template <typename T, int JB, int JMT>
 int block_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, T tol, unsigned* d_nrot, int max_sweeps, int* sweeps_out) {
     // (32-wide blocks with 32 lanes per pair would need 1024 rotating threads AND leave no wave to spare: they keep the quarter-wave layout)
-    if (JB == 16 && jacobi_qw() == 32) return block_jacobi_sweeps_qw<T, JB, JMT, (JB == 16 ? 32 : 16)>(c, m, n, A, lda, V, tol, d_nrot, max_sweeps, sweeps_out);
     return block_jacobi_sweeps_qw<T, JB, JMT, 16>(c, m, n, A, lda, V, tol, d_nrot, max_sweeps, sweeps_out);
 }
 
@@ -937,8 +925,7 @@ int jacobi_enqueue_rt(rlhip_ctx* c, int n, const T* R, int64_t ldr, int trans_up
     else {
         constexpr int JB = 16;
         if (n <= 32 || n > JM) return 1;
-        const char* pe = getenv("RLHIP_JACOBI_PERSIST");
-        if (pe && atoi(pe) == 0) return 1;
+        if (c->opt[RLHIP_OPT_JACOBI_PERSIST] == 0) return 1;
         int NBk = (n + JB - 1) / JB;
         if (NBk % 2) ++NBk;
         const int NW = NBk / 2;
@@ -1011,8 +998,7 @@ int gesvdj(rlhip_ctx* c, int64_t m, int64_t n64, T* A, int64_t lda, T* S, T* VT,
     if (n > 1 && m <= 2 * JM && sizeof(T) == 8) {
         // LDS-resident block Jacobi (see jacobi_block_kernel)
         constexpr int jb_sel = 16;         // block width (32: half the launches, four times the pairs per launch -- measured slower)
-        const char* pe = getenv("RLHIP_JACOBI_PERSIST");          // read per call: tests switch paths inside one process
-        const bool persist = !(pe && atoi(pe) == 0);
+        const bool persist = c->opt[RLHIP_OPT_JACOBI_PERSIST] != 0;
         bool done = false;
         if constexpr (sizeof(T) == 8) {
             // singular values / left vectors only and at most 256 rows: all sweeps in one resident launch (see jacobi_persist_kernel)

@@ -719,11 +719,6 @@ static unsigned laswp_grid(int64_t ncols) {
     return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
-static int reg_panel_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("RLHIP_LU_REG_PANEL"); v = (e && atoi(e) == 0) ? 0 : 1; }
-    return v;
-}
 
 template <typename T>
 int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_dev, int* info_host, int pivots_only) {
@@ -742,9 +737,7 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
     g.cand_val = ws_alloc<T>(c, 2 * Gmax); g.cand_row = ws_alloc<int64_t>(c, 2 * Gmax);
     g.cand_data = ws_alloc<T>(c, (size_t)2 * Gmax * PB); g.diag_data = ws_alloc<T>(c, 2 * PB + 64);
     g.bar = ws_alloc<unsigned>(c, 4); g.info = (int*)ws_alloc<int>(c, 4);
-    static int tag_on = -1;
-    if (tag_on < 0) { const char* e = getenv("RLHIP_LU_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
-    const bool use_tag = tag_on && m < ((int64_t)1 << 31);
+    const bool use_tag = m < ((int64_t)1 << 31);
     constexpr size_t TW = sizeof(T) / 4;
     // (the general register kernel may run more workgroups than CUs: the word buffer is sized -- and cleared -- for the largest grid of this call)
     const int64_t Gtw = std::max<int64_t>(Gmax, (m + 511) / 512 + 1);
@@ -758,15 +751,13 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         RLHIP_CHECK(hipMemsetAsync(g.tw, 0, tw_words * sizeof(unsigned long long), c->stream));
     }
     if (!g.cand_val || !g.cand_row || !g.cand_data || !g.diag_data || !g.bar || !g.info) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    // Two-level blocking (RLHIP_LU_OUTER = 64, 128, ...): the 32-column panel steps then update only the columns of their own
+    // Two-level blocking: the 32-column panel steps then update only the columns of their own
     // OUTER block; everything to the right of it gets the block's interchanges, one block forward substitution and ONE rank-nbo GEMM
     // when the block is finished.  Pays for very tall matrices only (numbers below); round 1 measured it slower everywhere because the
     // panel kernel, not the updates, dominated then.
-    static int64_t nbo_env = -1;
-    if (nbo_env < 0) { const char* e = getenv("RLHIP_LU_OUTER"); nbo_env = e ? atoll(e) : 0; if (nbo_env && nbo_env < PB) nbo_env = PB; nbo_env = (nbo_env / PB) * PB; }
     // default: with the faster fp32 panel step the HBM-bound K = 32 updates of a very tall matrix are worth saving again -- 65536 x 2048
     // fp32: 32.1 ms (outer = panel), 27.0 (64), 25.0 (128), 25.1 (256); 32768 rows: 20.7 / 20.4 / 20.5 / 21.5; 8192 rows: 16.4 / 17.1 / 17.9
-    const int64_t nbo = nbo_env ? nbo_env : ((m >= 49152 && n >= 256) ? 128 : PB);
+    const int64_t nbo = (m >= 49152 && n >= 256) ? 128 : PB;
 #ifdef RLHIP_LU_PROF
     hipMemsetAsync(g.diag_data, 0, (2 * PB + 64) * sizeof(T), c->stream);
 #endif
@@ -780,12 +771,11 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
         int64_t rpw = (rows + Gmax - 1) / Gmax;
         if (rpw < 256) rpw = 256;   // fewer, fatter workgroups: the per-column rendezvous and winner search shrink with G
         const int64_t rpw_max = (96 * 1024) / (PB * (int64_t)sizeof(T));
-        if (rpw > rpw_max && !(reg_panel_on() && use_tag && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
+        if (rpw > rpw_max && !(use_tag && rows >= 1024)) { rlhip_ws_release(c, mark); return -2; }   // LDS variant only: > num_cu * 384 rows (fp64)
         int64_t G = (rows + rpw - 1) / rpw;
         g.j0 = j0; g.pb = pb; g.rpw = rpw;
-        const int reg_panel = reg_panel_on();
         // (the tagged-word kernels never touch the barrier counter: only the first panel of a call needs the launch, for `info`)
-        if (j0 == 0 || !(reg_panel && use_tag && rows >= 1024))
+        if (j0 == 0 || !(use_tag && rows >= 1024))
             hipLaunchKernelGGL(lu_zero_kernel, dim3(1), dim3(1), 0, c->stream, g.bar, g.info, j0 == 0 ? 1 : 0);
         constexpr int RPT_BIG = (sizeof(T) == 4) ? 4 : 2;             // 128 VGPRs of panel per thread either way
         // resident capacity of the general register kernel (every workgroup spins on the others: all of them must be on the device at once)
@@ -809,22 +799,18 @@ int getrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* ipiv_d
             }
             c->path_count[7]++;
         } else
-        if (reg_panel && use_tag && rows >= 1024) {          // RLHIP_LU_TAG=0 / RLHIP_LU_REG_PANEL=0: the barrier-based LDS kernel (debug knob)
+        if (use_tag && rows >= 1024) {
             G = (rows + 256 * RPT_BIG - 1) / (256 * RPT_BIG);
             g.tag_base = (unsigned)(j0 / PB + 1) * 64u;
-            static int f32_fast = -1;
-            if (f32_fast < 0) { const char* e = getenv("RLHIP_LU_F32_FAST"); f32_fast = (e && atoi(e) == 0) ? 0 : 1; }
             bool launched = false;
             if constexpr (sizeof(T) == 4) {
-                if (f32_fast && G <= 64 && m < ((int64_t)1 << 31)) {        // up to 65536 rows below the diagonal: the step of lu_f32_step
+                if (G <= 64 && m < ((int64_t)1 << 31)) {        // up to 65536 rows below the diagonal: the step of lu_f32_step
                     rlhip_lu::launch_getrf_panel_f32(g, (unsigned)G, c->stream);
                     launched = true;
                 }
             }
             if constexpr (sizeof(T) == 8) {
-                static int f64_fast = -1;
-                if (f64_fast < 0) { const char* e = getenv("RLHIP_LU_F64_FAST"); f64_fast = (e && atoi(e) == 0) ? 0 : 1; }
-                if (f64_fast && G <= 64 && m < ((int64_t)1 << 31)) {        // up to 32768 rows below the diagonal: the step of lu_f64_step
+                if (G <= 64 && m < ((int64_t)1 << 31)) {        // up to 32768 rows below the diagonal: the step of lu_f64_step
                     rlhip_lu::launch_getrf_panel_f64(g, (unsigned)G, c->stream);
                     launched = true;
                 }

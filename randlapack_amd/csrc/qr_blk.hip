@@ -460,9 +460,7 @@ namespace rlhip {
 template <typename T>
 int geqrf_blk(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     constexpr int NT = 512, RPT = 4, IW = (sizeof(T) == 8) ? 4 : 8;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("RLHIP_QR_BLK"); on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!on || n > m || n < 1 || m > (int64_t)NT * RPT) return 0;
+    if (n > m || n < 1 || m > (int64_t)NT * RPT) return 0;
     const int64_t G = (n + 7) / 8;
     if (G > c->num_cu) return 0;                           // one chunk per workgroup, one workgroup per CU: all of them are resident
     size_t mark = rlhip_ws_mark(c);
@@ -508,9 +506,7 @@ template int geqrf_blk<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, flo
 template <typename T>
 int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
     constexpr int NT = 512, RPT = 4;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("RLHIP_QR_BLK"); on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!on || n < 1 || n > (int64_t)NT * RPT) return 0;
+    if (n < 1 || n > (int64_t)NT * RPT) return 0;
     const int64_t G = (n + 7) / 8;
     if (G > c->num_cu) return 0;
     size_t mark = rlhip_ws_mark(c);

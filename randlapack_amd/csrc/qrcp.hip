@@ -1017,9 +1017,6 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     if (n < 0) return -3;
     if (lda < (m > 1 ? m : 1)) return -5;
     if (m == 0 || n == 0) return 0;
-    static int guard = -1;
-    if (guard < 0) { const char* e = getenv("RLHIP_GEQRF_SCALE_GUARD"); guard = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!guard) return geqrf_core<T>(c, m, n, A, lda, tau_dev);
     size_t mark = rlhip_ws_mark(c);
     unsigned long long* w = ws_alloc<unsigned long long>(c, 4);
     if (!w) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
@@ -1195,9 +1192,7 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         if ((size_t)(cpw2 + 1) * m * sizeof(T) <= 140 * 1024) { G = G2; lds_bytes = (size_t)cpw2 * m * sizeof(T); use_lds = 1; }
         else lds_bytes = 0;
     }
-    static int pipe_on = -1;
-    if (pipe_on < 0) { const char* e = getenv("RLHIP_QR_PIPE"); pipe_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (!pivot && max_steps < 0 && pipe_on) {
+    if (!pivot && max_steps < 0) {
         size_t mark2 = rlhip_ws_mark(c);
         const int64_t kmax = m < n ? m : n;
         QrPipeArgs<T> pa;
@@ -1233,14 +1228,11 @@ static int qr_core(rlhip_ctx* c, int pivot, int64_t m, int64_t n, T* A, int64_t 
         rlhip_ws_release(c, mark2);
         return 0;
     }
-    static int tag_on = -1;
-    if (tag_on < 0) { const char* e = getenv("RLHIP_QRCP_TAG"); tag_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (pivot && use_lds && tag_on && m < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) - 2) {
+    if (pivot && use_lds && m < ((int64_t)1 << 31) - 2 && n < ((int64_t)1 << 31) - 2) {
         // the exchange no longer pays per participant, so the columns are spread thinner than for the rendezvous kernel: 4 per workgroup
-        // (RLHIP_QRCP_TAG_COLS, read per call, or rlhip_set_qrcp_cols: a caller that runs this factorization BESIDE another kernel asks for
+        // (rlhip_set_qrcp_cols: a caller that runs this factorization BESIDE another kernel asks for
         // fewer, fuller workgroups -- 1280 x 1024: 7.7 ms with 4 columns per workgroup, 8.7 with 8; 768 x 512: 3.5 / 3.9 / 4.9 ms with 4 / 8 / 16)
         int64_t g_env = 4;
-        { const char* e = getenv("RLHIP_QRCP_TAG_COLS"); if (e && atoi(e) > 0) g_env = atoi(e); }
         if (c->qrcp_cols_per_wg > 0) g_env = c->qrcp_cols_per_wg;
         int64_t Gt = (n + g_env - 1) / g_env;
         if (Gt > num_cu) Gt = num_cu;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <cstdio>
+#include "rlhip.h"
 
 #define RLHIP_ERR_HIP(e) (-1000 - (int)(e))
 
@@ -91,6 +92,7 @@ struct rlhip_ctx {
     // > 0: columns per workgroup of the tag-exchange pivoted QR (default 4; a caller that overlaps the factorization with another kernel packs
     // the columns into fewer workgroups so that it occupies fewer CUs)
     int qrcp_cols_per_wg = 0;
+    int64_t opt[RLHIP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // rlhip_set_option; -1 = default
     rlhip_ctx* side_ctx = nullptr;   // cached side context (rlhip_side_of): created on first use, destroyed with this one
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU
@@ -105,7 +107,7 @@ struct rlhip_ctx {
     // diagnostics: how often each specialised kernel path was taken (rlhip_path_count; tests assert the path under test ran)
     //   0 stream-K f64 GEMM, 1 stream-K f32 GEMM, 2 fused trsm block kernel, 3 substitution trsm sub-block, 4 fused out-of-place trsm
     //   (rlhip_trsm_gather), 5 sketch-preconditioned Cholesky-QR panel inside geqrf -- the list in include/rlhip.h is the contract
-    int64_t path_count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t path_count[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // every host wait of the library goes through here: the epoch lets deferred read-backs know that an earlier wait already covered them

@@ -523,11 +523,7 @@ struct SasoOp {
     SasoState st;
 };
 
-static int saso_default_mode() {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("RLHIP_SASO_MODE"); mode = (e && (e[0] == '0' || e[0] == 'a')) ? 0 : 1; }   // "0" / "affine": block affine
-    return mode;
-}
+static int saso_default_mode(const rlhip_ctx* c) { return c->opt[RLHIP_OPT_SASO_MODE] == 0 ? 0 : 1; }   // 0: block affine (RLHIP_OPT_SASO_MODE)
 
 // the operator's index arrays come from the context's caching pool (rlhip_malloc): no hipMalloc / hipFree in steady state
 #define RLHIP_SASO_ALLOC(field, bytes)                                                    \
@@ -542,7 +538,7 @@ int saso_destroy(rlhip_ctx* c, SasoOp* op);
 int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint32_t ctr[4], const uint32_t key[2],
                uint32_t next_ctr[4], SasoOp** out) {
     if (d <= 0 || m < 0 || nnz <= 0 || nnz > d || nnz > 128 || d >= ((int64_t)1 << 31)) return -2;
-    if (mode < 0) mode = saso_default_mode();
+    if (mode < 0) mode = saso_default_mode(c);
     if (mode > 1) return -5;
     SasoOp* op = new SasoOp();
     op->d = d; op->m = m; op->nnz = nnz; op->T = (m + d - 1) / d; op->mode = mode;

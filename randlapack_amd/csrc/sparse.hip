@@ -178,9 +178,7 @@ int csr_spmm_rowmajor(rlhip_ctx* c, int64_t nrows, int64_t nc, const int64_t* ro
                       const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
     if (nrows <= 0 || nc <= 0) return 0;
     const int64_t gx = std::min<int64_t>((nrows + 3) / 4, 256 * 64);
-    static int narrow_on = -1;
-    if (narrow_on < 0) { const char* e = getenv("RLHIP_SPMM_NARROW"); narrow_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (narrow_on && nc <= 32) {
+    if (nc <= 32) {
         const int rpw = nc <= 16 ? 4 : 2;
         dim3 grid((unsigned)std::min<int64_t>((nrows + 4 * rpw - 1) / (4 * rpw), 256 * 64), 1);
         if (nc <= 16) hipLaunchKernelGGL((csr_spmm_rm_narrow_kernel<T, 16>), grid, dim3(256), 0, c->stream, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);
@@ -209,12 +207,7 @@ int csr_spmm(rlhip_ctx* c, int layout_rowmajor, int64_t nrows, int64_t k, int64_
     if (nrows <= 0 || nc <= 0) return 0;
     if (layout_rowmajor) return csr_spmm_rowmajor<T>(c, nrows, nc, rowptr, colidx, vals, alpha, B, ldb, beta, C, ldc);
     const size_t mark = rlhip_ws_mark(c);
-    static int cmout_on = -1;
-    if (cmout_on < 0) {
-        const char* e = getenv("RLHIP_SPMM_NARROW"); const char* e2 = getenv("RLHIP_SPMM_CMOUT");
-        cmout_on = ((e && atoi(e) == 0) || (e2 && atoi(e2) == 0)) ? 0 : 1;
-    }
-    if (cmout_on && nc <= 32) {
+    if (nc <= 32) {
         T* Bt = ws_alloc<T>(c, (size_t)std::max<int64_t>(k, 1) * nc);
         if (!Bt) { rlhip_ws_release(c, mark); return -3; }
         int rc = 0;

@@ -188,8 +188,7 @@ template <typename T>
 int gesdd_tall_gram(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda, T* S, T* U, int64_t ldu, T* VT, int64_t ldvt, int* sweeps_host) {
     if constexpr (sizeof(T) != 8) { return 1; }
     else {
-        const char* ge = getenv("RLHIP_GESDD_GRAM");               // read per call: tests switch routes inside one process
-        if ((ge && atoi(ge) == 0) || n <= 32 || n > 256 || m < n) return 1;
+        if (c->opt[RLHIP_OPT_GESDD_GRAM] == 0 || n <= 32 || n > 256 || m < n) return 1;
         const int nn = (int)n;
         size_t mark = rlhip_ws_mark(c);
         T* G = ws_alloc<T>(c, (size_t)n * n);
@@ -280,9 +279,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
         // B^T of an RSVD of a Gaussian matrix) leaves max |Q^T Q - I| at a few eps: the second factorization would multiply by a
         // triangle that equals the identity to rounding, so it is skipped (one k x k Cholesky + one m x k triangular solve +
         // the R2 R1 product per call).  Threshold 1e-13 (fp64) keeps ||Q^T Q - I||_F below k * 1e-13.
-        static int skip_on = -1;
-        if (skip_on < 0) { const char* e = getenv("RLHIP_CHOLQR2_SKIP"); skip_on = (e && atoi(e) == 0) ? 0 : 1; }
-        if (skip_on) {
+        {
             double* d_dev = (double*)(c->d_mail + 25);
             hipLaunchKernelGGL(gram_identity_dev_kernel<T>, dim3(1), dim3(1024), 0, c->stream, (int)n, R2, (int64_t)n, d_dev);
             RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 25, d_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -328,9 +325,7 @@ int gesdd_tall(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* S, T* U
     // The diagonal ratio is only a LOWER bound on cond(R); the decision uses a rigorous upper bound instead:
     // cond_2(R) <= ||R||_F ||R^-1||_F, with R^-1 from one k x k substitution (I R^-1).
     bool recover_v = false;
-    static int rv_on = -1;
-    if (rv_on < 0) { const char* e = getenv("RLHIP_RECOVER_V"); rv_on = (e && atoi(e) == 0) ? 0 : 1; }
-    if (rv_on && ratio < 1e3) {
+    if (ratio < 1e3) {
         T nr = 0, ni = 0;
         rc = laset<T>(c, 2, n, n, T(0), T(1), VTx, n);
         if (!rc) rc = trsm_right_upper<T>(c, NonUnit, n, n, T(1), R2, n, VTx, n);

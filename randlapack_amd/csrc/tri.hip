@@ -662,16 +662,18 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(int64_t m, int64_t n, 
 #ifndef RLHIP_TF_XASM_DEFAULT
 #define RLHIP_TF_XASM_DEFAULT 1
 #endif
-inline bool tf_xasm() {
-    const char* e = getenv("RLHIP_TRSM_XASM");
-    return e ? (atoi(e) != 0) : (RLHIP_TF_XASM_DEFAULT != 0);
+// rows from which the one-launch fused solve is taken (>= one 64-row workgroup per CU); shorter inputs run the per-block kernels
+constexpr int64_t TF_MIN_ROWS = 16384;
+inline bool tf_xasm(const rlhip_ctx* c) {      // RLHIP_OPT_TRSM_XASM: -1 = what the build proved (Makefile: scripts/check_trsm_asm.py)
+    const int64_t o = c->opt[RLHIP_OPT_TRSM_XASM];
+    return o < 0 ? (RLHIP_TF_XASM_DEFAULT != 0) : (o != 0);
 }
 
 template <typename T, bool OOP>
 int tf_launch(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
               const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
     const dim3 grid((unsigned)((m + 127) / 128));
-    if (tf_xasm()) {
+    if (tf_xasm(c)) {
         RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, OOP, true>), fused_lds_bytes<T>());
         hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, OOP, true>), grid, dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
                            dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
@@ -702,13 +704,11 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     size_t mark = rlhip_ws_mark(c);
     T* Ut = ws_alloc<T>(c, (size_t)SB * SB);
     if (!Ut) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
-    static int blk_on = -1;
-    if (blk_on < 0) { const char* e = getenv("RLHIP_TRSM_BLK"); blk_on = (e && atoi(e) == 0) ? 0 : 1; }
     // blk path (one MFMA launch per 256-block): needs the explicit inverses of the 32 x 32 diagonal blocks, so it is taken per block
     // only where those are well conditioned (kappa_F <= 1e3: error eps * kappa stays at 1e-13); graded triangles -- the R factor of an
     // ill-conditioned sketch in CQRRPT's preconditioning step -- keep the componentwise-stable substitution kernels.
     const int64_t nblk = (n + BW - 1) / BW;
-    const bool try_blk = blk_on && m >= 16 && n >= 128 && nblk <= 32;   // narrow solves (orhr_col, potrf panels: n = 32) are one pack + one substitution launch already
+    const bool try_blk = m >= 16 && n >= 128 && nblk <= 32;   // narrow solves (orhr_col, potrf panels: n = 32) are one pack + one substitution launch already
     T* Upk_all = try_blk ? ws_alloc<T>(c, (size_t)nblk * BW * BW) : nullptr;
     T* Dinv_all = try_blk ? ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024) : nullptr;
     int* bad_dev = try_blk ? ws_alloc<int>(c, 32) : nullptr;
@@ -739,12 +739,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
     // substitution over every wave of every CU.)
     // fused path: ONE launch solves a whole run of well-conditioned 256-blocks (trsm_fused_kernel); blocks whose diagonal sub-blocks are
     // ill conditioned still take the substitution kernels below, with a GEMM bringing in everything to their left.
-    static int fused_on = -1, fused_min_rows = 0;
-    if (fused_on < 0) {
-        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
-        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;   // >= one 64-row workgroup per CU
-    }
-    const bool use_fused = try_blk && fused_on && m >= fused_min_rows && n >= BW && (4 * ldb + m) < ((int64_t)1 << 28);   // (32-bit lane offsets in the kernel)
+    const bool use_fused = try_blk && m >= TF_MIN_ROWS && n >= BW && (4 * ldb + m) < ((int64_t)1 << 28);   // (32-bit lane offsets in the kernel)
     const int64_t n_pad = nblk * BW;
     T* Uneg = nullptr;
     T* fdump = nullptr;
@@ -862,14 +857,8 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
     if (ldb < (m > 1 ? m : 1)) return -15;
     if (m == 0 || n == 0) return 0;
     if ((const T*)B == Bsrc) { if (perm_dev) return -14; return trsm_right_upper<T>(c, diag, m, n, alpha, A, lda, B, ldb); }
-    static int fused_on = -1, fused_min_rows = 0, blk_on = -1;
-    if (fused_on < 0) {
-        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
-        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;
-        const char* b = getenv("RLHIP_TRSM_BLK"); blk_on = (b && atoi(b) == 0) ? 0 : 1;
-    }
     const int64_t nblk = (n + BW - 1) / BW;
-    bool fused = blk_on && fused_on && m >= fused_min_rows && n >= BW && n % BW == 0 && nblk <= 32 && (4 * ldb + m) < ((int64_t)1 << 28);
+    bool fused = m >= TF_MIN_ROWS && n >= BW && n % BW == 0 && nblk <= 32 && (4 * ldb + m) < ((int64_t)1 << 28);
     size_t mark = rlhip_ws_mark(c);
     bool perm_checked = false;
     if (fused) {
@@ -880,28 +869,29 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         T* Uneg = ws_alloc<T>(c, (size_t)n * n);
         T* fdump = ws_alloc<T>(c, 512);
         if (!Upk_all || !Dinv_all || !bad_dev || !seen || !Uneg || !fdump) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-        RLHIP_CHECK(hipMemsetAsync(bad_dev, 0, 33 * sizeof(int), c->stream));
+        auto chk = [&](hipError_t e) { if (e != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(e); } return 0; };   // every error exit gives the arena mark back
+        if (int rc = chk(hipMemsetAsync(bad_dev, 0, 33 * sizeof(int), c->stream))) return rc;
         hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, n, diag, A, lda, Upk_all, Dinv_all, bad_dev,
                            1.0e6);
-        RLHIP_LAUNCH_CHECK();
+        if (int rc = chk(hipGetLastError())) return rc;
         if (perm_dev) {     // the pivot vector is validated on the device; its verdict rides on the guard's read-back (slot 32)
-            RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
+            if (int rc = chk(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream))) return rc;
             hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad_dev + 32, n);
-            RLHIP_LAUNCH_CHECK();
+            if (int rc = chk(hipGetLastError())) return rc;
             perm_checked = true;
         }
         // The verdict (33 words: the conditioning guard of every block, the pivot check) travels to the host while the device runs on: the
         // packed triangle and the fused solve are enqueued right behind the read-back, GATED on the same device words (a launch that finds
         // one of them set does nothing), and the host waits for the read-back only -- no idle device during the round trip.
-        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(hipEventRecord(c->ev_flag, c->stream));
+        if (int rc = chk(hipMemcpyAsync(c->h_mail + 16, bad_dev, 33 * sizeof(int), hipMemcpyDeviceToHost, c->stream))) return rc;
+        if (int rc = chk(hipEventRecord(c->ev_flag, c->stream))) return rc;
         hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
-        RLHIP_LAUNCH_CHECK();
+        if (int rc = chk(hipGetLastError())) return rc;
         {
             const int lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
             if (lrc) { rlhip_ws_release(c, mark); return lrc; }
         }
-        RLHIP_CHECK(hipEventSynchronize(c->ev_flag));
+        if (int rc = chk(hipEventSynchronize(c->ev_flag))) return rc;
         if (perm_checked && ((int*)(c->h_mail + 16))[32] != 0) { rlhip_ws_release(c, mark); return -7; }     // jpvt is not a permutation of 1..n (as col_swap reports it)
         for (int64_t b = 0; b < nblk; ++b) fused = fused && ((int*)(c->h_mail + 16))[b] == 0;
         if (fused) {
@@ -916,13 +906,16 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         unsigned* seen = ws_alloc<unsigned>(c, (size_t)n / 32 + 2);
         int* bad = ws_alloc<int>(c, 8);
         if (!seen || !bad) { rlhip_ws_release(c, mk2); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-        RLHIP_CHECK(hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream));
-        RLHIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad, n);
-        RLHIP_LAUNCH_CHECK();
-        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RLHIP_CHECK(rlhip_stream_sync(c));
+        hipError_t pe = hipMemsetAsync(seen, 0, ((size_t)n + 31) / 32 * sizeof(unsigned), c->stream);
+        if (pe == hipSuccess) pe = hipMemsetAsync(bad, 0, sizeof(int), c->stream);
+        if (pe == hipSuccess) {
+            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, perm_dev, (int64_t)1, seen, bad, n);
+            pe = hipGetLastError();
+        }
+        if (pe == hipSuccess) pe = hipMemcpyAsync(c->h_mail + 16, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (pe == hipSuccess) pe = rlhip_stream_sync(c);
         rlhip_ws_release(c, mk2);
+        if (pe != hipSuccess) return RLHIP_ERR_HIP(pe);
         if (*(int*)(c->h_mail + 16) != 0) return -7;
     }
     {
@@ -953,10 +946,8 @@ int trsm_right_upper_oop_range(rlhip_ctx* c, int diag, int64_t m, int64_t nsrc, 
     if (ldb < (m > 1 ? m : 1)) return -15;
     if (m == 0) return 0;
     if ((const T*)B == Bsrc) return -14;
-    const char* e = getenv("RLHIP_TRSM_FUSED"); const char* b = getenv("RLHIP_TRSM_BLK"); const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS");
-    const int64_t min_rows = r ? atoi(r) : 16384;
     const int64_t n = col1, nblk = n / BW;
-    if ((e && atoi(e) == 0) || (b && atoi(b) == 0) || m < min_rows || nblk > 32 || (4 * ldb + m) >= ((int64_t)1 << 28)) return 1;
+    if (m < TF_MIN_ROWS || nblk > 32 || (4 * ldb + m) >= ((int64_t)1 << 28)) return 1;
     size_t mark = rlhip_ws_mark(c);
     T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
     T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
@@ -1055,34 +1046,39 @@ int potrf_upper_enqueue(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_de
 // the ranks before it is factored.  Returns 1 when the shape is not served here (short or ragged inputs): the caller runs the three calls.
 template <typename T>
 int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int reduce_gram, int* info_host) {
-    static int fused_on = -1, fused_min_rows = 0, blk_on = -1;
-    if (fused_on < 0) {
-        const char* e = getenv("RLHIP_TRSM_FUSED"); fused_on = (e && atoi(e) == 0) ? 0 : 1;
-        const char* r = getenv("RLHIP_TRSM_FUSED_MIN_ROWS"); fused_min_rows = r ? atoi(r) : 16384;
-        const char* b = getenv("RLHIP_TRSM_BLK"); blk_on = (b && atoi(b) == 0) ? 0 : 1;
-    }
-    const char* fe = getenv("RLHIP_CHOLQRQ_FUSED");              // read per call (tests)
     const int64_t nblk = (k + BW - 1) / BW;
-    if ((fe && atoi(fe) == 0) || !fused_on || !blk_on || m < fused_min_rows || k < BW || k % BW != 0 || k > 448 || nblk > 31 || lda < m ||
-        (4 * lda + m) >= ((int64_t)1 << 28))
-        return 1;
+    // Served or not is decided from RANK-UNIFORM quantities only when the Gram matrix is summed over the ranks: every rank must issue the same
+    // collectives with the same counts (shards that straddle the row threshold used to split into an all-reduce of k*k + 1 words here
+    // and one of k*k words in the caller's fallback).  What is rank-local -- too few rows for the fused solve, the 32-bit lane offsets, no room
+    // for its scratch -- only selects the SOLVE kernel behind the common Gram / all-reduce / Cholesky sequence.
+    if (c->opt[RLHIP_OPT_CHOLQRQ_ONE_STREAM] == 0 || k < BW || k % BW != 0 || k > 448 || nblk > 31 || lda < (m > 1 ? m : 1)) return 1;
+    bool local_ok = m >= TF_MIN_ROWS && (4 * lda + m) < ((int64_t)1 << 28);
+    if (!reduce_gram && !local_ok) return 1;
     *info_host = 0;
     size_t mark = rlhip_ws_mark(c);
-    T* Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
-    T* Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
-    int* words = ws_alloc<int>(c, 40);                            // [0] potrf info, [1 .. nblk] guard verdicts
-    T* Uneg = ws_alloc<T>(c, (size_t)k * k);
-    T* fdump = ws_alloc<T>(c, 512 + 64);
-    if (!Upk_all || !Dinv_all || !words || !Uneg || !fdump) { rlhip_ws_release(c, mark); return 1; }
     auto fail = [&](int rc) { rlhip_ws_release(c, mark); return rc; };
+    int* words = ws_alloc<int>(c, 40);                            // [0] potrf info, [1 .. nblk] guard verdicts
+    if (!words) { rlhip_ws_release(c, mark); return reduce_gram ? RLHIP_ERR_HIP(hipErrorOutOfMemory) : 1; }
+    T *Upk_all = nullptr, *Dinv_all = nullptr, *Uneg = nullptr, *fdump = nullptr;
+    if (local_ok) {
+        Upk_all = ws_alloc<T>(c, (size_t)nblk * BW * BW);
+        Dinv_all = ws_alloc<T>(c, (size_t)nblk * (BW / 32) * 1024);
+        Uneg = ws_alloc<T>(c, (size_t)k * k);
+        fdump = ws_alloc<T>(c, 512 + 64);
+        if (!Upk_all || !Dinv_all || !Uneg || !fdump) {
+            if (!reduce_gram) return fail(1);
+            local_ok = false;                                     // (rank-local: the substitution route below needs none of them)
+        }
+    }
     hipError_t e0 = hipMemsetAsync(words, 0, 40 * sizeof(int), c->stream);
     if (e0 != hipSuccess) return fail(RLHIP_ERR_HIP(e0));
     int rc = laset<T>(c, 2, k, k, T(0), T(0), R, k);
-    if (!rc) rc = syrk<T>(c, Upper, 1, k, m, T(1), A, lda, T(0), R, k);
+    if (!rc && m > 0) rc = syrk<T>(c, Upper, 1, k, m, T(1), A, lda, T(0), R, k);
     if (!rc && reduce_gram) {
         if (sizeof(T) == 8 && c->norma_state == 1 && !c->norma_reduced) {
             // a deferred ||A||_F^2 is waiting (QB: rl_qb.hh:168): its sum over the ranks rides on THIS all-reduce as word k*k of the buffer instead
-            // of taking a scalar collective (and a host round trip) of its own
+            // of taking a scalar collective (and a host round trip) of its own.  (norma_state is set by the product that precedes this call on
+            // EVERY rank -- rank-uniform.)
             double* G2 = ws_alloc<double>(c, (size_t)k * k + 1);
             if (!G2) return fail(RLHIP_ERR_HIP(hipErrorOutOfMemory));
             hipError_t e = hipMemcpyAsync(G2, R, (size_t)k * k * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
@@ -1101,14 +1097,16 @@ int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int red
     }
     if (!rc) rc = potrf_upper_enqueue<T>(c, k, R, k, words);
     if (rc) return fail(rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown));
-    hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, k, (int)NonUnit, R, k, Upk_all, Dinv_all, words + 1, 1.0e6);
-    hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(k / 32), (unsigned)(k / 32)), dim3(256), 0, c->stream, k, k, R, k, Uneg);
-    {
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) return fail(RLHIP_ERR_HIP(le));
+    if (local_ok) {
+        hipLaunchKernelGGL(trsm_blk_pack_kernel<T>, dim3(BW / 32 + 24, (unsigned)nblk), dim3(256), 0, c->stream, k, (int)NonUnit, R, k, Upk_all, Dinv_all, words + 1, 1.0e6);
+        hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(k / 32), (unsigned)(k / 32)), dim3(256), 0, c->stream, k, k, R, k, Uneg);
+        {
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(RLHIP_ERR_HIP(le));
+        }
+        rc = tf_launch<T, false>(c, m, k, k, T(1), Uneg, Dinv_all, A, lda, 0, (int)nblk, 0, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0, words, 1 + (int)nblk);
+        if (rc) return fail(rc);
     }
-    rc = tf_launch<T, false>(c, m, k, k, T(1), Uneg, Dinv_all, A, lda, 0, (int)nblk, 0, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0, words, 1 + (int)nblk);
-    if (rc) return fail(rc);
     hipError_t e1 = hipMemcpyAsync(c->h_mail + 44, words, 40 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e1 == hipSuccess) e1 = rlhip_stream_sync(c);
     rlhip_ws_release(c, mark);
@@ -1116,7 +1114,7 @@ int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int red
     const int* w = (const int*)(c->h_mail + 44);
     *info_host = w[0];
     if (w[0] != 0) return 0;                                      // not positive definite: A untouched, R partially factored (as dpotrf leaves it)
-    bool guard = false;
+    bool guard = !local_ok;
     for (int64_t b = 0; b < nblk; ++b) guard = guard || (w[1 + b] != 0);
     if (guard) return trsm_right_upper<T>(c, NonUnit, m, k, T(1), R, k, A, lda);
     c->path_count[2]++;

@@ -190,6 +190,32 @@ class Context:
     def path_count(self, which: int) -> int:
         return int(self.lib.rlhip_path_count(self.h, which))
 
+    # ---- options (include/rlhip.h: enum rlhip_option; -1 restores the default)
+    OPT = dict(cholqrq_one_stream=0, gesdd_gram=1, jacobi_persist=2, trsm_xasm=3, saso_mode=4, hqrrp_tall_panel=5,
+               bqrrp_lookahead_min_elems=6, bqrrp_cholqr_fallback=7, cqrrpt_fold_pivoting=8, cqrrpt_split_qrcp=9, sparse_sketch_densify=10)
+
+    def set_option(self, name: str, value: int) -> None:
+        _lib.check(self.lib.rlhip_set_option(self.h, self.OPT[name], int(value)), "set_option")
+
+    def get_option(self, name: str) -> int:
+        return int(self.lib.rlhip_get_option(self.h, self.OPT[name]))
+
+    def options(self, **kw):
+        """context manager: set options for the duration of a block, then restore what was there"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return _cm()
+
     def gemm_norma(self, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, Cm, ldc):
         """gemm + ||A||_F in one pass (rlhip_gemm_norma_f64); returns (norm, fused flag)"""
         nrm, fused = C.c_double(), C.c_int()

@@ -10,10 +10,18 @@ import torch
 from randlapack_amd import device as d
 
 PEAK = {torch.float64: 78.6, torch.float32: 157.3}
+OPTS = {}      # --opt name=value ...: context options (include/rlhip.h, enum rlhip_option) applied to every context this script creates
+
+
+def _ctx():
+    ctx = _ctx()
+    for k, v in OPTS.items():
+        ctx.set_option(k, v)
+    return ctx
 
 
 def cqrrpt(steps):
-    ctx = d.Context(0)
+    ctx = _ctx()
     m, n, dd, nnz = 1048576, 1024, 1280, 4
     A = d.cm_empty(m, n)
     flops = 2.0 * nnz * m * n + (2.0 * dd * n * n - 2.0 / 3 * n**3) + 3.0 * m * n * n + n**3 / 3.0 + n**3
@@ -70,7 +78,7 @@ def cqrrpt(steps):
 
 
 def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
-    ctx = d.Context(0)
+    ctx = _ctx()
     n = m
     A = d.cm_empty(m, n, dtype=dtype)
     flops = 2.0 * b * m * n + 2.0 * m * n * n - 2.0 / 3 * n**3
@@ -115,7 +123,7 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
 def rsvd_p2(steps):
     """BASELINE configs[1] with power iterations (C2 at p = 2) on a rank-256-plus-noise matrix: four passes over the
     200000 x 20000 input (A Omega, A^T., A., A^T Q) instead of two, stabilisers on 200000 x 256 / 20000 x 256 blocks in between."""
-    ctx = d.Context(0)
+    ctx = _ctx()
     m, n, k, p = 200000, 20000, 256, 2
     sig = np.geomspace(1.0, 0.1, k)
     U = d.cm_empty(m, k); ctx.fill_dense(U, m, k, key=(101, 0))
@@ -166,7 +174,7 @@ def abrik(steps):
     per row with graded row / column scalings, as in tests/test_gpu_fullsize.py), block 32, 8 Krylov iterations (rank 128); and the
     dense 200000 x 20000 operator of the same rank for the GEMM-bound variant."""
     import scipy.sparse as sp
-    ctx = d.Context(0)
+    ctx = _ctx()
     m = n = 200000
     k, target = 32, 128
     rng = np.random.default_rng(77)
@@ -226,7 +234,9 @@ def abrik(steps):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64", "bqrrp_full", "abrik", "rsvd_p2"]); ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--opt", action="append", default=[], help="context option name=value (e.g. saso_mode=0, cqrrpt_split_qrcp=0)")
     a = ap.parse_args()
+    OPTS.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt})
     if a.what == "cqrrpt": cqrrpt(a.steps)
     elif a.what == "abrik": abrik(a.steps)
     elif a.what == "rsvd_p2": rsvd_p2(a.steps)

@@ -2,16 +2,17 @@
 # C3 (CQRRPT 1048576 x 1024 fp64) with and without the split QRCP: bench lines, kernel statistics, and the last call's kernel
 # timeline around the pivoted QR (which kernels ran beside each other).  Run on the GPU box; outputs under gpurun_out/c3split/.
 R=$GRAFT_REPO_ROOT
+TAG=${1:-round5}
 export PYTHONPATH=$R
 O=$R/gpurun_out/c3split; mkdir -p $O
 cd $R
-timeout 300 python scripts/bench_other.py cqrrpt --steps 4 < /dev/null > $O/round4_c3_cqrrpt_line.json 2> $O/c3.err
-RLHIP_CQRRPT_SPLIT_QRCP=0 timeout 300 python scripts/bench_other.py cqrrpt --steps 4 < /dev/null > $O/round4_c3_cqrrpt_one_piece_qrcp_line.json 2>> $O/c3.err
-RLHIP_SASO_MODE=affine timeout 300 python scripts/bench_other.py cqrrpt --steps 4 < /dev/null > $O/round4_c3_cqrrpt_affine_saso_line.json 2>> $O/c3.err
+timeout 300 python scripts/bench_other.py cqrrpt --steps 4 < /dev/null > $O/${TAG}_c3_cqrrpt_line.json 2> $O/c3.err
+timeout 300 python scripts/bench_other.py cqrrpt --steps 4 --opt cqrrpt_split_qrcp=0 < /dev/null > $O/${TAG}_c3_cqrrpt_one_piece_qrcp_line.json 2>> $O/c3.err
+timeout 300 python scripts/bench_other.py cqrrpt --steps 4 --opt saso_mode=0 < /dev/null > $O/${TAG}_c3_cqrrpt_affine_saso_line.json 2>> $O/c3.err
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/round4_c3_cqrrpt_line_profiled.json 2> $O/prof.err
-f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/round4_c3_cqrrpt_kernel_stats.csv
-python - <<PY > $O/round4_c3_split_timeline.txt 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/${TAG}_c3_cqrrpt_line_profiled.json 2> $O/prof.err
+f=$(find $O/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_c3_cqrrpt_kernel_stats.csv
+python - <<PY > $O/${TAG}_c3_split_timeline.txt 2>&1
 import csv, glob
 f = glob.glob("$O/prof/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -30,4 +31,4 @@ for r in rows[i0:i1]:
 PY
 rm -rf $O/prof
 for j in $O/*line.json; do echo "$(basename $j): $(cut -c1-200 $j)"; done
-cat $O/round4_c3_split_timeline.txt
+cat $O/${TAG}_c3_split_timeline.txt

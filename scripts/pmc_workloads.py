@@ -144,8 +144,8 @@ def getrf_panel_f32():
 
 
 def jacobi():
-    os.environ["RLHIP_JACOBI_PERSIST"] = "0"      # rocprofv3 --pmc aborts on cooperative launches (rc -11): the per-launch sweeps carry the counters
     d, ctx = _ctx()
+    ctx.set_option("jacobi_persist", 0)           # rocprofv3 --pmc aborts on cooperative launches (rc -11): the per-launch sweeps carry the counters
     import torch
 
     n, k = 20000, 256

@@ -1,16 +1,16 @@
 #!/bin/bash
 # re-measure every committed line under profiles/ with the current build (run on the GPU box; outputs under gpurun_out/refresh/).
 # usage: bash scripts/refresh_profiles.sh <round tag, e.g. round3>      (every number quoted in DESIGN.md / README.md comes from a file this writes)
-# other scripts kept here: stress_matrix_types.py, hqrrp_tall_check.py, trsm_bench.py, saso_time.py, linops_time.py, sk_group_ab.py
+# other scripts kept here: stress_matrix_types.py, hqrrp_tall_check.py, trsm_bench.py, saso_time.py, linops_time.py
 #   qrcp_wide_parts.py + lu_only.py (per-part timing of BQRRP's qrcp_wide step / the LU alone: DESIGN 4.10), ld_ab.py (leading-dimension A/B at C3's shape: DESIGN 4.10)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-round4}
+TAG=${1:-round5}
 export PYTHONPATH=$R
 O=$R/gpurun_out/refresh; mkdir -p $O
 cd $R
 timeout 300 python bench.py < /dev/null > $O/${TAG}_bench_line.json 2> $O/bench.err
 timeout 300 python scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/${TAG}_c3_cqrrpt_line.json 2> $O/c3.err
-RLHIP_SASO_MODE=affine timeout 300 python scripts/bench_other.py cqrrpt --steps 3 < /dev/null > $O/${TAG}_c3_cqrrpt_affine_saso_line.json 2>> $O/c3.err
+timeout 300 python scripts/bench_other.py cqrrpt --steps 3 --opt saso_mode=0 < /dev/null > $O/${TAG}_c3_cqrrpt_affine_saso_line.json 2>> $O/c3.err
 timeout 300 python scripts/bench_other.py bqrrp64 --steps 3 < /dev/null > $O/${TAG}_bqrrp_f64_16k_line.json 2> $O/b64.err
 timeout 300 python scripts/bench_other.py bqrrp_full --steps 2 < /dev/null > $O/${TAG}_c4_bqrrp_f32_65536_line.json 2> $O/c4.err
 timeout 300 python scripts/bench_other.py abrik --steps 2 < /dev/null > $O/${TAG}_c5_abrik_line.json 2> $O/c5.err
@@ -35,9 +35,8 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl -- python $R/b
 python $R/scripts/timeline.py $O/tl 5 > $O/${TAG}_rank_of_8_timeline.txt 2>&1; rm -rf $O/tl
 # the DVFS map behind the clock holders and the look-ahead A/B of BQRRP
 timeout 300 python $R/scripts/dvfs_probe.py > /dev/null 2> $O/${TAG}_dvfs_probe.txt
-for la in 0 1; do RLHIP_BQRRP_LOOKAHEAD=$la timeout 400 python $R/scripts/bqrrp_lookahead_ab.py 65536 2048 f32 2; done > $O/${TAG}_c4_lookahead_ab.txt 2>&1
+timeout 600 python $R/scripts/bqrrp_lookahead_ab.py 65536 2048 f32 2 > $O/${TAG}_c4_lookahead_ab.txt 2>&1
 # second half of round 4: C3 with and without the split QRCP + the timeline of one call, the sparse product A/B,
 # the cooperative Householder kernels before / after the address-space fix need the previous library and are not re-run here (profiles/round4_qr_addrspace_ab.txt)
-( cd $R && bash scripts/c3_split_evidence.sh > $O/c3split.log 2>&1; cp gpurun_out/c3split/${TAG}_c3_* $O/ 2>/dev/null )
-timeout 300 python $R/scripts/spmm_ab.py > $O/${TAG}_spmm_ab.txt 2>&1
+( cd $R && bash scripts/c3_split_evidence.sh $TAG > $O/c3split.log 2>&1; cp gpurun_out/c3split/${TAG}_c3_* $O/ 2>/dev/null )
 for j in $O/${TAG}_*line.json; do echo "$(basename $j): $(cut -c1-240 $j)"; done

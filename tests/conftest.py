@@ -33,3 +33,13 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _reset_ctx_options(request):
+    """Options a GPU test set on the shared context (Context.set_option) go back to their defaults when the test ends."""
+    yield
+    if request.node.get_closest_marker("gpu") and "ctx" in request.fixturenames:
+        c = request.getfixturevalue("ctx")
+        for name in c.OPT:
+            c.set_option(name, -1)

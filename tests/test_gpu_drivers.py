@@ -51,10 +51,10 @@ def test_cholqrq_one_stream_equals_three_calls(ctx, orc, monkeypatch, m, k, dtyp
     Y = rng.standard_normal((m, k)) @ (np.eye(k) + 0.01 * rng.standard_normal((k, k)))
     out = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("RLHIP_CHOLQRQ_FUSED", fused)
-        Yd = d.cm_from_numpy(Y).to(tdt)
-        before = ctx.path_count(11)
-        rc, fail = d.drv_stab(ctx, 0, Yd, m, k)
+        with ctx.options(cholqrq_one_stream=int(fused)):
+            Yd = d.cm_from_numpy(Y).to(tdt)
+            before = ctx.path_count(11)
+            rc, fail = d.drv_stab(ctx, 0, Yd, m, k)
         assert rc == 0 and not fail
         assert ctx.path_count(11) - before == (1 if fused == "1" else 0)
         out[fused] = d.cm_to_numpy(Yd)
@@ -67,7 +67,6 @@ def test_cholqrq_one_stream_equals_three_calls(ctx, orc, monkeypatch, m, k, dtyp
         assert rc_o == 0
         np.testing.assert_allclose(Q, Qo, atol=1e-11)
     # failure: a zero column -> a zero pivot; the reference returns 1 before its trsm, A keeps its values
-    monkeypatch.setenv("RLHIP_CHOLQRQ_FUSED", "1")
     Yb = Y.copy()
     Yb[:, 17] = 0.0
     Ybd = d.cm_from_numpy(Yb).to(tdt)
@@ -245,7 +244,7 @@ def test_cqrrpt_vs_oracle_shared_sketch(ctx, orc, m, n, rank, cond):
 def test_cqrrpt_folded_pivoting_equals_reference_statement_order(ctx, orc, n, cond, monkeypatch):
     """m >= 16384 with a full-rank sketch takes the folded flow (pivoting read inside the first solve, out-of-place solves through
     rlhip_trsm_gather; n = 300: its gather-copy route): same rank, pivots, R and Q as the reference's col_swap -> trsm -> syrk -> trsm
-    order (RLHIP_CQRRPT_FOLD_PIVOTING=0), and both against the oracle on the shared sketch."""
+    order (CQRRPT::fold_pivoting = false), and both against the oracle on the shared sketch."""
     d = _d()
     m = 20000
     rng = np.random.default_rng(n)
@@ -253,10 +252,10 @@ def test_cqrrpt_folded_pivoting_equals_reference_statement_order(ctx, orc, n, co
     eps_user = EPS**0.85
     res = {}
     for fold in ("1", "0"):
-        monkeypatch.setenv("RLHIP_CQRRPT_FOLD_PIVOTING", fold)
         Ad = d.cm_from_numpy(A)
         before = ctx.path_count(4)
-        r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, eps=eps_user, want_sketch=True, key=(3, 0))
+        with ctx.options(cqrrpt_fold_pivoting=int(fold)):
+            r = d.drv_cqrrpt(ctx, Ad, m, n, 1.25, 4, eps=eps_user, want_sketch=True, key=(3, 0))
         took_fused_gather = ctx.path_count(4) - before
         assert r["rc"] == 0
         res[fold] = (r["rank"], r["J"].cpu().numpy(), d.cm_to_numpy(r["R"]), d.cm_to_numpy(Ad), d.cm_to_numpy(r["sketch"]), took_fused_gather)

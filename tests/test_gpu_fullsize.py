@@ -638,12 +638,10 @@ def test_trsm_fused_with_an_ill_conditioned_block_in_the_middle(ctx):
                                       (8192, 2048, 16384, "T"), (16384, 1024, 2048, "N"),
                                       (1408 + 44, 256, 65536, "N")])
 def test_streamk_gemm_f32_entrywise(ctx, m, n, k, ta):
-    import os
-
     # contractions beyond 16384 are cut into chunks of 16384 that accumulate into C (beta applied by the first chunk only); a chunk goes
     # through the persistent kernel when its own shape passes the work gate, through the split-K kernel otherwise -- the numbers below
     # hold either way, the path counter is asserted for single-launch shapes only
-    chunked = k > 16384 and os.environ.get("RLHIP_STREAMK_F32") != "2"
+    chunked = k > 16384
 
     d = _d()
     rng = np.random.default_rng(m + n + k + 1)
@@ -674,9 +672,7 @@ def test_streamk_syrk_f32_upper_tiles(ctx, n, k):
     """fp32 Gram matrices through whatever route syrk takes BY DEFAULT: the persistent kernel's triangular tile map for contractions up to
     16384 (one fp32 fma chain per entry is only accurate that far), the split-K kernel with lower-triangle tiles skipped
     beyond -- the same contract either way: upper triangle to 4 eps sqrt(k), strictly lower triangle untouched."""
-    import os
-
-    single_launch = k <= 16384 or os.environ.get("RLHIP_STREAMK_F32") == "2"
+    single_launch = k <= 16384
     d = _d()
     rng = np.random.default_rng(n + k + 7)
     A = rng.standard_normal((k, n)).astype(np.float32)
@@ -767,13 +763,13 @@ def test_trsm_gather_range_pieces_are_the_whole_solve_bitwise(ctx):
 
 def test_cqrrpt_split_qrcp_equals_one_piece(ctx, monkeypatch):
     """CQRRPT with geqp3 of the sketch in two halves and the left half of the first solve beside the second one (rl_cqrrpt.hh; on for tall
-    inputs on one rank) against the one-piece order (RLHIP_CQRRPT_SPLIT_QRCP=0): the same pivots and rank, R and Q to rounding, three
+    inputs on one rank) against the one-piece order (CQRRPT::split_qrcp = false): the same pivots and rank, R and Q to rounding, three
     fused out-of-place solve launches instead of two."""
     d = _d()
     m, n = 1 << 18, 512
     res = {}
     for knob in ("0", "1"):
-        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        ctx.set_option("cqrrpt_split_qrcp", int(knob))
         A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(5, 0))
         # grade the columns a little: distinct column norms, no near-ties for the pivoting
         import torch
@@ -808,7 +804,7 @@ def test_cqrrpt_split_qrcp_rank_deficient_inputs_fall_back(ctx, monkeypatch, r):
     A0 = Rt @ L                                                                          # (n, m) tensor = column-major m x n matrix of rank r
     res = {}
     for knob in ("0", "1"):
-        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        ctx.set_option("cqrrpt_split_qrcp", int(knob))
         A = A0.clone()
         before = ctx.path_count(4)
         out = d.drv_cqrrpt(ctx, A, m, n, 1.25, 4, key=(3, 0))
@@ -850,7 +846,7 @@ def test_cqrrpt_split_qrcp_fp32_and_ranged_solve_fp32(ctx, monkeypatch):
     m = 1 << 18
     res = {}
     for knob in ("0", "1"):
-        monkeypatch.setenv("RLHIP_CQRRPT_SPLIT_QRCP", knob)
+        ctx.set_option("cqrrpt_split_qrcp", int(knob))
         A = d.cm_empty(m, n, dtype=f32); ctx.fill_dense(A, m, n, key=(6, 0))
         A.mul_(torch.logspace(0, -1.5, n, dtype=f32, device="cuda")[torch.randperm(n, generator=torch.Generator().manual_seed(4)).cuda()].unsqueeze(1))
         before = ctx.path_count(4)

@@ -148,7 +148,7 @@ def test_cqrrt_linops_sparse_sketch_fallback_path(ctx, orc, monkeypatch):
     d = _d()
     op, op_np, A = _ops("sparse", 31)
     fast = d.drv_qr_linops(ctx, "cqrrt", op, d_factor=2.0, key=(1, 0), want_sketch=True)
-    monkeypatch.setenv("RLHIP_SPARSE_SKETCH_DENSIFY", "1")
+    ctx.set_option("sparse_sketch_densify", 1)
     slow = d.drv_qr_linops(ctx, "cqrrt", op, d_factor=2.0, key=(1, 0), want_sketch=True)
     a, b = d.cm_to_numpy(fast["sketch"]), d.cm_to_numpy(slow["sketch"])
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * np.abs(b).max())
