@@ -231,7 +231,10 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
             if (la) {
                 ++L.lookaheads;
                 rlhip_path_note(q.ctx(), 12, 1);
-                if (!side) side = std::make_unique<blas::Queue>(q, typename blas::Queue::Side{});
+                // (the context's CACHED side queue: a side context per call costs a stream, two mailboxes and a 64 MiB arena to create and to
+                //  free -- and device memory that is unmapped and remapped between launches is what this library never does in steady state,
+                //  see DESIGN 4.12 "a mapping that outlived its memory")
+                if (!side) side = std::make_unique<blas::Queue>(q, typename blas::Queue::CachedSide{});
                 const T* Tptr = T_dat;
                 int64_t ldt = b_sz_const;
                 if (!use_t) { lapack::larft(q_rows, block_rank, A_work, lda, tau_sub, T_ormqr, block_rank, q); Tptr = T_ormqr; ldt = block_rank; }
@@ -342,9 +345,15 @@ public:
     /// block iteration (all-reduces over RCCL): the b x b Gram matrix of the panel ("R-factor all-reduce"), the b x b top block of
     /// the orthonormal panel (so that every rank can run the Householder reconstruction on [top block; its own rows]), W = V^T C
     /// (b x (cols - b)) for the compact-WY apply, and the b x (cols - b) block row R12 for the sketch down-date; once at the start the
-    /// d x n sketch.  Options: qrcp_wide free (it acts on the replicated sketch), qr_tall = cholqr, apply_trans_q = gemqrt, internal_nb = b.
+    /// d x n sketch.  Options: qrcp_wide free (it acts on the replicated sketch); qr_tall = cholqr (Gram all-reduce) or geqrf / geqrt (TSQR:
+    /// the b x b triangles stacked by one all-reduce) -- the reference's default triple {luqr, geqrf, ormqr} runs sharded as it stands;
+    /// apply_trans_q: gemqrt and ormqr name the same operator (one b x b T block per panel, internal_nb = b).
     int call_sharded(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, T* tau, int64_t* J, RandBLAS::RNGState<RNG>& state) {
-        randlapack_require(qr_tall == Subroutines::QRTall::cholqr) << "row-sharded BQRRP needs qr_tall = cholqr (Householder panels do not shard)";
+        // qr_tall: cholqr -> Cholesky-QR of the preconditioned panel (one b x b Gram all-reduce); geqrf / geqrt -> TSQR of the panel itself
+        // (local Householder QR, the ranks' b x b triangles stacked by ONE all-reduce, the stack factored on every rank).  Either way the
+        // orthonormal panel is then turned into the reflectors of the WHOLE panel by Householder reconstruction, which is LAPACK's geqrf
+        // representation (unique up to rounding): the sharded factorization equals the single-device one for every option.
+        const bool tsqr_panels = (qr_tall != Subroutines::QRTall::cholqr);
         int64_t m_glob = m, row0 = 0;
         q.shard_extent(m, m_glob, row0);
         // Row layout of this rank: segments (first global row, count) in increasing global order, stacked in A.
@@ -444,6 +453,7 @@ public:
                 if (std::abs(diag[i]) / std::abs(diag[0]) < tol) { block_rank = i; break; }
             const int64_t br = block_rank;
             T* tau_sub = &tau[curr_sz];
+            if (!tsqr_panels) {
             // ---- CholQR of the sharded panel: the Gram matrix is summed over the ranks
             if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_sk, d, A_work, lda, q);
             lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
@@ -451,6 +461,38 @@ public:
             q.allreduce_sum(R_tall_qr, b_sz_const * b_sz_const);
             lapack::potrf(Uplo::Upper, br, R_tall_qr, b_sz_const, q);
             if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
+            } else if (br > 0) {
+                // ---- TSQR of the sharded panel (the reference's default qr_tall = geqrf, rl_bqrrp.hh:506-523, on row-sharded data): my active
+                //      rows A_g = Q_g R_g (kr = min(rows, br) reflectors), every rank's R_g into its slot of a (P br) x br stack (zero rows
+                //      where a rank has fewer than br rows or none), ONE all-reduce (disjoint slots: an all-gather, bit for bit), the stack
+                //      = Qt R on every rank (same bits in, same kernels: same bits out), panel <- Q_g Qt_g.  R_tall_qr <- R.
+                const int64_t P = q.world(), me = q.rank();
+                const int64_t kr = std::min(loc_rows, br);
+                blas::Scratch wq(q);
+                T* stack = wq.alloc<T>(P * br * br);
+                T* tau_l = wq.alloc<T>(std::max<int64_t>(br, 1));
+                T* Qg = wq.alloc<T>(std::max<int64_t>(loc_rows, 1) * br);
+                lapack::laset(MatrixType::General, P * br, br, (T)0, (T)0, stack, P * br, q);
+                {
+                    blas::LocalOnly local(q);                                            // (the local and the stacked factorizations are single-rank work)
+                    if (loc_rows > 0) {
+                        lapack::geqrf(loc_rows, br, A_work, lda, tau_l, q);
+                        lapack::lacpy(MatrixType::Upper, kr, br, A_work, lda, stack + me * br, P * br, q);
+                        lapack::ungqr(loc_rows, kr, kr, A_work, lda, tau_l, q);          // Q_g: loc_rows x kr
+                        lapack::lacpy(MatrixType::General, loc_rows, kr, A_work, lda, Qg, loc_rows, q);
+                    }
+                }
+                q.allreduce_sum(stack, P * br * br);
+                {
+                    blas::LocalOnly local(q);
+                    lapack::geqrf(P * br, br, stack, P * br, tau_l, q);
+                    lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
+                    lapack::lacpy(MatrixType::Upper, br, br, stack, P * br, R_tall_qr, b_sz_const, q);
+                    lapack::ungqr(P * br, br, br, stack, P * br, tau_l, q);              // Qt
+                }
+                if (loc_rows > 0)
+                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, loc_rows, br, kr, (T)1.0, Qg, loc_rows, stack + me * br, P * br, (T)0.0, A_work, lda, q);
+            }
             // ---- Householder reconstruction on [top block (gathered); my rows below it]
             const int64_t top_hi = curr_sz + br;                                             // global rows [curr_sz, top_hi) form the top block
             // my rows of the top block are the first tcnt rows of my active suffix (both layouts keep local rows in global order,
@@ -472,7 +514,8 @@ public:
                 lapack::orhr_col(ldp, br, br, Pst, ldp, T_dat, b_sz_const, Dv, q);            // one br x br T block (internal_nb = b)
                 lapack::row_sign(br, R_tall_qr, b_sz_const, Dv, q);
                 lapack::tau_from_t(br, br, T_dat, b_sz_const, tau_sub, q);
-                blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 (replicated)
+                if (!tsqr_panels)
+                    blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 = R_chol R_sk (replicated)
                 // my rows of V back into A (strictly lower part of the top block is V1, the rest of my rows V2) ...
                 if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, Pst + toff, ldp, &A[t_loc + lda * curr_sz], lda, q);
                 if (below > 0) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, &A[b_loc + lda * curr_sz], lda, q);

@@ -9,12 +9,19 @@
 // and every operator carries the queue it runs on (member `q`).
 //
 //   DenseLinOp        column-major device matrix; MFMA GEMM.  `row_sharded`: one row block per rank, A^T X and S A all-reduced.
-//   SparseLinOp       device CSR (+ the CSR of the transpose, built once at construction); gather SpMM, csrc/sparse.hip.
+//   SparseLinOp       device CSR (+ the CSR of the transpose, built on first use); gather SpMM, csrc/sparse.hip.  Also built from CSC
+//                     (= the CSR of the transpose, SparseLinOp::from_csc) and COO (SparseLinOp::from_coo: two stable device sorts).
 //   CompositeOperator implicit product left_op * right_op through a scratch buffer.
+// Block views (rl_dense_linop.hh:295-330, rl_sparse_linop.hh:393-465 over rl_sparse_views.hh:41-216, rl_composite_linop.hh:505-530):
+// row_block / col_block / submatrix on all three.  Dense views are pointer offsets.  Sparse views in the storage direction (rows of the
+// CSR, columns of the transpose) borrow the parent's index / value arrays behind a rebased pointer array; the cross direction is built by
+// one stable device transposition.  The parent must outlive its views (as in the reference); submatrix keeps its intermediate alive.
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <memory>
+#include <vector>
 #include "rl_exceptions.hh"
 #include "rl_blaspp.hh"
 #include "rl_lapackpp.hh"
@@ -136,6 +143,27 @@ struct DenseLinOp {
         blas::gemm(layout, Op::NoTrans, Op::NoTrans, d, n, m, alpha, S.buff, d, A_buff, lda, beta, C, ldc, q);
     }
 
+    // ---- block views (rl_dense_linop.hh:295-330): non-owning, same storage, same queue
+    DenseLinOp<T> row_block(int64_t row_start, int64_t row_count) const {
+        randlapack_require(row_start >= 0) << "row_start=" << row_start << " must be >= 0";
+        randlapack_require(row_count > 0) << "row_count=" << row_count << " must be > 0";
+        randlapack_require(row_start + row_count <= n_rows) << "row_start=" << row_start << " + row_count=" << row_count << " exceeds n_rows=" << n_rows;
+        return DenseLinOp<T>(row_count, n_cols, A_buff + row_start, lda, buff_layout, q);
+    }
+    DenseLinOp<T> col_block(int64_t col_start, int64_t col_count) const {
+        randlapack_require(col_start >= 0) << "col_start=" << col_start << " must be >= 0";
+        randlapack_require(col_count > 0) << "col_count=" << col_count << " must be > 0";
+        randlapack_require(col_start + col_count <= n_cols) << "col_start=" << col_start << " + col_count=" << col_count << " exceeds n_cols=" << n_cols;
+        return DenseLinOp<T>(n_rows, col_count, A_buff + col_start * lda, lda, buff_layout, q);
+    }
+    DenseLinOp<T> submatrix(int64_t row_start, int64_t col_start, int64_t row_count, int64_t col_count) const {
+        randlapack_require(row_start >= 0 && col_start >= 0) << "row_start=" << row_start << ", col_start=" << col_start << " must be >= 0";
+        randlapack_require(row_count > 0 && col_count > 0) << "row_count=" << row_count << ", col_count=" << col_count << " must be > 0";
+        randlapack_require(row_start + row_count <= n_rows) << "row_start=" << row_start << " + row_count=" << row_count << " exceeds n_rows=" << n_rows;
+        randlapack_require(col_start + col_count <= n_cols) << "col_start=" << col_start << " + col_count=" << col_count << " exceeds n_cols=" << n_cols;
+        return DenseLinOp<T>(row_count, col_count, A_buff + row_start + col_start * lda, lda, buff_layout, q);
+    }
+
 private:
     void check_sketch_call(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, int64_t s_rows, int64_t s_cols,
                            int64_t ldc) const {
@@ -161,39 +189,123 @@ struct SparseLinOp {
     const int64_t n_rows;
     const int64_t n_cols;
     const int64_t nnz;
+    // CSR of A (null until built when the operator was given by its columns) and CSR of A^T = CSC of A (null until first needed)
     const int64_t* rowptr;
     const int64_t* colidx;
     const T* vals;
     blas::Queue& q;
-    int64_t* rowptr_t = nullptr;
-    int64_t* colidx_t = nullptr;
-    T* vals_t = nullptr;
+    const int64_t* rowptr_t = nullptr;
+    const int64_t* colidx_t = nullptr;
+    const T* vals_t = nullptr;
 
+    /// CSR input: rowptr (rows + 1), colidx (nnz), vals (nnz)
     SparseLinOp(int64_t rows, int64_t cols, int64_t nnz_, const int64_t* rp, const int64_t* ci, const T* v, blas::Queue& queue)
         : n_rows(rows), n_cols(cols), nnz(nnz_), rowptr(rp), colidx(ci), vals(v), q(queue) {
         randlapack_require(rows >= 0 && cols >= 0 && nnz_ >= 0) << "negative dimension";
+    }
+    /// CSC input (RandBLAS::sparse_data::CSCMatrix: colptr (cols + 1), rowidx (nnz), vals (nnz)): the CSR of the transpose, borrowed as it is;
+    /// the CSR of A itself is built by one device transposition the first time a product needs it
+    static SparseLinOp from_csc(int64_t rows, int64_t cols, int64_t nnz_, const int64_t* colptr, const int64_t* rowidx, const T* v, blas::Queue& queue) {
+        SparseLinOp op(rows, cols, nnz_, nullptr, nullptr, nullptr, queue);
+        op.rowptr_t = colptr; op.colidx_t = rowidx; op.vals_t = v;
+        return op;
+    }
+    /// COO input (RandBLAS::sparse_data::COOMatrix: rows[nnz], cols[nnz], vals[nnz], any order, duplicates summed by the products): sorted
+    /// into CSR by the stable device counting sort of csr_transpose -- once for the values, once for the column indices (the sort is
+    /// deterministic and stable, so both come out in the same order)
+    static SparseLinOp from_coo(int64_t rows, int64_t cols, int64_t nnz_, const int64_t* rowidx, const int64_t* colidx_in, const T* v, blas::Queue& queue) {
+        randlapack_require(rows >= 0 && cols >= 0 && nnz_ >= 0) << "negative dimension";
+        SparseLinOp op(rows, cols, nnz_, nullptr, nullptr, nullptr, queue);
+        int64_t* rp = blas::device_malloc<int64_t>(rows + 1, queue);
+        int64_t* ci = blas::device_malloc<int64_t>(std::max<int64_t>(nnz_, 1), queue);
+        T* vv = blas::device_malloc<T>(std::max<int64_t>(nnz_, 1), queue);
+        op.own_.assign({rp, ci, vv});
+        blas::Scratch ws(queue);
+        int64_t* one_row = ws.alloc<int64_t>(2);                       // the COO list as a 1 x rows "CSR" whose column indices are the ROW indices
+        int64_t* junk = ws.alloc<int64_t>(std::max<int64_t>(nnz_, 1));
+        double* ci_sorted = ws.alloc<double>(std::max<int64_t>(nnz_, 1));
+        const int64_t ends[2] = {0, nnz_};
+        blas::check(rlhip_memcpy_h2d(queue.ctx(), one_row, ends, sizeof(ends)), "h2d");
+        detail::csr_transpose(1, rows, one_row, rowidx, v, rp, junk, vv, queue);
+        // (the column indices ride through the same sort as 8-byte payloads: the sort only moves them)
+        detail::csr_transpose(1, rows, one_row, rowidx, reinterpret_cast<const double*>(colidx_in), rp, junk, ci_sorted, queue);
+        blas::device_copy_vector(nnz_, reinterpret_cast<const int64_t*>(ci_sorted), ci, queue);
+        queue.sync();                                                   // (the scratch goes back when this returns)
+        op.rowptr = rp; op.colidx = ci; op.vals = vv;
+        return op;
     }
     /// the CSR of the transpose, built on FIRST use (stable counting sort on the device, ~1 ms for 2e6 nonzeros): an operator that is
     /// only ever applied as A * X (or lives for a single product, as behind rlhip_linop_apply) never pays for it
     void ensure_transpose() {
         if (rowptr_t) return;
-        rowptr_t = blas::device_malloc<int64_t>(n_cols + 1, q);
-        colidx_t = blas::device_malloc<int64_t>(nnz, q);
-        vals_t = blas::device_malloc<T>(nnz, q);
-        detail::csr_transpose(n_rows, n_cols, rowptr, colidx, vals, rowptr_t, colidx_t, vals_t, q);
+        int64_t* rp = blas::device_malloc<int64_t>(n_cols + 1, q);
+        int64_t* ci = blas::device_malloc<int64_t>(std::max<int64_t>(nnz, 1), q);
+        T* vv = blas::device_malloc<T>(std::max<int64_t>(nnz, 1), q);
+        own_.insert(own_.end(), {rp, ci, vv});
+        detail::csr_transpose(n_rows, n_cols, rowptr, colidx, vals, rp, ci, vv, q);
+        rowptr_t = rp; colidx_t = ci; vals_t = vv;
+    }
+    /// the CSR of A itself when the operator was given by its columns (from_csc, col_block views)
+    void ensure_forward() {
+        if (rowptr) return;
+        int64_t* rp = blas::device_malloc<int64_t>(n_rows + 1, q);
+        int64_t* ci = blas::device_malloc<int64_t>(std::max<int64_t>(nnz, 1), q);
+        T* vv = blas::device_malloc<T>(std::max<int64_t>(nnz, 1), q);
+        own_.insert(own_.end(), {rp, ci, vv});
+        detail::csr_transpose(n_cols, n_rows, rowptr_t, colidx_t, vals_t, rp, ci, vv, q);
+        rowptr = rp; colidx = ci; vals = vv;
     }
     SparseLinOp(SparseLinOp const&) = delete;
     SparseLinOp& operator=(SparseLinOp const&) = delete;
+    SparseLinOp(SparseLinOp&& o) noexcept
+        : n_rows(o.n_rows), n_cols(o.n_cols), nnz(o.nnz), rowptr(o.rowptr), colidx(o.colidx), vals(o.vals), q(o.q), rowptr_t(o.rowptr_t),
+          colidx_t(o.colidx_t), vals_t(o.vals_t), row_sharded(o.row_sharded), densify_budget(o.densify_budget),
+          force_densified_sketch(o.force_densified_sketch), own_(std::move(o.own_)), parent_(std::move(o.parent_)) {
+        o.own_.clear();
+    }
     ~SparseLinOp() {
-        if (rowptr_t) blas::device_free(rowptr_t, q);
-        if (colidx_t) blas::device_free(colidx_t, q);
-        if (vals_t) blas::device_free(vals_t, q);
+        for (void* p : own_) blas::device_free(p, q);
+    }
+
+    // ---- block views (rl_sparse_linop.hh:393-465).  A view in the storage direction borrows the parent's index / value arrays and owns
+    //      only its rebased pointer array; the parent must outlive it.
+    SparseLinOp row_block(int64_t row_start, int64_t row_count) {
+        randlapack_require(row_start >= 0 && row_count > 0) << "row_start=" << row_start << " must be >= 0 and row_count=" << row_count << " must be > 0";
+        randlapack_require(row_start + row_count <= n_rows) << "row_start=" << row_start << " + row_count=" << row_count << " exceeds n_rows=" << n_rows;
+        ensure_forward();
+        int64_t base = 0;
+        int64_t* rp = rebased(rowptr, row_start, row_count, base);
+        int64_t end = 0;
+        blas::check(rlhip_memcpy_d2h(q.ctx(), &end, rp + row_count, sizeof(int64_t)), "d2h");
+        SparseLinOp v(row_count, n_cols, end, rp, colidx + base, vals + base, q);
+        v.own_.push_back(rp);
+        return v;
+    }
+    SparseLinOp col_block(int64_t col_start, int64_t col_count) {
+        randlapack_require(col_start >= 0 && col_count > 0 && col_start + col_count <= n_cols)
+            << "column range must satisfy col_start=" << col_start << " >= 0, col_count=" << col_count << " > 0, col_start+col_count <= n_cols=" << n_cols;
+        ensure_transpose();
+        int64_t base = 0;
+        int64_t* cp = rebased(rowptr_t, col_start, col_count, base);
+        int64_t end = 0;
+        blas::check(rlhip_memcpy_d2h(q.ctx(), &end, cp + col_count, sizeof(int64_t)), "d2h");
+        SparseLinOp v(n_rows, col_count, end, nullptr, nullptr, nullptr, q);     // given by its columns: the rows of the parent's transpose
+        v.rowptr_t = cp; v.colidx_t = colidx_t + base; v.vals_t = vals_t + base;
+        v.own_.push_back(cp);
+        return v;
+    }
+    SparseLinOp submatrix(int64_t row_start, int64_t col_start, int64_t row_count, int64_t col_count) {
+        auto rows_view = std::make_shared<SparseLinOp>(row_block(row_start, row_count));
+        SparseLinOp v = rows_view->col_block(col_start, col_count);
+        v.parent_ = rows_view;                                                   // (its arrays are slices of the row view's transpose)
+        return v;
     }
 
     bool row_sharded = false;
 
     T fro_nrm() {
-        const T loc = nnz > 0 ? lapack::lange(Norm::Fro, nnz, 1, vals, nnz, q) : (T)0;
+        const T* any_vals = vals ? vals : vals_t;                         // (the same entries in either storage order)
+        const T loc = nnz > 0 ? lapack::lange(Norm::Fro, nnz, 1, any_vals, nnz, q) : (T)0;
         if (!(row_sharded && q.world() > 1)) return loc;
         double ss = (double)loc * (double)loc;
         q.allreduce_sum_host(&ss, 1);
@@ -208,7 +320,7 @@ struct SparseLinOp {
         if (side == Side::Left) {
             const int64_t rows_A = nt ? m : k, cols_A = nt ? k : m;
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
-            if (nt) detail::csr_spmm((char)layout, m, n, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q);
+            if (nt) { ensure_forward(); detail::csr_spmm((char)layout, m, n, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q); }
             else {
                 ensure_transpose();
                 detail::csr_spmm((char)layout, m, n, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q);
@@ -224,7 +336,7 @@ struct SparseLinOp {
             randlapack_require(rows_A == n_rows && cols_A == n_cols) << "op(A) inferred as " << rows_A << " x " << cols_A << " but the operator is " << n_rows << " x " << n_cols;
             const char flipped = (layout == Layout::ColMajor) ? 'R' : 'C';
             if (nt) { ensure_transpose(); detail::csr_spmm(flipped, n, m, k, alpha, rowptr_t, colidx_t, vals_t, B, ldb, beta, C, ldc, q); }
-            else detail::csr_spmm(flipped, n, m, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q);
+            else { ensure_forward(); detail::csr_spmm(flipped, n, m, k, alpha, rowptr, colidx, vals, B, ldb, beta, C, ldc, q); }
         }
     }
     void operator()(Layout layout, Op trans_A, Op trans_B, int64_t m, int64_t n, int64_t k, T alpha, const T* B, int64_t ldb, T beta, T* C,
@@ -282,6 +394,20 @@ struct SparseLinOp {
     bool force_densified_sketch = false;          // tests: take the fallback path regardless of d
 
 private:
+    std::vector<void*> own_;                      // device arrays this operator allocated (transposes, rebased pointer arrays, COO sorts)
+    std::shared_ptr<SparseLinOp> parent_;         // submatrix: the row view whose arrays this view slices
+    /// ptr[start .. start + count] - ptr[start] as a new device array (host round trip of count + 1 words, as the reference's
+    /// csr_row_block builds its rebased vector); `base` = ptr[start]
+    int64_t* rebased(const int64_t* ptr, int64_t start, int64_t count, int64_t& base) {
+        std::vector<int64_t> h((size_t)count + 1);
+        blas::check(rlhip_memcpy_d2h(q.ctx(), h.data(), ptr + start, h.size() * sizeof(int64_t)), "d2h");
+        base = h[0];
+        for (auto& x : h) x -= base;
+        int64_t* out = blas::device_malloc<int64_t>(count + 1, q);
+        blas::check(rlhip_memcpy_h2d(q.ctx(), out, h.data(), h.size() * sizeof(int64_t)), "h2d");
+        return out;
+    }
+
     void check_sketch_call(Side side, Layout layout, Op trans_A, Op trans_S, int64_t d, int64_t n, int64_t m, int64_t s_rows, int64_t s_cols,
                            int64_t ldc) const {
         randlapack_require(side == Side::Right && layout == Layout::ColMajor && trans_A == Op::NoTrans && trans_S == Op::NoTrans)
@@ -305,12 +431,37 @@ struct CompositeOperator {
     LinOp2& right_op;
     blas::Queue& q;
 
-    CompositeOperator(int64_t rows, int64_t cols, LinOp1& left, LinOp2& right) : n_rows(rows), n_cols(cols), left_op(left), right_op(right), q(left.q) {
+    // block views own the operand(s) they cut (rl_composite_linop.hh:84-104: shared ownership of the blocked side, the other side borrowed)
+    CompositeOperator(int64_t rows, int64_t cols, std::shared_ptr<LinOp1> left, LinOp2& right)
+        : n_rows(rows), n_cols(cols), left_op(*left), right_op(right), q(left->q), own_left_(std::move(left)) { check_dims(); }
+    CompositeOperator(int64_t rows, int64_t cols, LinOp1& left, std::shared_ptr<LinOp2> right)
+        : n_rows(rows), n_cols(cols), left_op(left), right_op(*right), q(left.q), own_right_(std::move(right)) { check_dims(); }
+    CompositeOperator(int64_t rows, int64_t cols, std::shared_ptr<LinOp1> left, std::shared_ptr<LinOp2> right)
+        : n_rows(rows), n_cols(cols), left_op(*left), right_op(*right), q(left->q), own_left_(std::move(left)), own_right_(std::move(right)) { check_dims(); }
+    /// rows [row_start, row_start + row_count) of left * right = (those rows of left) * right; columns likewise from the right operand
+    CompositeOperator row_block(int64_t row_start, int64_t row_count) {                                                      // :505-510
+        return CompositeOperator(row_count, n_cols, std::make_shared<LinOp1>(left_op.row_block(row_start, row_count)), right_op);
+    }
+    CompositeOperator col_block(int64_t col_start, int64_t col_count) {                                                      // :513-518
+        return CompositeOperator(n_rows, col_count, left_op, std::make_shared<LinOp2>(right_op.col_block(col_start, col_count)));
+    }
+    CompositeOperator submatrix(int64_t row_start, int64_t col_start, int64_t row_count, int64_t col_count) {                // :521-529
+        return CompositeOperator(row_count, col_count, std::make_shared<LinOp1>(left_op.row_block(row_start, row_count)),
+                                 std::make_shared<LinOp2>(right_op.col_block(col_start, col_count)));
+    }
+
+    CompositeOperator(int64_t rows, int64_t cols, LinOp1& left, LinOp2& right) : n_rows(rows), n_cols(cols), left_op(left), right_op(right), q(left.q) { check_dims(); }
+
+private:
+    std::shared_ptr<LinOp1> own_left_;
+    std::shared_ptr<LinOp2> own_right_;
+    void check_dims() const {
         randlapack_require(left_op.n_rows == n_rows) << "left_op.n_rows=" << left_op.n_rows << " must match composite operator n_rows=" << n_rows;
         randlapack_require(left_op.n_cols == right_op.n_rows) << "left_op.n_cols=" << left_op.n_cols << " must match right_op.n_rows=" << right_op.n_rows << " for composite operator";   // :125
         randlapack_require(right_op.n_cols == n_cols) << "right_op.n_cols=" << right_op.n_cols << " must match composite operator n_cols=" << n_cols;                               // :126
     }
 
+public:
     /// dense operand (:168-282).  Side::Left: NoTrans = left (right B), Trans = right^T (left^T B).
     /// Side::Right: NoTrans = (B left) right, Trans = (B right^T) left^T.
     void operator()(Side side, Layout layout, Op trans_comp, Op trans_B, int64_t m, int64_t n, int64_t k, T alpha, const T* B, int64_t ldb,

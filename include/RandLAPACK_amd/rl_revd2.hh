@@ -69,6 +69,57 @@ private:
     }
 };
 
+/// A + mu_i I for one or several regularisation parameters (rl_sym_linops.hh:134-233): the stored UPPER triangle of a column-major A is
+/// symmetrised once into HBM (every product is then an MFMA GEMM); with `set_eval_includes_reg(true)` column i of the result also receives
+/// alpha * regs[min(i, num_ops - 1)] * B[:, i] (one device axpy per column, as the reference's loop).  regs is a HOST array (copied).
+template <typename T>
+struct RegExplicitSymLinOp {
+    using scalar_t = T;
+    const int64_t m;
+    const int64_t dim;
+    const int64_t n_rows;
+    const int64_t n_cols;
+    const T* A_buff;
+    const int64_t lda;
+    int64_t num_ops = 1;
+    std::vector<T> regs;
+    bool _eval_includes_reg = false;
+    static constexpr Uplo uplo = Uplo::Upper;
+    static constexpr Layout buff_layout = Layout::ColMajor;
+    blas::Queue& q;
+
+    RegExplicitSymLinOp(int64_t d, const T* A, int64_t ld, const T* arg_regs, int64_t arg_num_ops, blas::Queue& queue)
+        : m(d), dim(d), n_rows(d), n_cols(d), A_buff(A), lda(ld), q(queue), sym_(d, Uplo::Upper, A, ld, Layout::ColMajor, queue) {
+        randlapack_require(lda >= dim) << "lda=" << lda << " < dim=" << dim << " (lda must be >= operator dimension)";                 // :171
+        num_ops = std::max<int64_t>(arg_num_ops, 1);                                                                                     // :173-174
+        regs.assign((size_t)num_ops, T(0));
+        for (int64_t i = 0; i < arg_num_ops; ++i) regs[(size_t)i] = arg_regs[i];
+    }
+    RegExplicitSymLinOp(int64_t d, const T* A, int64_t ld, std::vector<T>& arg_regs, blas::Queue& queue)
+        : RegExplicitSymLinOp(d, A, ld, arg_regs.data(), (int64_t)arg_regs.size(), queue) {}
+    void set_eval_includes_reg(bool eir) { _eval_includes_reg = eir; }
+
+    /// C (dim x n) = alpha * (A [+ mu_i I]) * B + beta * C                                                                 (:200-217)
+    void operator()(Layout layout, int64_t n, T alpha, const T* B, int64_t ldb, T beta, T* C, int64_t ldc) {
+        randlapack_require(layout == buff_layout) << "operation layout must match the operator storage layout (buff_layout)";
+        randlapack_require(ldb >= dim) << "ldb=" << ldb << " < dim=" << dim << " (ldb must be >= operator dimension)";
+        randlapack_require(ldc >= dim) << "ldc=" << ldc << " < dim=" << dim << " (ldc must be >= operator dimension)";
+        sym_(layout, n, alpha, B, ldb, beta, C, ldc);
+        if (_eval_includes_reg) {
+            if (num_ops != 1) { randlapack_require(n == num_ops) << "with num_ops>1, n=" << n << " must equal num_ops=" << num_ops << " so each column gets its own regularization"; }
+            for (int64_t i = 0; i < n; ++i) {
+                const T coeff = alpha * regs[(size_t)std::min(i, num_ops - 1)];
+                axpby_(dim, coeff, B + i * ldb, T(1), C + i * ldc);
+            }
+        }
+    }
+
+private:
+    ExplicitSymLinOp<T> sym_;
+    void axpby_(int64_t n, double a, const double* x, double b, double* y) { blas::check(rlhip_axpby_f64(q.ctx(), n, a, x, b, y), "axpby"); }
+    void axpby_(int64_t n, float a, const float* x, float b, float* y) { blas::check(rlhip_axpby_f32(q.ctx(), n, a, x, b, y), "axpby"); }
+};
+
 }  // namespace linops
 
 namespace detail {

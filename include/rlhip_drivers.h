@@ -67,7 +67,8 @@ int rlhip_drv_hqrrp_timed_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, i
  * panel is re-factored with Householder reflectors (BQRRP::cholqr_fallback, default on; environment RLHIP_BQRRP_CHOLQR_FALLBACK=0
  * restores the reference's behaviour, which carries on with the half-factored Gram matrix, rl_bqrrp.hh:461).  Pivots, rank and
  * well-conditioned panels are unaffected.
- * Row-sharded context (rlhip_comm_*): m and A are this rank's rows, tau needs min(global rows, n) entries, qr_tall must be cholqr;
+ * Row-sharded context (rlhip_comm_*): m and A are this rank's rows, tau needs min(global rows, n) entries; every qr_tall runs sharded
+ * (cholqr: one b x b Gram all-reduce per panel; geqrf / geqrt: TSQR, the ranks' b x b triangles stacked by one all-reduce);
  * qr_tall = 1 + 16 selects the BLOCK-CYCLIC layout (global row blocks of b_sz rows dealt round-robin, block g on rank g % P, stacked in
  * increasing order in A) instead of one contiguous row block per rank.  A (m x n, lda) -> GEQP3
  * format, tau (min(m,n)), J (n) all on the device.  A_sk_in / A_sk_out: shared-sketch hooks as for CQRRPT (d x n,
@@ -128,7 +129,9 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
 
 /* ---- drivers over abstract linear operators (include/RandLAPACK_amd/rl_linops.hh, rl_qr_linops.hh).
  * An operator is described by plain arrays: kind 0 = dense column-major (dense, ld); kind 1 = CSR with int64 indices
- * (rowptr, colidx, vals; nnz entries).  All arrays are DEVICE pointers.  `right` == NULL: the operator is `left`;
+ * (rowptr, colidx, vals; nnz entries); kind 2 = CSC (RandBLAS::sparse_data::CSCMatrix: the `rowptr` field carries colptr (cols + 1), the `colidx`
+ * field the ROW indices); kind 3 = COO (COOMatrix: `rowptr` carries the nnz row indices, `colidx` the nnz column indices; any order, duplicates
+ * are summed).  All arrays are DEVICE pointers.  `right` == NULL: the operator is `left`;
  * otherwise it is the implicit product left * right (linops::CompositeOperator, rl_composite_linop.hh:43). */
 typedef struct rlhip_linop_desc {
     int kind;
@@ -167,6 +170,17 @@ int rlhip_drv_abrik_linop_timed_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left
  * callers that only want the SpMM / composite product.  side 'L' or 'R', trans 'N' or 'T', column-major B and C. */
 int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, char side, char trans, int64_t m,
                           int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+
+/* The same product with a BLOCK VIEW of the operator (rl_dense_linop.hh:295-330, rl_sparse_linop.hh:393-465, rl_composite_linop.hh:505-530):
+ * how 0 = row_block(view[0], view[2]), 1 = col_block(view[1], view[3]), 2 = submatrix(view[0], view[1], view[2], view[3]);
+ * view = {row_start, col_start, row_count, col_count}; m, n, k describe the product with the VIEW. */
+int rlhip_linop_apply_view_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int how, const int64_t view[4], char side,
+                               char trans, int64_t m, int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* linops::RegExplicitSymLinOp (rl_sym_linops.hh:134-233): C (dim x n) = alpha * (A + mu_i I) * B + beta * C with A given by its UPPER triangle
+ * (dim x dim, lda, DEVICE; the strictly lower triangle is never read); regs_host[num_ops] on the HOST; eval_includes_reg as
+ * set_eval_includes_reg; with num_ops > 1 column i takes regs[i] and n must equal num_ops. */
+int rlhip_regsym_apply_f64(rlhip_ctx* ctx, int64_t dim, const double* A, int64_t lda, const double* regs_host, int64_t num_ops, int eval_includes_reg,
+                           int64_t n, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
 
 /* gen::mat_gen (RandLAPACK/testing/rl_gen.hh:712-772) in HBM.  type: 0 polynomial, 1 exponential, 2 gaussian, 3 step, 4 spiked,
  * 5 adverserial, 6 bad_cholqr, 7 kahan (the enum order of rl_gen.hh:22-31).  A: m x n DEVICE (rank x rank, ld rank, when diag != 0).

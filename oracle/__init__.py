@@ -370,6 +370,50 @@ def _op_mul(A, X, trans=False):
     return np.asarray((A.T if trans else A) @ X)
 
 
+def linop_view(A, how, view):
+    """Block views of an operator (linops/rl_dense_linop.hh:295-330; rl_sparse_linop.hh:393-465 over rl_sparse_views.hh:41-216:
+    csr_row_block rebases rowptr, csr_col_block filters and re-indexes the columns; rl_composite_linop.hh:505-530: rows come from the
+    left operand, columns from the right one).  A: ndarray | scipy.sparse | (left, right); view = (row_start, col_start, row_count,
+    col_count); returns the same kind of object."""
+    r0, c0, rc, cc = view
+    rows, cols = _op_shape(A)
+    if how in ("row_block", "submatrix"):
+        if not (r0 >= 0 and rc > 0 and r0 + rc <= rows):
+            raise ValueError("row range outside the operator")          # randlapack_require in every block method
+    if how in ("col_block", "submatrix"):
+        if not (c0 >= 0 and cc > 0 and c0 + cc <= cols):
+            raise ValueError("column range outside the operator")
+    if isinstance(A, tuple):
+        L, Rr = A
+        if how == "row_block":
+            return (linop_view(L, "row_block", view), Rr)
+        if how == "col_block":
+            return (L, linop_view(Rr, "col_block", view))
+        return (linop_view(L, "row_block", view), linop_view(Rr, "col_block", view))
+    if how == "row_block":
+        return A[r0:r0 + rc, :]
+    if how == "col_block":
+        return A[:, c0:c0 + cc]
+    return A[r0:r0 + rc, :][:, c0:c0 + cc]                              # the reference cuts rows first, then columns (:441-447)
+
+
+def regsym_apply(A_upper, regs, eval_includes_reg, B, alpha=1.0, beta=0.0, C=None):
+    """linops::RegExplicitSymLinOp::operator() (linops/rl_sym_linops.hh:200-217): symm with the stored UPPER triangle, then per column
+    i an axpy with alpha * regs[min(i, num_ops - 1)] when the regularisation is part of the evaluation"""
+    A_upper = np.asarray(A_upper, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    U = np.triu(A_upper)
+    S = U + np.triu(U, 1).T
+    out = alpha * (S @ B) + (beta * C if C is not None else 0.0)
+    regs = list(regs) if len(regs) else [0.0]
+    if eval_includes_reg:
+        if len(regs) != 1 and B.shape[1] != len(regs):
+            raise ValueError("with num_ops > 1 the number of columns must equal num_ops")
+        for i in range(B.shape[1]):
+            out[:, i] += alpha * regs[min(i, len(regs) - 1)] * B[:, i]
+    return out
+
+
 def _gram_through_operator(A, M, b_eff, post=None):
     """G[:, blk] = A^T (A M[:, blk])  (post: G[:, blk] = post^T that) -- the column-block loop of rl_cholqr_linops.hh:108-150,
     rl_cqrrt_linops.hh:264-318, rl_scholqr3_linops.hh:224-236 / 296-312"""

@@ -184,6 +184,8 @@ SIGNATURES.update({
     "rlhip_drv_abrik_linop_timed_f64": (c_int, [c_vp, _ldp, c_i64, c_dbl, c_i64, dpp, dpp, dpp, u32p, C.POINTER(c_i64), C.POINTER(c_i64),
                                                 C.POINTER(c_dbl), c_int, C.POINTER(C.c_long)]),
     "rlhip_linop_apply_f64": (c_int, [c_vp, _ldp, _ldp, c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
+    "rlhip_linop_apply_view_f64": (c_int, [c_vp, _ldp, _ldp, c_int, C.POINTER(c_i64), c_char, c_char, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
+    "rlhip_regsym_apply_f64": (c_int, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_dbl), c_i64, c_int, c_i64, c_dbl, c_vp, c_i64, c_dbl, c_vp, c_i64]),
 })
 SIGNATURES["rlhip_drv_revd2_f64"] = (c_int, [c_vp, c_char, c_i64, c_vp, C.POINTER(c_i64), c_dbl, c_i64, c_i64, c_int, c_int, dpp, dpp, u32p,
                                                C.POINTER(c_dbl)])

@@ -297,7 +297,16 @@ int rlhip_malloc(rlhip_ctx* c, void** p, size_t bytes) {
         e = hipMalloc(p, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return RLHIP_ERR_HIP(e); }
     }
-    if (c->npool < 64) c->pool[c->npool++] = {*p, bytes, true, 0};
+    if (c->npool >= 256) {
+        // table full: the least recently freed idle block makes room, so that every block stays tracked and a request that repeats (a
+        // driver's sketching operator, call after call) is served from the table -- an untracked block would be hipMalloc'ed and hipFree'd
+        // by every call (a device synchronisation each time, and memory unmapped and remapped between launches)
+        int lru = -1;
+        for (int j = 0; j < c->npool; ++j)
+            if (!c->pool[j].in_use && (lru < 0 || c->pool[j].stamp < c->pool[lru].stamp)) lru = j;
+        if (lru >= 0) { (void)rlhip_stream_sync(c); pool_drop(c, lru); }
+    }
+    if (c->npool < 256) c->pool[c->npool++] = {*p, bytes, true, 0};
     return 0;
 }
 int rlhip_free(rlhip_ctx* c, void* p) {

@@ -78,7 +78,11 @@ std::unique_ptr<lo::DenseLinOp<T>> make_dense(blas::Queue& q, const rlhip_linop_
 }
 template <typename T>
 std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_linop_desc& d) {
-    auto op = std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
+    // kind 1 CSR; 2 CSC (rowptr field = colptr, colidx field = row indices); 3 COO (rowptr field = row indices, colidx field = column indices)
+    std::unique_ptr<lo::SparseLinOp<T>> op;
+    if (d.kind == 2) op = std::make_unique<lo::SparseLinOp<T>>(lo::SparseLinOp<T>::from_csc(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q));
+    else if (d.kind == 3) op = std::make_unique<lo::SparseLinOp<T>>(lo::SparseLinOp<T>::from_coo(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q));
+    else op = std::make_unique<lo::SparseLinOp<T>>(d.rows, d.cols, d.nnz, d.rowptr, d.colidx, (const T*)d.vals, q);
     op->force_densified_sketch = rlhip_get_option(q.ctx(), RLHIP_OPT_DRV_SPARSE_SKETCH_DENSIFY) == 1;              // (tests: the fallback path)
     op->row_sharded = q.world() > 1;
     return op;
@@ -86,8 +90,8 @@ std::unique_ptr<lo::SparseLinOp<T>> make_sparse(blas::Queue& q, const rlhip_lino
 template <typename T, typename F>
 int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_linop_desc* right, F&& f) {
     if (!left) throw RandLAPACK::Error("operator descriptor is null");
-    auto kind_ok = [](const rlhip_linop_desc* d) { return d->kind == 0 || d->kind == 1; };
-    if (!kind_ok(left) || (right && !kind_ok(right))) throw RandLAPACK::Error("operator kind must be 0 (dense) or 1 (CSR)");
+    auto kind_ok = [](const rlhip_linop_desc* d) { return d->kind >= 0 && d->kind <= 3; };
+    if (!kind_ok(left) || (right && !kind_ok(right))) throw RandLAPACK::Error("operator kind must be 0 (dense), 1 (CSR), 2 (CSC) or 3 (COO)");
     if (!right) {
         if (left->kind == 0) { auto A = make_dense<T>(q, *left); return f(*A); }
         auto A = make_sparse<T>(q, *left);
@@ -99,12 +103,12 @@ int with_operator(blas::Queue& q, const rlhip_linop_desc* left, const rlhip_lino
         lo::CompositeOperator<lo::DenseLinOp<T>, lo::DenseLinOp<T>> A(m, n, *L, *Rr);
         return f(A);
     }
-    if (left->kind == 0 && right->kind == 1) {
+    if (left->kind == 0 && right->kind >= 1) {
         auto L = make_dense<T>(q, *left); auto Rr = make_sparse<T>(q, *right); Rr->row_sharded = false;
         lo::CompositeOperator<lo::DenseLinOp<T>, lo::SparseLinOp<T>> A(m, n, *L, *Rr);
         return f(A);
     }
-    if (left->kind == 1 && right->kind == 0) {
+    if (left->kind >= 1 && right->kind == 0) {
         auto L = make_sparse<T>(q, *left); auto Rr = make_dense<T>(q, *right); Rr->row_sharded = false;
         lo::CompositeOperator<lo::SparseLinOp<T>, lo::DenseLinOp<T>> A(m, n, *L, *Rr);
         return f(A);
@@ -338,7 +342,6 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
-        if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
         apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
@@ -541,7 +544,6 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
         if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
-        if (q.world() > 1) alg.use_fast_subroutines();                          // the row-sharded call runs Cholesky-QR panels + compact-WY apply only
         apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
@@ -631,6 +633,40 @@ int rlhip_linop_apply_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rl
     });
 }
 
+
+// the same product with a BLOCK VIEW of the operator: how 0 row_block(view[0], view[2]), 1 col_block(view[1], view[3]), 2 submatrix(view[0..3])
+int rlhip_linop_apply_view_f64(rlhip_ctx* ctx, const rlhip_linop_desc* left, const rlhip_linop_desc* right, int how, const int64_t view[4], char side,
+                               char trans, int64_t m, int64_t n, int64_t k, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        if ((side != 'L' && side != 'R') || (trans != 'N' && trans != 'T')) throw RandLAPACK::Error("side must be L or R, trans N or T");
+        if (how < 0 || how > 2 || !view) throw RandLAPACK::Error("how must be 0 (row_block), 1 (col_block) or 2 (submatrix)");
+        return with_operator<double>(q, left, right, [&](auto& A) -> int {
+            auto apply = [&](auto&& V) {
+                V(side == 'L' ? RandLAPACK::Side::Left : RandLAPACK::Side::Right, RandLAPACK::Layout::ColMajor,
+                  trans == 'N' ? RandLAPACK::Op::NoTrans : RandLAPACK::Op::Trans, RandLAPACK::Op::NoTrans, m, n, k, alpha, B, ldb, beta, C, ldc);
+                q.sync();                   // (a view may own device arrays that go away with it)
+            };
+            if (how == 0) apply(A.row_block(view[0], view[2]));
+            else if (how == 1) apply(A.col_block(view[1], view[3]));
+            else apply(A.submatrix(view[0], view[1], view[2], view[3]));
+            return 0;
+        });
+    });
+}
+
+// linops::RegExplicitSymLinOp (rl_sym_linops.hh:134-233): C = alpha (A + mu_i I) B + beta C, A given by its UPPER triangle; regs on the HOST
+int rlhip_regsym_apply_f64(rlhip_ctx* ctx, int64_t dim, const double* A, int64_t lda, const double* regs_host, int64_t num_ops, int eval_includes_reg,
+                           int64_t n, double alpha, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    return guarded([&] {
+        blas::Queue q(ctx);
+        lo::RegExplicitSymLinOp<double> op(dim, A, lda, regs_host, num_ops, q);
+        op.set_eval_includes_reg(eval_includes_reg != 0);
+        op(RandLAPACK::Layout::ColMajor, n, alpha, B, ldb, beta, C, ldc);
+        q.sync();
+        return 0;
+    });
+}
 
 int rlhip_drv_mat_gen_f64(rlhip_ctx* ctx, int type, int64_t m, int64_t n, int64_t rank, double cond_num, double scaling, double exponent,
                           int diag, double theta, double perturb, double frac_spectrum_one, int check_true_rank, double* A,

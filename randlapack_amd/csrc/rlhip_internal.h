@@ -100,7 +100,7 @@ struct rlhip_ctx {
     // caching pool behind rlhip_malloc/rlhip_free (outputs the drivers allocate for the caller: Q, BT, U, S, V).
     // Blocks are recycled by exact size; reuse is ordered by the context's stream, so freeing does not synchronise.
     struct PoolBlk { void* p; size_t bytes; bool in_use; unsigned long stamp; };
-    PoolBlk pool[64];
+    PoolBlk pool[256];
     int npool = 0;
     size_t pool_idle_bytes = 0, pool_cap_bytes = 0;
     unsigned long pool_clock = 0;

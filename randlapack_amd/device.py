@@ -449,6 +449,37 @@ class CsrOperator:
                          self.vals.data_ptr())
 
 
+class CscOperator(CsrOperator):
+    """linops::SparseLinOp::from_csc: the operator given by its columns (colptr, row indices, values)"""
+
+    @classmethod
+    def from_scipy(cls, sp, device="cuda:0", dtype=None):
+        torch = _torch()
+        csc = sp.tocsc()
+        dt = dtype or torch.float64
+        return cls(csc.shape[0], csc.shape[1], torch.as_tensor(csc.indptr.astype(np.int64), device=device),
+                   torch.as_tensor(csc.indices.astype(np.int64), device=device), torch.as_tensor(csc.data, device=device).to(dt))
+
+    def desc(self):
+        from ._lib import LinOpDesc
+        return LinOpDesc(2, self.rows, self.cols, None, 0, int(self.vals.numel()), self.rowptr.data_ptr(), self.colidx.data_ptr(), self.vals.data_ptr())
+
+
+class CooOperator(CsrOperator):
+    """linops::SparseLinOp::from_coo: (row, col, value) triplets in any order, duplicates summed"""
+
+    @classmethod
+    def from_triplets(cls, rows, cols, ri, ci, v, device="cuda:0", dtype=None):
+        torch = _torch()
+        dt = dtype or torch.float64
+        return cls(rows, cols, torch.as_tensor(np.asarray(ri, dtype=np.int64), device=device), torch.as_tensor(np.asarray(ci, dtype=np.int64), device=device),
+                   torch.as_tensor(np.asarray(v), device=device).to(dt))
+
+    def desc(self):
+        from ._lib import LinOpDesc
+        return LinOpDesc(3, self.rows, self.cols, None, 0, int(self.vals.numel()), self.rowptr.data_ptr(), self.colidx.data_ptr(), self.vals.data_ptr())
+
+
 def _op_descs(op):
     """op: DenseOperator | CsrOperator | (left, right) -> (left desc, right desc or None, rows, cols, dtype)"""
     if isinstance(op, tuple):
@@ -524,6 +555,32 @@ def linop_apply(ctx: Context, op, side, trans, B, m, n, k, alpha=1.0, beta=0.0, 
     rc = ctx.lib.rlhip_linop_apply_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, side.encode(), trans.encode(), m, n, k,
                                        alpha, B.data_ptr(), ldb, beta, Cout.data_ptr(), m)
     _drv_check(ctx, rc, "linop_apply")
+    return Cout
+
+
+VIEW_HOW = {"row_block": 0, "col_block": 1, "submatrix": 2}
+
+
+def linop_apply_view(ctx: Context, op, how, view, side, trans, B, m, n, k, alpha=1.0, beta=0.0, C_in=None):
+    """the same product with a block view of the operator: how in VIEW_HOW, view = (row_start, col_start, row_count, col_count)"""
+    dev = f"cuda:{ctx.device}"
+    ld, rd, _, _, _ = _op_descs(op)
+    Cout = C_in if C_in is not None else cm_zeros(m, n, device=dev)
+    v = (C.c_int64 * 4)(*[int(x) for x in view])
+    rc = ctx.lib.rlhip_linop_apply_view_f64(ctx.h, C.byref(ld), C.byref(rd) if rd is not None else None, VIEW_HOW[how], v, side.encode(), trans.encode(),
+                                            m, n, k, alpha, B.data_ptr(), B.shape[1], beta, Cout.data_ptr(), m)
+    _drv_check(ctx, rc, "linop_apply_view")
+    return Cout
+
+
+def regsym_apply(ctx: Context, A, dim, regs, eval_includes_reg, B, n, alpha=1.0, beta=0.0, C_in=None, lda=None):
+    """linops::RegExplicitSymLinOp: C = alpha (A + mu_i I) B + beta C, A by its upper triangle (column-major tensor (dim, lda))"""
+    dev = f"cuda:{ctx.device}"
+    Cout = C_in if C_in is not None else cm_zeros(dim, n, device=dev)
+    rg = (C.c_double * max(len(regs), 1))(*[float(x) for x in regs])
+    rc = ctx.lib.rlhip_regsym_apply_f64(ctx.h, dim, A.data_ptr(), lda or dim, rg, len(regs), int(bool(eval_includes_reg)), n, alpha, B.data_ptr(),
+                                        B.shape[1], beta, Cout.data_ptr(), dim)
+    _drv_check(ctx, rc, "regsym_apply")
     return Cout
 
 

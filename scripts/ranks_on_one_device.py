@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""N ranks of a row-sharded driver in ONE process on ONE device -- the closest thing to an N-GPU run that a one-GPU box can execute.
+
+Every rank is a thread with its own rlhip context (its own scratch arena, mailbox, communicator record: world = N, rank = r) and ALL contexts
+are bound to the SAME HIP stream, so the device executes the ranks' kernels strictly one after the other: the wall time of the whole world is
+the SUM of the ranks' device times, and wall / N is one rank's share -- its 1/N of the rows plus EVERY replicated stage (the replicated
+k x k tail of RSVD, geqp3 of CQRRPT's sketch, BQRRP's qrcp_wide and b x b factors run once per rank, as on N devices).  The library's
+all-reduce hook (include/rlhip.h: rlhip_comm_set_hook) is served in place: the ranks meet at a barrier, rank 0 sums the N device buffers in
+rank order with torch ops on the shared stream and copies the sum back to every rank's buffer -- no transport, so what is measured is compute;
+the exchange volumes are printed so that the xGMI terms can be added.
+
+This is the REAL sharded code path at FULL size with world = 8 (Queue::allreduce_sum at every reduction point, shard_extent, block-cyclic rows
+for BQRRP); the result is checked against the single-device run on the assembled matrix (pivots identical, factors to rounding).
+
+usage: ranks_on_one_device.py {rsvd|cqrrpt|bqrrp} [--world 8] [--steps 2] [--check] [--m M --n N ...]
+"""
+import argparse, ctypes as C, json, os, sys, threading, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from randlapack_amd import _lib, device as d
+
+PEAK = {"f64": 78.6, "f32": 157.3}
+
+
+class World:
+    """N contexts on one stream + the in-place all-reduce"""
+
+    def __init__(self, n):
+        self.n = n
+        self.ctx = [d.Context(0) for _ in range(n)]
+        self.bar = threading.Barrier(n, timeout=600)
+        self.slots = [None] * n
+        self.bytes_reduced = 0
+        self.collectives = 0
+        self.err = []
+        self._cbs = []
+        for r in range(n):
+            cb = _lib.HOOK(self._make_hook(r))
+            self._cbs.append(cb)
+            _lib.check(self.ctx[r].lib.rlhip_comm_set_hook(self.ctx[r].h, cb, None, n, r), "rlhip_comm_set_hook")
+
+    def _view(self, ptr, count, is_f64):
+        class H:
+            pass
+        h = H()
+        h.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8" if is_f64 else "<f4", "data": (int(ptr), False), "version": 3}
+        return torch.as_tensor(h, device="cuda:0")
+
+    def _make_hook(self, r):
+        def hook(_user, dev_ptr, count, is_f64):
+            try:
+                self.slots[r] = (int(dev_ptr), int(count), int(is_f64))
+                self.bar.wait()
+                if r == 0:
+                    c0, f0 = self.slots[0][1], self.slots[0][2]
+                    assert all(s[1] == c0 and s[2] == f0 for s in self.slots), f"ranks disagree on a collective: {self.slots}"
+                    bufs = [self._view(*s) for s in self.slots]
+                    acc = bufs[0]
+                    for b in bufs[1:]:
+                        acc += b                       # fixed rank order: deterministic
+                    for b in bufs[1:]:
+                        b.copy_(acc)
+                    self.bytes_reduced += c0 * (8 if f0 else 4)
+                    self.collectives += 1
+                self.bar.wait()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                self.err.append(f"rank {r}: {e}")
+                try:
+                    self.bar.abort()
+                except Exception:
+                    pass
+                return -1
+        return hook
+
+    def run(self, fn):
+        """fn(rank, ctx) on every rank, concurrently; returns the list of results"""
+        out = [None] * self.n
+        exc = []
+
+        def work(r):
+            try:
+                out[r] = fn(r, self.ctx[r])
+            except Exception as e:  # noqa: BLE001
+                exc.append((r, e))
+                try:
+                    self.bar.abort()
+                except Exception:
+                    pass
+        ts = [threading.Thread(target=work, args=(r,)) for r in range(self.n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if exc or self.err:
+            raise RuntimeError(f"{exc} {self.err}")
+        return out
+
+
+def block_cyclic_rows(rank, world, m, b):
+    idx = [np.arange(g * b, min((g + 1) * b, m)) for g in range(rank, (m + b - 1) // b, world)]
+    return np.concatenate(idx).astype(np.int64) if idx else np.zeros(0, dtype=np.int64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["rsvd", "cqrrpt", "bqrrp"])
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--check", action="store_true", help="also run the single-device factorization of the assembled matrix and compare")
+    ap.add_argument("--m", type=int, default=0); ap.add_argument("--n", type=int, default=0); ap.add_argument("--k", type=int, default=256); ap.add_argument("--b", type=int, default=2048)
+    a = ap.parse_args()
+    N = a.world
+    if a.what == "rsvd":
+        m, n, dt = a.m or 200000, a.n or 20000, torch.float64
+    elif a.what == "cqrrpt":
+        m, n, dt = a.m or 1048576, a.n or 1024, torch.float64
+    else:
+        m, n, dt = a.m or 65536, a.n or 65536, torch.float32
+    W = World(N)
+    ctx1 = d.Context(0)                                               # world of one, for the single-device references
+    # ---- the global matrix as N row shards (rank r draws its own block: key 7 + r, as bench.py does)
+    if a.what == "bqrrp":
+        rows = [block_cyclic_rows(r, N, m, a.b) for r in range(N)]
+    else:
+        cut = [r * (m // N) for r in range(N)] + [m]
+        rows = [np.arange(cut[r], cut[r + 1]) for r in range(N)]
+    shards = []
+    for r in range(N):
+        Ar = d.cm_empty(len(rows[r]), n, dtype=dt)
+        ctx1.fill_dense(Ar, len(rows[r]), n, key=(7 + r, 0))
+        if a.what != "rsvd":                                          # graded columns: no pivot decision is a rounding-level near-tie
+            g = torch.Generator().manual_seed(1)
+            Ar.mul_(torch.logspace(0, -2 if dt == torch.float64 else -1, n, dtype=dt)[torch.randperm(n, generator=g)].cuda().unsqueeze(1))
+        shards.append(Ar)
+    ctx1.sync()
+
+    def step(r, ctx, A):
+        if a.what == "rsvd":
+            return d.drv_rsvd(ctx, A, len(rows[r]), n, a.k, a.k, 1e-12, 0, 1, key=(0, 0))
+        if a.what == "cqrrpt":
+            return d.drv_cqrrpt(ctx, A, len(rows[r]), n, 1.25, 4, key=(3, 0))
+        return d.drv_bqrrp(ctx, A, len(rows[r]), n, a.b, 1.0, key=(4, 0), qr_tall=1, apply_trans_q=1, m_global=m, block_cyclic=True)
+
+    best, res = None, None
+    for it in range(a.steps + 1):
+        work = [s.clone() for s in shards] if a.what != "rsvd" else shards          # the pivoted factorizations overwrite their input
+        torch.cuda.synchronize()
+        W.bytes_reduced = 0; W.collectives = 0
+        t0 = time.perf_counter()
+        res = W.run(lambda r, ctx: step(r, ctx, work[r]))
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        if it > 0:
+            best = dtm if best is None else min(best, dtm)
+    # ---- the same problem on ONE context (world of one)
+    single_ms = None
+    chk = {}
+    if a.check:
+        Ag = torch.empty((n, m), dtype=dt, device="cuda")
+        for r in range(N):
+            Ag[:, torch.from_numpy(rows[r]).cuda()] = shards[r]
+        ctx1.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if a.what == "rsvd":
+            r1 = d.drv_rsvd(ctx1, Ag, m, n, a.k, a.k, 1e-12, 0, 1, key=(0, 0))
+        elif a.what == "cqrrpt":
+            r1 = d.drv_cqrrpt(ctx1, Ag, m, n, 1.25, 4, key=(3, 0))
+        else:
+            r1 = d.drv_bqrrp(ctx1, Ag, m, n, a.b, 1.0, key=(4, 0), qr_tall=1, apply_trans_q=1)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) * 1e3
+        if a.what == "rsvd":
+            S8, S1 = res[0]["S"], r1["S"]
+            chk = dict(k=[res[0]["k"], r1["k"]], sigma_rel_diff=float(((S8 - S1).abs() / S1[0]).max()),
+                       ranks_agree=bool(all(torch.equal(res[0]["S"], res[r]["S"]) for r in range(N))))
+        elif a.what == "cqrrpt":
+            R8, R1 = res[0]["R"], r1["R"]
+            chk = dict(rank=[res[0]["rank"], r1["rank"]], J_equal=bool(torch.equal(res[0]["J"], r1["J"])),
+                       ranks_agree=bool(all(torch.equal(res[0]["J"], res[r]["J"]) for r in range(N))),
+                       R_rel_diff=float((R8 - R1).norm() / R1.norm()))
+        else:
+            J8, J1 = res[0]["J"], r1["J"]
+            same = (J8 == J1)
+            chk = dict(rank=[res[0]["rank"], r1["rank"]], J_equal=bool(same.all()), J_positions_equal=float(same.double().mean()),
+                       first_block_equal=bool(same[:a.b].all()), ranks_agree=bool(all(torch.equal(res[0]["J"], res[r]["J"]) for r in range(N))),
+                       tau_max_diff=float((res[0]["tau"] - r1["tau"]).abs().max()))
+    if a.what == "rsvd":
+        flops = 2.0 * 2 * m * n * a.k + 4.0 * m * a.k ** 2 + 6.0 * n * a.k ** 2 + 8.0 * a.k ** 3
+        name = f"RSVD {m}x{n} fp64 rank {a.k}"
+    elif a.what == "cqrrpt":
+        dd = int(1.25 * n)
+        flops = 2.0 * 4 * m * n + (2.0 * dd * n * n - 2.0 / 3 * n ** 3) + 3.0 * m * n * n + n ** 3 / 3.0 + n ** 3
+        name = f"CQRRPT {m}x{n} fp64"
+    else:
+        flops = 2.0 * a.b * m * n + (2.0 * m * n * n - 2.0 / 3 * n ** 3)
+        name = f"BQRRP {m}x{n} fp32 b={a.b}"
+    per_rank_ms = best * 1e3 / N
+    out = {"workload": f"{name}, {N} row-sharded ranks on ONE device (threads, one shared stream: the device runs the ranks one after the other)",
+           "world": N, "wall_ms_all_ranks": round(best * 1e3, 2), "ms_per_rank": round(per_rank_ms, 3),
+           "what_ms_per_rank_is": "1/N of the rows + every replicated stage, the real sharded code path; exchanges served in place (no transport time)",
+           "collectives_per_call": W.collectives, "bytes_all_reduced_per_call": W.bytes_reduced,
+           "single_device_ms": None if single_ms is None else round(single_ms, 2),
+           "algorithmic_flops": flops, "per_rank_tflops_if_alone": round(flops / N / (per_rank_ms * 1e-3) / 1e12, 2),
+           "check_vs_single_device": chk}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,8 +45,12 @@ def main():
     nbq, bb = min(n, 120), 32
     Abq = A[:, :nbq] * np.logspace(0, -2, nbq)
     Ab = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
-    rb = d.drv_bqrrp(ctx, Ab, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m)
+    rb = d.drv_bqrrp(ctx, Ab, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m)          # the reference's default triple {luqr, geqrf, ormqr}: TSQR panels
     Ab_loc, tau_b, J_b = d.cm_to_numpy(Ab), rb["tau"].cpu().numpy(), rb["J"].cpu().numpy()
+    # ... and the Cholesky-QR panels of the fast triple {luqr, cholqr, gemqrt}
+    Af = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
+    rf = d.drv_bqrrp(ctx, Af, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m, qrcp_wide=0, qr_tall=1, apply_trans_q=1)
+    Af_loc, tau_f, J_f = d.cm_to_numpy(Af), rf["tau"].cpu().numpy(), rf["J"].cpu().numpy()
     # the same factorization with the rows dealt block-cyclically (blocks of bb rows, block g on rank g % world)
     crows = np.concatenate([np.arange(g * bb, min((g + 1) * bb, m)) for g in range(rank, (m + bb - 1) // bb, world)] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
     Ac = d.cm_from_numpy(np.ascontiguousarray(Abq[crows]))
@@ -65,7 +69,7 @@ def main():
     lin = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx, alg, op_loc, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
     rsa = d.drv_abrik_linop(ctx, op_loc, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc, Af_loc))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
@@ -75,8 +79,9 @@ def main():
         Ua = np.zeros((m, ra["triplets"]))
         Abq_out = np.zeros((m, nbq))
         Acq_out = np.zeros((m, nbq))
-        for rr, u, u2, qq, ua, ab, cr, ac in gathered:
-            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac
+        Afq_out = np.zeros((m, nbq))
+        for rr, u, u2, qq, ua, ab, cr, ac, af in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac; Afq_out[rr] = af
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
@@ -104,6 +109,8 @@ def main():
             sp_abrik_trip=[rsa["triplets"], rsa1["triplets"]], sp_abrik_S=float(np.max(np.abs(Ssa[:6] - Ssa1[:6]) / Ssa1[:6])),
             bq_rank=rb["rank"], bq_rank1=rb1["rank"], bq_J_equal=bool(np.array_equal(J_b, rb1["J"].cpu().numpy())),
             bq_A=float(np.linalg.norm(Abq_out - Ab1n) / np.linalg.norm(Ab1n)), bq_tau=float(np.max(np.abs(tau_b - rb1["tau"].cpu().numpy()))),
+            bqf_rank=rf["rank"], bqf_J_equal=bool(np.array_equal(J_f, rb1["J"].cpu().numpy())),
+            bqf_A=float(np.linalg.norm(Afq_out - Ab1n) / np.linalg.norm(Ab1n)), bqf_tau=float(np.max(np.abs(tau_f - rb1["tau"].cpu().numpy()))),
             bqc_rank=rc_["rank"], bqc_J_equal=bool(np.array_equal(J_c, rb1["J"].cpu().numpy())),
             bqc_A=float(np.linalg.norm(Acq_out - Ab1n) / np.linalg.norm(Ab1n)), bqc_tau=float(np.max(np.abs(tau_c - rb1["tau"].cpu().numpy()))),
             bq_resid=float(np.linalg.norm(Abq[:, J_b - 1] - Qb @ Rb) / np.linalg.norm(Abq)), bq_orth=float(np.linalg.norm(Qb.T @ Qb - np.eye(nbq))),

@@ -357,3 +357,120 @@ def test_cqrrt_linops_at_scale_sparse_vs_dense_cqrrt(ctx):
     R2 = torch.triu(o2["R"].T)
     assert float(torch.linalg.norm(R - R2) / torch.linalg.norm(R2)) < 1e-11
     assert out["next_ctr"] == o2["next_ctr"]
+
+
+# ------------------------------------------------------------------------------------------------ block views, CSC / COO storage, A + mu I
+VIEWS = [("row_block", "mid"), ("row_block", "first"), ("row_block", "last"), ("col_block", "mid"), ("col_block", "first"), ("col_block", "last"),
+         ("submatrix", "mid"), ("submatrix", "corner"), ("submatrix", "end")]
+
+
+def _view_of(how, where, rows, cols):
+    """the reference's cases (test/linops/test_linop_block_views.cc: *_middle, *_first, *_last, submatrix_corner / _end) scaled to the operator"""
+    r = {"mid": (rows // 4, rows // 2), "first": (0, rows // 3), "last": (rows - rows // 3, rows // 3), "corner": (0, rows // 2), "end": (rows - rows // 2, rows // 2)}[where]
+    c = {"mid": (cols // 4, cols // 2), "first": (0, cols // 3), "last": (cols - cols // 3, cols // 3), "corner": (0, cols // 2), "end": (cols - cols // 2, cols // 2)}[where]
+    if how == "row_block":
+        return (r[0], 0, r[1], cols), r[1], cols
+    if how == "col_block":
+        return (0, c[0], rows, c[1]), rows, c[1]
+    return (r[0], c[0], r[1], c[1]), r[1], c[1]
+
+
+def _dense_of(A):
+    if isinstance(A, tuple):
+        return _dense_of(A[0]) @ _dense_of(A[1])
+    return A.toarray() if sp.issparse(A) else np.asarray(A)
+
+
+@pytest.mark.parametrize("how,where", VIEWS)
+@pytest.mark.parametrize("kind", ["dense", "sparse", "csc", "dense*sparse", "sparse*dense", "sparse*sparse"])
+def test_linop_block_views_match_the_oracle(ctx, orc, kind, how, where):
+    """row_block / col_block / submatrix of every operator type (rl_dense_linop.hh:295-330, rl_sparse_linop.hh:393-465,
+    rl_composite_linop.hh:505-530): the view applied to a block of vectors, both directions, against the numpy restatement of the
+    same view (oracle.linop_view) -- the reference's test_linop_block_views.cc cases at sizes where a device kernel is exercised."""
+    d = _d()
+    if kind == "csc":
+        S = _sparse(400, 50, 0.2, 77)
+        op, op_np = d.CscOperator.from_scipy(S), S
+    else:
+        op, op_np, _ = _ops(kind, 23)
+    rows, cols = orc._op_shape(op_np)
+    view, vr, vc = _view_of(how, where, rows, cols)
+    V = _dense_of(orc.linop_view(op_np, how, view))
+    assert V.shape == (vr, vc)
+    rng = np.random.default_rng(vr + 3 * vc)
+    for nb in (5, 40):
+        X = rng.standard_normal((vc, nb)); Z = rng.standard_normal((vr, nb)); C0 = rng.standard_normal((vr, nb))
+        Y = d.cm_to_numpy(d.linop_apply_view(ctx, op, how, view, "L", "N", d.cm_from_numpy(X), vr, nb, vc, alpha=1.5, beta=-0.5, C_in=d.cm_from_numpy(C0)))
+        ref = 1.5 * V @ X - 0.5 * C0
+        np.testing.assert_allclose(Y, ref, rtol=0, atol=1e-13 * max(1.0, np.abs(ref).max()) * 10)
+        Yt = d.cm_to_numpy(d.linop_apply_view(ctx, op, how, view, "L", "T", d.cm_from_numpy(Z), vc, nb, vr))
+        np.testing.assert_allclose(Yt, V.T @ Z, rtol=0, atol=1e-13 * max(1.0, np.abs(V.T @ Z).max()) * 10)
+    if not isinstance(op, tuple):                                      # Side::Right on plain operators: C = B * view
+        Bm = rng.standard_normal((7, vr))
+        Yr = d.cm_to_numpy(d.linop_apply_view(ctx, op, how, view, "R", "N", d.cm_from_numpy(Bm), 7, vc, vr))
+        np.testing.assert_allclose(Yr, Bm @ V, rtol=0, atol=1e-13 * max(1.0, np.abs(Bm @ V).max()) * 10)
+
+
+def test_linop_block_view_argument_errors(ctx):
+    """the randlapack_require checks of the block methods (negative starts, empty counts, ranges past the end)"""
+    d = _d()
+    op, _, _ = _ops("sparse", 5)
+    dop, _, _ = _ops("dense", 5)
+    X = d.cm_zeros(50, 3)
+    for o in (op, dop):
+        for how, view in (("row_block", (-1, 0, 10, 50)), ("row_block", (395, 0, 10, 50)), ("col_block", (0, 45, 400, 10)), ("submatrix", (0, 0, 0, 5)),
+                          ("submatrix", (10, 10, 5, 0))):
+            with pytest.raises(Exception):
+                d.linop_apply_view(ctx, o, how, view, "L", "N", X, view[2], 3, view[3])
+
+
+@pytest.mark.parametrize("storage", ["csc", "coo", "coo-duplicates"])
+def test_sparse_linop_from_csc_and_coo_storage(ctx, orc, storage):
+    """SparseLinOp over the other two RandBLAS sparse formats (CSCMatrix, COOMatrix; rl_sparse_linop.hh:41-113): products in both
+    directions, the Frobenius norm through a CholQR_linops call (its first use), and CholQR_linops' R against the oracle's."""
+    d = _d()
+    rng = np.random.default_rng(11)
+    S = _sparse(600, 40, 0.15, 9)
+    if storage == "csc":
+        op, S_np = d.CscOperator.from_scipy(S), S
+    else:
+        coo = S.tocoo()
+        ri, ci, v = coo.row.copy(), coo.col.copy(), coo.data.copy()
+        if storage == "coo-duplicates":                                 # every 7th entry split in two: the products sum duplicates
+            idx = np.arange(0, len(v), 7)
+            ri = np.concatenate([ri, ri[idx]]); ci = np.concatenate([ci, ci[idx]]); v = np.concatenate([v, 0.25 * v[idx]])
+            v[idx] *= 0.75
+        perm = rng.permutation(len(v))                                  # any order
+        op, S_np = d.CooOperator.from_triplets(600, 40, ri[perm], ci[perm], v[perm]), S
+    X = rng.standard_normal((40, 9)); Z = rng.standard_normal((600, 9))
+    Y = d.cm_to_numpy(d.linop_apply(ctx, op, "L", "N", d.cm_from_numpy(X), 600, 9, 40))
+    np.testing.assert_allclose(Y, S_np @ X, rtol=0, atol=1e-13 * np.abs(S_np @ X).max() * 10)
+    Yt = d.cm_to_numpy(d.linop_apply(ctx, op, "L", "T", d.cm_from_numpy(Z), 40, 9, 600))
+    np.testing.assert_allclose(Yt, S_np.T @ Z, rtol=0, atol=1e-13 * np.abs(S_np.T @ Z).max() * 10)
+    r = d.drv_qr_linops(ctx, "cholqr", op, want_Q=True)
+    o = orc.cholqr_linops(S_np)
+    assert r["rc"] == o["rc"] == 0
+    np.testing.assert_allclose(d.cm_to_numpy(r["R"]), o["R"], rtol=0, atol=1e-12 * np.abs(o["R"]).max())
+
+
+@pytest.mark.parametrize("num_ops,eir", [(1, True), (1, False), (6, True), (0, True)])
+def test_reg_explicit_sym_linop_vs_oracle(ctx, orc, num_ops, eir):
+    """linops::RegExplicitSymLinOp (rl_sym_linops.hh:134-233): A + mu_i I applied to a block, one mu or one per column; the strictly
+    lower triangle of the buffer holds NaNs (it must never be read); lda > dim."""
+    d = _d()
+    import torch
+
+    rng = np.random.default_rng(4 + num_ops)
+    dim, lda, n = 300, 320, 6
+    G0 = rng.standard_normal((dim, dim)); G = G0 @ G0.T / dim
+    buf = np.full((lda, dim), np.nan); buf[:dim] = np.triu(G) + np.tril(np.full((dim, dim), np.nan), -1)
+    regs = list(rng.random(num_ops) + 0.1)
+    B = rng.standard_normal((dim, n)); C0 = rng.standard_normal((dim, n))
+    Ad = d.cm_from_numpy(buf)
+    out = d.cm_to_numpy(d.regsym_apply(ctx, Ad, dim, regs, eir, d.cm_from_numpy(B), n, alpha=0.7, beta=0.3, C_in=d.cm_from_numpy(C0), lda=lda))
+    ref = orc.regsym_apply(np.triu(G), regs, eir, B, alpha=0.7, beta=0.3, C=C0)
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-13 * np.abs(ref).max() * 10)
+    if num_ops == 6:                                                    # n != num_ops is rejected (rl_sym_linops.hh:209)
+        with pytest.raises(Exception):
+            d.regsym_apply(ctx, Ad, dim, regs, True, d.cm_from_numpy(B[:, :4]), 4, lda=lda)

@@ -42,7 +42,7 @@ def test_bqrrp_lookahead_f64_pivots_exact_vs_oracle_and_serial(ctx, orc, qrcp_wi
     Fl, tl, Jl, kl, sk, nl = res["lookahead"]
     Fs, ts, Js, ks, sk2, ns = res["serial"]
     assert ns == 0 and nl == min(m, n) // b - 1, f"side-queue iterations: forced {nl}, serial {ns}"
-    assert np.array_equal(sk, sk2)
+    assert np.array_equal(sk, sk2), f"the two calls formed different sketches: max {np.abs(sk - sk2).max():.3e} at {int((sk != sk2).sum())} entries"
     o = orc.bqrrp(A, b, 1.0, qrcp_wide=qrcp_wide, qr_tall=qr_tall, apply_trans_q=apply_q, sketch=sk)
     assert o["rc"] == 0 and kl == ks == o["rank"]
     np.testing.assert_array_equal(Jl, Js)                               # the two orders: the same pivots, bit for bit
@@ -113,3 +113,37 @@ def test_bqrrp_f32_graded_columns_all_blocks_pivots_exact(ctx, orc, lookahead):
     Ro = np.triu(o64["A"])[:n]
     assert np.linalg.norm(np.triu(F)[:n] - Ro) <= EPS32**0.6 * np.linalg.norm(Ro)
     np.testing.assert_allclose(r["tau"].cpu().numpy(), o64["tau"], atol=2e-4, rtol=0)
+
+
+def test_repeated_calls_with_a_crowded_output_pool_form_the_same_sketch(ctx):
+    """Regression (round 5): with the context's caching pool full of other sizes the sketching operator of every BQRRP call used to be
+    hipMalloc'ed and hipFree'd around its product, and the look-ahead created and destroyed a side context (64 MiB arena, uncached exchange
+    buffer) per call -- device memory unmapped and remapped between launches, after which the SECOND call's sketch came out wrong in the
+    contributions of its first 128 rows.  Now the pool keeps every block tracked (least recently freed idle block evicted when
+    the table is full) and the side queue is the context's cached one: the same call twice forms the same sketch, bit for bit, and equals
+    S A computed independently."""
+    import ctypes as C
+
+    d = _d()
+    ptrs = []
+    for i in range(300):                                            # crowd the pool: 300 idle blocks of distinct sizes
+        p = C.c_void_p()
+        assert ctx.lib.rlhip_malloc(ctx.h, C.byref(p), 4096 * (i + 1) + 256) == 0
+        ptrs.append(p)
+    for p in ptrs:
+        assert ctx.lib.rlhip_free(ctx.h, p) == 0
+    m, n, b = 2048, 1536, 256
+    rng = np.random.default_rng(3)
+    A = _graded(m, n, rng, 4.0)
+    S = d.cm_empty(b, m); ctx.fill_dense(S, b, m, key=(21, 0))
+    ref = d.cm_to_numpy(S) @ A
+    sks = []
+    for thresh in (0, NEVER, 0, NEVER):
+        Ad = d.cm_from_numpy(A)
+        with ctx.options(bqrrp_lookahead_min_elems=thresh):
+            r = d.drv_bqrrp(ctx, Ad, m, n, b, 1.0, want_sketch=True, key=(21, 0), qrcp_wide=1, qr_tall=1, apply_trans_q=1)
+        sks.append(d.cm_to_numpy(r["sketch"]))
+    for sk in sks:
+        assert np.abs(sk - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.array_equal(sk, sks[0])
+    ctx.lib.rlhip_trim(ctx.h)

@@ -41,9 +41,12 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     # row-sharded CQRRPT == single-device CQRRPT (same SASO, same pivots; R to rounding)
     assert out["cq_rank"] == out["cq_rank1"] and out["cq_J_equal"]
     assert out["cq_R"] <= 1e-10 and out["cq_resid"] <= 1e-12 and out["cq_orth"] <= 1e-11
-    # row-sharded BQRRP == single-device BQRRP: same pivots, GEQP3-format output (V, R, tau) equal to rounding, valid factorization
+    # row-sharded BQRRP == single-device BQRRP: same pivots, GEQP3-format output (V, R, tau) equal to rounding, valid factorization --
+    # with the reference's DEFAULT subroutines {luqr, geqrf, ormqr} (sharded: TSQR panels) and with the fast triple {luqr, cholqr, gemqrt}
     assert out["bq_rank"] == out["bq_rank1"] and out["bq_J_equal"]
     assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
+    assert out["bqf_rank"] == out["bq_rank1"] and out["bqf_J_equal"]
+    assert out["bqf_A"] <= 1e-10 and out["bqf_tau"] <= 1e-10
     # linop QR drivers and ABRIK on a row-sharded CSR operator: same R / Ritz values as on one device
     assert all(v <= 1e-10 for v in out["lin_R"].values()), out["lin_R"]
     assert out["sp_abrik_trip"][0] == out["sp_abrik_trip"][1] and out["sp_abrik_S"] <= 1e-9

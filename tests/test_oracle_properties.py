@@ -470,3 +470,41 @@ def test_benchmark_metric_helpers_cpu():
     R = np.triu(rng.standard_normal((37, 37)))
     want = np.array([np.linalg.norm(R[i:, i:]) for i in range(37)])
     np.testing.assert_allclose(ns["trailing_norms"](R), want, rtol=1e-13)
+
+
+# ---- operator block views and A + mu I (test infrastructure for tests/test_gpu_linops.py)
+def test_oracle_linop_views_reproduce_the_reference_structure_cases(orc):
+    """the structure cases of test/linops/test_linop_block_views.cc (rebased row pointers of a CSR row block, filtered and re-indexed
+    columns of a CSR column block, composite views cut the left / right operand) on the numpy restatement"""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    S = sp.random(20, 15, 0.3, random_state=np.random.default_rng(1), format="csr")
+    D = S.toarray()
+    rb = orc.linop_view(S, "row_block", (5, 0, 8, 15))
+    assert rb.shape == (8, 15) and rb.indptr[0] == 0 and rb.nnz == S.indptr[13] - S.indptr[5]           # csr_row_block: rebased, nnz of the slice
+    np.testing.assert_array_equal(rb.toarray(), D[5:13])
+    cb = orc.linop_view(S, "col_block", (0, 4, 20, 7))
+    assert cb.shape == (20, 7) and cb.indices.max() < 7                                                   # csr_col_block: indices re-based to the block
+    np.testing.assert_array_equal(cb.toarray(), D[:, 4:11])
+    np.testing.assert_array_equal(orc.linop_view(S, "submatrix", (12, 9, 8, 6)).toarray(), D[12:20, 9:15])
+    L = rng.standard_normal((9, 20))
+    lv, rv = orc.linop_view((L, S), "submatrix", (2, 3, 4, 5))
+    np.testing.assert_allclose(lv @ rv.toarray(), (L @ D)[2:6, 3:8], atol=1e-14)
+    for bad in (("row_block", (-1, 0, 3, 15)), ("row_block", (18, 0, 3, 15)), ("col_block", (0, 14, 20, 2)), ("submatrix", (0, 0, 0, 1))):
+        with pytest.raises(ValueError):
+            orc.linop_view(S, *bad)
+
+
+def test_oracle_regsym_apply(orc):
+    rng = np.random.default_rng(2)
+    G0 = rng.standard_normal((12, 12)); G = G0 + G0.T
+    B = rng.standard_normal((12, 3))
+    U = np.triu(G) + np.tril(np.full((12, 12), 7.0), -1)                  # the strictly lower triangle is never read
+    np.testing.assert_allclose(orc.regsym_apply(U, [0.5], False, B), G @ B, atol=1e-13)
+    np.testing.assert_allclose(orc.regsym_apply(U, [0.5], True, B, alpha=2.0), 2.0 * (G + 0.5 * np.eye(12)) @ B, atol=1e-13)
+    mus = [0.1, 0.2, 0.3]
+    ref = np.column_stack([(G + mus[i] * np.eye(12)) @ B[:, i] for i in range(3)])
+    np.testing.assert_allclose(orc.regsym_apply(U, mus, True, B), ref, atol=1e-13)
+    with pytest.raises(ValueError):
+        orc.regsym_apply(U, mus, True, B[:, :2])
