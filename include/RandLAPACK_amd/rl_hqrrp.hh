@@ -27,8 +27,121 @@
 #include "rl_lapackpp.hh"
 #include "rl_randblas.hh"
 #include "rl_util.hh"
+#include "rl_sharded_panel.hh"
 
 namespace RandLAPACK {
+
+inline void detail_hq_axpy(int64_t n, double a, const double* x, double* y, blas::Queue& q) { blas::check(rlhip_axpby_f64(q.ctx(), n, a, x, 1.0, y), "axpby"); }
+inline void detail_hq_axpy(int64_t n, float a, const float* x, float* y, blas::Queue& q) { blas::check(rlhip_axpby_f32(q.ctx(), n, a, x, 1.0f, y), "axpby"); }
+
+/// hqrrp on a ROW-SHARDED matrix (one process per GPU; this rank holds a contiguous row block of m_loc rows; not in the reference, which has
+/// no distributed code).  Replicated on every rank: the sketch Y = G A (summed once), its pivoted QR and down-dates, jpvt, tau, the b x b
+/// factors.  Sharded by rows: A (reflectors and trailing matrix) and, by columns, the sketching matrix G (rank g owns the columns of its rows).
+/// Exchanges per block of nb_alg columns: the panel's triangles (TSQR: one stack; two with pivoted panels, whose pivots come from the QRCP of
+/// the unpivoted panel's R factor -- the tall-panel order of the single-device code), the top block of the orthonormal panel, W = V^T C for the
+/// compact-WY apply, G V for the update of G, and G1 R12 for the down-date of Y.  Same pivots as the single-device factorization, factors to
+/// rounding (tests/test_gpu_sharded.py).  Returns 0; 1 when a Cholesky-QR panel (qr_type 2, unpivoted) broke down.
+template <typename T, typename RNG>
+int64_t hqrrp_sharded(int64_t m_loc, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff_jpvt, T* buff_tau, int64_t nb_alg, int64_t pp,
+                      int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, blas::Queue& q, T* G_export = nullptr) {
+    detail::ShardRows L;
+    L.init(q, m_loc);
+    const int64_t m_A = L.m_glob, mn_A = std::min(m_A, n_A);
+    if (mn_A == 0) return 0;
+    const int64_t m_Y = nb_alg + pp, ldY = m_Y;
+    blas::Scratch ws(q);
+    T* Y = ws.alloc<T>(m_Y * n_A);
+    T* Vc = ws.alloc<T>(m_Y * n_A);
+    T* G = ws.alloc<T>(m_Y * std::max<int64_t>(m_loc, 1));               // my columns of the global (nb + pp) x m sketching matrix
+    T* T1 = ws.alloc<T>(nb_alg * nb_alg);
+    T* Rp = ws.alloc<T>(nb_alg * nb_alg);
+    T* Q1 = ws.alloc<T>(nb_alg * nb_alg);
+    T* tau_scr = ws.alloc<T>(n_A);
+    int64_t* Jloc = ws.alloc<int64_t>(n_A);
+    {
+        std::vector<int64_t> iota_((size_t)n_A);
+        for (int64_t i = 0; i < n_A; ++i) iota_[(size_t)i] = i + 1;
+        blas::copy_to_device(n_A, iota_.data(), buff_jpvt, q);
+    }
+    {   // G: ONE global Uniform(-1, 1) operator (rl_hqrrp.hh:929-930); this rank draws its column block (stream positions m_Y * row0 ...)
+        RandBLAS::DenseDist Dall(m_Y * m_A, 1, RandBLAS::ScalarDist::Uniform);
+        auto st_in = state;
+        state = RandBLAS::fill_dense_rows(Dall, 0, 0, G, st_in, q);
+        if (m_loc > 0) RandBLAS::fill_dense_rows(Dall, m_Y * L.row0, m_Y * m_loc, G, st_in, q);
+        if (G_export && m_loc > 0) blas::device_copy_vector(m_Y * m_loc, G, G_export, q);
+        if (m_loc > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n_A, m_loc, (T)1, G, m_Y, buff_A, ldim_A, (T)0, Y, ldY, q);
+        else lapack::laset(MatrixType::General, m_Y, n_A, (T)0, (T)0, Y, ldY, q);
+        q.allreduce_sum(Y, m_Y * n_A);
+    }
+    for (int64_t j = 0; j < mn_A; j += nb_alg) {
+        const int64_t b = std::min(nb_alg, std::min(n_A - j, m_A - j));
+        const bool last_iter = (j + nb_alg >= m_A) || (j + nb_alg >= n_A);
+        const int64_t n_R = n_A - j, n2 = std::max<int64_t>(0, n_A - j - b);
+        const int64_t act_loc = L.local_from(j), loc_rows = m_loc - act_loc;
+        T* A_R = &buff_A[j * ldim_A];
+        T* Y_R = &Y[j * ldY];
+        if (!last_iter) {                                                    // pivots of the block from the (replicated) sketch
+            blas::LocalOnly replicated(q);
+            lapack::lacpy(MatrixType::General, m_Y, n_R, Y_R, ldY, &Vc[j * ldY], ldY, q);
+            lapack::qrp_partial(m_Y, n_R, b, &Vc[j * ldY], ldY, Jloc, tau_scr, q);
+            if (m_loc > 0) util::col_swap(m_loc, n_R, n_R, A_R, ldim_A, Jloc, q);
+            util::col_swap(m_Y, n_R, n_R, Y_R, ldY, Jloc, q);
+            util::col_swap(n_R, n_R, &buff_jpvt[j], Jloc, q);
+        }
+        T* A_work = (loc_rows > 0) ? &buff_A[act_loc + j * ldim_A] : nullptr;
+        if (qr_type == 2 && !panel_pivoting) {                               // Cholesky-QR panel: one b x b Gram all-reduce
+            lapack::laset(MatrixType::General, nb_alg, nb_alg, (T)0, (T)0, Rp, nb_alg, q);
+            if (loc_rows > 0) blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, b, loc_rows, (T)1, A_work, ldim_A, (T)0, Rp, nb_alg, q);
+            q.allreduce_sum(Rp, nb_alg * nb_alg);
+            if (lapack::potrf(Uplo::Upper, b, Rp, nb_alg, q)) return 1;     // (replicated Gram matrix: every rank takes the same exit)
+            if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, b, (T)1, Rp, nb_alg, A_work, ldim_A, q);
+        } else {
+            if (panel_pivoting) {
+                // A = Q R has the same pivoted QR as its b x b factor R: the panel's pivots come from the QRCP of the R factor of its
+                // unpivoted TSQR (the tall-panel order of the single-device code, here for every panel: a pivoted sweep does not shard)
+                blas::Scratch w2(q);
+                T* Pc = w2.alloc<T>(std::max<int64_t>(loc_rows, 1) * b);
+                if (loc_rows > 0) lapack::lacpy(MatrixType::General, loc_rows, b, A_work, ldim_A, Pc, loc_rows, q);
+                detail::tsqr_r(q, loc_rows, b, Pc, std::max<int64_t>(loc_rows, 1), Rp, nb_alg);
+                {
+                    blas::LocalOnly replicated(q);
+                    lapack::qrp_partial(b, b, b, Rp, nb_alg, Jloc, tau_scr, q);
+                }
+                if (m_loc > 0) util::col_swap(m_loc, b, b, A_R, ldim_A, Jloc, q);     // the panel's columns, all my rows (A01 above it, the panel itself)
+                util::col_swap(m_Y, b, b, Y_R, ldY, Jloc, q);
+                util::col_swap(b, b, &buff_jpvt[j], Jloc, q);
+            }
+            detail::tsqr(q, loc_rows, b, A_work, ldim_A, Rp, nb_alg);
+        }
+        blas::Scratch keep(q);
+        lapack::laset(MatrixType::General, nb_alg, nb_alg, (T)0, (T)0, T1, nb_alg, q);
+        auto S = detail::reconstruct(q, keep, L, buff_A, ldim_A, j, j, b, Rp, nb_alg, T1, nb_alg, &buff_tau[j], Q1);
+        detail::apply_qt(q, S, T1, nb_alg, buff_A, ldim_A, j + b, n2);                                       // :1108-1118
+        if (!last_iter) {                                                                                   // :1135-1145, NoFLA_Downdate_Y
+            // G_R <- G_R Q = G_R - (G_R V) T V^T: G_R V sums over the ranks (my columns of G_R times my rows of V)
+            blas::Scratch w3(q);
+            T* GV = w3.alloc<T>(m_Y * b);
+            T* Z = w3.alloc<T>(m_Y * b);
+            const int64_t vr = S.vrows();
+            T* G_act = G + act_loc * m_Y;
+            if (vr > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, b, vr, (T)1, G_act, m_Y, S.Vexp, S.ldv, (T)0, GV, m_Y, q);
+            else lapack::laset(MatrixType::General, m_Y, b, (T)0, (T)0, GV, m_Y, q);
+            q.allreduce_sum(GV, m_Y * b);
+            blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, b, b, (T)1, GV, m_Y, T1, nb_alg, (T)0, Z, m_Y, q);
+            if (vr > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::Trans, m_Y, vr, b, (T)-1, Z, m_Y, S.Vexp, S.ldv, (T)1, G_act, m_Y, q);
+            // Y2 -= G1 R12: G1 = the updated columns of G of the top block's rows, R12 = those rows of the updated trailing matrix -- both
+            // live on the top block's owners, whose products are summed
+            if (n2 > 0) {
+                T* D = w3.alloc<T>(m_Y * n2);
+                if (S.tcnt > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, m_Y, n2, S.tcnt, (T)1, G_act, m_Y, &buff_A[act_loc + (j + b) * ldim_A], ldim_A, (T)0, D, m_Y, q);
+                else lapack::laset(MatrixType::General, m_Y, n2, (T)0, (T)0, D, m_Y, q);
+                q.allreduce_sum(D, m_Y * n2);
+                detail_hq_axpy(m_Y * n2, (T)-1, D, &Y[(j + b) * ldY], q);
+            }
+        }
+    }
+    return 0;
+}
 
 /// returns 0; 1 if a CholQR panel (qr_type == 2) broke down.  `G_export`, when not null, receives the (nb_alg+pp) x m
 /// sketching matrix before it is updated (tests share it with the CPU path, cf. test_bqrrp_gpu.cu:91-110).
@@ -51,7 +164,8 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
     randlapack_require(n_A >= 0) << "hqrrp: n_A is < 0";
     randlapack_require(ldim_A >= std::max<int64_t>(1, m_A)) << "hqrrp: ldim_A is < max(1, m_A)";
     randlapack_require(nb_alg > 0 && pp >= 0) << "hqrrp: nb_alg must be > 0 and pp >= 0";
-    randlapack_require(q.world() == 1) << "hqrrp is not row-sharded (inside CQRRPT it runs on the replicated sketch: use CQRRPT)";
+    if (q.world() > 1)                        // row-sharded queue: m_A is this rank's row count (tau then has min(global rows, n) entries)
+        return hqrrp_sharded<T, RNG>(m_A, n_A, buff_A, ldim_A, buff_jpvt, buff_tau, nb_alg, pp, panel_pivoting, qr_type, state, q, G_export);
     const int64_t mn_A = std::min(m_A, n_A);
     if (mn_A == 0) return 0;
     const int64_t m_Y = nb_alg + pp, n_Y = n_A, ldim_Y = m_Y, ldim_V = m_Y, m_G = nb_alg + pp, n_G = m_A, ldim_G = m_G;

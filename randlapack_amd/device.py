@@ -584,11 +584,12 @@ def regsym_apply(ctx: Context, A, dim, regs, eval_includes_reg, B, n, alpha=1.0,
     return Cout
 
 
-def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), want_G=False):
-    """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G])."""
+def drv_hqrrp(ctx: Context, A, m, n, nb_alg=64, pp=10, panel_pivoting=1, qr_type=0, ctr=(0, 0, 0, 0), key=(0, 0), want_G=False, m_global=None):
+    """hqrrp: A (column-major tensor (n, m)) is overwritten in GEQP3 format.  Returns dict(rc, tau, J, next_ctr[, G]).
+    Row-sharded context: m = this rank's rows, m_global = the matrix's (tau has min(m_global, n) entries)."""
     torch = _torch()
     dev = f"cuda:{ctx.device}"
-    tau = torch.zeros(min(m, n), dtype=A.dtype, device=dev)
+    tau = torch.zeros(min(m_global or m, n), dtype=A.dtype, device=dev)
     J = torch.zeros(n, dtype=torch.int64, device=dev)
     G = cm_empty(nb_alg + pp, m, dtype=A.dtype, device=dev) if want_G else None
     st = _state_arr(ctr, key)

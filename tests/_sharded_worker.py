@@ -56,6 +56,14 @@ def main():
     Ac = d.cm_from_numpy(np.ascontiguousarray(Abq[crows]))
     rc_ = d.drv_bqrrp(ctx, Ac, len(crows), nbq, bb, 1.0, key=(8, 0), m_global=m, block_cyclic=True)
     Ac_loc, tau_c, J_c = d.cm_to_numpy(Ac), rc_["tau"].cpu().numpy(), rc_["J"].cpu().numpy()
+    # standalone hqrrp on the shards (TSQR panels, pivots of a pivoted panel from the QRCP of its R factor): three panel types
+    nhq, nbh = min(n, 112), 32
+    Ahq = A[:, :nhq] * np.logspace(0, -3, nhq)[np.random.default_rng(4).permutation(nhq)]
+    hq = {}
+    for tag, (pv, qt) in (("piv", (1, 0)), ("qr", (0, 0)), ("chol", (0, 2))):
+        Ah = d.cm_from_numpy(np.ascontiguousarray(Ahq[rows]))
+        rh = d.drv_hqrrp(ctx, Ah, len(rows), nhq, nb_alg=nbh, pp=8, panel_pivoting=pv, qr_type=qt, key=(13, 0), m_global=m)
+        hq[tag] = (d.cm_to_numpy(Ah), rh["tau"].cpu().numpy(), rh["J"].cpu().numpy(), rh["rc"])
     # ABRIK on the row-sharded operator (CQRRT panels)
     ka, ita = 8, 8
     ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
@@ -69,7 +77,7 @@ def main():
     lin = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx, alg, op_loc, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
     rsa = d.drv_abrik_linop(ctx, op_loc, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc, Af_loc))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc, Af_loc, {t: v[0] for t, v in hq.items()}))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
@@ -80,8 +88,11 @@ def main():
         Abq_out = np.zeros((m, nbq))
         Acq_out = np.zeros((m, nbq))
         Afq_out = np.zeros((m, nbq))
-        for rr, u, u2, qq, ua, ab, cr, ac, af in gathered:
+        Hq_out = {t: np.zeros((m, nhq)) for t in hq}
+        for rr, u, u2, qq, ua, ab, cr, ac, af, hh in gathered:
             U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac; Afq_out[rr] = af
+            for t in hh:
+                Hq_out[t][rr] = hh[t]
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
         S2, V2 = r2["S"].cpu().numpy(), d.cm_to_numpy(r2["V"])
         ctx1 = d.Context(0)
@@ -104,7 +115,19 @@ def main():
         lin1 = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx1, alg, op1, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
         rsa1 = d.drv_abrik_linop(ctx1, op1, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
         Ssa, Ssa1 = rsa["S"].cpu().numpy(), rsa1["S"].cpu().numpy()
+        hq_cmp = {}
+        for tag, (pv, qt) in (("piv", (1, 0)), ("qr", (0, 0)), ("chol", (0, 2))):
+            Ah1 = d.cm_from_numpy(Ahq)
+            rh1 = d.drv_hqrrp(ctx1, Ah1, m, nhq, nb_alg=nbh, pp=8, panel_pivoting=pv, qr_type=qt, key=(13, 0))
+            F1, Fs = d.cm_to_numpy(Ah1), Hq_out[tag]
+            Jh = hq[tag][2]
+            Qh = oracle.ungqr(Fs, hq[tag][1])
+            hq_cmp[tag] = dict(rc=[hq[tag][3], rh1["rc"]], J_equal=bool(np.array_equal(Jh, rh1["J"].cpu().numpy())),
+                               A=float(np.linalg.norm(Fs - F1) / np.linalg.norm(F1)), tau=float(np.max(np.abs(hq[tag][1] - rh1["tau"].cpu().numpy()))),
+                               resid=float(np.linalg.norm(Ahq[:, Jh - 1] - Qh @ np.triu(Fs)[:nhq]) / np.linalg.norm(Ahq)),
+                               orth=float(np.linalg.norm(Qh.T @ Qh - np.eye(min(m, nhq)))))
         out = dict(
+            hqrrp=hq_cmp,
             lin_R={alg: float(np.linalg.norm(np.triu(lin[alg]) - np.triu(lin1[alg])) / np.linalg.norm(np.triu(lin1[alg]))) for alg in lin},
             sp_abrik_trip=[rsa["triplets"], rsa1["triplets"]], sp_abrik_S=float(np.max(np.abs(Ssa[:6] - Ssa1[:6]) / Ssa1[:6])),
             bq_rank=rb["rank"], bq_rank1=rb1["rank"], bq_J_equal=bool(np.array_equal(J_b, rb1["J"].cpu().numpy())),

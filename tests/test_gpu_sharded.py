@@ -47,6 +47,10 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
     assert out["bqf_rank"] == out["bq_rank1"] and out["bqf_J_equal"]
     assert out["bqf_A"] <= 1e-10 and out["bqf_tau"] <= 1e-10
+    # row-sharded standalone hqrrp (pivoted / Householder / Cholesky-QR panels) == the single-device factorization
+    for tag, h in out["hqrrp"].items():
+        assert h["rc"] == [0, 0] and h["J_equal"], (tag, h)
+        assert h["A"] <= 1e-10 and h["tau"] <= 1e-10 and h["resid"] <= 1e-12 and h["orth"] <= 1e-11, (tag, h)
     # linop QR drivers and ABRIK on a row-sharded CSR operator: same R / Ritz values as on one device
     assert all(v <= 1e-10 for v in out["lin_R"].values()), out["lin_R"]
     assert out["sp_abrik_trip"][0] == out["sp_abrik_trip"][1] and out["sp_abrik_S"] <= 1e-9
