@@ -47,14 +47,7 @@ def cqrrpt(steps):
     for _ in range(3): ctx.syrk("U", "T", n, m, 1.0, W, ldw, 0.0, G, n)
     gms = ctx.timer_stop_ms() / 3
     del W
-    traffic = None
-    try:
-        import glob
-        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_trsm_fused_oop.json")))[-1]
-        traffic = json.load(open(tf)).get("traffic_bytes")
-        traffic_source = os.path.relpath(tf, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape; not re-measured by this run)"
-    except Exception:
-        traffic_source = None
+    traffic, traffic_source = quote_traffic("trsm_fused_oop", kms)
     # CPU baseline: oracle CQRRPT (sketch supplied, so the reference's SASO apply is excluded) on a 131072-row sample
     import oracle
     oracle.load(); oracle.set_threads(os.cpu_count() or 1)
@@ -88,8 +81,20 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
         t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps), qrcp_wide=0, qr_tall=1, apply_trans_q=1); ctx.sync(); dt = time.perf_counter() - t0
         if it > 0: best = dt if best is None else min(best, dt)
     apply_us = r["times_us"][5]
-    ach = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
+    ach_phase = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
     pk = PEAK[dtype]
+    # dominant kernel, timed alone with HIP events at the shape its counter file was taken at: C -= V W of the compact-WY apply,
+    # rows x 16384 x b (half of the apply's flops run through launches of this kernel; the other half is W = V^T C)
+    kr, kc = m, min(16384, n - b)
+    V_ = d.cm_empty(kr, b, dtype=dtype); ctx.fill_dense(V_, kr, b, key=(1, 0))
+    C_ = d.cm_empty(kr, kc, dtype=dtype); ctx.fill_dense(C_, kr, kc, key=(2, 0))
+    W_ = d.cm_zeros(b, kc, dtype=dtype)
+    ctx.gemm("N", "N", kr, kc, b, -1.0, V_, kr, W_, b, 1.0, C_, kr); ctx.sync(); ctx.timer_start()
+    for _ in range(3): ctx.gemm("N", "N", kr, kc, b, -1.0, V_, kr, W_, b, 1.0, C_, kr)
+    kms = ctx.timer_stop_ms() / 3
+    ach = 2.0 * kr * kc * b / (kms * 1e-3) / 1e12
+    traffic, traffic_source = quote_traffic("gemm_f32_nn" if (dtype == torch.float32 and m == 65536) else "none", kms)
+    del V_, C_, W_
     # the headline time is taken WITHOUT subroutine timers (they drain the streams at every lap, which also switches the look-ahead off)
     best_timed = best
     for it in range(2):
@@ -115,8 +120,10 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
                       "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic iid N(0,1), generated on-device",
                       "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"],
                                  "ms_with_subroutine_timers": round(best_timed * 1e3, 1), "frac_of_peak_whole_job": round(flops / best / 1e12 / pk, 4)},
-                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": None,
-                                   "kernel": "compact-WY apply (gemqrt: generic MFMA GEMMs), wall time of the apply phase over all iterations (timed run)"},
+                      "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": traffic,
+                                   "traffic_source": traffic_source, "launch_ms": round(kms, 3), "flops_per_launch": 2.0 * kr * kc * b,
+                                   "kernel": f"C -= V W of the compact-WY apply ({kr} x {kc} x {b}, accumulating MFMA GEMM), HIP events on the kernel's stream",
+                                   "apply_phase_tflops_timed_run": round(ach_phase, 2)},
                       "cpu_baseline": cpu}))
 
 
@@ -200,6 +207,7 @@ def abrik(steps):
     nnz = G.nnz
     bytes_alg = (nnz * k + m * k) * 8.0 + 16.0 * nnz
     ach = bytes_alg / (kms * 1e-3) / 1e9
+    traffic5, traffic5_source = quote_traffic("spmm_c5", kms, part_of_launch=True)
     # dense operator of the same rank: 200000 x 20000 fp64 (32 GB), two GEMM products per iteration
     md, nd = 200000, 20000
     A = d.cm_empty(md, nd); ctx.fill_dense(A, md, nd, key=(7, 0)); ctx.sync()
@@ -227,7 +235,7 @@ def abrik(steps):
                       "config": {"workload": "ABRIK m=n=200000 nnz=2e6 b=32 iters=8 qr_exp=cqrrt-default", "triplets": r["triplets"], "iters": r["iters"],
                                  "times_us": dict(zip(d.ABRIK_TIMES, r.get("times_us", []))),
                                  "dense_200000x20000_same_rank": {"ms": round(bd * 1e3, 1), "iters": rd_["iters"], "TFLOP/s of the operator products": round(fl_dense / bd / 1e12, 1)}},
-                      "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                      "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic5, "traffic_source": traffic5_source,
                                    "kernel": "rlhip_linop_apply on the CSR operator (A * X, 32 column-major columns) = transpose of X + csr_spmm_cmout_narrow_kernel: algorithmic bytes (nnz b + rows b) 8 + 16 nnz", "launch_ms": round(kms, 4)},
                       "cpu_baseline": cpu}))
 

@@ -130,6 +130,33 @@ def gemm_f32_nn():
     _gemm_f32("N")
 
 
+def c5_operator(d):
+    """the banded Gaussian CSR operator of the C5 line (scripts/bench_other.py abrik): 200000 x 200000, 10 nonzeros per row, graded scalings"""
+    import numpy as np
+    import scipy.sparse as sp
+    m = n = 200000
+    rng = np.random.default_rng(77)
+    nnz_row = 10
+    rows = np.repeat(np.arange(m), nnz_row)
+    colsi = (rows + np.tile(np.arange(-4, 6), m)) % n
+    vals = rng.standard_normal(m * nnz_row)
+    d1 = np.exp(-np.arange(m) / 4.0) + 1e-13
+    d2 = np.exp(-np.arange(n) / 4.0) + 1e-13
+    G = sp.csr_matrix((vals * d1[rows] * d2[colsi], (rows, colsi)), shape=(m, n)); G.sum_duplicates()
+    return d.CsrOperator.from_scipy(G), G.nnz
+
+
+def spmm_c5():
+    d, ctx = _ctx()
+    op, nnz = c5_operator(d)
+    m = n = 200000
+    X = d.cm_empty(n, 32); ctx.fill_dense(X, n, 32, key=(9, 0))
+    Y = d.linop_apply(ctx, op, "L", "N", X, m, 32, n)
+    for _ in range(REPS + 2):
+        d.linop_apply(ctx, op, "L", "N", X, m, 32, n, C_in=Y)
+    ctx.sync()
+
+
 def getrf_panel_f32():
     d, ctx = _ctx()
     import torch
@@ -191,6 +218,8 @@ WORKLOADS = {
                     4.0 * (16384 * 2048 + 16384 * 16384 + 2048 * 16384), 2.0 * 2048 * 16384 * 16384, "mfma"),
     "gemm_f32_nn": (gemm_f32_nn, "gemm_sk_kernel<float, false>", "C -= V W, 65536 x 16384 x 2048 fp32 (C4's compact-WY apply)",
                     4.0 * (65536 * 2048 + 2 * 65536 * 16384 + 2048 * 16384), 2.0 * 65536 * 16384 * 2048, "mfma"),
+    "spmm_c5": (spmm_c5, "csr_spmm", "Y = A X, A 200000 x 200000 CSR with 2e6 nonzeros, X 32 columns fp64 (C5's operator product; the SpMM kernel of the launch)",
+                (2000000 * 32 + 200000 * 32) * 8.0 + 16.0 * 2000000, 2.0 * 2000000 * 32, "hbm"),
     "getrf_panel_f32": (getrf_panel_f32, "getrf_panel_f32_kernel", "row-pivoted LU panel steps of the 65536 x 2048 fp32 transposed sketch (C4 qrcp_wide)",
                         None, None, "latency"),
     "jacobi": (jacobi, "jacobi_block_kernel", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),

@@ -475,7 +475,7 @@ def test_bqrrp_state_and_internal_nb(ctx, orc):
 
 
 def test_bqrrp_midsize_properties(ctx, orc):
-    # 8192 x 8192, b = 512: residual through the implicit Q (apply Q^T to A[:, J] with the device gemqrt-equivalent)
+    # 4096 x 4096, b = 256: residual through the implicit Q (apply Q^T to A[:, J] with the device gemqrt-equivalent)
     import torch
 
     d = _d()
