@@ -312,16 +312,18 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
 //     product, so solved columns feed later products without leaving the register file);
 //   * U is packed once per call as Uneg = -(strictly block-upper part of U), ROW-major, zero inside the 32 x 32 diagonal blocks
 //     (those are applied through their explicit inverses Dinv, as in the blk path and under the same kappa_F <= 1e3 guard);
-//   * the four waves of a workgroup share U through LDS: half panels of 16 rows x 256 columns (row stride 272 elements: the four
-//     row groups of an MFMA operand read land on disjoint banks) are DMA'd (global_load_lds) into a two-deep ring, ONE barrier per
-//     half panel, the next half panel in flight during the 64 MFMAs per wave of the current one;
+//   * the eight waves of a workgroup share U through LDS: stages of 32 rows x 256 columns (row stride 272 elements: the four row
+//     groups of an MFMA operand read land on disjoint banks) are DMA'd (global_load_lds) into two stages, ONE rendezvous per stage
+//     (32 rows of U = 128 MFMAs per wave), the next stage in flight meanwhile (round 5; rounds 1-4: a ring of three 16-row panels,
+//     a rendezvous per 16 rows, and 116 bytes of register spills per lane that the coarser loop no longer needs);
 //   * block J: T = alpha B_J - sum_{I < J} X_I U_IJ with X_I read back from B (this wave wrote those rows itself), then
 //     right-looking over the eight 32-column sub-blocks: X_s = T_s inv(U_ss); T_t -= X_s U_st for t > s -- all 14 - 2 s tile
 //     updates of a step are independent accumulators, so the matrix pipe is never waiting on a dependent result;
 //   * two workgroups per CU (68 KiB + 8 KiB of LDS, <= 256 VGPRs): one's HBM phases (tile load / store) overlap the other's MFMAs.
 // Per 16 rows and n = 1024: 8320 MFMAs, 32 KiB read + 8 KiB x (1 + 2 + 3 + 4) re-read from L2/MALL + 32 KiB written.
 constexpr int FSTR = 272;          // LDS row stride of a half panel (elements)
-template <typename T> constexpr int fused_lds_bytes() { return 3 * 16 * FSTR * (int)sizeof(T) + 2 * 32 * 32 * (int)sizeof(T); }   // three U panels + two inverses
+// two stages of HPR = 32 rows of U (one rendezvous per 32 rows) + two inverses
+template <typename T, int HPR> constexpr int fused_lds_bytes() { return 2 * HPR * FSTR * (int)sizeof(T) + 2 * 32 * 32 * (int)sizeof(T); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void trsm_neg_pack_kernel(int64_t n, int64_t n_pad, const T* __restrict__ U, int64_t ldu, T* __restrict__ Uneg) {
@@ -342,7 +344,7 @@ template <int N> struct IntC { static constexpr int value = N; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// NW = wavefronts per workgroup (16 rows each), HPR = rows of U per LDS panel (16), ring of three panels
+// NW = wavefronts per workgroup (16 rows each), HPR = rows of U per LDS stage (32 = two 16-row half panels), two stages
 // OOP = out of place: the right-hand side is READ from Bsrc (column c of the solve = column perm[c] - pbase of Bsrc when perm is given:
 // CQRRPT's column pivoting folded into the solve, rl_cqrrpt.hh:288-300) and the solution is WRITTEN to B; the solved tiles needed by
 // later blocks are re-read from B.  The pivot entries of a tile are wave-uniform (scalar loads), only the choice among the lane
@@ -362,13 +364,13 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         for (int i = 0; i < ngate; ++i) closed |= gate[i];
         if (closed) return;
     }
-    static_assert(HPR == 16, "the diagonal phase below is written for 16-row panels (two per 32-column sub-block)");
+    static_assert(HPR == 32, "an LDS stage holds two 16-row half panels");
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef const __attribute__((address_space(1))) void glb_void_t;
-    constexpr int RING = 3;
-    constexpr int HPB = HPR * FSTR * (int)sizeof(T);            // bytes per panel (34 KiB fp64, 17 KiB fp32)
+    constexpr int RING = 2;
+    constexpr int HPB = HPR * FSTR * (int)sizeof(T);            // bytes per stage (16 rows: 34 KiB fp64, 17 KiB fp32)
     constexpr int NCH = HPB / 1024;                             // 1 KiB DMA pieces per panel
     constexpr int EPC = 1024 / (int)sizeof(T);                  // elements per piece
     constexpr int EPL = 16 / (int)sizeof(T);                    // elements per lane of a piece
@@ -376,9 +378,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
                                                                 // slot falls beyond the panel re-fetches an earlier piece), so that the
                                                                 // counted s_waitcnt vmcnt(...) below are compile-time constants
     constexpr int DCH = 32 * 32 * (int)sizeof(T) / 1024;        // pieces of one 32 x 32 inverse (one per wave, duplicates allowed)
-    constexpr int NQ = HPR / 4;                                 // k-steps (MFMA depth 4) per panel
-    constexpr int PPB = 256 / HPR;                              // panels per 256-block
-    constexpr int NDP = 14;                                     // diagonal-block panels that still have tiles to update
+    constexpr int NQ = 4;                                       // k-steps (MFMA depth 4) per 16-row half panel
+    constexpr int PPB = 16;                                     // half panels per 256-block
     constexpr int DBY = 32 * 32 * (int)sizeof(T);               // bytes of one inverse
     extern __shared__ __attribute__((aligned(1024))) unsigned char tf_smem[];
     unsigned char* sD = tf_smem + RING * HPB;                   // two stages: the inverse of diagonal sub-block s lives in stage s & 1
@@ -416,13 +417,13 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     // OOP: the source column of every column of a 256-block is staged in LDS once per block (identity without a pivot vector), so a tile
     // element is ONE lane-indexed LDS read + ONE global load.  (With four scalar loads of the pivot entries and a per-lane choice per element
     // hipcc built ~390 branches with an s_waitcnt vmcnt(0) in most of them: the eight loads of a retired tile went out one HBM round trip at a time.)
-    __shared__ long long s_perm[OOP ? 2 : 1][OOP ? 256 : 1];
+    __shared__ int s_perm[OOP ? 2 : 1][OOP ? 256 : 1];          // (source column indices: 32 bits -- as 64-bit words the tile loads' temporaries spilled)
     auto fill_perm = [&](int Jb) {
         if constexpr (OOP) {
             if (threadIdx.x < 256) {
                 int64_t cidx = (int64_t)Jb * 256 + threadIdx.x;
                 if (cidx > n - 1) cidx = n - 1;
-                s_perm[Jb & 1][threadIdx.x] = perm ? (long long)(perm[cidx] - pbase) : (long long)cidx;
+                s_perm[Jb & 1][threadIdx.x] = perm ? (int)(perm[cidx] - pbase) : (int)cidx;
             }
         }
     };
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     auto load_raw = [&](int64_t cb0, int jj, int r) -> T {
         if constexpr (!OOP) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
         else {
-            const long long mc = s_perm[(int)(cb0 >> 8) & 1][16 * jj + CS * r + CL * fk];
+            const long long mc = (long long)s_perm[(int)(cb0 >> 8) & 1][16 * jj + CS * r + CL * fk];
             return Bsrc[mc * ldsrc + rowc];
         }
     };
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         }
     };
     // first element of panel t of block J (t counts from the first fused block row K0blk; the diagonal block follows seamlessly)
-    auto panel_ptr = [&](int J, int t) -> const T* { return Uneg + ((int64_t)K0blk * 256 + (int64_t)t * HPR) * n_pad + (int64_t)J * 256; };
+    auto panel_ptr = [&](int J, int t) -> const T* { return Uneg + ((int64_t)K0blk * 256 + (int64_t)t * 16) * n_pad + (int64_t)J * 256; };   // t counts 16-row halves
 
 #ifdef RLHIP_TF_PROF
     long long tfp[20]; for (int i = 0; i < 20; ++i) tfp[i] = 0;
@@ -506,7 +507,6 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     issue_panel(panel_ptr(J0, 0), 0);
-    issue_panel(panel_ptr(J0, 1), 1);
     issue_dinv((int64_t)J0 * 8);
     {
 #pragma unroll
@@ -532,32 +532,38 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[j][r] = alpha * acc[j][r];
         const T* xp = B + (int64_t)K0blk * 256 * ldb;                    // first column of panel t (uniform); the lane adds xoff = row + fk * ldb
-        const int64_t xstep = (int64_t)HPR * ldb;
+        const int64_t xstep = (int64_t)16 * ldb;
         // ---- blocks left of the diagonal block: X from memory, all 16 tiles
         // two steps per trip: the operand registers alternate (xc: even panels, xn: odd panels; ntoff is a multiple of 16), no copies.
         // (A rendezvous in the MIDDLE of a panel with the next panel's first fragments prefetched across the boundary, as in the stream-K
         // GEMM, was built and measured: 4.18 us per panel step either way -- the boundary bubble is not what the step loses.)
-        auto pstep = [&](int t, T (&cur)[NQ], T (&nxt)[NQ]) {
-            // panel t and the X operands of this step have landed; the P pieces of panel t + 1 (issued one step ago) may still fly.
-            // (t == 0: the X operands were the LAST thing requested before this block, so everything must have landed)
-            if (t == 0) wait_vm<0>(); else wait_vm<P>();
-            xlanded(cur);
-            __builtin_amdgcn_s_barrier();
-            const int nring = (ring + 2 >= RING) ? ring + 2 - RING : ring + 2;
-            const T* nbase = panel_ptr(J, t + 2);               // (always inside this block: the diagonal panels follow)
-            xp += xstep;
-            const bool more_x = (t + 1 < ntoff);
-            panel_mma(IntC<0>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), cur, [&]() {
-                if (more_x) xissue(xp, nxt);
-                issue_panel(nbase, nring);
-            });
-            ring = (ring + 1 >= RING) ? 0 : ring + 1;
-        };
-        for (int t = 0; t < ntoff; t += 2) {
-            pstep(t, xc, xn);
-            pstep(t + 1, xn, xc);
+        {
+            // ---- 32-row stages (two of them): ONE rendezvous per 32 rows of U.  Pair p = half panels 2p, 2p + 1 in stage `ring`; the stage of
+            //      pair p + 1 is requested right behind the rendezvous of pair p (every wave has left the other stage by then) and has a
+            //      whole pair (~7 us) to land; the X operands keep their 16-row cadence (xc: even halves, xn: odd halves) and their counted
+            //      waits: behind the first half only the P stage pieces are younger than xn's loads.
+            for (int t = 0; t < ntoff; t += 2) {
+                wait_vm<0>();                                   // stage of this pair (requested one pair ago) and xc (requested half a pair ago)
+                xlanded(xc);
+                __builtin_amdgcn_s_barrier();
+                const T* sU = reinterpret_cast<const T*>(tf_smem + ring * HPB);
+                const T* nbase = panel_ptr(J, t + 2);           // (always inside this block: the diagonal halves follow)
+                xp += xstep;
+                panel_mma(IntC<0>{}, acc, sU, xc, [&]() {
+                    xissue(xp, xn);
+                    issue_panel(nbase, ring ^ 1);
+                });
+                wait_vm<P>();
+                xlanded(xn);
+                xp += xstep;
+                const bool more_x = (t + 2 < ntoff);
+                panel_mma(IntC<0>{}, acc, sU + 16 * FSTR, xn, [&]() {
+                    if (more_x) xissue(xp, xc);
+                });
+                ring ^= 1;
+            }
+            TF_MARK(0)
         }
-        TF_MARK(0)
         // ---- diagonal block: right-looking over the 32-column sub-blocks, X in registers
         auto solve_sub = [&](int s) {                           // X_s = T_s * inv(U_ss)   (compile-time s after unrolling)
             const T* dv = reinterpret_cast<const T*>(sD + (s & 1) * DBY) + fr;
@@ -574,9 +580,8 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         // sub-block s is final: its two tiles go back to B and the registers take the same tiles of the NEXT block (raw, scaled at
         // that block's start).  ALWAYS 8 stores + 8 loads per wave, so that the counted waits stay exact: rows / columns outside the
         // matrix store to a scratch line, the last block re-loads its own tile (values unused).
-        auto retire_tiles = [&](int s) {
+        auto retire_store = [&](int s) {
             T* bj = B + col0 * ldb;
-            const int64_t cbn = has_next ? col0 + 256 : col0;
             T* dl = dump + threadIdx.x;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -585,50 +590,54 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
                     T* dst = bj + (int64_t)(16 * (2 * s + u) + CS * r) * ldb + loff;
                     *(live ? dst : dl) = acc[2 * s + u][r];
                 }
+        };
+        auto retire_load = [&](int s) {
+            const int64_t cbn = has_next ? col0 + 256 : col0;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[2 * s + u][r] = load_raw(cbn, 2 * s + u, r);
         };
-        auto diag_step = [&](auto h_c) {
-            constexpr int h = decltype(h_c)::value;
-            constexpr int s = h >> 1, hh = h & 1;
-            // Requests that may still fly when panel h is consumed = everything the previous step issued (every count below is exact):
-            // P panel pieces; at even steps also one piece of the next inverse and, from step 2 on, the 16 loads / stores of the
-            // tiles retired there.  h == 0: P (after an off-diagonal step) or nothing (first step of the launch / after a block end).
-            constexpr int prev = h - 1;
-            constexpr int allowed = (h == 0) ? 0 : (P + ((prev & 1) == 0 ? 1 + (prev >= 2 ? 16 : 0) : 0));
-            if (h == 0) { if (ntoff > 0) wait_vm<P>(); else wait_vm<0>(); }
-            else wait_vm<allowed>();
-            __builtin_amdgcn_s_barrier();
-            const int nring = (ring + 2 >= RING) ? ring + 2 - RING : ring + 2;
-            if (hh == 0) solve_sub(s);
-            T y[NQ];
+        auto retire_tiles = [&](int s) { retire_store(s); retire_load(s); };
+        {
+            // diagonal block with 32-row stages: one rendezvous per 32-column sub-block.  Requests of a pair in issue order: the 8 STORES of the
+            // tiles retired there, the next stage's P pieces, one piece of the next inverse, then the 8 LOADS that refill the retired
+            // registers -- the only requests that may still fly at the next rendezvous.  The allowed window holds loads only: loads return in
+            // order among themselves, so it cannot open while an older load (stage, inverse) is outstanding, whenever the stores are
+            // acknowledged.  (A window of "the 16 youngest loads and stores" is NOT safe: a store acknowledged before older loads lets the
+            // count reach 16 with a piece of the inverse on its way -- seen as a wrong second tile of sub-block 7 in some workgroups.)
+            auto dpair = [&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                wait_vm<(s >= 2) ? 8 : 0>();
+                __builtin_amdgcn_s_barrier();
+                const T* sU = reinterpret_cast<const T*>(tf_smem + ring * HPB);
+                solve_sub(s);
+                T y[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) y[q] = M::operand(acc[2 * s + (hh * HPR + 4 * q) / 16], (hh * HPR + 4 * q) % 16, lane);
-            panel_mma(IntC<2 * s + 2>{}, acc, reinterpret_cast<const T*>(tf_smem + ring * HPB), y, [&]() {
-                if (hh == 0 && h >= 2) retire_tiles(s - 1);
-                // two panels ahead: this block's, then the next block's first two (the last block re-fetches its own first panel into
-                // the free stage: nobody reads it, the request count stays uniform)
-                issue_panel((h + 2 < NDP) ? panel_ptr(J, ntoff + h + 2) : (has_next ? panel_ptr(J + 1, h + 2 - NDP) : panel_ptr(J, 0)), nring);
-                if (hh == 0) issue_dinv((int64_t)J * 8 + s + 1);                           // needed two steps from now, other stage
-            });
-            ring = (ring + 1 >= RING) ? 0 : ring + 1;
-            TF_MARK(1 + h)
-        };
-        diag_step(IntC<0>{}); diag_step(IntC<1>{}); diag_step(IntC<2>{}); diag_step(IntC<3>{}); diag_step(IntC<4>{});
-        diag_step(IntC<5>{}); diag_step(IntC<6>{}); diag_step(IntC<7>{}); diag_step(IntC<8>{}); diag_step(IntC<9>{});
-        diag_step(IntC<10>{}); diag_step(IntC<11>{}); diag_step(IntC<12>{}); diag_step(IntC<13>{});
-        // the last inverse (requested at step 12) must have landed; step 13's P pieces may still fly
-        wait_vm<P>();
-        __builtin_amdgcn_s_barrier();
-        solve_sub(7);
-        retire_tiles(6);
-        retire_tiles(7);
-        TF_MARK(15)
-        if (has_next) {
-            issue_dinv((int64_t)(J + 1) * 8);
-            xissue(B + (int64_t)K0blk * 256 * ldb, xc);                                               // the next block always has blocks to its left
+                for (int q = 0; q < NQ; ++q) y[q] = M::operand(acc[2 * s], 4 * q, lane);
+                panel_mma(IntC<2 * s + 2>{}, acc, sU, y, [&]() {
+                    if (s >= 1) retire_store(s - 1);
+                    issue_panel((s + 1 < 7) ? panel_ptr(J, ntoff + 2 * (s + 1)) : (has_next ? panel_ptr(J + 1, 0) : panel_ptr(J, 0)), ring ^ 1);
+                    issue_dinv((int64_t)J * 8 + s + 1);                                      // other stage: read last by solve_sub(s - 1)
+                    if (s >= 1) retire_load(s - 1);
+                });
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) y[q] = M::operand(acc[2 * s + 1], 4 * q, lane);
+                panel_mma(IntC<2 * s + 2>{}, acc, sU + 16 * FSTR, y, [&]() {});
+                ring ^= 1;
+                TF_MARK(1 + 2 * s)
+            };
+            dpair(IntC<0>{}); dpair(IntC<1>{}); dpair(IntC<2>{}); dpair(IntC<3>{}); dpair(IntC<4>{}); dpair(IntC<5>{}); dpair(IntC<6>{});
+            wait_vm<8>();                                       // the last inverse and the next block's first stage have landed; the 8 loads of retire(5) may fly
+            __builtin_amdgcn_s_barrier();
+            solve_sub(7);
+            retire_tiles(6);
+            retire_tiles(7);
+            TF_MARK(15)
+            if (has_next) {
+                issue_dinv((int64_t)(J + 1) * 8);
+                xissue(B + (int64_t)K0blk * 256 * ldb, xc);
+            }
         }
     }
 #ifdef RLHIP_TF_PROF
@@ -669,21 +678,28 @@ inline bool tf_xasm(const rlhip_ctx* c) {      // RLHIP_OPT_TRSM_XASM: -1 = what
     return o < 0 ? (RLHIP_TF_XASM_DEFAULT != 0) : (o != 0);
 }
 
-template <typename T, bool OOP>
-int tf_launch(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
-              const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
+template <typename T, bool OOP, int HPR>
+int tf_launch_hpr(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
+                  const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
     const dim3 grid((unsigned)((m + 127) / 128));
+    constexpr int lds = fused_lds_bytes<T, HPR>();
     if (tf_xasm(c)) {
-        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, OOP, true>), fused_lds_bytes<T>());
-        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, OOP, true>), grid, dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, HPR, OOP, true>), lds);
+        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, HPR, OOP, true>), grid, dim3(512), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
                            dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
     } else {
-        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, 16, OOP, false>), fused_lds_bytes<T>());
-        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, 16, OOP, false>), grid, dim3(512), fused_lds_bytes<T>(), c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, HPR, OOP, false>), lds);
+        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, HPR, OOP, false>), grid, dim3(512), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
                            dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
     }
     RLHIP_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T, bool OOP>
+int tf_launch(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
+              const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
+    return tf_launch_hpr<T, OOP, 32>(c, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk, dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
 }
 
 }  // namespace

@@ -13,8 +13,26 @@ PEAK = {torch.float64: 78.6, torch.float32: 157.3}
 OPTS = {}      # --opt name=value ...: context options (include/rlhip.h, enum rlhip_option) applied to every context this script creates
 
 
+def quote_traffic(pattern, live_ms, part_of_launch=False):
+    """(traffic bytes per launch, source string) from the newest committed counter file profiles/round*_pmc_<pattern>.json -- quoted ONLY when
+    that file's own launch time (taken under the counters) is within 5 % of the live one: a stale file reports null, not a wrong number"""
+    import glob
+    try:
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"round*_pmc_{pattern}.json")), key=lambda f: int(os.path.basename(f).split("_")[0][5:]))[-1]
+        tj = json.load(open(tf))
+        pmc_ms = float(tj.get("launch_ms_fetch_pass") or 0.0)
+        rel = os.path.relpath(tf, ROOT)
+        if part_of_launch and 0 < pmc_ms <= live_ms:      # the counter file covers ONE kernel of a multi-kernel launch: quoted with both times
+            return tj.get("traffic_bytes"), f"{rel} (counters of the SpMM kernel alone: {pmc_ms:.3f} ms of the {live_ms:.3f} ms launch, the rest is the transpose of X; not re-measured by this run)"
+        if pmc_ms > 0 and abs(pmc_ms - live_ms) <= 0.05 * live_ms:
+            return tj.get("traffic_bytes"), f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this shape; launch {pmc_ms:.3f} ms under counters vs {live_ms:.3f} ms live: within 5 %; not re-measured by this run)"
+        return None, f"{rel} NOT quoted: its launch time {pmc_ms:.3f} ms is not within 5 % of the live {live_ms:.3f} ms"
+    except Exception:
+        return None, None
+
+
 def _ctx():
-    ctx = _ctx()
+    ctx = d.Context(0)
     for k, v in OPTS.items():
         ctx.set_option(k, v)
     return ctx
