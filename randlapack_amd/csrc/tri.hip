@@ -327,7 +327,9 @@ template <typename T, int HPR> constexpr int fused_lds_bytes() { return 2 * HPR 
 
 template <typename T>
 __global__ __launch_bounds__(256) void trsm_neg_pack_kernel(int64_t n, int64_t n_pad, const T* __restrict__ U, int64_t ldu, T* __restrict__ Uneg) {
-    // Uneg[k * n_pad + c] = -U[k, c] where 32-block(k) < 32-block(c), zero elsewhere; 32 x 32 tiles through LDS (coalesced both ways)
+    // Uneg[k * n_pad + p(c)] = -U[k, c] where 32-block(k) < 32-block(c), zero elsewhere; 32 x 32 tiles through LDS (coalesced both ways).
+    // p interleaves the two 16-column MFMA tiles of every 32 columns -- column 32 b + 16 h + f sits at 32 b + 2 f + h -- so that ONE 16-byte
+    // (fp32: 8-byte) LDS read of the solve kernel fetches a lane's operand for both tiles.
     __shared__ T tile[32][33];
     const int64_t k0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -337,9 +339,12 @@ __global__ __launch_bounds__(256) void trsm_neg_pack_kernel(int64_t n, int64_t n
         tile[j][tx] = (upper && k < n && c < n) ? -U[k + c * ldu] : T(0);
     }
     __syncthreads();
-    for (int i = ty; i < 32; i += 8) Uneg[(k0 + i) * n_pad + c0 + tx] = tile[tx][i];
+    for (int i = ty; i < 32; i += 8) Uneg[(k0 + i) * n_pad + c0 + 2 * (tx & 15) + (tx >> 4)] = tile[tx][i];
 }
 
+#ifndef RLHIP_TF_DRAIN
+#define RLHIP_TF_DRAIN 0
+#endif
 template <int N> struct IntC { static constexpr int value = N; };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -357,7 +362,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <typename T, int NW, int HPR, bool OOP, bool XASM>
 __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64_t n, int64_t n_pad, T alpha, const T* __restrict__ Uneg,
                                                                 const T* __restrict__ Dinv, T* __restrict__ B, int64_t ldb, int J0, int J1,
-                                                                int K0blk, T* __restrict__ dump, const T* __restrict__ Bsrc, int64_t ldsrc,
+                                                                int K0blk, T* __restrict__ dump, const T* Bsrc, int64_t ldsrc,
                                                                 const int64_t* __restrict__ perm, int64_t pbase, const int* __restrict__ gate, int ngate) {
     if (gate != nullptr) {
         int closed = 0;
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     typedef __attribute__((address_space(3))) void lds_void_t;
     typedef const __attribute__((address_space(1))) void glb_void_t;
     constexpr int RING = 2;
+    constexpr int DW = RLHIP_TF_DRAIN ? 0 : 8;                  // requests that may fly at a rendezvous of the diagonal block (see dpair)
     constexpr int HPB = HPR * FSTR * (int)sizeof(T);            // bytes per stage (16 rows: 34 KiB fp64, 17 KiB fp32)
     constexpr int NCH = HPB / 1024;                             // 1 KiB DMA pieces per panel
     constexpr int EPC = 1024 / (int)sizeof(T);                  // elements per piece
@@ -459,28 +465,36 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     auto issue_dinv = [&](int64_t sblk) {                       // ONE piece per wave: inverse of global diagonal sub-block sblk -> stage sblk & 1
         __builtin_amdgcn_global_load_lds((glb_void_t*)(Dinv + sblk * 1024 + dsrc), (lds_void_t*)(sD + (int)(sblk & 1) * DBY + ddst), 16, 0, 0);
     };
-    // One panel: acc[j] += Uneg-panel(rows 4q + fk, tile j) * y[q] for the tiles j >= JLO, in groups of eight products with the LDS
-    // fragments of the next group fetched before the MFMAs of the current one are queued; `side()` runs behind the first group.
+    // One half panel: acc[j] += Uneg-panel(rows 4q + fk, tile j) * y[q] for the tiles j >= JLO (even), in groups of four products whose two
+    // LDS fragments -- one 2-element read per tile PAIR, the packed operand interleaves the pair's columns -- are fetched before the MFMAs
+    // of the group in front are queued; `side()` runs behind the first group.
     auto panel_mma = [&](auto jlo_c, acc_t (&acc)[16], const T* sU, const T (&y)[NQ], auto&& side) {
+        typedef T v2_t __attribute__((ext_vector_type(2)));
         constexpr int JLO = decltype(jlo_c)::value;
-        constexpr int NTL = 16 - JLO, TOT = NQ * NTL, G = 4, NG = (TOT + G - 1) / G;
-        const T* su = sU + fk * FSTR + fr;
-        T fa[G], fb[G];
+        static_assert(JLO % 2 == 0, "tiles are consumed in pairs");
+        constexpr int NP = (16 - JLO) / 2, TOT = NQ * NP, G = 2, NG = (TOT + G - 1) / G;
+        const T* su = sU + fk * FSTR + 2 * fr;
+        v2_t fa[G], fb[G];
 #pragma unroll
         for (int e = 0; e < G; ++e)
-            if (e < TOT) fa[e] = su[4 * (e / NTL) * FSTR + 16 * (JLO + e % NTL)];
+            if (e < TOT) fa[e] = *reinterpret_cast<const v2_t*>(su + 4 * (e / NP) * FSTR + 32 * (JLO / 2 + e % NP));
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const int f = (g + 1) * G + e;
-                if (f < TOT) fb[e] = su[4 * (f / NTL) * FSTR + 16 * (JLO + f % NTL)];
+                if (f < TOT) fb[e] = *reinterpret_cast<const v2_t*>(su + 4 * (f / NP) * FSTR + 32 * (JLO / 2 + f % NP));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
                 const int f = g * G + e;
-                if (f < TOT) acc[JLO + f % NTL] = M::mma(fa[e], y[f / NTL], acc[JLO + f % NTL]);
+                if (f < TOT) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int j = JLO + 2 * (f % NP);
+                    acc[j] = M::mma(fa[e][0], y[f / NP], acc[j]);
+                    acc[j + 1] = M::mma(fa[e][1], y[f / NP], acc[j + 1]);
+                }
             }
             if (g == 0) side();
             __builtin_amdgcn_sched_barrier(0);
@@ -602,13 +616,16 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         {
             // diagonal block with 32-row stages: one rendezvous per 32-column sub-block.  Requests of a pair in issue order: the 8 STORES of the
             // tiles retired there, the next stage's P pieces, one piece of the next inverse, then the 8 LOADS that refill the retired
-            // registers -- the only requests that may still fly at the next rendezvous.  The allowed window holds loads only: loads return in
-            // order among themselves, so it cannot open while an older load (stage, inverse) is outstanding, whenever the stores are
-            // acknowledged.  (A window of "the 16 youngest loads and stores" is NOT safe: a store acknowledged before older loads lets the
-            // count reach 16 with a piece of the inverse on its way -- seen as a wrong second tile of sub-block 7 in some workgroups.)
+            // registers -- the only requests that may still fly at the next rendezvous (DW = 8).  That count is only right while the 8
+            // loads really SIT behind the LDS-DMA pieces in the instruction stream, and they are hipcc's to place: with Bsrc declared
+            // `const __restrict__` it treated them as invariant and sank all 64 of a block to the block's end, across the waits, so that
+            // vmcnt(8) let 8 of the 10 pieces fly -- seen as a wrong second tile of a sub-block in some wavefronts of the out-of-place solve.
+            // Bsrc is a plain pointer now (a load may not cross a wait's memory clobber), and scripts/check_trsm_asm.py proves on every
+            // build that no LDS-DMA piece is outstanding at any s_barrier; if that proof fails the Makefile rebuilds with
+            // -DRLHIP_TF_DRAIN=1 (every rendezvous of the diagonal block drains the counter) and proves that build.
             auto dpair = [&](auto s_c) {
                 constexpr int s = decltype(s_c)::value;
-                wait_vm<(s >= 2) ? 8 : 0>();
+                wait_vm<(s >= 2) ? DW : 0>();
                 __builtin_amdgcn_s_barrier();
                 const T* sU = reinterpret_cast<const T*>(tf_smem + ring * HPB);
                 solve_sub(s);
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
                 TF_MARK(1 + 2 * s)
             };
             dpair(IntC<0>{}); dpair(IntC<1>{}); dpair(IntC<2>{}); dpair(IntC<3>{}); dpair(IntC<4>{}); dpair(IntC<5>{}); dpair(IntC<6>{});
-            wait_vm<8>();                                       // the last inverse and the next block's first stage have landed; the 8 loads of retire(5) may fly
+            wait_vm<DW>();                                      // the last inverse and the next block's first stage have landed; the 8 loads of retire(5) may fly
             __builtin_amdgcn_s_barrier();
             solve_sub(7);
             retire_tiles(6);

@@ -80,7 +80,7 @@ def cqrrpt(steps):
                       "config": {"workload": "CQRRPT m=1048576 n=1024 d=1280 nnz=4 qrcp=geqp3", "rank": r["rank"], "times_us": r.get("times_us")},
                       "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": traffic,
                                    "traffic_source": traffic_source,
-                                   "kernel": "trsm_fused_kernel<double, 8, 16, OOP> (right-upper solve with the pivoting folded in, 2 launches per call)",
+                                   "kernel": "trsm_fused_kernel<double, 8, 32, OOP> (right-upper solve with the pivoting folded in, 2 launches per call)",
                                    "launch_ms": round(kms, 3), "flops_per_launch": 1.0 * m * n * n,
                                    "also": {"kernel": "gemm_sk_kernel<TN, tri> (Gram matrix A^T A, upper tiles)", "launch_ms": round(gms, 3),
                                             "achieved": round(1.0 * m * n * n / (gms * 1e-3) / 1e12, 2)}},

@@ -15,8 +15,15 @@ against a model of the vector-memory counter:
   * the replay is linear in program order; at a label the FIFO is kept (a loop body is checked with the state its first entry leaves --
     the kernel's waits are the same on every trip, so the first trip is the representative one) and at `s_endpgm` it is cleared.
 
-Exit status 0: every instantiation is clean.  1: a violation (printed with the assembly line) -- the Makefile then rebuilds tri.o with
--DRLHIP_TF_XASM_DEFAULT=0, i.e. the plain-C++-load twin of the kernel becomes the default and the asm twin stays available for A/B only.
+Second obligation, for EVERY instantiation (XASM or not): the panels of U and the inverses of the diagonal blocks reach LDS through LDS-DMA
+(`global_load_lds_*`) and are read by all wavefronts after an `s_barrier`; the wait in front of that barrier is a COUNTED one wherever
+younger register loads may keep flying.  The count is only right if those loads sit behind the DMA pieces in the instruction stream -- and
+hipcc may move them (it sank them to the end of the block in one build: 8 of 10 pieces were allowed to fly, a wrong tile in some wavefronts).
+So: at every `s_barrier`, NO LDS-DMA request may be left in the FIFO.
+
+Exit status: bit 0 set = an asm-load violation (the Makefile rebuilds tri.o with -DRLHIP_TF_XASM_DEFAULT=0: the plain-C++-load twin becomes the
+default); bit 1 set = an LDS-DMA piece can be outstanding at a barrier (the Makefile rebuilds with -DRLHIP_TF_DRAIN=1 -- the diagonal block's
+rendezvous drain the counter -- and checks THAT build; if it still fails the build stops).
 usage: check_trsm_asm.py tri.gfx950.s
 """
 import re
@@ -41,6 +48,7 @@ def check_function(name, lines):
     fifo = []          # entries: (is_asm_load, dest_regs, line_no, text)
     guarded = {}       # register -> (line_no, text) of the asm load in flight that owns it
     problems = []
+    dma_problems = []  # (barrier line, DMA line, text)
     prev_nop4 = False
     n_asm = 0
     for ln, raw in lines:
@@ -53,6 +61,12 @@ def check_function(name, lines):
             continue
         if op == "s_endpgm":
             fifo.clear(); guarded.clear(); prev_nop4 = False
+            continue
+        if op == "s_barrier":
+            for (_, _, dln, dtext) in fifo:
+                if dtext.startswith("global_load_lds"):
+                    dma_problems.append((ln, dln, dtext))
+            prev_nop4 = False
             continue
         if op == "s_waitcnt":
             m = WAIT.search(text)
@@ -86,7 +100,7 @@ def check_function(name, lines):
                         problems.append((ln, raw.strip(), r, guarded[r]))
                     guarded[r] = (ln, text)
         prev_nop4 = False
-    return n_asm, problems
+    return n_asm, problems, dma_problems
 
 
 def main(path):
@@ -108,16 +122,23 @@ def main(path):
         print("check_trsm_asm: no trsm_fused_kernel<..., XASM = true> instantiation found in", path)
         return 1
     bad = 0
-    for n, lines in sorted(xasm.items()):
-        n_asm, problems = check_function(n, lines)
-        if n_asm == 0:
+    for n, lines in sorted(funcs.items()):
+        is_xasm = n in xasm
+        n_asm, problems, dma = check_function(n, lines)
+        if is_xasm and n_asm == 0:
             print(f"check_trsm_asm: {n}: no asm-issued load recognised (pattern changed?)")
-            bad += 1
-        for ln, text, r, owner in problems[:12]:
-            print(f"check_trsm_asm: {n}: line {ln}: `{text}` names v{r} while the asm load of line {owner[0]} (`{owner[1]}`) is still in flight")
-        bad += len(problems)
-        print(f"check_trsm_asm: {n[:60]}...: {n_asm} asm-issued loads, {len(problems)} violations")
-    return 1 if bad else 0
+            bad |= 1
+        if is_xasm:
+            for ln, text, r, owner in problems[:12]:
+                print(f"check_trsm_asm: {n}: line {ln}: `{text}` names v{r} while the asm load of line {owner[0]} (`{owner[1]}`) is still in flight")
+            if problems:
+                bad |= 1
+        for bln, dln, dtext in dma[:12]:
+            print(f"check_trsm_asm: {n}: s_barrier at line {bln} while the LDS-DMA request of line {dln} (`{dtext}`) may be outstanding")
+        if dma:
+            bad |= 2
+        print(f"check_trsm_asm: {n[:60]}...: {n_asm} asm-issued loads, {len(problems) if is_xasm else 0} violations, {len(dma)} LDS-DMA requests open at a barrier")
+    return bad
 
 
 if __name__ == "__main__":

@@ -858,3 +858,32 @@ def test_cqrrpt_split_qrcp_fp32_and_ranged_solve_fp32(ctx, monkeypatch):
     assert np.array_equal(J0, J1)
     assert np.abs(R0 - R1).max() <= 2e-4 * np.abs(R0).max()
     assert float((Q0 - Q1).abs().max()) <= 2e-4
+
+
+def test_trsm_gather_full_size_is_deterministic_and_right_every_time(ctx):
+    """1048576 x 1024 fp64 out-of-place solve with a pivot vector, six times: every run solves the system (residual at rounding level in every
+    column) and returns the same bits.  Round 5: hipcc sank the loads that refill retired tiles to the end of a block, the counted wait in
+    front of a rendezvous then let LDS-DMA pieces of a diagonal inverse fly, and SOME wavefronts of SOME runs produced a wrong second tile of a
+    32-column sub-block (errors ~0.5 in 16 columns of ~64 rows): only repetition at full size shows that."""
+    import torch
+
+    d = _d()
+    m, n = 1048576, 1024
+    A = d.cm_empty(m, n); ctx.fill_dense(A, m, n, key=(3, 0))
+    U = d.cm_empty(n, n); ctx.fill_dense(U, n, n, key=(2, 0))
+    ctx.lib.rlhip_add_diag_f64(ctx.h, n, 40.0, U.data_ptr(), n)
+    Um = torch.triu(U.T)
+    ldw = m + 32
+    W = torch.empty((n, ldw), dtype=torch.float64, device="cuda")
+    Jp = torch.randperm(n, generator=torch.Generator().manual_seed(5)).cuda() + 1
+    first = None
+    for it in range(6):
+        W.zero_()
+        ctx.trsm_gather(m, n, 1.0, U, n, A, m, Jp, W, ldw); ctx.sync()
+        X = W[:, :m]
+        err = ((Um.T @ X) - A[Jp - 1]).abs().amax(dim=1)
+        assert float(err.max()) <= 1e-11, (it, (err > 1e-11).nonzero().flatten()[:8].tolist())
+        if first is None:
+            first = X.clone()
+        else:
+            assert torch.equal(first, X), it
