@@ -29,6 +29,7 @@
 //     fragment x, lane fr  <->  row 4*fr + x.  Accumulator layout of the f32 MFMA: lane (fr, fk), register r = C[row(fr)][16u + 4fk + r].
 #include "rlhip_internal.h"
 #include <cstdlib>
+#include <type_traits>
 #include <cstdio>
 
 namespace {
@@ -146,7 +147,12 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, bool A_KC>
+// O32: the per-lane source offsets of the DMA pieces are unsigned 32-bit BYTE offsets from a wave-uniform pointer (the host takes this
+// form whenever 256 rows of either operand span less than 4 GiB): the request is `global_load_lds voff, s[base]` -- one VGPR per piece instead
+// of a 64-bit lane pointer built per K-tile.  With 64-bit offsets (round 4) the fp64 kernels ran out of registers IN the K loop: hipcc
+// spilled the LDS destination offset and reloaded it between the first and the second DMA request of every K-tile, behind an
+// s_waitcnt vmcnt(0) -- i.e. every wave waited one HBM round trip for the piece it had just requested, with the matrix pipe draining.
+template <typename T, bool A_KC, bool O32>
 __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
     using S = SkT<T>;
     using frag_t = typename S::frag_t;
@@ -154,7 +160,9 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
     constexpr int BK = S::BK, EPP = S::EPP, NH = S::NH;
     constexpr bool F64 = (sizeof(T) == 8);
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    using off_t = typename std::conditional<O32, unsigned, int64_t>::type;      // byte offsets
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);                      // wave-uniform, and known to be: everything derived from it lives in SGPRs
     const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
 
@@ -180,44 +188,44 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 
     // ---- per-lane source offsets of this wave's 6 DMA pieces per K-tile (elements, relative to tile origin)
     // A: chunks {wid, wid+8}; B: chunks {wid, wid+8, wid+16, wid+24}
-    int64_t a_src[2], b_src[4];
+    off_t a_src[2], b_src[4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = wid + 8 * h;
         if constexpr (A_KC) {
             const int r = 8 * c + (lane >> 3), q = lane & 7;
-            a_src[h] = (int64_t)r * g.lda + EPP * (q ^ ((r >> 1) & 7));
+            a_src[h] = (off_t)(((int64_t)r * g.lda + EPP * (q ^ ((r >> 1) & 7))) * (int64_t)sizeof(T));
         } else if constexpr (F64) {
-            a_src[h] = (int64_t)c * g.lda + 2 * lane;                                  // chunk = one k-row of 128 doubles
+            a_src[h] = (off_t)(((int64_t)c * g.lda + 2 * lane) * (int64_t)sizeof(T));                                  // chunk = one k-row of 128 doubles
         } else {
-            a_src[h] = (int64_t)(2 * c + (lane >> 5)) * g.lda + 4 * (lane & 31);       // chunk = two k-rows of 128 floats
+            a_src[h] = (off_t)(((int64_t)(2 * c + (lane >> 5)) * g.lda + 4 * (lane & 31)) * (int64_t)sizeof(T));       // chunk = two k-rows of 128 floats
         }
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int c = wid + 8 * h;
         const int r = 8 * c + (lane >> 3), q = lane & 7;
-        b_src[h] = (int64_t)r * g.ldb + EPP * (q ^ ((r >> 1) & 7));
+        b_src[h] = (off_t)(((int64_t)r * g.ldb + EPP * (q ^ ((r >> 1) & 7))) * (int64_t)sizeof(T));
     }
     const int64_t a_step = A_KC ? (int64_t)BK : (int64_t)BK * g.lda;
     // the last tile row may be partial (M % 128 rows): its DMA pieces take the rows past the end from the last valid piece instead -- a row
     // of C depends on the same row of op(A) only, so what those rows hold never reaches a stored entry
     const int64_t m_rag0 = (g.tri || g.M % BM == 0) ? g.M : (g.M / BM) * BM;     // first row of the partial tile row (M: there is none)
     const int m_rem = (int)(g.M - m_rag0);
-    int64_t a_src_rag[2];
+    off_t a_src_rag[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = wid + 8 * h;
         if constexpr (A_KC) {
             const int r = 8 * c + (lane >> 3), q = lane & 7;
             const int re = (m_rem > 0) ? r % m_rem : 0;                               // (spread over the valid rows: 96 lanes on ONE line would serialise in the texture path)
-            a_src_rag[h] = (int64_t)re * g.lda + EPP * (q ^ ((r >> 1) & 7));
+            a_src_rag[h] = (off_t)(((int64_t)re * g.lda + EPP * (q ^ ((r >> 1) & 7))) * (int64_t)sizeof(T));
         } else if constexpr (F64) {
             const int ro = (m_rem > 1) ? (2 * lane) % m_rem : 0;                      // (m_rem is even here)
-            a_src_rag[h] = (int64_t)c * g.lda + ro;
+            a_src_rag[h] = (off_t)(((int64_t)c * g.lda + ro) * (int64_t)sizeof(T));
         } else {
             const int ro = (m_rem > 3) ? (4 * (lane & 31)) % m_rem : 0;               // (m_rem is a multiple of 4 here)
-            a_src_rag[h] = (int64_t)(2 * c + (lane >> 5)) * g.lda + ro;
+            a_src_rag[h] = (off_t)(((int64_t)(2 * c + (lane >> 5)) * g.lda + ro) * (int64_t)sizeof(T));
         }
     }
     // which of this thread's two 16-byte pieces of an A stage (pieces tid and tid + 512) hold rows of the partial tile that exist
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         const SkTile td = sk_tile(g, tile);
         const int64_t m0 = td.m0, n0 = td.nA0, k0 = kt0 * BK;
         const bool rag = (m0 >= m_rag0);                                // (never for the tri map)
-        const int64_t as0 = rag ? a_src_rag[0] : a_src[0], as1 = rag ? a_src_rag[1] : a_src[1];
+        const off_t as0 = rag ? a_src_rag[0] : a_src[0], as1 = rag ? a_src_rag[1] : a_src[1];
         const int64_t m_lim = g.tri ? ((int64_t)1 << 62) : g.M;
 
         const T* Ag = A_KC ? (g.A + k0 + m0 * g.lda) : (g.A + m0 + k0 * g.lda);
@@ -253,14 +261,17 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         // of 128 * lda * sizeof(T) apart, which land on a handful of memory channels (31.2 ms against 30.0 ungrouped at C2); a few tiles apart
         // they hit different channels while the rows of the shared operand Q stay within a ~1 MiB window of L2.  The sum over a segment is taken
         // in the rotated order: fixed per (shape, grid), so results stay reproducible.
-        const int64_t rot = (A_KC && GS > 1 && g.stag > 0) ? ((int64_t)who.member * g.stag) % nk : 0;
-        auto issue = [&](int64_t t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
+        // (32-bit tile counters: there is no scalar 64-bit >=, so with 64-bit ones the wrap-around below -- and every address after it -- was
+        // computed per lane in the vector unit, between the MFMAs)
+        const int nk_i = (int)nk;
+        const int rot = (A_KC && GS > 1 && g.stag > 0) ? (int)(((int64_t)who.member * g.stag) % nk) : 0;
+        auto issue = [&](int t, int stage) {   // DMA K-tile t of this segment into ring stage `stage`
             unsigned char* st = smem + stage * STAGE;
             t += rot;
-            if (t >= nk) t -= nk;
-            const T* Ap = Ag + t * a_step;
-            const T* Bp = Bg + t * BK;
-            const T* Bp1 = Bg1 + t * BK;
+            if (t >= nk_i) t -= nk_i;
+            const char* Ap = reinterpret_cast<const char*>(Ag + (int64_t)t * a_step);          // wave-uniform
+            const char* Bp = reinterpret_cast<const char*>(Bg + (int64_t)t * BK);
+            const char* Bp1 = reinterpret_cast<const char*>(Bg1 + (int64_t)t * BK);
 #pragma unroll
             for (int h = 0; h < 2; ++h) glds16(Ap + (h ? as1 : as0), st + (wid + 8 * h) * 1024);
 #pragma unroll
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 
         __builtin_amdgcn_s_barrier();   // nobody still reads the ring (previous segment)
         issue(0, 0);
-        if (nk > 1) {
+        if (nk_i > 1) {
             issue(1, 1);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
         __builtin_amdgcn_s_barrier();   // tile 0 visible
         fetch(smem, 0, fa0, fb0);
         int st_cur = 0;   // ring stage holding tile t
-        for (int64_t t = 0; t < nk; ++t) {
+        for (int t = 0; t < nk_i; ++t) {
             const int st_next = (st_cur == 2) ? 0 : st_cur + 1;
             const int st_prev = (st_cur == 0) ? 2 : st_cur - 1;
             fetch(smem + st_cur * STAGE, 1, fa1, fb1);
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
             mma16(fa0, fb0, HC<0>{});
             mma16(fa0, fb0, HC<1>{});
             if constexpr (NH == 4) { mma16(fa0, fb0, HC<2>{}); mma16(fa0, fb0, HC<3>{}); }
-            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t + 1 < nk_i) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // unconditional (straight-line code lets hipcc use a counted lgkmcnt for F1 instead of lgkmcnt(0));
             // on the last tile this reads a stale stage and the values are never used
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
             mma16(fa1, fb1, HC<0>{});
             if constexpr (NH == 4) mma16(fa1, fb1, HC<1>{});
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nk) issue(t + 2, st_prev);   // DMA issue slots hidden behind the MFMAs just queued
+            if (t + 2 < nk_i) issue(t + 2, st_prev);   // DMA issue slots hidden behind the MFMAs just queued
             __builtin_amdgcn_sched_barrier(0);
             mma16(fa1, fb1, HC<NH / 2>{});
             if constexpr (NH == 4) mma16(fa1, fb1, HC<3>{});
@@ -592,13 +603,17 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     if (want_clk < 0) { const char* e = getenv("RLHIP_SK_CLOCK"); want_clk = e ? atoi(e) : 0; }
     g.clk = want_clk ? ws_alloc<unsigned long long>(c, 4) : nullptr;
     constexpr int smem = NSTAGE * STAGE;
-    if (transA) {
-        RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, true>), smem);
-        hipLaunchKernelGGL((gemm_sk_kernel<T, true>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
-    } else {
-        RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, false>), smem);
-        hipLaunchKernelGGL((gemm_sk_kernel<T, false>), dim3((unsigned)P), dim3(512), smem, c->stream, g);
-    }
+    // 32-bit byte offsets for the DMA pieces when the 256 rows a stage takes from either operand span < 4 GiB (ld < 2 M doubles / 4 M floats)
+    const int64_t span = (int64_t)sizeof(T) * (256 * (lda > ldb ? lda : ldb) + 512);
+    const bool o32 = span < ((int64_t)1 << 32);
+#define RLHIP_SK_LAUNCH(KC, O)                                                                                           \
+    do {                                                                                                                 \
+        RLHIP_FUNC_LDS(c, (gemm_sk_kernel<T, KC, O>), smem);                                                             \
+        hipLaunchKernelGGL((gemm_sk_kernel<T, KC, O>), dim3((unsigned)P), dim3(512), smem, c->stream, g);                \
+    } while (0)
+    if (transA) { if (o32) RLHIP_SK_LAUNCH(true, true); else RLHIP_SK_LAUNCH(true, false); }
+    else { if (o32) RLHIP_SK_LAUNCH(false, true); else RLHIP_SK_LAUNCH(false, false); }
+#undef RLHIP_SK_LAUNCH
     RLHIP_LAUNCH_CHECK();
     // (few tiles cut into many slabs -- the Gram matrix of a 200000 x 256 factor: 2 tiles x 128 slabs -- get more slices per tile: with 16 the
     // 32 blocks of that fix-up took as long as the product itself, 0.42 ms)
