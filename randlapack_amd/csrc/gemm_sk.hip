@@ -162,7 +162,12 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     using off_t = typename std::conditional<O32, unsigned, int64_t>::type;      // byte offsets
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);                      // wave-uniform, and known to be: everything derived from it lives in SGPRs
+    // wave-uniform, and (UW) known to be: everything derived from it -- LDS destinations, M0, the stage bases -- then lives in SGPRs and the
+    // K loop of the fp64 kernels fits its registers.  Measured per instantiation (scripts/exp/ab_gemm_f32.py, ms at the C2 / C4 shapes,
+    // round-4 build -> lane-derived wid -> uniform wid):  fp64 NN 29.7 -> 29.7 -> 28.7;  fp64 TN 30.9 -> 30.4 -> 29.1;  fp32 NN 32.8 -> 32.55
+    // -> 32.2;  fp32 TN 8.20 -> 8.05 -> 8.66 (same MFMA stream, all-scalar DMA issue; not understood) -- so fp32 TN keeps the lane-derived form.
+    constexpr bool UW = !(A_KC && !F64);
+    const int wid = UW ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int wm0 = (wid & 1) * 64, wn0 = (wid >> 1) * 64;
     const int fr = lane & 15, fk = lane >> 4;
 
