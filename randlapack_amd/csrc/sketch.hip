@@ -185,7 +185,8 @@ __global__ void saso_ind_scatter_kernel(int64_t d, int64_t m, int nnz, const int
 }
 
 // every list sorted by source row: the summation order of the gather no longer depends on the arrival order of the scatter
-__global__ void saso_ind_sort_kernel(int64_t nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ ent) {
+// (ent16: nullptr, or the same lists with 16-bit entries: source row | sign << 15)
+__global__ void saso_ind_sort_kernel(int64_t nkeys, const int32_t* __restrict__ ptr, int32_t* __restrict__ ent, uint16_t* __restrict__ ent16) {
     const int64_t key = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     const int32_t p0 = ptr[key], p1 = ptr[key + 1];
@@ -195,6 +196,11 @@ __global__ void saso_ind_sort_kernel(int64_t nkeys, const int32_t* __restrict__ 
         while (q >= p0 && (ent[q] & 0x7fffffff) > (e & 0x7fffffff)) { ent[q + 1] = ent[q]; --q; }
         ent[q + 1] = e;
     }
+    if (ent16)
+        for (int32_t p = p0; p < p1; ++p) {
+            const uint32_t e = (uint32_t)ent[p];
+            ent16[p] = (uint16_t)((e & 0x7fffu) | ((e >> 16) & 0x8000u));
+        }
 }
 
 template <typename T>
@@ -430,6 +436,184 @@ __global__ __launch_bounds__(256, (NR == 5) ? 4 : 1) void saso_apply_kernel(int6
     }
 }
 
+
+// ---- the same product with the slab brought in by LDS-DMA and the index one step ahead (independent-column operators, the default) ----
+// What the register-staged kernel above loses (C3, scripts/saso_time.py): staging alone 1.63 ms, staging + gather 2.91 ms --
+// and 2.89 ms with every gather address replaced by a conflict-free one.  The gather's cost is not LDS bank conflicts but the index:
+// bounds -> entries are two DEPENDENT round trips (L2 / fabric latency each) that start only after the slab's rendezvous, with four
+// workgroups per CU to hide them; hoisting them in front of the slab's loads needs 40 more registers than a 128-register wave has.
+// Here the slab needs no registers at all: every wave requests its 1 KiB pieces of the NEXT block with global_load_lds into the other of
+// two LDS buffers right behind the rendezvous, the lists of the next block (16-bit entries, sixteen per row = two 16-byte loads + one
+// dword for an odd start) and the bounds of the block after it are requested behind those, and everything lands under the gather of the
+// current block.  ONE wait per block -- s_waitcnt vmcnt(0) at the top, when everything outstanding is one block old -- so no counted
+// wait depends on where hipcc puts a load (tri.hip's lesson).  LDS image of a buffer: CT planes of d elements, column after column,
+// i.e. byte 16 p of the buffer = 16-byte piece p of the slab: the DMA destination is lane-linear as the instruction demands.
+// Lists longer than sixteen entries (1e-6 of them at 4 nonzeros per column) finish in a tail loop.
+template <typename T, int NR, int NJ, int DD>
+__global__ __launch_bounds__(256, 2) void saso_apply_dma_kernel(int64_t d_rt, int64_t n, const uint16_t* __restrict__ src16, const int32_t* __restrict__ ptr,
+                                                               const T* A, int64_t lda, int64_t t_per_group, T* __restrict__ partial, int64_t row0,
+                                                               int64_t fb0, int64_t fb1) {
+    constexpr int CT = 4;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void glb_void_t;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    const int64_t d = DD ? (int64_t)DD : d_rt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t c0 = (int64_t)blockIdx.x * CT, g = blockIdx.y;
+    const int64_t t0 = fb0 + g * t_per_group, t1 = (t0 + t_per_group < fb1) ? (t0 + t_per_group) : fb1;
+    const int slab_bytes = (int)(CT * d * (int64_t)sizeof(T));
+    const int buf_stride = (slab_bytes + 1023) & ~1023;
+    const int npieces = slab_bytes / 16, nchunks = (npieces + 63) / 64, ppc = (int)(d * (int64_t)sizeof(T) / 16);
+    // per-lane source byte offsets of this wave's pieces, relative to the first element of the block's first column
+    unsigned goff[NJ];
+    int kdst[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int k = wid + 4 * j;
+        if (k >= nchunks) k %= nchunks;                          // a duplicate: the same bytes to the same place
+        int pc = k * 64 + lane;
+        if (pc > npieces - 1) pc = npieces - 1;                   // lanes past the slab's end land in the buffer's padding
+        const int col = pc / ppc, rp = pc - col * ppc;
+        goff[j] = (unsigned)(((int64_t)col * lda) * (int64_t)sizeof(T) + (int64_t)rp * 16);
+        kdst[j] = k * 1024;
+    }
+    auto issue_slab = [&](int64_t t, int buf) {
+        const char* base = reinterpret_cast<const char*>(A + c0 * lda + (t * d - row0));
+        unsigned char* dst = smem_raw + buf * buf_stride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) __builtin_amdgcn_global_load_lds((glb_void_t*)(base + goff[j]), (lds_void_t*)(dst + kdst[j]), 16, 0, 0);
+    };
+    // index of one block: bounds first (p0, len), then 18 half-words from the even position at or below the list start
+    int rr[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) { const int r = tid + 256 * q; rr[q] = (r < (int)d) ? r : (int)d - 1; }
+    // (raw list starts and ends: nothing is computed from them here -- an instruction that uses a loaded value makes hipcc wait for the
+    // load on the spot, and with it for every older request, the slab's pieces included)
+    auto load_bounds = [&](int64_t t, int32_t (&p0)[NR], int32_t (&p1)[NR]) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { p0[q] = ptr[t * d + rr[q]]; p1[q] = ptr[t * d + rr[q] + 1]; }
+    };
+    auto load_entries = [&](const int32_t (&p0)[NR], int4 (&ea)[NR], int4 (&eb)[NR], int (&ec)[NR]) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int* w = reinterpret_cast<const int*>(src16 + (p0[q] & ~1));
+            int tmp[9];
+            __builtin_memcpy(tmp, w, 36);
+            ea[q] = int4{tmp[0], tmp[1], tmp[2], tmp[3]};
+            eb[q] = int4{tmp[4], tmp[5], tmp[6], tmp[7]};
+            ec[q] = tmp[8];
+        }
+    };
+    T acc[NR][CT];
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = T(0);
+    // index registers: (M, E) = bounds + entries of a block, two sets that alternate (a: even steps of a trip, b: odd); X = the bounds in flight
+    int32_t p0a[NR], lena[NR], p0b[NR], lenb[NR], p0x[NR], p1x[NR];
+    int4 eaa[NR], eba[NR], eab[NR], ebb[NR];
+    int eca[NR], ecb[NR];
+    auto take_bounds = [&](int32_t (&p0)[NR], int32_t (&len)[NR]) {      // X (landed) -> a set; rows past d get empty lists
+#pragma unroll
+        for (int q = 0; q < NR; ++q) { p0[q] = p0x[q]; len[q] = (tid + 256 * q < (int)d) ? p1x[q] - p0x[q] : 0; }
+    };
+    // the gather of one block: entries in batches of GB, every batch branch-free (an entry past the end of a lane's list reads element
+    // 0 with weight 0) so that its LDS reads go out back to back; a batch is skipped when NO lane of the wave has that many entries (a
+    // scalar branch).  The (row, batch) slots of a thread form ONE static sequence and the reads of a slot are issued in front of the
+    // additions of the slot before it: with two waves per SIMD there is nobody else to cover an LDS round trip.
+    constexpr int GB = 2, NB = 16 / GB;                             // entries per batch, batches per row
+    auto gather = [&](const T* sA, const int32_t (&p0)[NR], const int32_t (&len)[NR], const int4 (&ea)[NR], const int4 (&eb)[NR], const int (&ec)[NR]) {
+        T sg[2][GB], v[2][GB][CT];
+        bool act[2] = {false, false};
+#pragma unroll
+        for (int sl = 0; sl <= NR * NB; ++sl) {
+            const int q = sl / NB, bt = sl % NB, cur = sl & 1, prv = cur ^ 1;
+            if (sl < NR * NB) {
+                act[cur] = __builtin_amdgcn_ballot_w64(len[q] > GB * bt) != 0;
+                if (act[cur]) {
+                    const unsigned w9[9] = {(unsigned)ea[q].x, (unsigned)ea[q].y, (unsigned)ea[q].z, (unsigned)ea[q].w, (unsigned)eb[q].x,
+                                            (unsigned)eb[q].y, (unsigned)eb[q].z, (unsigned)eb[q].w, (unsigned)ec[q]};
+                    const unsigned sh = (unsigned)(p0[q] & 1) * 16u;
+#pragma unroll
+                    for (int h4 = 0; h4 < GB; ++h4) {
+                        const int k = GB * bt + h4, i = k >> 1;
+                        const unsigned pair = __builtin_amdgcn_alignbit(w9[i + 1], w9[i], sh);      // entries 2 i, 2 i + 1 of the list
+                        const unsigned e = (k & 1) ? (pair >> 16) : (pair & 0xffffu);
+                        const bool on = k < len[q];
+                        sg[cur][h4] = on ? ((e & 0x8000u) ? T(-1) : T(1)) : T(0);
+                        const T* el = sA + (on ? (e & 0x7fffu) : 0u);
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) v[cur][h4][c] = el[(int64_t)c * d];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (sl > 0 && act[prv]) {
+                const int qp = (sl - 1) / NB;
+#pragma unroll
+                for (int h4 = 0; h4 < GB; ++h4)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[qp][c] += sg[prv][h4] * v[prv][h4][c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+            for (int32_t k = 16; k < len[q]; ++k) {
+                const unsigned e = src16[p0[q] + k];
+                const T sg1 = (e & 0x8000u) ? T(-1) : T(1);
+                const T* el1 = sA + (e & 0x7fffu);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[q][c] += sg1 * el1[(int64_t)c * d];
+            }
+    };
+    // Every prefetch below is UNCONDITIONAL (past the last block the index of the last block is fetched again, and its slab once more into
+    // the idle buffer): a load under `if (t + 1 < t1)` merges with the old register value at the join, hipcc puts the copy there, and the copy
+    // waits for the load -- and for the slab's pieces in front of it.
+    const int64_t tl = t1 - 1;
+    auto cl = [&](int64_t t) { return t < tl ? t : tl; };
+    if (t0 < t1) {
+        issue_slab(t0, 0);
+        load_bounds(t0, p0x, p1x);
+        take_bounds(p0a, lena);                                     // (waits for the bounds: prologue only)
+        load_entries(p0a, eaa, eba, eca);
+        load_bounds(cl(t0 + 1), p0x, p1x);
+    }
+    // one step = one block; two steps per trip so that the index sets alternate without copies of registers still in flight
+    for (int64_t t = t0; t < t1; t += 2) {
+        // slab t, entries t, bounds t + 1: all requested one block ago.  (The builtin, not inline asm: hipcc's own wait insertion then KNOWS the
+        // counter is drained and adds nothing in front of the first use of those registers -- where a conservative wait would also cover
+        // the requests issued just below.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        asm volatile("" ::: "memory");
+        __syncthreads();                                            // slab t visible to all; everybody has left slab t - 1
+        issue_slab(cl(t + 1), 1);
+        take_bounds(p0b, lenb);
+        load_entries(p0b, eab, ebb, ecb);
+        load_bounds(cl(t + 2), p0x, p1x);
+        gather(reinterpret_cast<const T*>(smem_raw), p0a, lena, eaa, eba, eca);
+        if (t + 1 >= t1) break;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" ::: "memory");
+        __syncthreads();
+        issue_slab(cl(t + 2), 0);
+        take_bounds(p0a, lena);
+        load_entries(p0a, eaa, eba, eca);
+        load_bounds(cl(t + 3), p0x, p1x);
+        gather(reinterpret_cast<const T*>(smem_raw + buf_stride), p0b, lenb, eab, ebb, ecb);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // nothing of this workgroup is in flight when it ends
+    T* out = partial + g * d * n;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int64_t r = tid + 256 * q;
+        if (r < d)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) out[r + (c0 + c) * d] = acc[q][c];
+    }
+}
+
 template <typename T>
 __global__ void saso_reduce_kernel(int64_t total, int G, const T* __restrict__ partial, T alpha, T beta,
                                    T* __restrict__ out, int64_t d, int64_t ldo) {
@@ -520,6 +704,7 @@ struct SasoOp {
     int64_t* afwd;      // T   (the forward multiplier a_t; the sparse-operand path scatters)   (mode 0)
     int32_t* rows;      // m * nnz: the columns' own row lists (mode 1; forward map for the sparse-operand path and the dense copy)
     int32_t* ptr;       // T * d + 1 list starts               (mode 1)
+    uint16_t* src16;    // mode 1, d <= 32768: the entries of src as 16 bits (source row | sign << 15), same positions (the DMA apply kernel)
     SasoState st;
 };
 
@@ -542,7 +727,7 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
     if (mode > 1) return -5;
     SasoOp* op = new SasoOp();
     op->d = d; op->m = m; op->nnz = nnz; op->T = (m + d - 1) / d; op->mode = mode;
-    op->src = nullptr; op->ainv = nullptr; op->b = nullptr; op->afwd = nullptr; op->rows = nullptr; op->ptr = nullptr;
+    op->src = nullptr; op->ainv = nullptr; op->b = nullptr; op->afwd = nullptr; op->rows = nullptr; op->ptr = nullptr; op->src16 = nullptr;
     const int64_t T = op->T > 0 ? op->T : 1;
     SasoState st;
     for (int i = 0; i < 4; ++i) st.ctr[i] = ctr[i];
@@ -570,6 +755,10 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
         RLHIP_SASO_ALLOC(op->src, sizeof(int32_t) * (nent + 8));        // + 8: the apply kernel reads eight entries from any list start
         RLHIP_CHECK(hipMemsetAsync(op->src + nent, 0, sizeof(int32_t) * 8, c->stream));
         RLHIP_SASO_ALLOC(op->ptr, sizeof(int32_t) * (nkeys + 1));
+        if (d <= 32768) {                                               // + 20: the DMA apply kernel reads 18 entries from the even position at or below any list start
+            RLHIP_SASO_ALLOC(op->src16, sizeof(uint16_t) * (nent + 20));
+            RLHIP_CHECK(hipMemsetAsync(op->src16 + nent, 0, sizeof(uint16_t) * 20, c->stream));
+        }
         if (op->T > 0) {
             size_t mark = rlhip_ws_mark(c);
             int32_t* cnt = ws_alloc<int32_t>(c, nkeys);
@@ -581,7 +770,7 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
             hipLaunchKernelGGL(saso_ind_scan_kernel, dim3((unsigned)op->T), dim3(256), 0, c->stream, d, nnz, cnt, op->ptr, op->T);
             hipLaunchKernelGGL(saso_ind_scatter_kernel, dim3((unsigned)((m * nnz + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, op->rows,
                                op->ptr, cursor, op->src);
-            hipLaunchKernelGGL(saso_ind_sort_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, c->stream, (int64_t)nkeys, op->ptr, op->src);
+            hipLaunchKernelGGL(saso_ind_sort_kernel, dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, c->stream, (int64_t)nkeys, op->ptr, op->src, op->src16);
             RLHIP_LAUNCH_CHECK();
             rlhip_ws_release(c, mark);
         }
@@ -603,7 +792,7 @@ int saso_destroy(rlhip_ctx* c, SasoOp* op) {
     // back to the context's pool: stream-ordered reuse, no device synchronisation (with hipFree the destructor of a sketching operator
     // made the host wait for the apply it had just enqueued -- and the device then idled while the host prepared the next launch:
     // 0.6 ms between the sketch and its pivoted QR in CQRRPT's timeline)
-    rlhip_free(c, op->src); rlhip_free(c, op->ainv); rlhip_free(c, op->b); rlhip_free(c, op->afwd); rlhip_free(c, op->rows); rlhip_free(c, op->ptr);
+    rlhip_free(c, op->src); rlhip_free(c, op->ainv); rlhip_free(c, op->b); rlhip_free(c, op->afwd); rlhip_free(c, op->rows); rlhip_free(c, op->ptr); rlhip_free(c, op->src16);
     delete op;
     return 0;
 }
@@ -652,31 +841,63 @@ int saso_apply_rows(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T*
     const int64_t tpg = (nTb + G - 1) / G;
     G = (nTb + tpg - 1) / tpg;
     if (G < 1) G = 1;
+    // LDS-DMA route (saso_apply_dma_kernel): independent-column operator with 16-bit lists, whole 4-column slabs, 16-byte aligned
+    // columns and blocks, d <= 1280 rows (five per thread: with eight the index sets of two blocks no longer fit the registers); its blocks are the ones that lie entirely inside
+    // this shard's rows [row0, row0 + mloc) -- a ragged first / last block goes through the register-staged kernel into its own partial group
+    const int64_t fb0 = (row0 + d - 1) / d, fb1_raw = (row0 + mloc) / d, fb1 = fb1_raw > fb0 ? fb1_raw : fb0;
+    const int64_t nfb = fb1 - fb0;
+    const size_t slab2 = 2 * (((size_t)4 * d * sizeof(T) + 1023) & ~(size_t)1023);
+    const bool dma = op->mode == 1 && op->src16 && CT == 4 && n % 4 == 0 && d <= 1280 && (d * sizeof(T)) % 16 == 0 && (lda * sizeof(T)) % 16 == 0 &&
+                     ((uintptr_t)A % 16) == 0 && (((fb0 * d - row0) * (int64_t)sizeof(T)) % 16) == 0 && slab2 <= lds_cap &&
+                     (int64_t)sizeof(T) * (4 * lda + d) < ((int64_t)1 << 32) && nfb >= 8;
+    const int head = dma ? (int)(fb0 - tb0) : 0, tail = dma ? (int)(tb1 - fb1) : 0;      // 0 or 1 ragged blocks each
+    if (dma) {
+        G = (512 + ctiles - 1) / ctiles;                             // two workgroups per CU in flight
+        if (G > nfb) G = nfb;
+        if (G < 1) G = 1;
+    }
+    const int64_t tpg_d = dma ? (nfb + G - 1) / G : tpg;
+    if (dma) G = (nfb + tpg_d - 1) / tpg_d;
+    const int64_t Gtot = G + head + tail;
     size_t mark = rlhip_ws_mark(c);
-    T* partial = ws_alloc<T>(c, (size_t)G * d * n);
+    T* partial = ws_alloc<T>(c, (size_t)Gtot * d * n);
     if (!partial) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     if (nTb == 0) RLHIP_CHECK(hipMemsetAsync(partial, 0, sizeof(T) * (size_t)(d * n), c->stream));
     // sketch rows per thread and pass: 5 (d <= 1280, the CQRRPT sketches of the benchmark configurations: 40 accumulator registers
     // instead of 64) or 8
-    auto launch = [&](auto kern, int nr) -> int {
+    auto launch = [&](auto kern, int nr, T* part, int64_t groups, int64_t per_group, int64_t b0, int64_t b1) -> int {
         RLHIP_FUNC_LDS_DYN(c, kern, lds_cap);       // per kernel ADDRESS: the twelve instantiations share this lambda's statics
         for (int64_t r_base = 0; r_base < d; r_base += 256 * nr)
-            hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, tpg, r_base,
-                               partial, row0, mloc, tb0, tb1, op->ptr);
+            hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)groups), dim3(256), smem, c->stream, d, n, m, op->T, op->nnz, op->src, A, lda, per_group, r_base,
+                               part, row0, mloc, b0, b1, op->ptr);
         return 0;
     };
     if (nTb > 0) {
-        int rc;
+        int rc = 0;
         const bool small = d <= 1280;
-#define RLHIP_SASO_LAUNCH(CTV, MODEV) (small ? launch(saso_apply_kernel<T, CTV, MODEV, 5>, 5) : launch(saso_apply_kernel<T, CTV, MODEV, 8>, 8))
-        if (op->mode == 1) rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 1) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 1) : RLHIP_SASO_LAUNCH(1, 1);
-        else rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 0) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 0) : RLHIP_SASO_LAUNCH(1, 0);
+#define RLHIP_SASO_LAUNCH(CTV, MODEV, PART, GR, PG, B0, B1) (small ? launch(saso_apply_kernel<T, CTV, MODEV, 5>, 5, PART, GR, PG, B0, B1) : launch(saso_apply_kernel<T, CTV, MODEV, 8>, 8, PART, GR, PG, B0, B1))
+        if (dma) {
+            const int nchunks = (int)((4 * d * sizeof(T) / 16 + 63) / 64), nj = (nchunks + 3) / 4;
+            auto launch_dma = [&](auto kern) -> int {
+                RLHIP_FUNC_LDS_DYN(c, kern, lds_cap);
+                hipLaunchKernelGGL(kern, dim3((unsigned)ctiles, (unsigned)G), dim3(256), slab2, c->stream, d, n, (const uint16_t*)op->src16, (const int32_t*)op->ptr, A, lda,
+                                   tpg_d, partial, row0, fb0, fb1);
+                return 0;
+            };
+            if (d == 1280 && sizeof(T) == 8) rc = launch_dma(saso_apply_dma_kernel<T, 5, 10, 1280>);
+            else if (nj <= 5) rc = launch_dma(saso_apply_dma_kernel<T, 5, 5, 0>);
+            else rc = launch_dma(saso_apply_dma_kernel<T, 5, 10, 0>);
+            c->path_count[14]++;
+            if (!rc && head) rc = RLHIP_SASO_LAUNCH(4, 1, partial + (size_t)G * d * n, 1, 1, tb0, fb0);
+            if (!rc && tail) rc = RLHIP_SASO_LAUNCH(4, 1, partial + (size_t)(G + head) * d * n, 1, 1, fb1, tb1);
+        } else if (op->mode == 1) rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 1, partial, G, tpg, tb0, tb1) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 1, partial, G, tpg, tb0, tb1) : RLHIP_SASO_LAUNCH(1, 1, partial, G, tpg, tb0, tb1);
+        else rc = (CT == 4) ? RLHIP_SASO_LAUNCH(4, 0, partial, G, tpg, tb0, tb1) : (CT == 2) ? RLHIP_SASO_LAUNCH(2, 0, partial, G, tpg, tb0, tb1) : RLHIP_SASO_LAUNCH(1, 0, partial, G, tpg, tb0, tb1);
 #undef RLHIP_SASO_LAUNCH
         if (rc) { rlhip_ws_release(c, mark); return rc; }
     }
     RLHIP_LAUNCH_CHECK();
     const int64_t total = d * n;
-    hipLaunchKernelGGL(saso_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, total, (int)G,
+    hipLaunchKernelGGL(saso_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, total, (int)Gtot,
                        partial, alpha, beta, B, d, ldb);
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);

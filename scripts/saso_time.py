@@ -2,6 +2,9 @@
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from randlapack_amd import _lib
+import pathlib
+if os.environ.get("RLHIP_EXP_LIB"): _lib.LIB_PATH = pathlib.Path(os.environ["RLHIP_EXP_LIB"]).resolve()
 from randlapack_amd import device as d
 ctx = d.Context(0)
 m, n, dd, nnz = 1048576, 1024, 1280, 4

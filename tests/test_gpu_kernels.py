@@ -1035,3 +1035,44 @@ def test_lange_extreme_magnitudes_and_col_swap_rejects_non_permutations(ctx):
     good = torch.tensor([4, 1, 3, 2], dtype=torch.int64, device="cuda")
     assert ctx.lib.rlhip_col_swap_f64(ctx.h, 3, 4, 4, Ad.data_ptr(), 3, good.data_ptr()) == 0
     assert np.array_equal(d.cm_to_numpy(Ad), A[:, [3, 0, 2, 1]])
+
+
+@pytest.mark.parametrize("dd,m,n,nnz", [(1280, 1280 * 9 + 300, 8, 4), (96, 96 * 12 + 10, 12, 3), (1280, 1280 * 10, 4, 8), (40, 40 * 30 + 6, 16, 4)])
+def test_saso_apply_lds_dma_route_whole_and_row_shards(ctx, orc, dd, m, n, nnz):
+    """The LDS-DMA apply kernel (independent columns, d <= 1280, whole 4-column slabs: sketch.hip::saso_apply_dma_kernel) against the dense
+    product of the oracle's operator: whole operand (ragged last block -> the register-staged kernel's partial group), and the operand cut
+    into row shards whose windows start and end INSIDE a block (ragged head and tail); every result bitwise reproducible."""
+    import ctypes as C
+
+    d = _dev()
+    rng = np.random.default_rng(dd + n)
+    u32 = lambda v: (C.c_uint32 * len(v))(*v)
+    S = C.c_void_p(); nxt = (C.c_uint32 * 4)()
+    ctr, key = (11, 0, 0, 0), (2, 7)
+    assert ctx.lib.rlhip_saso_create_mode(ctx.h, dd, m, nnz, 1, u32(ctr), u32(key), nxt, C.byref(S)) == 0
+    So, _ = orc.saso_dense(dd, m, nnz, ctr, key, 1)
+    A = rng.standard_normal((m, n))
+    Ad = d.cm_from_numpy(A)
+    ref = So @ A
+    tol = 1e-13 * np.abs(ref).max() * nnz * 8
+    Bd = d.cm_zeros(dd, n)
+    before = ctx.path_count(14)
+    assert ctx.lib.rlhip_saso_apply_f64(ctx.h, S, n, 1.0, Ad.data_ptr(), m, 0.0, Bd.data_ptr(), dd) == 0
+    assert ctx.path_count(14) == before + 1, "the LDS-DMA kernel did not take this shape"
+    B1 = d.cm_to_numpy(Bd)
+    assert np.abs(B1 - ref).max() <= tol
+    Bd2 = d.cm_zeros(dd, n)
+    assert ctx.lib.rlhip_saso_apply_f64(ctx.h, S, n, 1.0, Ad.data_ptr(), m, 0.0, Bd2.data_ptr(), dd) == 0
+    assert np.array_equal(d.cm_to_numpy(Bd2), B1)
+    # three row shards with even, block-interior cuts; each rank holds only its rows (lda = its row count)
+    cuts = [0, (m // 3) & ~1, (2 * m // 3 + 2) & ~1, m]
+    acc = np.zeros((dd, n))
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        Ash = d.cm_from_numpy(np.ascontiguousarray(A[r0:r1]))
+        Bs = d.cm_zeros(dd, n)
+        assert ctx.lib.rlhip_saso_apply_rows_f64(ctx.h, S, n, 1.0, Ash.data_ptr(), r1 - r0, r0, r1 - r0, 0.0, Bs.data_ptr(), dd) == 0
+        part = d.cm_to_numpy(Bs)
+        assert np.abs(part - So[:, r0:r1] @ A[r0:r1]).max() <= tol
+        acc += part
+    assert np.abs(acc - ref).max() <= 2 * tol
+    ctx.lib.rlhip_saso_destroy(ctx.h, S)
