@@ -62,7 +62,7 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
     T* sInv = sRow + 32;                               // [32] : 1 / u_kk
     T* sU12 = sInv + 32;                               // [rest16][PS_LD] : sU12[c*PS_LD + l] = U12[l, c], zero padded to 16 columns
     __shared__ int s_bad;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (info_base > 0 && *info != 0) return;           // a diagonal block of an earlier step of the two-level driver already failed
     if (tid == 0) s_bad = 0;
     __syncthreads();

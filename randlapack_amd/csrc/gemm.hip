@@ -191,7 +191,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, MINW) void gemm_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wid % NWM) * WM;
     const int wn0 = (wid / NWM) * WN;
 
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, T 
     typedef double d4s_t __attribute__((ext_vector_type(4)));
     typedef float f4s_t __attribute__((ext_vector_type(4)));
     using acc_t = typename std::conditional<sizeof(T) == 8, d4s_t, f4s_t>::type;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     const int i0 = blockIdx.x * 32 + (wid & 1) * 16, j0 = blockIdx.y * 32 + (wid >> 1) * 16;
     if (i0 >= M || j0 >= N) return;

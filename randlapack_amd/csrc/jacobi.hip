@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(int64_t m, int n, int
         aa += x * x; bb += y * y; ab += x * y;
     }
     aa = wsum(aa); bb = wsum(bb); ab = wsum(ab);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (lane == 0) { red[0][w] = aa; red[1][w] = bb; red[2][w] = ab; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Xs = reinterpret_cast<T*>(smem_raw);            // [JP][JMT] column-major
     T* Js = Xs + JP * JMT;                              // [JP][JP] column-major
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // block pair of this workgroup (circle method over NB blocks)
     int P, Q;
     {

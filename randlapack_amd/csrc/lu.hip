@@ -184,7 +184,7 @@ __device__ __attribute__((noinline)) unsigned lu_tag_get(const unsigned long lon
 template <typename T, int RPT, int C, bool TAG>
 __device__ __forceinline__ void lu_reg_step(const LuArgs<T>& g, LuRegState<T, RPT>& st, unsigned& epoch, T* s_wv, int64_t* s_wr, int* s_ww, T* s_piv,
                                             T* s_drow) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t G = gridDim.x, me = blockIdx.x, m = g.m;
     const int64_t j = g.j0 + C;
     constexpr int par = C & 1;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void getf2_colmax_kernel(int64_t m, int64_t j,
                                                            int64_t* __restrict__ prow) {
     __shared__ T s_v[4];
     __shared__ int64_t s_r[4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     T bv = T(-1); int64_t br = m;
     for (int64_t i = j + (int64_t)blockIdx.x * 256 + tid; i < m; i += (int64_t)gridDim.x * 256) {
         const T v = fabs(A[i + j * lda]);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void getf2_pivot_kernel(int64_t m, int64_t j0,
     __shared__ T s_v[4];
     __shared__ int64_t s_r[4];
     __shared__ int64_t s_p;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     T bv = T(-1); int64_t br = m;
     for (int i = tid; i < nparts; i += 256) argmax_take(bv, br, pval[i], prow[i], m);
 #pragma unroll
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void laswp_kernel(int64_t c_lo, int64_t c_hi, 
     __shared__ int64_t s_pos[2 * PB], s_src[2 * PB];
     __shared__ int s_n;
     __shared__ T sL[SOLVE ? PB : 1][PB + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (SOLVE) {
         for (int e = tid; e < PB * PB; e += 256) {
             const int i = e % PB, j = e / PB;

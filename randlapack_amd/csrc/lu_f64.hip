@@ -63,7 +63,7 @@ struct LuF64Shared {
 
 template <int C>
 __device__ __forceinline__ void lu_f64_step(const LuArgs<double>& g, LuRegState<double, LD_RPT>& st, LuF64Shared& sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = (int)gridDim.x, me = (int)blockIdx.x;
     const unsigned m = (unsigned)g.m;
     const unsigned j = (unsigned)g.j0 + C;

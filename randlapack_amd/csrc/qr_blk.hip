@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT) void qr_blk_kernel(QbArgs<T> g) {
     __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     constexpr int NW = NT / 64, NP = 8 / IW, NV = IW * 8, LPE = 64 / NV;
     static_assert(NW <= 8, "the column rounds hand one partial sum to every lane of a wave");
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int me = blockIdx.x;
     const int64_t m = g.m, lda = g.lda;
     __shared__ T s_red[NP][NW][NV];

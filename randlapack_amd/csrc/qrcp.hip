@@ -95,7 +95,7 @@ __device__ __forceinline__ T wave_sum_fast(T x) {
 //  is a generic pointer, and every access through it a flat_ instruction)
 template <typename T, bool USE_LDS, bool V_IN_LDS>
 __global__ __launch_bounds__(256) void qrcp_kernel(QrcpArgs<T> g) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t G = gridDim.x, me = blockIdx.x;
     const int64_t m = g.m, n = g.n;
     const int64_t kmin = m < n ? m : n;
@@ -431,7 +431,7 @@ constexpr int QT_SPEC = 6;    // workgroups whose candidate ranked this high amo
 template <typename T>
 __global__ __launch_bounds__(256) void qrcp_tag_kernel(QrcpTagArgs<T> g) {
     constexpr int W = (int)sizeof(T) / 4;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 32-bit indices throughout (the host guarantees m, n < 2^31 - 2) and owned columns addressed by SLOT s (position me + G s):
     // 64-bit divisions by G on every access cost ~1 us per step
     const int G = (int)gridDim.x, me = (int)blockIdx.x;
@@ -735,7 +735,7 @@ struct QrPipeArgs {
 // access may land on either side, is waited for with vmcnt(0) AND lgkmcnt(0).
 template <typename T, bool USE_LDS, bool V_IN_LDS>
 __global__ __launch_bounds__(256) void qr_pipe_kernel(QrPipeArgs<T> g) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t G = gridDim.x, me = blockIdx.x;
     const int64_t m = g.m, n = g.n;
     const int64_t kmax = m < n ? m : n;

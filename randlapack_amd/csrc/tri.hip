@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
     // solves the sub-blocks s_lo .. of the block's first nb columns; the columns < c_lo have been applied by the caller (one GEMM)
     using M = BlkMma<T>;
     using acc_t = typename M::acc_t;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wid) * (16 * RT);      // a wave owns RT row tiles of 16 rows: every U fragment feeds RT MFMAs
     if (row0 >= m) return;

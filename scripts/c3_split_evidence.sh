@@ -18,7 +18,7 @@ f = glob.glob("$O/prof/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the LAST untimed CQRRPT call: find the last-but-one saso_apply launch (the last call of the bench is the timed one, which runs unsplit)
-sa = [i for i, r in enumerate(rows) if "saso_apply_kernel" in r["Kernel_Name"]]
+sa = [i for i, r in enumerate(rows) if "saso_apply_dma" in r["Kernel_Name"]]
 i0 = sa[-2]; i1 = sa[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
 qk = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"

@@ -202,21 +202,21 @@ def qrcp_tag():
 GB = 1e9
 # name -> (function, kernel-name filter, what, algorithmic bytes per launch, flops per launch, bound)
 WORKLOADS = {
-    "gemm_sk_nn": (gemm_sk_nn, "gemm_sk_kernel<double, false>", "Y = A*Omega, 200000 x 20000 x 256 fp64 (C2 pass 1)",
+    "gemm_sk_nn": (gemm_sk_nn, "gemm_sk_kernel<double, false,", "Y = A*Omega, 200000 x 20000 x 256 fp64 (C2 pass 1)",
                    8.0 * (200000 * 20000 + 20000 * 256 + 200000 * 256), 2.0 * 200000 * 20000 * 256, "mfma"),
-    "gemm_sk_tn": (gemm_sk_tn, "gemm_sk_kernel<double, true>", "B^T = A^T*Q, 20000 x 256 x 200000 fp64 (C2 pass 2)",
+    "gemm_sk_tn": (gemm_sk_tn, "gemm_sk_kernel<double, true,", "B^T = A^T*Q, 20000 x 256 x 200000 fp64 (C2 pass 2)",
                    8.0 * (200000 * 20000 + 20000 * 256 + 200000 * 256), 2.0 * 200000 * 20000 * 256, "mfma"),
-    "gemm_sk_tri": (gemm_sk_tri, "gemm_sk_kernel<double, true>", "Gram matrix A^T A (upper 128-blocks), 1048576 x 1024 fp64 with CQRRPT's padded leading dimension m + 32 (C3)",
+    "gemm_sk_tri": (gemm_sk_tri, "gemm_sk_kernel<double, true,", "Gram matrix A^T A (upper 128-blocks), 1048576 x 1024 fp64 with CQRRPT's padded leading dimension m + 32 (C3)",
                     8.0 * (1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
     "trsm_fused": (trsm_fused, "trsm_fused_kernel<double, 8, 32, false", "X U = B in place, 1048576 x 1024 fp64 (C3 second solve, reference order)",
                    8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
     "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 32, true", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
                        8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
-    "saso_apply": (saso_apply, "saso_apply_kernel<double", "A_hat = S*A, S 1280 x 1048576 with 4 nonzeros per column, A 1048576 x 1024 fp64 (C3)",
+    "saso_apply": (saso_apply, "saso_apply_dma_kernel<double", "A_hat = S*A, S 1280 x 1048576 with 4 nonzeros per column, A 1048576 x 1024 fp64 (C3)",
                    8.0 * 1048576 * 1024 + 8.0 * 1280 * 1024, 2.0 * 4 * 1048576 * 1024, "hbm"),
-    "gemm_f32_tn": (gemm_f32_tn, "gemm_sk_kernel<float, true>", "W = V^T C, 2048 x 16384 x 16384 fp32 (one chunk of C4's compact-WY apply)",
+    "gemm_f32_tn": (gemm_f32_tn, "gemm_sk_kernel<float, true,", "W = V^T C, 2048 x 16384 x 16384 fp32 (one chunk of C4's compact-WY apply)",
                     4.0 * (16384 * 2048 + 16384 * 16384 + 2048 * 16384), 2.0 * 2048 * 16384 * 16384, "mfma"),
-    "gemm_f32_nn": (gemm_f32_nn, "gemm_sk_kernel<float, false>", "C -= V W, 65536 x 16384 x 2048 fp32 (C4's compact-WY apply)",
+    "gemm_f32_nn": (gemm_f32_nn, "gemm_sk_kernel<float, false,", "C -= V W, 65536 x 16384 x 2048 fp32 (C4's compact-WY apply)",
                     4.0 * (65536 * 2048 + 2 * 65536 * 16384 + 2048 * 16384), 2.0 * 65536 * 16384 * 2048, "mfma"),
     "spmm_c5": (spmm_c5, "csr_spmm", "Y = A X, A 200000 x 200000 CSR with 2e6 nonzeros, X 32 columns fp64 (C5's operator product; the SpMM kernel of the launch)",
                 (2000000 * 32 + 200000 * 32) * 8.0 + 16.0 * 2000000, 2.0 * 2000000 * 32, "hbm"),
