@@ -350,7 +350,7 @@ template <int N> struct IntC { static constexpr int value = N; };
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NW = wavefronts per workgroup (16 rows each), HPR = rows of U per LDS stage (32 = two 16-row half panels), two stages
-// OOP = out of place: the right-hand side is READ from Bsrc (column c of the solve = column perm[c] - pbase of Bsrc when perm is given:
+// OOP = 1, 2 (0: in place) = out of place: the right-hand side is READ from Bsrc (column c of the solve = column perm[c] - pbase of Bsrc when perm is given:
 // CQRRPT's column pivoting folded into the solve, rl_cqrrpt.hh:288-300) and the solution is WRITTEN to B; the solved tiles needed by
 // later blocks are re-read from B.  The pivot entries of a tile are wave-uniform (scalar loads), only the choice among the lane
 // group's four columns is per lane, so the number of vector-memory requests per step -- which the counted waits rely on -- is unchanged.
@@ -359,7 +359,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // between its issue and the counted wait that covers it -- scripts/check_trsm_asm.py proves that on the disassembly of every build, and
 // the build falls back to XASM = false when the proof fails.  gate / ngate: the launch does nothing when any of the ngate device words is
 // non-zero (cholqrq below: the Cholesky factorization failed, or a diagonal block failed the conditioning guard).
-template <typename T, int NW, int HPR, bool OOP, bool XASM>
+template <typename T, int NW, int HPR, int OOP, bool XASM>
 __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64_t n, int64_t n_pad, T alpha, const T* __restrict__ Uneg,
                                                                 const T* __restrict__ Dinv, T* __restrict__ B, int64_t ldb, int J0, int J1,
                                                                 int K0blk, T* __restrict__ dump, const T* Bsrc, int64_t ldsrc,
@@ -423,9 +423,11 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     // OOP: the source column of every column of a 256-block is staged in LDS once per block (identity without a pivot vector), so a tile
     // element is ONE lane-indexed LDS read + ONE global load.  (With four scalar loads of the pivot entries and a per-lane choice per element
     // hipcc built ~390 branches with an s_waitcnt vmcnt(0) in most of them: the eight loads of a retired tile went out one HBM round trip at a time.)
-    __shared__ int s_perm[OOP ? 2 : 1][OOP ? 256 : 1];          // (source column indices: 32 bits -- as 64-bit words the tile loads' temporaries spilled)
+    // OOP = 2: no pivot vector -- column c of the source is column c: the loads are the in-place kernel's with another base (no LDS look-up, no
+    // 64-bit multiply per element; CQRRPT's second solve, W -> A: 18.35 -> in-place speed)
+    __shared__ int s_perm[OOP == 1 ? 2 : 1][OOP == 1 ? 256 : 1];          // (source column indices: 32 bits -- as 64-bit words the tile loads' temporaries spilled)
     auto fill_perm = [&](int Jb) {
-        if constexpr (OOP) {
+        if constexpr (OOP == 1) {
             if (threadIdx.x < 256) {
                 int64_t cidx = (int64_t)Jb * 256 + threadIdx.x;
                 if (cidx > n - 1) cidx = n - 1;
@@ -434,9 +436,11 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
         }
     };
     const int64_t rowc = live ? row : m - 1;
+    const unsigned loffsrc = (unsigned)(rowc + (int64_t)CL * fk * ldsrc);      // (OOP = 2; the host takes it only while 4 ldsrc + m < 2^28, as for loff)
     // raw right-hand-side element of this lane in tile (jj, r) of the 256-block starting at column cb0
     auto load_raw = [&](int64_t cb0, int jj, int r) -> T {
-        if constexpr (!OOP) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
+        if constexpr (OOP == 0) return (B + (cb0 + 16 * jj + CS * r) * ldb)[loff];
+        else if constexpr (OOP == 2) return (Bsrc + (cb0 + 16 * jj + CS * r) * ldsrc)[loffsrc];
         else {
             const long long mc = (long long)s_perm[(int)(cb0 >> 8) & 1][16 * jj + CS * r + CL * fk];
             return Bsrc[mc * ldsrc + rowc];
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, 2) void trsm_fused_kernel(int64_t m, int64
     T xc[NQ], xn[NQ];
     int ring = 0;                                               // ring stage of the panel the next step consumes
     // ---- prologue: the first two panels, the first inverse, the first tile, the first X operands
-    if constexpr (OOP) {
+    if constexpr (OOP == 1) {
         fill_perm(J0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -695,7 +699,7 @@ inline bool tf_xasm(const rlhip_ctx* c) {      // RLHIP_OPT_TRSM_XASM: -1 = what
     return o < 0 ? (RLHIP_TF_XASM_DEFAULT != 0) : (o != 0);
 }
 
-template <typename T, bool OOP, int HPR>
+template <typename T, int OOP, int HPR>
 int tf_launch_hpr(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
                   const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
     const dim3 grid((unsigned)((m + 127) / 128));
@@ -713,7 +717,7 @@ int tf_launch_hpr(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, co
     return 0;
 }
 
-template <typename T, bool OOP>
+template <typename T, int OOP>
 int tf_launch(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
               const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
     return tf_launch_hpr<T, OOP, 32>(c, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk, dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
@@ -803,7 +807,7 @@ int trsm_right_upper(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, cons
                 a = T(1);
             }
             {
-                const int lrc = tf_launch<T, false>(c, m, n, n_pad, a, Uneg, Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0,
+                const int lrc = tf_launch<T, 0>(c, m, n, n_pad, a, Uneg, Dinv_all, B, ldb, Jb, Je, Jb, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0,
                                                     (const int*)nullptr, 0);
                 if (lrc) { rlhip_ws_release(c, mark); return lrc; }
             }
@@ -921,7 +925,10 @@ int trsm_right_upper_oop(rlhip_ctx* c, int diag, int64_t m, int64_t n, T alpha, 
         hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
         if (int rc = chk(hipGetLastError())) return rc;
         {
-            const int lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
+            // (no pivot vector: the identity-column twin of the kernel, when the source's lane offsets fit 32 bits too)
+            const bool ident = !perm_dev && (4 * ldsrc + m) < ((int64_t)1 << 28);
+            const int lrc = ident ? tf_launch<T, 2>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33)
+                                  : tf_launch<T, 1>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, 0, (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
             if (lrc) { rlhip_ws_release(c, mark); return lrc; }
         }
         if (int rc = chk(hipEventSynchronize(c->ev_flag))) return rc;
@@ -1009,7 +1016,7 @@ int trsm_right_upper_oop_range(rlhip_ctx* c, int diag, int64_t m, int64_t nsrc, 
     hipLaunchKernelGGL(trsm_neg_pack_kernel<T>, dim3((unsigned)(n / 32), (unsigned)(n / 32)), dim3(256), 0, c->stream, n, n, A, lda, Uneg);
     he = hipGetLastError();
     int lrc = (he == hipSuccess) ? 0 : RLHIP_ERR_HIP(he);
-    if (!lrc) lrc = tf_launch<T, true>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, (int)(col0 / BW), (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
+    if (!lrc) lrc = tf_launch<T, 1>(c, m, n, n, alpha, Uneg, Dinv_all, B, ldb, (int)(col0 / BW), (int)nblk, 0, fdump, Bsrc, ldsrc, perm_dev, (int64_t)1, (const int*)bad_dev, 33);
     he = hipEventSynchronize(c->ev_flag);
     if (!lrc && he != hipSuccess) lrc = RLHIP_ERR_HIP(he);
     if (!lrc && perm_dev && ((int*)(c->h_mail + 16))[32] != 0) lrc = -7;
@@ -1137,7 +1144,7 @@ int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int64_t lda, T* R, int red
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(RLHIP_ERR_HIP(le));
         }
-        rc = tf_launch<T, false>(c, m, k, k, T(1), Uneg, Dinv_all, A, lda, 0, (int)nblk, 0, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0, words, 1 + (int)nblk);
+        rc = tf_launch<T, 0>(c, m, k, k, T(1), Uneg, Dinv_all, A, lda, 0, (int)nblk, 0, fdump, (const T*)nullptr, (int64_t)0, (const int64_t*)nullptr, (int64_t)0, words, 1 + (int)nblk);
         if (rc) return fail(rc);
     }
     hipError_t e1 = hipMemcpyAsync(c->h_mail + 44, words, 40 * sizeof(int), hipMemcpyDeviceToHost, c->stream);

@@ -117,7 +117,7 @@ def main(path):
                     cur = None
                     continue
                 cur.append((ln, raw))
-    xasm = {n: l for n, l in funcs.items() if re.search(r"Lb[01]ELb1EEE", n)}       # <T, NW, HPR, OOP, XASM = true>
+    xasm = {n: l for n, l in funcs.items() if re.search(r"Li[012]ELb1EEE", n)}       # <T, NW, HPR, OOP, XASM = true>
     if not xasm:
         print("check_trsm_asm: no trsm_fused_kernel<..., XASM = true> instantiation found in", path)
         return 1

@@ -19,3 +19,9 @@ for _ in range(3):
     t2 = ctx.timer_stop_ms() / 5
     res.append((round(t1, 3), round(t2, 3)))
 print("HPR", os.environ.get("RLHIP_DBG_TF_HPR", "16"), "oop / in-place ms:", res, flush=True)
+res = []
+for _ in range(2):
+    ctx.trsm_gather(m, n, 1.0, U, n, A, m, None, W, ldw); ctx.sync(); ctx.timer_start()
+    for _ in range(5): ctx.trsm_gather(m, n, 1.0, U, n, A, m, None, W, ldw)
+    res.append(round(ctx.timer_stop_ms() / 5, 3))
+print("oop without a pivot vector ms:", res, flush=True)

@@ -208,9 +208,9 @@ WORKLOADS = {
                    8.0 * (200000 * 20000 + 20000 * 256 + 200000 * 256), 2.0 * 200000 * 20000 * 256, "mfma"),
     "gemm_sk_tri": (gemm_sk_tri, "gemm_sk_kernel<double, true,", "Gram matrix A^T A (upper 128-blocks), 1048576 x 1024 fp64 with CQRRPT's padded leading dimension m + 32 (C3)",
                     8.0 * (1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
-    "trsm_fused": (trsm_fused, "trsm_fused_kernel<double, 8, 32, false", "X U = B in place, 1048576 x 1024 fp64 (C3 second solve, reference order)",
+    "trsm_fused": (trsm_fused, "trsm_fused_kernel<double, 8, 32, 0", "X U = B in place, 1048576 x 1024 fp64 (C3 second solve, reference order)",
                    8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
-    "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 32, true", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
+    "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 32, 1", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
                        8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
     "saso_apply": (saso_apply, "saso_apply_dma_kernel<double", "A_hat = S*A, S 1280 x 1048576 with 4 nonzeros per column, A 1048576 x 1024 fp64 (C3)",
                    8.0 * 1048576 * 1024 + 8.0 * 1280 * 1024, 2.0 * 4 * 1048576 * 1024, "hbm"),
