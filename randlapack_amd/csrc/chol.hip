@@ -195,6 +195,72 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
     if (tid == 0) *info = s_bad ? info_base + s_bad : 0;
 }
 
+
+// Block row of the two-level factorization: U12 = U11^-T A12, in place.  Every column of A12 (jb x rest, jb <= 256) is an independent forward
+// substitution with the lower triangular U11^T, so ONE launch with a wavefront per column does the whole block row: the column lives in
+// the wave's registers (lane l holds rows l, l + 64, ...), step k divides by the pivot and subtracts x_k times column k of U11^T (= row k of
+// U11, read from the transposed copy UT so that the lanes' loads are contiguous; the next column is requested before the division of the
+// current step).  It replaces transpose -> blocked right-side solve (pack kernels, conditioning guard with its host read, one MFMA solve
+// kernel) -> transpose: ~190 us of launches and a host round trip per 256-block for 2 * 256^2 * rest flops (C3's 1024 x 1024 Gram matrix:
+// 1.38 ms for the whole factorization, 0.74 of it in the four diagonal blocks).  Plain substitution: no explicit inverse, no guard needed.
+__device__ __forceinline__ double cr_lane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float cr_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_rowsolve_kernel(int jb, int64_t rest, const T* __restrict__ UT, T* __restrict__ A12, int64_t lda,
+                                                            const int* __restrict__ info) {
+    if (*info != 0) return;                                 // a diagonal block failed: nothing right of it is read by anybody
+    constexpr int RPL = 4, PD = 4;                          // rows per lane; columns of U11^T in flight (a step is ~200 cycles of dependent
+                                                            // arithmetic, a load from L2 three to four times that: one column ahead the chain waited for it, 68 us per launch)
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= rest) return;                                // (wave-uniform)
+    T* b = A12 + col * lda;
+    T x[RPL], u[PD][RPL];
+    auto fetch = [&](int k, T (&dst)[RPL]) {                // column k of U11^T (clamped: past the end the last one again, unused)
+        const int kc = (k < jb) ? k : jb - 1;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int i = lane + 64 * q;
+            dst[q] = (i < jb) ? UT[i + (int64_t)kc * jb] : T(1);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const int i = lane + 64 * q;
+        x[q] = (i < jb) ? b[i] : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < PD; ++t) fetch(t, u[t]);
+#pragma unroll
+    for (int q0 = 0; q0 < RPL; ++q0) {
+        for (int l4 = 0; l4 < 64; l4 += PD) {
+            if (64 * q0 + l4 >= jb) break;
+#pragma unroll
+            for (int t = 0; t < PD; ++t) {
+                const int l0 = l4 + t, k = 64 * q0 + l0;
+                if (k < jb) {                               // (wave-uniform)
+                    const T xk = cr_lane(x[q0], l0) / cr_lane(u[t][q0], l0);
+                    if (lane == l0) x[q0] = xk;
+#pragma unroll
+                    for (int q = q0; q < RPL; ++q) {
+                        const int i = lane + 64 * q;
+                        if (i > k && i < jb) x[q] -= u[t][q] * xk;
+                    }
+                }
+                fetch(k + PD, u[t]);                        // the slot is free: its column is requested PD steps ahead of its use
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+        const int i = lane + 64 * q;
+        if (i < jb) b[i] = x[q];
+    }
+}
+
 }  // namespace
 
 namespace rlhip {
@@ -227,13 +293,13 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
     {
         // Two-level blocking for the n x n Gram matrices of CQRRPT / BQRRP's Cholesky-QR panels (n = 1024 .. 4096): 256-wide block steps,
         //   diagonal block      : the one-workgroup kernel above (its 32-wide panels never leave the CU),
-        //   block row           : U12 = U11^-T A12 as the RIGHT-side solve of the transposed slab (W = A12^T, W <- W U11^-1, A12 = W^T)
-        //                         on the blocked trsm of tri.hip,
+        //   block row           : U12 = U11^-T A12, a wavefront per column of A12 in one launch (chol_rowsolve_kernel above; rounds 1-5a: the
+        //                         RIGHT-side solve of the transposed slab on the blocked trsm of tri.hip, between two transposes),
         //   trailing update     : A22 -= U12^T U12 with K = 256 on the MFMA tri-tile GEMM.
         constexpr int64_t BS = 256;
         const size_t mark = rlhip_ws_mark(c);
-        T* W = (n > BS) ? ws_alloc<T>(c, (size_t)(n - BS) * BS) : nullptr;
-        if (n > BS && !W) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+        T* UT = ws_alloc<T>(c, (size_t)BS * BS);                 // U11^T of the current step (chol_rowsolve_kernel)
+        if (!UT) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
         RLHIP_FUNC_LDS(c, potrf_small_kernel<T>, 150 * 1024);
         hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, c->stream, d_info);
         int rc = 0;
@@ -247,9 +313,13 @@ int potrf_upper(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_host) {
             if (rest <= 0) break;
             T* A12 = A + j0 + (j0 + jb) * lda;
             T* A22 = A + (j0 + jb) + (j0 + jb) * lda;
-            rc = transpose<T>(c, jb, rest, A12, lda, W, rest, 0);
-            if (!rc) rc = trsm_right_upper<T>(c, 0, rest, jb, T(1), A11, lda, W, rest);
-            if (!rc) rc = transpose<T>(c, rest, jb, W, rest, A12, lda, 0);
+            rc = transpose<T>(c, jb, jb, A11, lda, UT, jb, 0);
+            if (!rc) {
+                hipLaunchKernelGGL(chol_rowsolve_kernel<T>, dim3((unsigned)((rest + 3) / 4)), dim3(256), 0, c->stream, (int)jb, rest, (const T*)UT, A12, lda,
+                                   (const int*)d_info);
+                const hipError_t le = hipGetLastError();
+                if (le != hipSuccess) rc = RLHIP_ERR_HIP(le);        // (the arena mark is released below on every path)
+            }
             if (!rc) rc = gemm_impl<T>(c, 1, 0, rest, rest, jb, T(-1), A12, lda, A12, lda, T(1), A22, lda, 1);
         }
         rlhip_ws_release(c, mark);
