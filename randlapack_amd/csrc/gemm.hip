@@ -358,6 +358,91 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N
     }
 }
 
+// ---- C (m x n, both <= 64) = alpha * A^T B + beta * C for TALL operands (k rows from 8192 up): the Gram matrices and cross products of
+// narrow panels -- ABRIK's 200000 x 32 Krylov blocks, CQRRT / Cholesky-QR on a few dozen columns, larft's V^T V.  The tiled kernel above
+// spends a 128 x 128 (or 256 x 32) output tile on them, 6-16 x the MFMA work and a split-K slab per 128 x 128 tile: 138 us for the
+// 32 x 32 Gram matrix of a 200000 x 32 block, whose 51 MB stream in 10 us (profiles/round5_c5_abrik_timeline.txt).  Here a workgroup
+// streams 64 KiB slabs of rows -- every column of A (and of B, unless B IS A) with its rows contiguous: 512-byte wavefront loads -- into an
+// LDS image [column][rows + 2] (the padding makes the fragment read of 16 columns x 2 rows hit 32 distinct bank pairs), each of its four
+// wavefronts multiplies a quarter of the slab's rows on the matrix core (v_mfma_*_16x16x4: A-operand lane (i, kk) = column i of A at row kk,
+// B-operand lane (kk, j) = column j of B) into 16 x 16 accumulator tiles that stay in registers across the workgroup's slabs, the four
+// wavefronts' tiles are added in wave order, and the workgroup's m x n partial goes to a slab that splitk_reduce_kernel sums in fixed
+// order: bitwise reproducible.  tri: only tiles touching the upper triangle are multiplied (B is A).
+template <typename T, int NTA, int NTB, bool SAME>
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(int m, int n, int64_t k, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                             int64_t ldb, T* __restrict__ slab) {
+    using M = Mma<T>;
+    using acc_t = typename M::acc_t;
+    constexpr int WA = 16 * NTA, WB = SAME ? 0 : 16 * NTB, W = WA + WB;
+    constexpr int NTJ = SAME ? NTA : NTB;
+    constexpr int KS = (W <= 32) ? 256 : (W <= 64) ? 128 : 64;      // rows per slab: 64 KiB of fp64 per slab whatever the width
+    constexpr int S = KS + 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+    T* sm = reinterpret_cast<T*>(tn_smem);                           // [W][S]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    acc_t acc[NTA][NTJ];
+#pragma unroll
+    for (int ti = 0; ti < NTA; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) acc[ti][tj] = acc_t{0, 0, 0, 0};
+    const int64_t nslab = (k + KS - 1) / KS;
+    for (int64_t sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+        const int64_t r0 = sl * KS;
+        __syncthreads();                                             // everybody has left the previous slab
+#pragma unroll 8
+        for (int e = tid; e < W * KS; e += 256) {
+            const int cc = e / KS, r = e - cc * KS;
+            const int64_t row = r0 + r;
+            T v = T(0);
+            if (row < k) {
+                if (cc < WA) { if (cc < m) v = A[row + (int64_t)cc * lda]; }
+                else { const int cb = cc - WA; if (cb < n) v = B[row + (int64_t)cb * ldb]; }
+            }
+            sm[cc * S + r] = v;
+        }
+        __syncthreads();
+        const T* sa = sm + fr * S + wid * (KS / 4) + fk;
+#pragma unroll 4
+        for (int kk = 0; kk < KS / 4; kk += 4) {
+            T fa[NTA], fb[NTJ];
+#pragma unroll
+            for (int ti = 0; ti < NTA; ++ti) fa[ti] = sa[16 * ti * S + kk];
+#pragma unroll
+            for (int tj = 0; tj < NTJ; ++tj) fb[tj] = SAME ? fa[tj] : sa[(WA + 16 * tj) * S + kk];
+#pragma unroll
+            for (int ti = 0; ti < NTA; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NTJ; ++tj)
+                    if (!SAME || ti <= tj) acc[ti][tj] = M::mma(fa[ti], fb[tj], acc[ti][tj]);
+        }
+    }
+    // the four wavefronts' tiles, added in wave order through LDS; then the workgroup's partial (m x n, column-major) to its slab
+    __syncthreads();
+    T* red = sm;                                                     // [NTA * 16][NTJ * 16], row index fastest
+    constexpr int RM = 16 * NTA;
+    for (int w = 0; w < 4; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int ti = 0; ti < NTA; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NTJ; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + M::drow(lane, r), j = 16 * tj + fr;
+                        const T v = acc[ti][tj][r];
+                        red[i + j * RM] = (w == 0) ? v : red[i + j * RM] + v;
+                    }
+        }
+        __syncthreads();
+    }
+    T* out = slab + (int64_t)blockIdx.x * m * n;
+    for (int e = tid; e < m * n; e += 256) {
+        const int i = e % m, j = e / m;
+        out[e] = red[i + j * RM];
+    }
+}
+
 template <typename T>
 __global__ void scale_kernel(int64_t M, int64_t N, T beta, T* __restrict__ C, int64_t ldc) {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,6 +640,50 @@ static int try_streamk(rlhip_ctx* c, int ta, int tb, int64_t m, int64_t n, int64
     return gemm_streamk<T>(c, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, ssq, tri);
 }
 
+// returns 1 if the product was done here (gemm_tn_skinny_kernel), 0 if the caller should carry on, < 0 on error
+template <typename T>
+static int gemm_tn_skinny(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T alpha, const T* A, int64_t lda, const T* B, int64_t ldb, T beta, T* C,
+                          int64_t ldc, int tri) {
+    if (m > 64 || n > 64 || k < 8192) return 0;
+    const bool same = (A == B) && lda == ldb && m == n;
+    if (tri && !same) return 0;
+    const int nta = m <= 32 ? 2 : 4, ntb = n <= 32 ? 2 : 4;
+    const int W = same ? 16 * nta : 16 * (nta + ntb);
+    const int KS = (W <= 32) ? 256 : (W <= 64) ? 128 : 64;
+    const size_t lds = (size_t)W * (KS + 2) * sizeof(T) > (size_t)64 * 64 * sizeof(T) ? (size_t)W * (KS + 2) * sizeof(T) : (size_t)64 * 64 * sizeof(T);
+    const int64_t nslab = (k + KS - 1) / KS;
+    // two workgroups per CU in flight, and every workgroup the same number of slabs (782 slabs on 512 workgroups: half of them walk two,
+    // half one -- 391 workgroups walk two each); the partials of G workgroups are what the reduction reads: no more of them than needed
+    int64_t G = 2 * (int64_t)c->num_cu;
+    if (G > nslab) G = nslab;
+    { const int64_t per = (nslab + G - 1) / G; G = (nslab + per - 1) / per; }
+    size_t mark = rlhip_ws_mark(c);
+    T* slab = ws_alloc<T>(c, (size_t)G * m * n);
+    if (!slab) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    hipError_t le = hipSuccess;
+#define RLHIP_TN_LAUNCH(NA, NB_, SM)                                                                                                  \
+    do {                                                                                                                              \
+        RLHIP_FUNC_LDS(c, (gemm_tn_skinny_kernel<T, NA, NB_, SM>), 150 * 1024);                                                       \
+        hipLaunchKernelGGL((gemm_tn_skinny_kernel<T, NA, NB_, SM>), dim3((unsigned)G), dim3(256), lds, c->stream, (int)m, (int)n, k, A, lda, B, ldb, slab); \
+        le = hipGetLastError();                                                                                                       \
+    } while (0)
+    if (same) { if (nta == 2) RLHIP_TN_LAUNCH(2, 2, true); else RLHIP_TN_LAUNCH(4, 4, true); }
+    else if (nta == 2 && ntb == 2) RLHIP_TN_LAUNCH(2, 2, false);
+    else if (nta == 4 && ntb == 2) RLHIP_TN_LAUNCH(4, 2, false);
+    else if (nta == 2 && ntb == 4) RLHIP_TN_LAUNCH(2, 4, false);
+    else RLHIP_TN_LAUNCH(4, 4, false);
+#undef RLHIP_TN_LAUNCH
+    if (le == hipSuccess) {
+        const int64_t total = m * n;
+        int blocks = (int)((4 * total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, m, n, (int)G, (const T*)slab, alpha, beta, C, ldc, tri, 0);
+        le = hipGetLastError();
+    }
+    rlhip_ws_release(c, mark);
+    if (le != hipSuccess) return RLHIP_ERR_HIP(le);
+    return 1;
+}
+
 template <typename T>
 int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_t k, T alpha, const T* A,
               int64_t lda, const T* B, int64_t ldb, T beta, T* C, int64_t ldc, int tri, double* ssqA_dev, int* ssq_done) {
@@ -576,6 +705,10 @@ int gemm_impl(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int64_
     if (lda < (arows > 1 ? arows : 1)) return -8;
     if (ldb < (brows > 1 ? brows : 1)) return -10;
     if (ldc < (m > 1 ? m : 1)) return -13;
+    if (transA && !transB && !ssqA_dev) {        // narrow tall products: Gram matrices / cross products of panels of <= 64 columns
+        const int rc = gemm_tn_skinny<T>(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+        if (rc != 0) return rc < 0 ? rc : 0;
+    }
     // contraction lengths that are not a multiple of the k-step (row shards of 200000/8 = 25000 rows): the multiple-of-16
     // part goes down the persistent path, the < 16 leftover is one accumulate pass of the generic kernel
     constexpr int64_t SKK = (sizeof(T) == 8) ? 16 : 32;      // K-tile of the persistent kernel (128 bytes per row)

@@ -977,15 +977,26 @@ template int qrp_partial<float>(rlhip_ctx*, int64_t, int64_t, int64_t, float*, i
 template <typename T>
 __global__ __launch_bounds__(256) void geqrf_absmax_kernel(int64_t m, int64_t n, const T* __restrict__ A, int64_t lda, unsigned long long* __restrict__ w) {
     unsigned long long best = 0;
-    for (int64_t j = blockIdx.y; j < n; j += gridDim.y)
+    for (int64_t j = blockIdx.y; j < n; j += gridDim.y) {
+#pragma unroll 8
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
             const double v = fabs((double)A[i + j * lda]);
             const unsigned long long b = (unsigned long long)__double_as_longlong(v);
             best = b > best ? b : best;
         }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(best, off, 64); best = o > best ? o : best; }
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(w, best);
+    // ONE atomic per workgroup: the atomics on the single result word serialise (~12-35 ns each) -- with one per wavefront and 2048
+    // workgroups they, not the 51 MB of a 200000 x 32 panel, were the kernel's 100 us
+    __shared__ unsigned long long wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wmax[0];
+        for (int q = 1; q < 4; ++q) b = wmax[q] > b ? wmax[q] : b;
+        if (b) atomicMax(w, b);
+    }
 }
 // the scale this matrix needs (1 inside the safe window, and for zero / non-finite matrices)
 template <typename T>
@@ -1020,9 +1031,10 @@ int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev) {
     size_t mark = rlhip_ws_mark(c);
     unsigned long long* w = ws_alloc<unsigned long long>(c, 4);
     if (!w) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
-    int64_t bx = (m + 1023) / 1024, by = n;            // a thread walks ~4 rows of a column: coalesced, no index divisions
+    // a thread walks rows of a column: coalesced, no index divisions, eight loads in flight; at most 1024 workgroups (one atomic each)
+    int64_t bx = (m + 1023) / 1024, by = n;
     if (bx > 64) bx = 64;
-    if (by > 4096 / bx) by = 4096 / bx;
+    if (by > 1024 / bx) by = 1024 / bx;
     const dim3 blocks((unsigned)bx, (unsigned)(by < 1 ? 1 : by));
     hipError_t e = hipMemsetAsync(w, 0, sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(e); }

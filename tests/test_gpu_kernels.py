@@ -119,6 +119,46 @@ def test_gemm_is_deterministic_run_to_run(ctx):
     assert relerr(outs[0], A.T @ B) < 1e-12
 
 
+@pytest.mark.parametrize("m,n,k,dt", [(32, 32, 20000, "f64"), (17, 29, 8192, "f64"), (64, 32, 33001, "f64"), (5, 64, 9000, "f64"), (64, 64, 16389, "f64"),
+                                      (32, 48, 40000, "f32"), (1, 1, 8192, "f64")])
+def test_gemm_tn_tall_skinny_panels(ctx, m, n, k, dt):
+    """C (m x n, both <= 64) = alpha A^T B + beta C over >= 8192 rows: the narrow-panel kernel (gemm.hip::gemm_tn_skinny_kernel -- ABRIK's Krylov
+    blocks, CQRRT / Cholesky-QR on a few dozen columns) with sub-matrix leading dimensions, a ragged last slab, padded column tiles, alpha / beta,
+    and bitwise reproducibility."""
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m * 131 + n * 7 + k)
+    npdt, tdt, tol = (np.float64, torch.float64, 1e-13) if dt == "f64" else (np.float32, torch.float32, 2e-5)
+    lda, ldb, ldc = k + 3, k + 8, m + 2
+    A = rng.standard_normal((lda, m)).astype(npdt); B = rng.standard_normal((ldb, n)).astype(npdt); C0 = rng.standard_normal((ldc, n)).astype(npdt)
+    Ad, Bd = d.cm_from_numpy(A), d.cm_from_numpy(B)
+    outs = []
+    for _ in range(2):
+        Cd = d.cm_from_numpy(C0)
+        ctx.gemm("T", "N", m, n, k, 1.5, Ad, lda, Bd, ldb, -0.5, Cd, ldc)
+        outs.append(d.cm_to_numpy(Cd))
+    ref = C0.astype(np.float64).copy()
+    ref[:m] = 1.5 * A[:k].astype(np.float64).T @ B[:k].astype(np.float64) - 0.5 * C0[:m]
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0] - ref).max() <= tol * np.sqrt(k) * max(1.0, np.abs(ref).max())
+    assert np.array_equal(outs[0][m:], C0[m:])                                    # rows below the product are not touched
+
+
+@pytest.mark.parametrize("n,k", [(32, 200000), (20, 9000), (64, 30000), (48, 8200)])
+def test_syrk_upper_tall_narrow(ctx, n, k):
+    """the same kernel as a Gram matrix (B is A): upper triangle only, the strictly lower triangle of C is not touched"""
+    d = _dev()
+    rng = np.random.default_rng(n + k)
+    A = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((n, n))
+    Cd = d.cm_from_numpy(C0)
+    ctx.syrk("U", "T", n, k, 1.0, d.cm_from_numpy(A), k, 0.0, Cd, n)
+    got = d.cm_to_numpy(Cd)
+    assert relerr(np.triu(got), np.triu(A.T @ A)) < 1e-13
+    assert np.array_equal(np.tril(got, -1), np.tril(C0, -1))
+
+
 @pytest.mark.parametrize("n,k", [(256, 5000), (100, 300), (300, 2000), (1, 10), (130, 17)])
 def test_syrk_upper(ctx, n, k):
     d = _dev()
