@@ -387,21 +387,37 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(int m, int n, int64
 #pragma unroll
         for (int tj = 0; tj < NTJ; ++tj) acc[ti][tj] = acc_t{0, 0, 0, 0};
     const int64_t nslab = (k + KS - 1) / KS;
-    for (int64_t sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+    // a slab travels through registers: ALL of a thread's NE loads of slab s + 1 are in flight while slab s is multiplied out of LDS (eight
+    // at a time, each batch behind the previous one's LDS stores, a slab cost four HBM round trips)
+    constexpr int NE = W * KS / 256;
+    static_assert(W * KS % 256 == 0, "whole rounds of the workgroup");
+    T regs[NE];
+    auto fetch = [&](int64_t sl) {
         const int64_t r0 = sl * KS;
-        __syncthreads();                                             // everybody has left the previous slab
-#pragma unroll 8
-        for (int e = tid; e < W * KS; e += 256) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + 256 * u;
             const int cc = e / KS, r = e - cc * KS;
             const int64_t row = r0 + r;
-            T v = T(0);
-            if (row < k) {
-                if (cc < WA) { if (cc < m) v = A[row + (int64_t)cc * lda]; }
-                else { const int cb = cc - WA; if (cb < n) v = B[row + (int64_t)cb * ldb]; }
-            }
-            sm[cc * S + r] = v;
+            // (clamped address + select: the loads stay unconditional and go out together)
+            const bool inA = cc < WA;
+            const int col = inA ? (cc < m ? cc : m - 1) : ((cc - WA) < n ? (cc - WA) : n - 1);
+            const int64_t rw = row < k ? row : k - 1;
+            const T v = inA ? A[rw + (int64_t)col * lda] : B[rw + (int64_t)col * ldb];
+            regs[u] = (row < k && (inA ? cc < m : (cc - WA) < n)) ? v : T(0);
+        }
+    };
+    if ((int64_t)blockIdx.x < nslab) fetch(blockIdx.x);
+    for (int64_t sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+        __syncthreads();                                             // everybody has left the previous slab
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + 256 * u;
+            const int cc = e / KS, r = e - cc * KS;
+            sm[cc * S + r] = regs[u];
         }
         __syncthreads();
+        if (sl + gridDim.x < nslab) fetch(sl + gridDim.x);
         const T* sa = sm + fr * S + wid * (KS / 4) + fk;
 #pragma unroll 4
         for (int kk = 0; kk < KS / 4; kk += 4) {
