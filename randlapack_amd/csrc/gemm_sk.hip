@@ -500,11 +500,27 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkArgs<T> g) {
 
 // Sums the partial slabs of every tile that was cut by a share boundary, in increasing k order.
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t P) {
-    const int64_t KT = g.ktiles, tile = blockIdx.x;
+__global__ __launch_bounds__(256) void gemm_sk_fixup_kernel(SkArgs<T> g, int64_t P, int by_boundary) {
+    const int64_t KT = g.ktiles;
     const int64_t GS = g.gs;
-    const int64_t unit = tile / GS, member = tile - unit * GS;
     const int64_t W = ((g.ntiles + GS - 1) / GS) * KT;
+    // by_boundary: blockIdx.x = (b - 1) * GS + member enumerates the P - 1 share boundaries -- only a unit with a boundary INSIDE it was cut.
+    // (A product with many tiles -- BQRRP's C -= V W: 70656 tiles, 255 of them cut -- used to launch a workgroup per tile and slice, 1.1 M
+    // workgroups that returned at once: 1.2 ms per launch.)  The first boundary inside a unit handles the unit.
+    int64_t tile = blockIdx.x;
+    if (by_boundary) {
+        const int64_t b = blockIdx.x / GS + 1, mem = blockIdx.x % GS;
+        const int64_t pos = (b * W) / P;
+        if (pos % KT == 0) return;                                   // the boundary sits on a unit's edge: nothing was cut there
+        const int64_t u = pos / KT;
+        if (b >= 2) {
+            const int64_t prev = ((b - 1) * W) / P;
+            if (prev % KT != 0 && prev / KT == u) return;            // an earlier boundary lies inside the same unit
+        }
+        tile = u * GS + mem;
+        if (tile >= g.ntiles) return;                                // (the last unit may be short)
+    }
+    const int64_t unit = tile / GS, member = tile - unit * GS;
     const int64_t lo = unit * KT, hi = lo + KT;
     // first / last share (group) intersecting [lo, hi)      (P = number of groups)
     int64_t w0 = (lo * P) / W;
@@ -625,7 +641,11 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
     int64_t fy = 2048 / ntiles;
     fy = fy < 16 ? 16 : (fy > 128 ? 128 : fy);
     while (SLAB_ELEMS % fy) --fy;
-    hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)ntiles, (unsigned)fy), dim3(256), 0, c->stream, g, P / g.gs);
+    {
+        const int64_t Pg = P / g.gs, nbnd = (Pg - 1) * g.gs;        // share boundaries x group members
+        const bool by_boundary = nbnd > 0 && ntiles > nbnd;
+        hipLaunchKernelGGL(gemm_sk_fixup_kernel<T>, dim3((unsigned)(by_boundary ? nbnd : ntiles), (unsigned)fy), dim3(256), 0, c->stream, g, Pg, by_boundary ? 1 : 0);
+    }
     RLHIP_LAUNCH_CHECK();
     if (ssqA_dev) {
         hipLaunchKernelGGL(ssq_sum_kernel, dim3(1), dim3(256), 0, c->stream, (int)P, g.ssq_part, ssqA_dev);
