@@ -327,11 +327,15 @@ __global__ __launch_bounds__(256) void trsm_blk_kernel(int64_t m, int nb, T alph
 // when the row stride is a multiple of 256 bytes -- no padding.  (Rounds 1-4 read 8 bytes per lane, lanes 0-31 together, and wanted the
 // rows 128 bytes apart modulo 256: stride 272.  Round 5 paired the tiles -- 16-byte reads -- and kept the padding: every operand read of
 // the fp64 kernel was a 2-way conflict, SQ_LDS_BANK_CONFLICT = 3.8 cycles per LDS instruction cycle in profiles/round5_pmc_trsm_fused.json.)
-// fp32 still reads 8 bytes per lane (lanes 0-31 = rows fk, fk + 1 together).
+// fp32 reads 8 bytes per lane (lanes 0-31 = rows fk, fk + 1 together: the two rows have to sit 128 bytes apart modulo 256 -- stride 288;
+// 272 left them 64 bytes apart, half of the lanes in a 2-way conflict: 2.365 -> 2.34 ms at BQRRP's 49152 x 2048 panel).
 #ifndef RLHIP_TF_FSTR64
 #define RLHIP_TF_FSTR64 256
 #endif
-template <typename T> constexpr int fused_stride() { return sizeof(T) == 8 ? RLHIP_TF_FSTR64 : 272; }
+#ifndef RLHIP_TF_FSTR32
+#define RLHIP_TF_FSTR32 288
+#endif
+template <typename T> constexpr int fused_stride() { return sizeof(T) == 8 ? RLHIP_TF_FSTR64 : RLHIP_TF_FSTR32; }
 // two stages of HPR = 32 rows of U (one rendezvous per 32 rows) + two inverses
 template <typename T, int HPR> constexpr int fused_lds_bytes() { return 2 * HPR * fused_stride<T>() * (int)sizeof(T) + 2 * 32 * 32 * (int)sizeof(T); }
 
