@@ -108,12 +108,15 @@ __global__ void saso_lists_kernel(int64_t d, int64_t m, int64_t T, int nnz, Saso
 // ---- mode 1 (independent columns): generation and the inverse lists ----------------------------------------------------------
 // rows[j * nnz + i] = r | (sign << 31): the nnz distinct sketch rows of column j (Fisher-Yates over a virtual identity vector:
 // only the touched positions are tracked); cnt[(j / d) * d + r] counts the sources of sketch row r inside row block j / d.
+// (MAXNZ: capacity of the per-thread table of touched positions -- 8 for the usual few nonzeros per column keeps it in registers; with
+// the general 128 the table lives in scratch memory, 1 KiB per thread: 120 us for C3's 1048576 columns of 4)
+template <int MAXNZ>
 __global__ void saso_ind_gen_kernel(int64_t d, int64_t m, int nnz, SasoState st, int32_t* __restrict__ rows, int32_t* __restrict__ cnt) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const int64_t NB = (nnz + 1) / 2;
     const int64_t t = j / d;
-    int32_t mp[128], mv[128];            // touched positions beyond the ones already drawn, and what they hold now
+    int32_t mp[MAXNZ], mv[MAXNZ];        // touched positions beyond the ones already drawn, and what they hold now
     int nm = 0;
     uint32_t w[4] = {0, 0, 0, 0};
     for (int i = 0; i < nnz; ++i) {
@@ -766,7 +769,8 @@ int saso_build(rlhip_ctx* c, int64_t d, int64_t m, int nnz, int mode, const uint
             if (!cnt || !cursor) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
             RLHIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nkeys, c->stream));
             RLHIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(int32_t) * nkeys, c->stream));
-            hipLaunchKernelGGL(saso_ind_gen_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, st, op->rows, cnt);
+            if (nnz <= 8) hipLaunchKernelGGL(saso_ind_gen_kernel<8>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, st, op->rows, cnt);
+            else hipLaunchKernelGGL(saso_ind_gen_kernel<128>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, st, op->rows, cnt);
             hipLaunchKernelGGL(saso_ind_scan_kernel, dim3((unsigned)op->T), dim3(256), 0, c->stream, d, nnz, cnt, op->ptr, op->T);
             hipLaunchKernelGGL(saso_ind_scatter_kernel, dim3((unsigned)((m * nnz + 255) / 256)), dim3(256), 0, c->stream, d, m, nnz, op->rows,
                                op->ptr, cursor, op->src);
