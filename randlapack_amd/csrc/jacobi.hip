@@ -339,7 +339,7 @@ __device__ __forceinline__ void jacobi_pair_rounds(T* __restrict__ Xs, T* __rest
 template <typename T, int JB, int JMT, int QW>
 __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(int m, int n, int NB, int oround, int intra, T* __restrict__ A,
                                                                int64_t lda, T* __restrict__ V, int64_t ldv, T tol,
-                                                               unsigned* __restrict__ nrot) {
+                                                               unsigned* __restrict__ nrot, int multi) {
     constexpr int JP = 2 * JB;
     constexpr int NT = (JMT == 256) ? 1024 : 512;                           // all 16 waves move data; the first 16*JB threads rotate
     constexpr int NW = NT / 64;
@@ -369,6 +369,29 @@ __global__ __launch_bounds__(JMT == 256 ? 1024 : 512) void jacobi_block_kernel(i
     float my_cos2 = 0.f;                               // 1: a cosine above 1e-9 was met before rotating (convergence shortcut)
     float my_nmax = 0.f, my_nmin = 3e38f;
     __shared__ double Ns[JB == 16 ? JP : 1];
+    if (multi > 0) {
+        // TWO blocks (n <= 2 JB columns: the whole matrix is this workgroup's panel): complete sweeps -- pairs inside the blocks, then the cross
+        // pairs -- repeated HERE until one rotates nothing, instead of two launches and a host read per sweep (ABRIK's projected matrix, 64 x 32:
+        // 10 launches + 5 round trips = 0.65 ms of a 4.8 ms call).  nrot[0] ends up with the LAST sweep's rotations (0 = converged), nrot[2] = sweeps.
+        // (the workgroup-wide "did anybody rotate" goes through the device word nrot[3]: the panel and J fill the CU's LDS to the last byte
+        //  -- __syncthreads_or's own LDS word no longer fits)
+        int sw = 0;
+        unsigned seen = 0;
+        while (sw < multi) {
+            unsigned rot = 0;
+            jacobi_pair_rounds<T, JB, JMT, QW>(Xs, Js, V != nullptr, 1, (double)tol * (double)tol, rot, my_cos2, Ns, my_nmax, my_nmin);
+            jacobi_pair_rounds<T, JB, JMT, QW>(Xs, Js, V != nullptr, 0, (double)tol * (double)tol, rot, my_cos2, Ns, my_nmax, my_nmin);
+            ++sw;
+            my_rot = rot;
+            if (__builtin_amdgcn_ballot_w64(rot != 0) != 0 && lane == 0) atomicAdd(nrot + 3, 1u);
+            __syncthreads();
+            const unsigned now = __hip_atomic_load(nrot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();                           // nobody counts the next sweep before everybody has read this one's total
+            if (now == seen) break;
+            seen = now;
+        }
+        if (tid == 0) nrot[2] = (unsigned)sw;
+    } else
     jacobi_pair_rounds<T, JB, JMT, QW>(Xs, Js, V != nullptr, intra, (double)tol * (double)tol, my_rot, my_cos2, Ns, my_nmax, my_nmin);
     // one atomic pair per wavefront
     {
@@ -871,13 +894,25 @@ int block_jacobi_sweeps_qw(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T* V, 
     constexpr int NT = (JMT == 256) ? 1024 : 512;
     RLHIP_FUNC_LDS(c, (jacobi_block_kernel<T, JB, JMT, QW>), smem);
     int sweep = *sweeps_out;                           // sweeps already done by the persistent kernel (0 otherwise)
+    if (NBk == 2 && sweep < max_sweeps) {
+        // the whole matrix is one workgroup's panel: every sweep inside ONE launch, one host read
+        RLHIP_CHECK(hipMemsetAsync(d_nrot, 0, 4 * sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT, QW>), dim3(1), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V, (int64_t)n, tol, d_nrot,
+                           max_sweeps - sweep);
+        RLHIP_LAUNCH_CHECK();
+        RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        RLHIP_CHECK(rlhip_stream_sync(c));
+        const unsigned* hw = (const unsigned*)(c->h_mail + 16);
+        *sweeps_out = sweep + (int)hw[2];
+        return 0;                                      // (hw[0] != 0: the sweep limit was reached, as the loop below would leave it)
+    }
     for (; sweep < max_sweeps; ++sweep) {
         hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, c->stream, d_nrot);
         hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT, QW>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, 0, 1, A, lda, V,
-                           (int64_t)n, tol, d_nrot);
+                           (int64_t)n, tol, d_nrot, 0);
         for (int oround = 0; oround < NBk - 1; ++oround)
             hipLaunchKernelGGL((jacobi_block_kernel<T, JB, JMT, QW>), dim3(NBk / 2), dim3(NT), smem, c->stream, m, n, NBk, oround, 0, A, lda,
-                               V, (int64_t)n, tol, d_nrot);
+                               V, (int64_t)n, tol, d_nrot, 0);
         RLHIP_LAUNCH_CHECK();
         RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 16, d_nrot, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         RLHIP_CHECK(rlhip_stream_sync(c));
