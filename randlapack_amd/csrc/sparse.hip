@@ -276,7 +276,15 @@ __global__ void ct_chunk_scan_kernel(int64_t nb, int64_t k, int* __restrict__ cn
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= k) return;
     int run = 0;
-    for (int64_t b = 0; b < nb; ++b) {
+    int64_t b = 0;
+    for (; b + 8 <= nb; b += 8) {                      // eight loads in flight per thread (one at a time the walk over 333 chunks of a
+        int t[8];                                      // 200000-column operator took 209 us for 533 MB)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = cnt[(b + u) * k + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { cnt[(b + u) * k + j] = run; run += t[u]; }
+    }
+    for (; b < nb; ++b) {
         const int t = cnt[b * k + j];
         cnt[b * k + j] = run;
         run += t;
