@@ -367,10 +367,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N
 // wavefronts multiplies a quarter of the slab's rows on the matrix core (v_mfma_*_16x16x4: A-operand lane (i, kk) = column i of A at row kk,
 // B-operand lane (kk, j) = column j of B) into 16 x 16 accumulator tiles that stay in registers across the workgroup's slabs, the four
 // wavefronts' tiles are added in wave order, and the workgroup's m x n partial goes to a slab that splitk_reduce_kernel sums in fixed
-// order: bitwise reproducible.  tri: only tiles touching the upper triangle are multiplied (B is A).
+// order: bitwise reproducible.  B == A shares the fragments; tri (a Gram matrix's upper triangle): only tiles touching it are multiplied.
 template <typename T, int NTA, int NTB, bool SAME>
 __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(int m, int n, int64_t k, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-                                                             int64_t ldb, T* __restrict__ slab) {
+                                                             int64_t ldb, T* __restrict__ slab, int tri) {
     using M = Mma<T>;
     using acc_t = typename M::acc_t;
     constexpr int WA = 16 * NTA, WB = SAME ? 0 : 16 * NTB, W = WA + WB;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(int m, int n, int64
             for (int ti = 0; ti < NTA; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < NTJ; ++tj)
-                    if (!SAME || ti <= tj) acc[ti][tj] = M::mma(fa[ti], fb[tj], acc[ti][tj]);
+                    if (!(SAME && tri) || ti <= tj) acc[ti][tj] = M::mma(fa[ti], fb[tj], acc[ti][tj]);      // (tri: wave-uniform)
         }
     }
     // the four wavefronts' tiles, added in wave order through LDS; then the workgroup's partial (m x n, column-major) to its slab
@@ -680,7 +680,7 @@ static int gemm_tn_skinny(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T alpha
 #define RLHIP_TN_LAUNCH(NA, NB_, SM)                                                                                                  \
     do {                                                                                                                              \
         RLHIP_FUNC_LDS(c, (gemm_tn_skinny_kernel<T, NA, NB_, SM>), 150 * 1024);                                                       \
-        hipLaunchKernelGGL((gemm_tn_skinny_kernel<T, NA, NB_, SM>), dim3((unsigned)G), dim3(256), lds, c->stream, (int)m, (int)n, k, A, lda, B, ldb, slab); \
+        hipLaunchKernelGGL((gemm_tn_skinny_kernel<T, NA, NB_, SM>), dim3((unsigned)G), dim3(256), lds, c->stream, (int)m, (int)n, k, A, lda, B, ldb, slab, tri); \
         le = hipGetLastError();                                                                                                       \
     } while (0)
     if (same) { if (nta == 2) RLHIP_TN_LAUNCH(2, 2, true); else RLHIP_TN_LAUNCH(4, 4, true); }

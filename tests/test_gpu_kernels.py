@@ -145,6 +145,19 @@ def test_gemm_tn_tall_skinny_panels(ctx, m, n, k, dt):
     assert np.array_equal(outs[0][m:], C0[m:])                                    # rows below the product are not touched
 
 
+@pytest.mark.parametrize("n,k", [(32, 9000), (64, 20000), (24, 8192)])
+def test_gemm_tn_tall_skinny_same_operand_full_result(ctx, n, k):
+    """A^T A asked for as a GEMM (both operands the same matrix, no triangle flag -- the orthogonality checks of the drivers do that): the
+    narrow-panel kernel shares the operand fragments but must still deliver the WHOLE n x n result, lower triangle included"""
+    d = _dev()
+    rng = np.random.default_rng(n * 3 + k)
+    A = rng.standard_normal((k, n))
+    Ad = d.cm_from_numpy(A)
+    Cd = d.cm_from_numpy(np.full((n, n), np.nan))
+    ctx.gemm("T", "N", n, n, k, 1.0, Ad, k, Ad, k, 0.0, Cd, n)
+    assert relerr(d.cm_to_numpy(Cd), A.T @ A) < 1e-13
+
+
 @pytest.mark.parametrize("n,k", [(32, 200000), (20, 9000), (64, 30000), (48, 8200)])
 def test_syrk_upper_tall_narrow(ctx, n, k):
     """the same kernel as a Gram matrix (B is A): upper triangle only, the strictly lower triangle of C is not touched"""
