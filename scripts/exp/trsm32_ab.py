@@ -8,7 +8,8 @@ from randlapack_amd import device as d
 ctx = d.Context(0)
 m, n = 49152, 2048
 A = d.cm_empty(m, n, dtype=torch.float32); ctx.fill_dense(A, m, n, key=(3, 0)); U = d.cm_empty(n, n, dtype=torch.float32); ctx.fill_dense(U, n, n, key=(2, 0))
-ctx.lib.rlhip_add_diag_f32(ctx.h, n, C_f := __import__("ctypes").c_float(60.0), U.data_ptr(), n)
+import ctypes
+ctx.lib.rlhip_add_diag_f32(ctx.h, n, ctypes.c_float(60.0), U.data_ptr(), n)
 best = 1e9
 ctx.trsm(m, n, 1.0, U, n, A, m); ctx.sync()
 for _ in range(4):
