@@ -669,20 +669,35 @@ __global__ __launch_bounds__(256) void perm_apply_kernel(int64_t m, T* __restric
     const int64_t nm = *nmoves;
     T* row = A + r;
     T saved = 0;
-    int64_t start = 0, cur = 0;
-    for (int64_t q = 0; q < nm; ++q) {
-        const int64_t v = moves[q];
-        if (v < 0) {                           // new cycle: close the previous one first
-            if (q > 0) row[cur * lda] = saved;
-            start = -v - 1;
-            saved = row[start * lda];
-            cur = start;
-        } else {
-            row[cur * lda] = row[v * lda];
-            cur = v;
+    int64_t cur = 0;
+    bool open = false;
+    // Eight moves at a time: their eight SOURCE elements are loaded first, then stored in order.  A column of a cycle is read at its own step
+    // and overwritten at the NEXT one (the start column: read when the cycle opens, overwritten by its first move), and cycles are disjoint,
+    // so a load may always run ahead of the stores in front of it.  One load -> one store at a time (each behind the previous store: the
+    // compiler cannot prove the columns distinct) the walk was latency-bound: 1.39 ms for ~4100 moved columns of a 65536-row matrix, 1.5 TB/s.
+    constexpr int W = 8;
+    for (int64_t q0 = 0; q0 < nm; q0 += W) {
+        int64_t mv[W];
+        T val[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) mv[u] = (q0 + u < nm) ? moves[q0 + u] : (int64_t)0;      // (padding: column 0, loaded and ignored)
+#pragma unroll
+        for (int u = 0; u < W; ++u) val[u] = row[(mv[u] < 0 ? -mv[u] - 1 : mv[u]) * lda];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            if (q0 + u >= nm) break;
+            if (mv[u] < 0) {                   // new cycle: close the previous one first
+                if (open) row[cur * lda] = saved;
+                saved = val[u];
+                cur = -mv[u] - 1;
+                open = true;
+            } else {
+                row[cur * lda] = val[u];
+                cur = mv[u];
+            }
         }
     }
-    if (nm > 0) row[cur * lda] = saved;
+    if (open) row[cur * lda] = saved;
 }
 
 // integer vector overload (rl_util.hh:174-198): permutes the first k entries by a permutation of 1..k
