@@ -663,19 +663,22 @@ __global__ void perm_moves_kernel(int64_t n, const int64_t* __restrict__ idx, in
 template <typename T>
 __global__ __launch_bounds__(256) void perm_apply_kernel(int64_t m, T* __restrict__ A, int64_t lda,
                                                          const int64_t* __restrict__ moves,
-                                                         const int64_t* __restrict__ nmoves) {
+                                                         const int64_t* __restrict__ nmoves, const int64_t* __restrict__ chunk) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
-    const int64_t nm = *nmoves;
+    // chunk != nullptr: blockIdx.y takes the moves [chunk[y], chunk[y + 1]) -- whole cycles, cut by the host: cycles touch disjoint columns, so
+    // the chunks run side by side (a 2048-row sketch is 8 workgroups of rows: with one walk over ~4000 moves each the launch was a latency chain)
+    if (chunk) moves += chunk[blockIdx.y];
+    const int64_t nm = chunk ? chunk[blockIdx.y + 1] - chunk[blockIdx.y] : *nmoves;
     T* row = A + r;
     T saved = 0;
     int64_t cur = 0;
     bool open = false;
-    // Eight moves at a time: their eight SOURCE elements are loaded first, then stored in order.  A column of a cycle is read at its own step
+    // Sixteen moves at a time: their SOURCE elements are loaded first, then stored in order.  A column of a cycle is read at its own step
     // and overwritten at the NEXT one (the start column: read when the cycle opens, overwritten by its first move), and cycles are disjoint,
     // so a load may always run ahead of the stores in front of it.  One load -> one store at a time (each behind the previous store: the
     // compiler cannot prove the columns distinct) the walk was latency-bound: 1.39 ms for ~4100 moved columns of a 65536-row matrix, 1.5 TB/s.
-    constexpr int W = 8;
+    constexpr int W = 16;
     for (int64_t q0 = 0; q0 < nm; q0 += W) {
         int64_t mv[W];
         T val[W];
@@ -997,6 +1000,8 @@ int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, c
     int64_t* nmoves = ws_alloc<int64_t>(c, 1);
     unsigned char* seen = ws_alloc<unsigned char>(c, (size_t)n);
     if (!moves || !nmoves || !seen) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    std::vector<int64_t> h_chunk;
+    int64_t* chunk_dev = nullptr;
     if (n >= 4096) {
         // The cycle decomposition is a serial pointer chase (3-6 ms for one device thread at n = 32768, more than the data movement
         // it steers): for long index vectors it runs on the host instead -- 8n bytes down, the move list up, one stream sync.
@@ -1021,14 +1026,29 @@ int col_swap(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, T* A, int64_t lda, c
                 if (s_ < 0 || s_ >= n || (s_ != i && h_seen[(size_t)s_])) { rlhip_ws_release(c, mark); return -7; }   // not a permutation
             }
         }
+        // chunks of whole cycles for the apply kernel's second grid dimension: ~1024 workgroups in all, at least 64 moves per chunk
+        {
+            const int64_t gx = (m + 255) / 256;
+            int64_t want = gx >= 1024 ? 1 : (1024 + gx - 1) / gx;
+            if (want > 256) want = 256;
+            const int64_t per = std::max<int64_t>(64, (w + want - 1) / std::max<int64_t>(want, 1));
+            h_chunk.clear(); h_chunk.push_back(0);
+            for (int64_t q = 1; q < w; ++q)
+                if (h_moves[(size_t)q] < 0 && q - h_chunk.back() >= per) h_chunk.push_back(q);
+            h_chunk.push_back(w);
+        }
         h_moves[(size_t)(2 * n + 1)] = w;                       // nmoves travels in the same copy when adjacent
         RLHIP_CHECK(hipMemcpyAsync(moves, h_moves.data(), sizeof(int64_t) * (size_t)std::max<int64_t>(w, 1), hipMemcpyHostToDevice, c->stream));
         RLHIP_CHECK(hipMemcpyAsync(nmoves, &h_moves[(size_t)(2 * n + 1)], sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (h_chunk.size() > 2) {
+            chunk_dev = ws_alloc<int64_t>(c, h_chunk.size());
+            if (chunk_dev) RLHIP_CHECK(hipMemcpyAsync(chunk_dev, h_chunk.data(), sizeof(int64_t) * h_chunk.size(), hipMemcpyHostToDevice, c->stream));
+        }
         RLHIP_CHECK(rlhip_stream_sync(c));           // the host vectors die at the end of this scope
     } else
         hipLaunchKernelGGL(perm_moves_kernel, dim3(1), dim3(1), 0, c->stream, n, idx_dev, moves, nmoves, seen);
-    hipLaunchKernelGGL(perm_apply_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, A, lda, moves,
-                       nmoves);
+    hipLaunchKernelGGL(perm_apply_kernel<T>, dim3((unsigned)((m + 255) / 256), (unsigned)(chunk_dev ? h_chunk.size() - 1 : 1)), dim3(256), 0, c->stream, m, A, lda,
+                       moves, nmoves, (const int64_t*)chunk_dev);
     RLHIP_LAUNCH_CHECK();
     rlhip_ws_release(c, mark);
     return 0;
