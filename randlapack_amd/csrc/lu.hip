@@ -679,13 +679,17 @@ __global__ void luqrcp_piv_kernel(int64_t sd, int64_t cols, const int64_t* __res
 // 0.56 ms at lim = 2048): positions below lim live in an LDS array, the at most lim touched positions beyond it in an LDS hash table
 // (open addressing, 2 * LQ_MAX slots); one thread walks the swaps in ~20 ns a step, the workgroup writes the touched entries back.
 constexpr int LQ_MAX = 2048;
+__global__ __launch_bounds__(256) void luqrcp_iota_kernel(int64_t cols, int64_t* __restrict__ J) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cols) J[i] = i + 1;
+}
 __global__ __launch_bounds__(256) void luqrcp_piv_lds_kernel(int64_t sd, int64_t cols, const int64_t* __restrict__ ipiv, int64_t* __restrict__ J) {
     __builtin_amdgcn_s_setprio(3);          // latency-bound: when a look-ahead runs this beside a GEMM on the same CUs, its waves issue first
     __shared__ int s_low[LQ_MAX];                 // J[i] - 1 for i < lim
     __shared__ int s_piv[LQ_MAX];                 // ipiv[i] - 1
     __shared__ int s_key[2 * LQ_MAX], s_val[2 * LQ_MAX];
     const int lim = (int)(sd < cols ? sd : cols);
-    for (int64_t i = threadIdx.x; i < cols; i += blockDim.x) J[i] = i + 1;
+    // (J = iota(1 .. cols) is written by luqrcp_iota_kernel in front of this launch: one workgroup filling 65536 entries took 0.3 of this kernel's 0.39 ms)
     for (int i = threadIdx.x; i < lim; i += blockDim.x) { s_low[i] = i; s_piv[i] = (int)(ipiv[i] - 1); }
     for (int i = threadIdx.x; i < 2 * LQ_MAX; i += blockDim.x) s_key[i] = -1;
     __syncthreads();
@@ -907,7 +911,10 @@ template int laswp<float>(rlhip_ctx*, int64_t, float*, int64_t, int64_t, int64_t
 int luqrcp_piv(rlhip_ctx* c, int64_t sd, int64_t cols, const int64_t* ipiv_dev, int64_t* J_dev) {
     if (cols <= 0) return 0;
     const int64_t lim = sd < cols ? sd : cols;
-    if (lim <= LQ_MAX && cols < ((int64_t)1 << 31)) hipLaunchKernelGGL(luqrcp_piv_lds_kernel, dim3(1), dim3(256), 0, c->stream, sd, cols, ipiv_dev, J_dev);
+    if (lim <= LQ_MAX && cols < ((int64_t)1 << 31)) {
+        hipLaunchKernelGGL(luqrcp_iota_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, c->stream, cols, J_dev);
+        hipLaunchKernelGGL(luqrcp_piv_lds_kernel, dim3(1), dim3(256), 0, c->stream, sd, cols, ipiv_dev, J_dev);
+    }
     else hipLaunchKernelGGL(luqrcp_piv_kernel, dim3(1), dim3(256), 0, c->stream, sd, cols, ipiv_dev, J_dev);
     RLHIP_LAUNCH_CHECK();
     return 0;
