@@ -476,7 +476,7 @@ def test_saso_generation_and_apply_vs_oracle(ctx, orc, mode):
     rng = np.random.default_rng(0)
     u32 = lambda v: (C.c_uint32 * len(v))(*v)
     for (dd, m, n, nnz) in [(40, 1000, 16, 4), (25, 333, 9, 2), (64, 64, 5, 8), (1280, 5000, 24, 4), (7, 50, 3, 7), (1, 5, 2, 1),
-                            (6000, 13000, 6, 3), (11000, 12000, 3, 2)]:
+                            (6000, 13000, 6, 3), (11000, 12000, 3, 2), (48, 300, 4, 12), (4000, 9000, 5, 4)]:
         S = C.c_void_p()
         nxt = (C.c_uint32 * 4)()
         ctr, key = (0xFFFFFFF0, 3, 0, 0), (5, 9)
