@@ -730,22 +730,39 @@ inline bool tf_xasm(const rlhip_ctx* c) {      // RLHIP_OPT_TRSM_XASM: -1 = what
     return o < 0 ? (RLHIP_TF_XASM_DEFAULT != 0) : (o != 0);
 }
 
-template <typename T, int OOP, int HPR>
-int tf_launch_hpr(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
-                  const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
-    const dim3 grid((unsigned)((m + 127) / 128));
+template <typename T, int NW, int OOP, int HPR>
+int tf_launch_nw(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
+                 const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
+    const dim3 grid((unsigned)((m + 16 * NW - 1) / (16 * NW)));
     constexpr int lds = fused_lds_bytes<T, HPR>();
     if (tf_xasm(c)) {
-        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, HPR, OOP, true>), lds);
-        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, HPR, OOP, true>), grid, dim3(512), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, NW, HPR, OOP, true>), lds);
+        hipLaunchKernelGGL((trsm_fused_kernel<T, NW, HPR, OOP, true>), grid, dim3(64 * NW), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
                            dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
     } else {
-        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, 8, HPR, OOP, false>), lds);
-        hipLaunchKernelGGL((trsm_fused_kernel<T, 8, HPR, OOP, false>), grid, dim3(512), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
+        RLHIP_FUNC_LDS(c, (trsm_fused_kernel<T, NW, HPR, OOP, false>), lds);
+        hipLaunchKernelGGL((trsm_fused_kernel<T, NW, HPR, OOP, false>), grid, dim3(64 * NW), lds, c->stream, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk,
                            dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
     }
     RLHIP_LAUNCH_CHECK();
     return 0;
+}
+
+// Wavefronts per workgroup.  A launch costs ceil(workgroups / CUs) rounds of ~NW time units (one workgroup per CU, the CU throughput-bound
+// inside a round: profiles/round5_late_experiments.txt), so a row count that leaves the last round of 128-row workgroups half empty pays for
+// rows it does not have: 49152 rows = 384 workgroups = two rounds = the price of 65536 rows.  The fp32 in-place solve (BQRRP's panels, whose
+// row count shrinks by b per iteration) therefore has a 192-row instantiation (twelve wavefronts, three per SIMD: its 148 VGPRs fit) taken
+// when its rounds cost less: 49152 rows = 256 workgroups = ONE round of 12 units instead of two of 8.
+template <typename T, int OOP, int HPR>
+int tf_launch_hpr(rlhip_ctx* c, int64_t m, int64_t n, int64_t n_pad, T alpha, const T* Uneg, const T* Dinv, T* B, int64_t ldb, int J0, int J1, int K0blk, T* dump,
+                  const T* Bsrc, int64_t ldsrc, const int64_t* perm, int64_t pbase, const int* gate, int ngate) {
+    if constexpr (sizeof(T) == 4 && OOP == 0) {
+        const int64_t ncu = c->num_cu > 0 ? c->num_cu : 256;
+        auto cost = [&](int64_t nw) { const int64_t wg = (m + 16 * nw - 1) / (16 * nw); return ((wg + ncu - 1) / ncu) * nw; };
+        if (cost(12) < cost(8))
+            return tf_launch_nw<T, 12, OOP, HPR>(c, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk, dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
+    }
+    return tf_launch_nw<T, 8, OOP, HPR>(c, m, n, n_pad, alpha, Uneg, Dinv, B, ldb, J0, J1, K0blk, dump, Bsrc, ldsrc, perm, pbase, gate, ngate);
 }
 
 template <typename T, int OOP>

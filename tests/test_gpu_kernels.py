@@ -922,6 +922,35 @@ def test_trsm_fused_asm_and_plain_loads_agree_bitwise(ctx, monkeypatch, m, n, dt
     assert np.linalg.norm(X @ R - B[:4096]) <= 200 * eps * np.linalg.norm(B[:4096]) * np.sqrt(n)
 
 
+@pytest.mark.parametrize("m,n", [(40970, 512), (49152, 256), (33000, 1024)])
+def test_trsm_fused_fp32_192_row_workgroups_equal_128_row_ones_bitwise(ctx, m, n):
+    """fp32 in-place fused solve: row counts whose 128-row workgroups would leave the last round over the CUs half empty run 192-row
+    workgroups (twelve wavefronts; tri.hip::tf_launch_hpr).  A row of X depends on its own row of B only and both instantiations do the
+    same arithmetic in the same order, so the head and the tail of the tall solve must equal, BIT FOR BIT, the same rows solved as two
+    20000-row problems (128-row workgroups); residual checked in fp64 on both ends (ragged last workgroup and ragged last wavefront)."""
+    import torch
+
+    d = _dev()
+    rng = np.random.default_rng(m + n)
+    R = (np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + 2.0 * np.eye(n)).astype(np.float32)
+    B = rng.standard_normal((m, n)).astype(np.float32)
+    Rd = d.cm_from_numpy(R)
+    full = d.cm_from_numpy(B)
+    assert full.dtype == torch.float32
+    before = ctx.path_count(2)
+    ctx.trsm(m, n, 1.0, Rd, n, full, m)
+    assert ctx.path_count(2) > before, "the fused solve did not run"
+    X = d.cm_to_numpy(full)
+    h = 20000
+    for lo in (0, m - h):
+        part = d.cm_from_numpy(B[lo:lo + h])
+        ctx.trsm(h, n, 1.0, Rd, n, part, h)
+        assert np.array_equal(d.cm_to_numpy(part), X[lo:lo + h])
+    eps = np.finfo(np.float32).eps
+    for sl in (slice(0, 2048), slice(m - 2048, m)):
+        assert np.linalg.norm(X[sl].astype(np.float64) @ R.astype(np.float64) - B[sl]) <= 200 * eps * np.linalg.norm(B[sl]) * np.sqrt(n)
+
+
 @pytest.mark.parametrize("m,n,kind,gram", [(20000, 256, "flat", True), (3000, 200, "flat", True), (5000, 128, "cond5", True), (1000, 256, "flat", True), (300, 256, "flat", None),
                                            (2000, 256, "cond100", False), (4000, 96, "cond1e6", False), (1500, 64, "rank-deficient", False)])
 def test_gesdd_gram_route(ctx, monkeypatch, m, n, kind, gram):
