@@ -83,6 +83,20 @@ def _trsm(oop):
     ctx.sync()
 
 
+def trsm_fused_f32_192():
+    """BQRRP's Cholesky-QR panel solve at a row count that takes the 192-row workgroups (49152 x 2048 fp32, in place)"""
+    d, ctx = _ctx()
+    import torch
+
+    m, n = 49152, 2048
+    B = d.cm_empty(m, n, dtype=torch.float32); ctx.fill_dense(B, m, n, key=(1, 0))
+    U = d.cm_empty(n, n, dtype=torch.float32); ctx.fill_dense(U, n, n, key=(2, 0))
+    ctx.lib.rlhip_add_diag_f32(ctx.h, n, C.c_float(60.0), U.data_ptr(), n)
+    for _ in range(REPS):
+        ctx.trsm(m, n, 1.0, U, n, B, m)
+    ctx.sync()
+
+
 def trsm_fused():
     _trsm(False)
 
@@ -212,6 +226,8 @@ WORKLOADS = {
                    8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
     "trsm_fused_oop": (trsm_fused_oop, "trsm_fused_kernel<double, 8, 32, 1", "W = (A P) inv(U) out of place with the pivoting folded in, 1048576 x 1024 fp64 (C3)",
                        8.0 * (2 * 1048576 * 1024 + 1024 * 1024 / 2), 1.0 * 1048576 * 1024 * 1024, "mfma"),
+    "trsm_fused_f32_192": (trsm_fused_f32_192, "trsm_fused_kernel<float, 12, 32, 0", "X U = B in place, 49152 x 2048 fp32, 192-row workgroups (a Cholesky-QR panel of C4)",
+                           4.0 * (2 * 49152 * 2048 + 2048 * 2048 / 2), 1.0 * 49152 * 2048 * 2048, "mfma"),
     "saso_apply": (saso_apply, "saso_apply_dma_kernel<double", "A_hat = S*A, S 1280 x 1048576 with 4 nonzeros per column, A 1048576 x 1024 fp64 (C3)",
                    8.0 * 1048576 * 1024 + 8.0 * 1280 * 1024, 2.0 * 4 * 1048576 * 1024, "hbm"),
     "gemm_f32_tn": (gemm_f32_tn, "gemm_sk_kernel<float, true,", "W = V^T C, 2048 x 16384 x 16384 fp32 (one chunk of C4's compact-WY apply)",
