@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void potrf_small_kernel(int n, T* __restrict_
                         col[k] = ukj;
                         if (lane < 32) sRow[j] = (j >= k) ? ukj : T(0);
                         if (lane == 0) sInv[k] = (T)y;
-                        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the LDS row is written (single wave)
+                        // (no wait on the write: the LDS executes one wavefront's requests in order, the reads below follow it)
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int i = k + 1; i < NB; ++i) col[i] -= sRow[i] * ukj;   // a_ij -= u_ki u_kj  (i > k, column j)
