@@ -109,6 +109,54 @@ def test_csr_transpose_and_densify(ctx):
                                            cit.data_ptr(), vt.data_ptr()) == -2
 
 
+@pytest.mark.parametrize("case", ["short_rows", "one_dense_column", "long_and_short", "empty", "fp32_wide"])
+def test_csr_transpose_both_routes_equal_scipy(ctx, case):
+    """csr_transpose has two scatter routes (sparse.hip): transposed rows of at most 512 entries are scattered by entry number through
+    atomics and sorted row by row; a longer row anywhere takes the stable counting sort over chunks.  Both must give scipy's transpose
+    with ascending source rows inside every transposed row (= the order that makes A^T X bit-reproducible), twice the same bits."""
+    d = _d()
+    import torch
+
+    rng = np.random.default_rng(7)
+    dt, tdt, suf = np.float64, torch.float64, "f64"
+    if case == "short_rows":
+        m, k = 6000, 4100
+        S = _sparse(m, k, 0.004, 11)
+    elif case == "one_dense_column":                                     # column 5 holds 3000 entries: the counting-sort route
+        m, k = 3000, 700
+        S = _sparse(m, k, 0.01, 12).tolil(); S[:, 5] = rng.standard_normal((m, 1)); S = S.tocsr()
+    elif case == "long_and_short":                                       # 513 entries in one column: just over the limit
+        m, k = 2000, 90
+        S = _sparse(m, k, 0.02, 13).tolil(); S[:, 40] = 0; S[:513, 40] = rng.standard_normal((513, 1)); S = S.tocsr()
+    elif case == "empty":
+        m, k = 50, 70
+        S = sp.csr_matrix((m, k))
+    else:
+        m, k = 900, 30000
+        S = _sparse(m, k, 0.002, 14).astype(np.float32)
+        dt, tdt, suf = np.float32, torch.float32, "f32"
+    S.sort_indices()
+    nnz = S.nnz
+    rowptr = torch.as_tensor(S.indptr.astype(np.int64), device="cuda:0")
+    colidx = torch.as_tensor(S.indices.astype(np.int64), device="cuda:0") if nnz else torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    vals = torch.as_tensor(S.data.astype(dt), device="cuda:0") if nnz else torch.zeros(1, dtype=tdt, device="cuda:0")
+    fn = getattr(ctx.lib, "rlhip_csr_transpose_" + suf)
+    outs = []
+    for rep in range(2):
+        rpt = torch.full((k + 1,), -1, dtype=torch.int64, device="cuda:0")
+        cit = torch.full((max(nnz, 1),), -1, dtype=torch.int64, device="cuda:0")
+        vt = torch.zeros(max(nnz, 1), dtype=tdt, device="cuda:0")
+        assert fn(ctx.h, m, k, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), rpt.data_ptr(), cit.data_ptr(), vt.data_ptr()) == 0
+        outs.append((rpt.cpu().numpy(), cit.cpu().numpy()[:nnz], vt.cpu().numpy()[:nnz]))
+    rp, ci, v = outs[0]
+    ref = S.T.tocsr(); ref.sort_indices()
+    np.testing.assert_array_equal(rp, ref.indptr)
+    np.testing.assert_array_equal(ci, ref.indices)                       # ascending source rows inside every transposed row
+    np.testing.assert_array_equal(v, ref.data)
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("d_sk,nnz", [(120, 2), (500, 4), (2000, 8)])
 def test_saso_apply_csr_matches_dense_path_and_is_reproducible(ctx, d_sk, nnz):
     d = _d()
