@@ -382,9 +382,27 @@ __global__ __launch_bounds__(256) void ct_scatter_key_kernel(int64_t nnz, const 
 template <typename T>
 __global__ __launch_bounds__(256) void ct_sortfill_kernel(int64_t k, const int64_t* __restrict__ rowptrT, int64_t* __restrict__ colidxT,
                                                           const int64_t* __restrict__ rowid, const T* __restrict__ vals, T* __restrict__ valsT) {
+    __shared__ int64_t slab[256 * 17];                      // rows of <= 16 entries are sorted in a private LDS strip (stride 17: no bank conflicts)
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= k) return;
     const int64_t p0 = rowptrT[c], p1 = rowptrT[c + 1];
+    if (p1 - p0 <= 16) {
+        int64_t* my = slab + threadIdx.x * 17;
+        const int len = (int)(p1 - p0);
+        for (int q = 0; q < len; ++q) my[q] = colidxT[p0 + q];
+        for (int q = 1; q < len; ++q) {
+            const int64_t e = my[q];
+            int r = q - 1;
+            while (r >= 0 && my[r] > e) { my[r + 1] = my[r]; --r; }
+            my[r + 1] = e;
+        }
+        for (int q = 0; q < len; ++q) {
+            const int64_t p = my[q];
+            valsT[p0 + q] = vals[p];
+            colidxT[p0 + q] = rowid[p];
+        }
+        return;
+    }
     for (int64_t q = p0 + 1; q < p1; ++q) {                 // insertion sort of the entry numbers (colidxT holds them until the loop below)
         const int64_t e = colidxT[q];
         int64_t r = q - 1;
