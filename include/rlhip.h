@@ -51,7 +51,7 @@ int rlhip_destroy(rlhip_ctx* ctx);
 enum rlhip_option {
     RLHIP_OPT_CHOLQRQ_ONE_STREAM = 0,   /* 1: rlhip_cholqrq_* serves tall 256-aligned inputs as one stream of kernels; 0: returns 1 (caller runs syrk, potrf, trsm) */
     RLHIP_OPT_GESDD_GRAM = 1,           /* 1: device SVD of a well-conditioned tall factor, 32 < k <= 256, by Jacobi on its Gram matrix; 0: classic route always */
-    RLHIP_OPT_JACOBI_PERSIST = 2,       /* 1: all Jacobi sweeps in one cooperative launch; 0: one launch per round (what rocprofv3 --pmc can profile) */
+    RLHIP_OPT_JACOBI_PERSIST = 2,       /* 1: all Jacobi sweeps in one cooperative launch (blocks handed over through the XCD's L2 when the workers share one); 2: the same, hand-over through uncached memory always; 0: one launch per round (what rocprofv3 --pmc can profile) */
     RLHIP_OPT_TRSM_XASM = 3,            /* fused solve: X loads issued from inline asm (1) or plain loads (0); default = what scripts/check_trsm_asm.py proved for this build */
     RLHIP_OPT_SASO_MODE = 4,            /* rlhip_saso_create: 1 independent columns (RandBLAS's short-axis SASO), 0 block-affine family */
     RLHIP_OPT_HQRRP_TALL_PANEL = 5,     /* hqrrp: 1 pivots of a tall panel from the QRCP of its R factor; 0: one pivoted sweep (the reference's order) */

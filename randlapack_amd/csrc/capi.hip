@@ -95,6 +95,16 @@ void* rlhip_xchg_buffer(rlhip_ctx* c, size_t bytes) {
     return p;
 }
 
+void* rlhip_xloc_buffer(rlhip_ctx* c, size_t bytes) {
+    if (bytes <= c->xloc_bytes) return c->xloc;
+    if (c->xloc) { rlhip_stream_sync(c); hipFree(c->xloc); c->xloc = nullptr; c->xloc_bytes = 0; }
+    bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->xloc = p; c->xloc_bytes = bytes;
+    return p;
+}
+
 size_t rlhip_ws_mark(rlhip_ctx* c) { return c->nsegs ? seg_vstart(c, c->cur_seg) + c->cur_used : 0; }
 
 void rlhip_ws_release(rlhip_ctx* c, size_t mark) {
@@ -241,6 +251,7 @@ int rlhip_destroy(rlhip_ctx* c) {
     for (int i = 0; i < c->nsegs; ++i) hipFree(c->segs[i].base);
     if (c->d_mail) hipFree(c->d_mail);
     if (c->xchg) hipFree(c->xchg);
+    if (c->xloc) hipFree(c->xloc);
     if (c->h_mail) hipHostFree(c->h_mail);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -484,6 +484,11 @@ struct JpArgs {
     float norm_ratio_lim;         // > 0: give up (status -9) when max / min of the squared column norms exceeds it at the end of a sweep
     int trans_upper;              // 1: the input is X = R^T of the UPPER triangle stored in A (X(r, c) = A(c, r) for c <= r, else 0): the Cholesky factor as potrf left it
     const int* skip;              // nullptr, or a device word: != 0 -> the launch does nothing and reports status -8 (an earlier kernel of the stream failed)
+    // same-XCD hand-over (below): local_try != 0 puts worker w on workgroup 8 w; XL / bflagL are CACHED twins of X / bflag, census [NB/2] words of the exchange buffer
+    int local_try;
+    unsigned long long* XL;
+    unsigned long long* bflagL;
+    unsigned long long* census;
 };
 
 // Clock holders.  The part's clock follows the occupancy of the shader array, not the power budget: with 8 of 256 CUs at work (this
@@ -535,8 +540,16 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
     __shared__ unsigned s_rot, s_cos, s_lost, s_nmax, s_nmin;
     __shared__ double Ns[JP];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = blockIdx.x, NW = g.NB / 2, m = g.m;
-    if (w >= NW) { jacobi_clock_holder(g.done, &s_lost, g.hold_mode, g.hold_nap, (long long)g.hold_delay_us * 100); return; }
+    // Same-XCD hand-over.  The eight XCDs have one L2 each: a block handed over through the uncached exchange buffer makes a round trip to
+    // the memory side (~2.5 us of a ~14 us step).  Workgroup b is observed to run on XCD b % 8 (no contract: MI355X_MICROARCH.md), so with
+    // local_try the workers are workgroups 0, 8, 16, ... -- one XCD if the observation holds -- and a CENSUS decides: every worker
+    // publishes its HW_REG_XCC_ID through the uncached buffer and reads everybody's; only if all are equal the blocks travel through a
+    // CACHED buffer with plain stores (the line stays in the XCD's L2) and sc1 loads (past the CU's L1, served by that L2).  Any other
+    // placement keeps the uncached protocol -- same words, same order, same results.
+    const int NW = g.NB / 2, m = g.m;
+    const bool is_worker = g.local_try ? ((blockIdx.x & 7) == 0 && (int)(blockIdx.x >> 3) < NW) : ((int)blockIdx.x < NW);
+    const int w = g.local_try ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (!is_worker) { jacobi_clock_holder(g.done, &s_lost, g.hold_mode, g.hold_nap, (long long)g.hold_delay_us * 100); return; }
     if (g.skip != nullptr && *g.skip != 0) {           // (every worker reads the same word: all of them leave)
         if (w == 0 && tid == 0) {
             g.out[0] = -8; g.out[1] = g.sweep0;
@@ -554,16 +567,36 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
         if (g.trans_upper) Xs[e] = (r < m && gc < g.n && gc <= r) ? g.A[gc + (int64_t)r * g.lda] : T(0);
         else Xs[e] = (r < m && gc < g.n) ? g.A[r + (int64_t)gc * g.lda] : T(0);
     }
-    if (tid == 0) { s_lost = 0; }
+    if (tid == 0) { s_lost = 0; s_rot = 0; }
     __syncthreads();
+    bool local = false;
+    if (g.local_try) {
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            __hip_atomic_store(g.census + w, (0xCE5505ull << 32) | (unsigned long long)((xcc & 15u) + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < NW) {
+            unsigned long long got = 0;
+            if (!jp_wait(g.census + tid, 0xCE5505u, &got)) atomicExch(&s_lost, 1u);
+            else atomicOr(&s_rot, 1u << ((unsigned)got & 31u));          // the set of XCDs the workers sit on
+        }
+        __syncthreads();
+        local = !s_lost && __builtin_popcount(s_rot) == 1;
+        __syncthreads();
+        if (tid == 0) { s_rot = 0; if (w == 0) g.out[3] = local ? 1 : 0; }
+        __syncthreads();
+    }
+    unsigned long long* const Xx = local ? g.XL : g.X;               // where blocks travel during the sweeps (the RESULT always leaves through g.X)
+    unsigned long long* const bfx = local ? g.bflagL : g.bflag;
     // A block is JB x m values = PER_T per thread (4 at m = 256).  All of a thread's loads of a hand-over are issued before the first one is
     // consumed: one round trip to the uncached buffer instead of PER_T dependent ones (the first version took ~11 us per hand-over, two
     // thirds of every step; rocprof timeline in DESIGN.md 4.3).
     constexpr int PER_T = (JB * JMT + NT - 1) / NT;
     // (write-through stores issued from inline asm: in front of every agent-scope atomic store of such a loop hipcc places an
     // s_waitcnt vmcnt(0), i.e. the PER_T stores of a thread went out one acknowledged round trip at a time -- most of the 4.5 us a hand-over took)
-    auto publish = [&](int half, int blk) {            // LDS half -> exchange buffer
-        unsigned long long* dst = g.X + (size_t)blk * JB * m;
+    auto publish = [&](int half, int blk, unsigned long long* base, bool plain) {            // LDS half -> exchange buffer
+        unsigned long long* dst = base + (size_t)blk * JB * m;
         unsigned long long val[PER_T];
 #pragma unroll
         for (int q = 0; q < PER_T; ++q) {
@@ -574,13 +607,16 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
 #pragma unroll
         for (int q = 0; q < PER_T; ++q) {
             const int e = tid + q * NT;
-            if (e < JB * m) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst + e), "v"(val[q]) : "memory");
+            if (e < JB * m) {
+                if (plain) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst + e), "v"(val[q]) : "memory");
+                else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst + e), "v"(val[q]) : "memory");
+            }
         }
     };
     auto fetch2 = [&](bool f0, int blk0, bool f1, int blk1) {      // both halves in ONE batch of loads
         unsigned long long v[2][PER_T];
-        const unsigned long long* src0 = g.X + (size_t)blk0 * JB * m;
-        const unsigned long long* src1 = g.X + (size_t)blk1 * JB * m;
+        const unsigned long long* src0 = Xx + (size_t)blk0 * JB * m;
+        const unsigned long long* src1 = Xx + (size_t)blk1 * JB * m;
 #pragma unroll
         for (int q = 0; q < PER_T; ++q) {
             const int e = tid + q * NT;
@@ -613,17 +649,23 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
             ++gs;
             const bool out0 = held[0] != want[0], out1 = held[1] != want[1];
             __builtin_amdgcn_s_waitcnt(0x0F70);                         // (vmcnt(0), said to the compiler: no conservative wait between the two hand-overs below)
-            if (out0) publish(0, held[0]);
-            if (out1) publish(1, held[1]);
+            if (out0) publish(0, held[0], Xx, local);
+            if (out1) publish(1, held[1], Xx, local);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the block's words have been acknowledged ...
             __syncthreads();
             if (tid == 0) {                                              // ... before its version word goes out
-                if (out0) __hip_atomic_store(g.bflag + held[0], ((unsigned long long)gs << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (out1) __hip_atomic_store(g.bflag + held[1], ((unsigned long long)gs << 32) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long word = ((unsigned long long)gs << 32) | 1u;
+                if (local) {                                             // (plain: the word stays in the XCD's L2, where the next owner's sc1 poll finds it)
+                    if (out0) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(bfx + held[0]), "v"(word) : "memory");
+                    if (out1) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(bfx + held[1]), "v"(word) : "memory");
+                } else {
+                    if (out0) __hip_atomic_store(bfx + held[0], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (out1) __hip_atomic_store(bfx + held[1], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (tid < 2 && (tid == 0 ? out0 : out1)) {
                 unsigned long long got;
-                if (!jp_wait(g.bflag + want[tid], gs, &got)) atomicExch(&s_lost, 1u);
+                if (!jp_wait(bfx + want[tid], gs, &got)) atomicExch(&s_lost, 1u);
             }
             __syncthreads();
             if (s_lost) { lost = true; break; }
@@ -686,8 +728,8 @@ __global__ __launch_bounds__(1024) void jacobi_persist_kernel(JpArgs<T> g) {
         status = -7;
         if (tid == 0) atomicExch(g.out + 2, 1);        // whoever loses a word says so: workgroup 0 may well have run to a verdict
     } else {
-        publish(0, held[0]);
-        publish(1, held[1]);
+        publish(0, held[0], g.X, false);
+        publish(1, held[1], g.X, false);
     }
     if (w == 0 && tid == 0) {
         g.out[0] = status; g.out[1] = sweep;
@@ -810,17 +852,24 @@ int jp_launch_qw(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int
     const JpHold h = jp_hold(c);
     g.m = m; g.NB = NBk; g.X = buf; g.bflag = buf + xwords; g.sflag = g.bflag + NBk; g.done = g.sflag + 8 * (size_t)NW;
     g.hold_mode = h.mode; g.hold_nap = h.nap; g.hold_delay_us = h.delay;
-    hipError_t e1 = hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 8 * (size_t)NW + 1) * sizeof(unsigned long long), c->stream);
+    g.census = g.done + 1;
+    // the whole device when the clock holders are wanted and fit (one 1024-thread workgroup per CU), else the workers alone
+    const unsigned grid_hold = (h.mode && c->num_cu > NW) ? (unsigned)(NW + (h.wgs < c->num_cu - NW ? h.wgs : c->num_cu - NW)) : (unsigned)NW;
+    // same-XCD hand-over (kernel comment): needs the launch to cover workgroups 0, 8, ..., 8 (NW - 1) and a CU per worker inside one XCD
+    unsigned long long* loc = (grid_hold >= 8u * (unsigned)NW && NW <= 16 && c->opt[RLHIP_OPT_JACOBI_PERSIST] != 2)
+                                  ? (unsigned long long*)rlhip_xloc_buffer(c, (xwords + (size_t)NBk) * sizeof(unsigned long long)) : nullptr;
+    g.local_try = loc ? 1 : 0; g.XL = loc; g.bflagL = loc ? loc + xwords : nullptr;
+    hipError_t e1 = hipMemsetAsync(g.bflag, 0, ((size_t)NBk + 8 * (size_t)NW + 1 + (size_t)NW) * sizeof(unsigned long long), c->stream);
+    if (e1 == hipSuccess && loc) e1 = hipMemsetAsync(g.bflagL, 0, (size_t)NBk * sizeof(unsigned long long), c->stream);
     if (e1 == hipSuccess) e1 = hipMemsetAsync(g.out, 0, 16 * sizeof(int), c->stream)     /* (out has >= 16 ints: the Gram route keeps its defect word behind the 8 of this launch) */;
     if (e1 != hipSuccess) return RLHIP_ERR_HIP(e1);
     constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
     RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT, QW>), smem);
     void* kargs[] = {(void*)&g};
-    // the whole device when the clock holders are wanted and fit (one 1024-thread workgroup per CU), else the workers alone
-    const unsigned grid_hold = (h.mode && c->num_cu > NW) ? (unsigned)(NW + (h.wgs < c->num_cu - NW ? h.wgs : c->num_cu - NW)) : (unsigned)NW;
     hipError_t le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT, QW>, dim3(grid_hold), dim3(1024), kargs, (unsigned)smem, c->stream);
     if (le != hipSuccess && grid_hold != (unsigned)NW) {
         (void)hipGetLastError();
+        g.local_try = 0;                               // (the workers alone are workgroups 0 .. NW - 1)
         le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT, QW>, dim3((unsigned)NW), dim3(1024), kargs, (unsigned)smem, c->stream);
     }
     if (le != hipSuccess) { (void)hipGetLastError(); return 1; }
@@ -844,7 +893,7 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
     if (NBk % 2) ++NBk;
     const int NW = NBk / 2;
     if (NW > c->num_cu || NW > 512) return 1;
-    const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1;
+    const size_t xwords = (size_t)NBk * JB * m, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1 + (size_t)NW;
     const int hold = jp_hold(c).mode;
     unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
     size_t mark = rlhip_ws_mark(c);
@@ -864,7 +913,7 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
             static int want_clk = -1;
             if (want_clk < 0) { const char* e = getenv("RLHIP_JACOBI_CLOCK"); want_clk = e ? atoi(e) : 0; }
             const unsigned long long* tk = reinterpret_cast<const unsigned long long*>((const int*)(c->h_mail + 16) + 4);
-            if (want_clk && tk[1]) fprintf(stderr, "[jacobi clock] %d sweeps, %.1f us at %.0f MHz (hold %d)\n", done_sweeps - sweep, (double)tk[1] / 100.0, (double)tk[0] / ((double)tk[1] / 100.0), hold);
+            if (want_clk && tk[1]) fprintf(stderr, "[jacobi clock] %d sweeps, %.1f us at %.0f MHz (hold %d, same-XCD hand-over %d)\n", done_sweeps - sweep, (double)tk[1] / 100.0, (double)tk[0] / ((double)tk[1] / 100.0), hold, *((const int*)(c->h_mail + 16) + 3));
         }
         if ((status != 1 && status != 2 && status != 3) || any_lost) { rlhip_ws_release(c, mark); *sweeps_out = sweep; return 1; }   // -7, a lost word anywhere, or nothing written: A untouched by this launch
         int rc = rlhip::lacpy<T>(c, 2, m, n, reinterpret_cast<const T*>(buf), m, A, lda);
@@ -965,7 +1014,7 @@ int jacobi_enqueue_rt(rlhip_ctx* c, int n, const T* R, int64_t ldr, int trans_up
         if (NBk % 2) ++NBk;
         const int NW = NBk / 2;
         if (NW > c->num_cu) return 1;
-        const size_t xwords = (size_t)NBk * JB * n, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1;
+        const size_t xwords = (size_t)NBk * JB * n, words = xwords + (size_t)NBk + 8 * (size_t)NW + 1 + (size_t)NW;
         unsigned long long* buf = (unsigned long long*)rlhip_xchg_buffer(c, words * sizeof(unsigned long long));
         if (!buf) return 1;
         JpArgs<T> g;

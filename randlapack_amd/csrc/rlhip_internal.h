@@ -76,6 +76,8 @@ struct rlhip_ctx {
     int64_t* d_mail = nullptr;   // 64 x int64 device
     void* xchg = nullptr;        // exchange words of the persistent panel kernels (see rlhip_xchg_buffer)
     size_t xchg_bytes = 0;
+    void* xloc = nullptr;        // ordinary (cached) twin of the exchange buffer: same-XCD hand-overs of the persistent Jacobi launch (rlhip_xloc_buffer)
+    size_t xloc_bytes = 0;
     // timing of the most recent GEMM-family launch set (bench.py roofline leg)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_flag = nullptr;   // marks a flag read-back INSIDE a stream of launches: the host waits for the flags only, the device runs on (tri.hip)
@@ -127,6 +129,7 @@ static inline T* ws_alloc(rlhip_ctx* c, size_t n) { return (T*)rlhip_ws_alloc(c,
 // device buffer for the tagged-word exchanges between workgroups (QRCP / LU panel kernels); grows, lives with the context.
 // RLHIP_XCHG = 0: ordinary device memory, 1: fine-grained, 2: uncached (default)
 void* rlhip_xchg_buffer(rlhip_ctx* c, size_t bytes);
+void* rlhip_xloc_buffer(rlhip_ctx* c, size_t bytes);
 
 // ---- typed internal entry points (implemented in the .hip files; the extern "C" ABI wraps them) ----
 namespace rlhip {

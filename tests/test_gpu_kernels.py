@@ -865,7 +865,9 @@ def test_gesdd_clustered_singular_values(ctx, m, n, kind):
 def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n, kind):
     """The one-launch Jacobi (resident workgroups exchanging blocks through the uncached buffer, jacobi_persist_kernel) runs the same
     pairing and the same round arithmetic as the per-launch sweeps: S, U and V^T come out BITWISE identical, with the same sweep count;
-    path counter 6 proves which one ran.  `cluster` / `identity` take the hand-back to the host's Gram verification and a relaunch."""
+    path counter 6 proves which one ran.  `cluster` / `identity` take the hand-back to the host's Gram verification and a relaunch.
+    Option value 2 = the persistent launch with the hand-over through uncached memory only; 1 lets the workers hand blocks over through
+    their XCD's L2 when the census finds them on one XCD (jacobi.hip) -- a transport change only: bitwise the same again."""
     import ctypes as C
     import torch
 
@@ -878,7 +880,7 @@ def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n
         A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * s) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
     res = {}
     ctx.set_option("gesdd_gram", 0)                    # the classic route (Cholesky-QR + Jacobi on R^T): the one that has both sweep drivers
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "2"):
         ctx.set_option("jacobi_persist", int(mode))
         Ad = d.cm_from_numpy(A)
         S = torch.zeros(n, dtype=torch.float64, device="cuda")
@@ -891,6 +893,9 @@ def test_gesdd_persistent_jacobi_equals_per_launch_sweeps(ctx, monkeypatch, m, n
     assert c1 == 1 and c0 == 0, "the persistent kernel did not run (or ran with the jacobi_persist option off)"
     assert sw1 == sw0 and sw1 > 0
     assert np.array_equal(S1, S0) and np.array_equal(U1, U0) and np.array_equal(V1, V0)
+    U2, S2, V2, sw2, c2 = res["2"]
+    assert c2 == 1 and sw2 == sw1
+    assert np.array_equal(S1, S2) and np.array_equal(U1, U2) and np.array_equal(V1, V2)
     assert np.linalg.norm((U1 * S1) @ V1 - A) <= 1e-13 * np.linalg.norm(A) * np.sqrt(n)
     assert np.linalg.norm(U1.T @ U1 - np.eye(n)) <= 1e-11 * np.sqrt(n)
 
