@@ -155,6 +155,34 @@ public:
     ~LocalOnly() { --q_.local_only; }
 };
 
+// RAII: a named phase for profilers (roctx range; the reference's NVTX ranges, drivers/rl_bqrrp_gpu.hh:335-403).  Free when no profiler listens.
+class Range {
+public:
+    explicit Range(const char* name) { rlhip_range_push(name); }
+    ~Range() { rlhip_range_pop(); }
+    Range(Range const&) = delete;
+    Range& operator=(Range const&) = delete;
+};
+
+// a sequence of phases inside one scope: ph("a") ... ph("b") closes "a" and opens "b"; the destructor (or end()) closes the last one
+class Phases {
+    bool open_ = false;
+public:
+    void operator()(const char* name) { end(); rlhip_range_push(name); open_ = true; }
+    void end() { if (open_) { rlhip_range_pop(); open_ = false; } }
+    ~Phases() { end(); }
+};
+
+// RAII: inside the scope the queue launches no kernel that holds every CU until it is done (tiled GEMMs instead of the persistent stream-K
+// ones), so that a side queue's kernels run beside its products
+class GiveWay {
+    Queue& q_;
+    int prev_;
+public:
+    explicit GiveWay(Queue& q) : q_(q), prev_(rlhip_avoid_persistent(q.ctx(), 1)) {}
+    ~GiveWay() { rlhip_avoid_persistent(q_.ctx(), prev_ > 0 ? 1 : 0); }
+};
+
 // RAII scope over the queue's stream-ordered scratch arena
 class Scratch {
     Queue& q_;

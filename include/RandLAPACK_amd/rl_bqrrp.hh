@@ -23,6 +23,7 @@
 #include "rl_lapackpp.hh"
 #include "rl_randblas.hh"
 #include "rl_util.hh"
+#include "rl_sharded_panel.hh"
 
 namespace RandLAPACK {
 
@@ -129,10 +130,13 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
     bool pre_on_side = false;          // this iteration's sketch (down-dated) lives on the side stream: its QRCP goes there too
 
     for (int64_t iter = 0; iter < maxiter; ++iter) {
+        blas::Range ph_iter("Iteration");        // phase names: the reference's NVTX ranges (rl_bqrrp_gpu.hh:335-403)
+        blas::Phases ph;
         b_sz = std::min(b_sz, mn - curr_sz);                                                                // :322-324
         inb = std::min(inb, b_sz);
         block_rank = b_sz;
         auto ta = stamp();
+        ph("qrcp_wide");
         {
             blas::Queue& qq = pre_on_side ? *side : q;
             if (!lu) {
@@ -150,15 +154,18 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
             }
             if (pre_on_side) { q.wait_for(*side); pre_on_side = false; }     // the main stream continues behind the pivots and behind its own tail
         }
+        ph("piv_A");
         util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);                                 // :369
         bool block_zero = !lapack::any_abs_gt(rows, A_work, std::numeric_limits<T>::epsilon(), q);         // :373-379
         lap(L.piv_A, ta);
+        ph("update_J");
         if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);                                      // :383-387 / :402-406
         else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
         lap(L.upd_J, ta);
         if (block_zero) { rank = curr_sz; return 0; }                                                       // :380-399
         T* Work1 = &A_work[lda * b_sz];
         T* R_sk = A_sk;
+        ph("qr_tall");
         lapack::get_diag(b_sz, R_sk, d, diag.data(), q);
         for (int64_t i = 0; i < b_sz; ++i) {                                                                // :421-427
             if (std::abs(diag[i]) / std::abs(diag[0]) < P.tol) { block_rank = i; inb = std::min(inb, block_rank); break; }
@@ -204,6 +211,7 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
             } else {
                 blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, rows, block_rank, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
                 lap(L.qr_tall, ta);
+                ph("orhr_col");
                 lapack::orhr_col(rows, block_rank, inb, A_work, lda, T_dat, b_sz_const, Work2, q);           // :480
                 lapack::row_sign(block_rank, R_tall_qr, b_sz_const, Work2, q);                              // :485-487
                 lapack::tau_from_t(block_rank, inb, T_dat, b_sz_const, tau_sub, q);                         // :490-491
@@ -225,6 +233,7 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
         const bool more = (curr_sz + b_sz < mn) && (block_rank == b_sz_const);           // another panel follows (:576-618)
         const bool use_t = (P.apply_trans_q == Sub::ApplyTransQ::gemqrt && have_T);
         bool la = false;
+        ph("update_A");
         if (cols - b_sz > 0 && block_rank > 0) {
             // one compact-WY block and a next panel to prepare: head on the main stream, the side queue starts behind it, tail on the main stream
             la = la_ok && W2_la && more && (!use_t || inb >= block_rank) && q_rows > block_rank;
@@ -253,6 +262,7 @@ int bqrrp_factor(blas::Queue& q, const BqrrpOpts<T>& P, int64_t m, int64_t n, T*
         A_work = &Work1[b_sz];                                                                               // :624
         // sketch down-date (:633-651) -- beside the tail of the apply when the look-ahead is on
         blas::Queue& qd = la ? *side : q;
+        ph("update_Sk");
         if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, qd);        // get_U(b, b, R_sk, d)
         blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R11, lda, R_sk, d, qd);
         blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, cols - b_sz, b_sz, (T)-1.0, R_sk, d, R12, lda, (T)1.0, &R_sk[d * b_sz], d, qd);
@@ -315,6 +325,7 @@ public:
         if (sketch_override) {
             lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_sk, d, q);
         } else {                                                                                            // :309-313
+            blas::Range ph("skop");
             T* S = blas::device_malloc<T>(d * m, q);
             RandBLAS::DenseDist D(d, m);
             state = RandBLAS::fill_dense(D, S, state, q);
@@ -347,7 +358,16 @@ public:
     /// (b x (cols - b)) for the compact-WY apply, and the b x (cols - b) block row R12 for the sketch down-date; once at the start the
     /// d x n sketch.  Options: qrcp_wide free (it acts on the replicated sketch); qr_tall = cholqr (Gram all-reduce) or geqrf / geqrt (TSQR:
     /// the b x b triangles stacked by one all-reduce) -- the reference's default triple {luqr, geqrf, ormqr} runs sharded as it stands;
-    /// apply_trans_q: gemqrt and ormqr name the same operator (one b x b T block per panel, internal_nb = b).
+    /// apply_trans_q: gemqrt and ormqr name the same operator (one b x b T block per panel, internal_nb = b) on full-rank blocks; on a
+    /// rank-deficient block (block_rank < b_sz, the last one) they differ as in the single-device loop -- gemqrt applies the T factor of the whole
+    /// panel, ormqr (and every geqrf panel) the T factor of the reflectors CUT to their first block_rank rows (:535-547 with q_rows = block_rank).
+    ///
+    /// Look-ahead (as in detail::bqrrp_factor, same members): the replicated chain -- sketch down-date + the next QRCP of the sketch, the same
+    /// work on every rank whatever the world size, so the part that Amdahl's law leaves standing -- goes to the side queue as soon as the
+    /// block row R12 is final and exchanged: W = V^T C and its all-reduce, W2 = T^T W, then the HEAD (my rows of the top block: C1 -= V1 W2,
+    /// which finishes R12), the R12 all-reduce, and from there the side queue runs beside the TAIL (my rows below the block: C2 -= V2 W2, half
+    /// of this rank's flops of the apply).  Collectives stay on the main stream in the same order on every rank; the decision is a function of
+    /// rank-uniform quantities only.
     int call_sharded(int64_t m, int64_t n, T* A, int64_t lda, T d_factor, T* tau, int64_t* J, RandBLAS::RNGState<RNG>& state) {
         // qr_tall: cholqr -> Cholesky-QR of the preconditioned panel (one b x b Gram all-reduce); geqrf / geqrt -> TSQR of the panel itself
         // (local Householder QR, the ranks' b x b triangles stacked by ONE all-reduce, the stack factored on every rank).  Either way the
@@ -387,6 +407,7 @@ public:
             return m_glob;
         };
         const int64_t mn = std::min(m_glob, n);
+        lookaheads = 0;
         if (mn == 0) { rank = 0; return 0; }
         int64_t cols = n, curr_sz = 0, b_sz = block_size;
         const int64_t maxiter = (int64_t)std::ceil(mn / (T)b_sz);
@@ -404,11 +425,16 @@ public:
         T* A_sk_trans = lu ? ws.alloc<T>(n * d) : nullptr;
         int64_t* J_buffer_lu = lu ? ws.alloc<int64_t>(std::min(d, n)) : nullptr;
         T* A_sk = A_sk_base;
+        const bool la_ok = lookahead && (double)m_glob * (double)n >= lookahead_min_elems && b_sz_const >= lookahead_min_block;
+        T* R12_la = la_ok ? ws.try_alloc<T>(b_sz_const * n) : nullptr;         // read by the side queue: lives as long as the call
+        std::unique_ptr<blas::Queue> side;
+        bool pre_on_side = false;
         // ---- sketch: S (d x m_glob) is ONE global Gaussian operator; this rank generates its column block S[:, row0 : row0 + m]
         //      (stream positions d*row0 ... of the same fill) and contributes S_g A_g; the state advances as for the full fill
         if (sketch_override) {
             lapack::lacpy(MatrixType::General, d, n, sketch_override, d, A_sk, d, q);
         } else {
+            blas::Range ph("skop");
             blas::Scratch w2(q);
             T* S = w2.alloc<T>(std::max<int64_t>(d * m, 1));
             RandBLAS::DenseDist Dall(d * m_glob, 1);
@@ -424,148 +450,191 @@ public:
         std::vector<T> diag(b_sz_const);
 
         for (int64_t iter = 0; iter < maxiter; ++iter) {
+            blas::Range ph_iter("Iteration");
             b_sz = std::min(b_sz, mn - curr_sz);
             block_rank = b_sz;
-            if (!lu) {
-                lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, q);
-            } else {
-                blas::check(transpose_call(sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
-                lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, q);   // only J_buffer_lu is read below
-                lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, q);
-                util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, q);
-                lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, q);
+            {
+                blas::Range ph("qrcp_wide");
+                blas::Queue& qq = pre_on_side ? *side : q;                                     // replicated work: every rank, the same bits
+                if (!lu) {
+                    lapack::geqp3(sampling_dimension, cols, A_sk, d, J_buffer, Work2, qq);
+                } else {
+                    blas::check(transpose_call(qq, sampling_dimension, cols, A_sk, d, A_sk_trans, n), "transposition");
+                    lapack::getrf_pivots(cols, sampling_dimension, A_sk_trans, n, J_buffer_lu, qq);   // only J_buffer_lu is read below
+                    lapack::luqrcp_piv(sampling_dimension, cols, J_buffer_lu, J_buffer, qq);
+                    util::col_swap(sampling_dimension, cols, cols, A_sk, d, J_buffer, qq);
+                    lapack::geqrf(sampling_dimension, cols, A_sk, d, Work2, qq);
+                }
+                if (pre_on_side) { q.wait_for(*side); pre_on_side = false; }
             }
-            if (m > 0) util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);
             // local row bookkeeping for this iteration (global rows [curr_sz, m_glob) are active)
             const int64_t act_loc = local_from(curr_sz);                                      // my active rows are the local suffix [act_loc, m)
             const int64_t loc_rows = m - act_loc;
             T* A_work = (loc_rows > 0) ? &A[act_loc + lda * curr_sz] : nullptr;               // my active rows of the panel / trailing matrix
-            double nz = 0;                                                                      // zero test on the panel's first column
-            if (loc_rows > 0) nz = lapack::any_abs_gt(loc_rows, A_work, std::numeric_limits<T>::epsilon(), q) ? 1.0 : 0.0;
-            q.allreduce_sum_host(&nz, 1);
-            const bool block_zero = (nz == 0.0);
-            if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);
-            else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
+            bool block_zero;
+            {
+                blas::Range ph("piv_A");
+                if (m > 0) util::col_swap(m, cols, cols, &A[lda * curr_sz], lda, J_buffer, q);
+                double nz = 0;                                                                  // zero test on the panel's first column
+                if (loc_rows > 0) nz = lapack::any_abs_gt(loc_rows, A_work, std::numeric_limits<T>::epsilon(), q) ? 1.0 : 0.0;
+                q.allreduce_sum_host(&nz, 1);
+                block_zero = (nz == 0.0);
+            }
+            {
+                blas::Range ph("update_J");
+                if (iter == 0) blas::device_copy_vector(cols, J_buffer, J, q);
+                else util::col_swap(cols, cols, &J[curr_sz], J_buffer, q);
+            }
             if (block_zero) { rank = curr_sz; return 0; }
             T* R_sk = A_sk;
             lapack::get_diag(b_sz, R_sk, d, diag.data(), q);
             for (int64_t i = 0; i < b_sz; ++i)
                 if (std::abs(diag[i]) / std::abs(diag[0]) < tol) { block_rank = i; break; }
             const int64_t br = block_rank;
+            // pc = the panel columns that get reflectors: a Cholesky-QR panel factors its block_rank leading columns (:454-505: the others stay as
+            // they are, R11's columns to their right are R_chol R_sk), a Householder panel ALL b_sz columns whatever the rank estimate says
+            // (geqrf(rows, b_sz, ...), :506-523) -- so R11 is a full b_sz x b_sz triangle and tau has b_sz entries there
+            const int64_t pc = tsqr_panels ? b_sz : br;
             T* tau_sub = &tau[curr_sz];
             if (!tsqr_panels) {
-            // ---- CholQR of the sharded panel: the Gram matrix is summed over the ranks
-            if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_sk, d, A_work, lda, q);
-            lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
-            if (loc_rows > 0) blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, br, loc_rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
-            q.allreduce_sum(R_tall_qr, b_sz_const * b_sz_const);
-            lapack::potrf(Uplo::Upper, br, R_tall_qr, b_sz_const, q);
-            if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
-            } else if (br > 0) {
-                // ---- TSQR of the sharded panel (the reference's default qr_tall = geqrf, rl_bqrrp.hh:506-523, on row-sharded data): my active
-                //      rows A_g = Q_g R_g (kr = min(rows, br) reflectors), every rank's R_g into its slot of a (P br) x br stack (zero rows
-                //      where a rank has fewer than br rows or none), ONE all-reduce (disjoint slots: an all-gather, bit for bit), the stack
-                //      = Qt R on every rank (same bits in, same kernels: same bits out), panel <- Q_g Qt_g.  R_tall_qr <- R.
-                const int64_t P = q.world(), me = q.rank();
-                const int64_t kr = std::min(loc_rows, br);
-                blas::Scratch wq(q);
-                T* stack = wq.alloc<T>(P * br * br);
-                T* tau_l = wq.alloc<T>(std::max<int64_t>(br, 1));
-                T* Qg = wq.alloc<T>(std::max<int64_t>(loc_rows, 1) * br);
-                lapack::laset(MatrixType::General, P * br, br, (T)0, (T)0, stack, P * br, q);
-                {
-                    blas::LocalOnly local(q);                                            // (the local and the stacked factorizations are single-rank work)
-                    if (loc_rows > 0) {
-                        lapack::geqrf(loc_rows, br, A_work, lda, tau_l, q);
-                        lapack::lacpy(MatrixType::Upper, kr, br, A_work, lda, stack + me * br, P * br, q);
-                        lapack::ungqr(loc_rows, kr, kr, A_work, lda, tau_l, q);          // Q_g: loc_rows x kr
-                        lapack::lacpy(MatrixType::General, loc_rows, kr, A_work, lda, Qg, loc_rows, q);
-                    }
-                }
-                q.allreduce_sum(stack, P * br * br);
-                {
-                    blas::LocalOnly local(q);
-                    lapack::geqrf(P * br, br, stack, P * br, tau_l, q);
+                // ---- CholQR of the sharded panel: the Gram matrix is summed over the ranks
+                blas::Range ph("qr_tall");
+                if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_sk, d, A_work, lda, q);
+                lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
+                if (loc_rows > 0) blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, br, loc_rows, (T)1.0, A_work, lda, (T)0.0, R_tall_qr, b_sz_const, q);
+                q.allreduce_sum(R_tall_qr, b_sz_const * b_sz_const);
+                lapack::potrf(Uplo::Upper, br, R_tall_qr, b_sz_const, q);
+                if (loc_rows > 0) blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, loc_rows, br, (T)1.0, R_tall_qr, b_sz_const, A_work, lda, q);
+            } else {
+                // ---- TSQR of the sharded panel (the reference's default qr_tall = geqrf, rl_bqrrp.hh:506-523, on row-sharded data): my active rows
+                //      A_g = Q_g R_g, the ranks' triangles stacked by ONE all-reduce (disjoint slots: an all-gather, bit for bit), the stack = Qt R
+                //      on every rank (same bits in, same kernels: same bits out), panel <- Q_g Qt_g, R_tall_qr <- R (rl_sharded_panel.hh)
+                blas::Range ph("qr_tall");
+                T* Rp = R_tall_qr;
+                blas::Scratch wr(q);
+                if (pc != b_sz_const) Rp = wr.alloc<T>(pc * pc);                              // (a last, narrower block)
+                detail::tsqr(q, loc_rows, pc, A_work, lda, Rp, pc);
+                if (Rp != R_tall_qr) {
                     lapack::laset(MatrixType::General, b_sz_const, b_sz_const, (T)0, (T)0, R_tall_qr, b_sz_const, q);
-                    lapack::lacpy(MatrixType::Upper, br, br, stack, P * br, R_tall_qr, b_sz_const, q);
-                    lapack::ungqr(P * br, br, br, stack, P * br, tau_l, q);              // Qt
+                    lapack::lacpy(MatrixType::Upper, pc, pc, Rp, pc, R_tall_qr, b_sz_const, q);
                 }
-                if (loc_rows > 0)
-                    blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, loc_rows, br, kr, (T)1.0, Qg, loc_rows, stack + me * br, P * br, (T)0.0, A_work, lda, q);
             }
             // ---- Householder reconstruction on [top block (gathered); my rows below it]
-            const int64_t top_hi = curr_sz + br;                                             // global rows [curr_sz, top_hi) form the top block
+            const int64_t top_hi = curr_sz + pc;                                             // global rows [curr_sz, top_hi) form the top block
             // my rows of the top block are the first tcnt rows of my active suffix (both layouts keep local rows in global order,
             // and a cyclic block never straddles a panel); toff = where they sit inside the block
             const int64_t tcnt = local_from(top_hi) - act_loc;
             const int64_t toff = (tcnt > 0) ? global_of(act_loc) - curr_sz : 0;
             const int64_t t_loc = act_loc, b_loc = act_loc + tcnt;                            // local starts: my top rows / my rows below the block
             const int64_t below = m - b_loc;
-            lapack::laset(MatrixType::General, br, br, (T)0, (T)0, Q1buf, br, q);
-            if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, &A[t_loc + lda * curr_sz], lda, Q1buf + toff, br, q);
-            q.allreduce_sum(Q1buf, br * br);
-            {
+            // the rows the apply acts on: all my active rows, or -- on a deficient block, as the reference (:535-547 with q_rows = block_rank) --
+            // only those among the first block_rank rows of the block: a prefix of my top rows
+            const int64_t acnt = (br != b_sz_const) ? std::max<int64_t>(0, std::min(tcnt, local_from(curr_sz + br) - act_loc)) : tcnt;
+            const bool more = (curr_sz + b_sz < mn) && (br == b_sz_const);                    // another panel follows
+            bool la = false;
+            if (pc > 0) {
                 blas::Scratch w3(q);
-                const int64_t ldp = br + below;
-                T* Pst = w3.alloc<T>(ldp * br);
-                T* Dv = w3.alloc<T>(br);
-                lapack::lacpy(MatrixType::General, br, br, Q1buf, br, Pst, ldp, q);
-                if (below > 0) lapack::lacpy(MatrixType::General, below, br, &A[b_loc + lda * curr_sz], lda, Pst + br, ldp, q);
-                lapack::orhr_col(ldp, br, br, Pst, ldp, T_dat, b_sz_const, Dv, q);            // one br x br T block (internal_nb = b)
-                lapack::row_sign(br, R_tall_qr, b_sz_const, Dv, q);
-                lapack::tau_from_t(br, br, T_dat, b_sz_const, tau_sub, q);
-                if (!tsqr_panels)
-                    blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 = R_chol R_sk (replicated)
-                // my rows of V back into A (strictly lower part of the top block is V1, the rest of my rows V2) ...
-                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, br, Pst + toff, ldp, &A[t_loc + lda * curr_sz], lda, q);
-                if (below > 0) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, &A[b_loc + lda * curr_sz], lda, q);
-                // ... and my rows of R11 on and above the diagonal of the top block
-                if (tcnt > 0) lapack::lacpy(MatrixType::Upper, tcnt, b_sz - toff, R_tall_qr + toff + toff * b_sz_const, b_sz_const,
-                                            &A[t_loc + lda * (curr_sz + toff)], lda, q);
+                const int64_t ldp = pc + below;
+                T* Pst = w3.alloc<T>(ldp * pc);
+                T* Dv = w3.alloc<T>(pc);
+                {
+                    blas::Range ph("orhr_col");
+                    lapack::laset(MatrixType::General, pc, pc, (T)0, (T)0, Q1buf, pc, q);
+                    if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, pc, &A[t_loc + lda * curr_sz], lda, Q1buf + toff, pc, q);
+                    q.allreduce_sum(Q1buf, pc * pc);
+                    lapack::lacpy(MatrixType::General, pc, pc, Q1buf, pc, Pst, ldp, q);
+                    if (below > 0) lapack::lacpy(MatrixType::General, below, pc, &A[b_loc + lda * curr_sz], lda, Pst + pc, ldp, q);
+                    lapack::orhr_col(ldp, pc, pc, Pst, ldp, T_dat, b_sz_const, Dv, q);            // one pc x pc T block (internal_nb = b)
+                    lapack::row_sign(pc, R_tall_qr, b_sz_const, Dv, q);
+                    lapack::tau_from_t(pc, pc, T_dat, b_sz_const, tau_sub, q);
+                    if (!tsqr_panels)
+                        blas::trmm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, br, b_sz, (T)1.0, R_sk, d, R_tall_qr, b_sz_const, q);   // R11 = R_chol R_sk (replicated)
+                    // my rows of V back into A (strictly lower part of the top block is V1, the rest of my rows V2) ...
+                    if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, pc, Pst + toff, ldp, &A[t_loc + lda * curr_sz], lda, q);
+                    if (below > 0) lapack::lacpy(MatrixType::General, below, pc, Pst + pc, ldp, &A[b_loc + lda * curr_sz], lda, q);
+                    // ... and my rows of R11 on and above the diagonal of the top block
+                    if (tcnt > 0) lapack::lacpy(MatrixType::Upper, tcnt, b_sz - toff, R_tall_qr + toff + toff * b_sz_const, b_sz_const,
+                                                &A[t_loc + lda * (curr_sz + toff)], lda, q);
+                }
                 // ---- compact-WY apply to the trailing columns: W = sum over ranks of V_g^T C_g, C_g -= V_g (T^T W)
                 const int64_t rest = cols - b_sz;
-                const int64_t vrows = (br != b_sz_const) ? tcnt : (tcnt + below);             // reference: a deficient block acts on the top rows only
+                const int64_t vrows = (br != b_sz_const) ? acnt : (tcnt + below);
                 if (rest > 0 && br > 0) {
+                    blas::Range ph("update_A");
                     T* Vexp = w3.alloc<T>(std::max<int64_t>(vrows, 1) * br);
                     T* W = w3.alloc<T>(br * rest);
                     T* W2 = w3.alloc<T>(br * rest);
                     const int64_t ldvx = std::max<int64_t>(vrows, 1);
-                    if (tcnt > 0) lapack::vrows_explicit(br, toff, tcnt, Pst, ldp, Vexp, ldvx, q);
-                    if (vrows > tcnt) lapack::lacpy(MatrixType::General, below, br, Pst + br, ldp, Vexp + tcnt, ldvx, q);
+                    if (acnt > 0) lapack::vrows_explicit(br, toff, acnt, Pst, ldp, Vexp, ldvx, q);
+                    if (vrows > acnt) lapack::lacpy(MatrixType::General, below, br, Pst + pc, ldp, Vexp + acnt, ldvx, q);
+                    // T of the br reflectors: the leading block of the panel's T factor, or -- deficient block under ormqr semantics / geqrf panels --
+                    // the T factor of the reflectors cut to their first br rows (every rank holds the whole top block: replicated, no exchange)
+                    const T* Tap = T_dat;
+                    int64_t ldtap = b_sz_const;
+                    const bool full_t = (br == b_sz_const) || (apply_trans_q == Subroutines::ApplyTransQ::gemqrt && qr_tall != Subroutines::QRTall::geqrf);
+                    if (!full_t) {
+                        T* Tcut = w3.alloc<T>(br * br);
+                        lapack::larft(br, br, Pst, ldp, tau_sub, Tcut, br, q);
+                        Tap = Tcut; ldtap = br;
+                    }
                     T* Cg = (vrows > 0) ? &A[act_loc + lda * (curr_sz + b_sz)] : nullptr;
                     if (vrows > 0) blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, vrows, (T)1.0, Vexp, ldvx, Cg, lda, (T)0.0, W, br, q);
                     else lapack::laset(MatrixType::General, br, rest, (T)0, (T)0, W, br, q);
                     q.allreduce_sum(W, br * rest);
-                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, br, (T)1.0, T_dat, b_sz_const, W, br, (T)0.0, W2, br, q);
-                    if (vrows > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, vrows, rest, br, (T)-1.0, Vexp, ldvx, W2, br, (T)1.0, Cg, lda, q);
+                    blas::gemm(Layout::ColMajor, Op::Trans, Op::NoTrans, br, rest, br, (T)1.0, Tap, ldtap, W, br, (T)0.0, W2, br, q);
+                    la = la_ok && R12_la && more;
+                    if (!la) {
+                        if (vrows > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, vrows, rest, br, (T)-1.0, Vexp, ldvx, W2, br, (T)1.0, Cg, lda, q);
+                    } else {
+                        ++lookaheads;
+                        rlhip_path_note(q.ctx(), 12, 1);
+                        if (!side) side = std::make_unique<blas::Queue>(q, typename blas::Queue::CachedSide{});
+                        // head: my rows of the top block -> R12 is final; exchanged; the side queue may start
+                        if (tcnt > 0) blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, tcnt, rest, br, (T)-1.0, Vexp, ldvx, W2, br, (T)1.0, Cg, lda, q);
+                        lapack::laset(MatrixType::General, b_sz, rest, (T)0, (T)0, R12_la, b_sz, q);
+                        if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, Cg, lda, R12_la + toff, b_sz, q);
+                        q.allreduce_sum(R12_la, b_sz * rest);
+                        side->wait_for(q);
+                        // tail: my rows below the block, on kernels whose workgroups retire continuously (the side queue's kernels find CUs)
+                        if (below > 0) {
+                            blas::GiveWay gw(q);
+                            blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, below, rest, br, (T)-1.0, Vexp + tcnt, ldvx, W2, br, (T)1.0, Cg + tcnt, lda, q);
+                        }
+                    }
                 }
             }
             curr_sz += b_sz;
             if (curr_sz >= mn || block_rank != b_sz_const) { rank = curr_sz; return 0; }
             // ---- sketch down-date: R12 = the b_sz rows just finished of the updated trailing matrix, gathered from their owners
             {
+                blas::Range ph("update_Sk");
+                blas::Queue& qd = la ? *side : q;
                 blas::Scratch w4(q);
                 const int64_t rest = cols - b_sz;
-                T* R12 = w4.alloc<T>(b_sz * rest);
-                lapack::laset(MatrixType::General, b_sz, rest, (T)0, (T)0, R12, b_sz, q);
-                if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, &A[t_loc + lda * curr_sz], lda, R12 + toff, b_sz, q);
-                q.allreduce_sum(R12, b_sz * rest);
-                if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, q);
-                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R_tall_qr, b_sz_const, R_sk, d, q);
-                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, rest, b_sz, (T)-1.0, R_sk, d, R12, b_sz, (T)1.0, &R_sk[d * b_sz], d, q);
+                T* R12 = R12_la;
+                if (!la) {
+                    R12 = w4.alloc<T>(b_sz * rest);
+                    lapack::laset(MatrixType::General, b_sz, rest, (T)0, (T)0, R12, b_sz, q);
+                    if (tcnt > 0) lapack::lacpy(MatrixType::General, tcnt, rest, &A[t_loc + lda * curr_sz], lda, R12 + toff, b_sz, q);
+                    q.allreduce_sum(R12, b_sz * rest);
+                }
+                if (b_sz > 1) lapack::laset(MatrixType::Lower, b_sz - 1, b_sz, (T)0, (T)0, R_sk + 1, d, qd);
+                blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, b_sz, b_sz, (T)1.0, R_tall_qr, b_sz_const, R_sk, d, qd);
+                blas::gemm(Layout::ColMajor, Op::NoTrans, Op::NoTrans, b_sz, rest, b_sz, (T)-1.0, R_sk, d, R12, b_sz, (T)1.0, &R_sk[d * b_sz], d, qd);
+                sampling_dimension = std::min(sampling_dimension, cols);
+                if (sampling_dimension - b_sz > 1)
+                    lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0, &R_sk[(d + 1) * b_sz] + 1, d, qd);
+                pre_on_side = la;
             }
-            sampling_dimension = std::min(sampling_dimension, cols);
-            if (sampling_dimension - b_sz > 1)
-                lapack::laset(MatrixType::Lower, sampling_dimension - b_sz - 1, sampling_dimension - b_sz, (T)0, (T)0, &R_sk[(d + 1) * b_sz] + 1, d, q);
             A_sk = &A_sk[d * b_sz];
             cols -= b_sz;
         }
         return 0;
     }
 
-    int transpose_call(int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
-        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
-        else return rlhip_transpose_f32(q.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+    int transpose_call(blas::Queue& qq, int64_t mm, int64_t nn, const T* X, int64_t ldx, T* XT, int64_t ldxt) {
+        if constexpr (std::is_same<T, double>::value) return rlhip_transpose_f64(qq.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
+        else return rlhip_transpose_f32(qq.ctx(), mm, nn, X, ldx, XT, ldxt, 0);
     }
 
     blas::Queue& q;

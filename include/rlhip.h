@@ -51,7 +51,7 @@ int rlhip_destroy(rlhip_ctx* ctx);
 enum rlhip_option {
     RLHIP_OPT_CHOLQRQ_ONE_STREAM = 0,   /* 1: rlhip_cholqrq_* serves tall 256-aligned inputs as one stream of kernels; 0: returns 1 (caller runs syrk, potrf, trsm) */
     RLHIP_OPT_GESDD_GRAM = 1,           /* 1: device SVD of a well-conditioned tall factor, 32 < k <= 256, by Jacobi on its Gram matrix; 0: classic route always */
-    RLHIP_OPT_JACOBI_PERSIST = 2,       /* 1: all Jacobi sweeps in one cooperative launch (blocks handed over through the XCD's L2 when the workers share one); 2: the same, hand-over through uncached memory always; 0: one launch per round (what rocprofv3 --pmc can profile) */
+    RLHIP_OPT_JACOBI_PERSIST = 2,       /* 1: all Jacobi sweeps in one cooperative launch (blocks handed over through the XCD's L2 when the workers share one); 2: the same, hand-over through uncached memory always; 3: the workers alone through an ordinary (non-cooperative) launch -- the route rocprofv3 --pmc can profile, idle device only; 0: one launch per round */
     RLHIP_OPT_TRSM_XASM = 3,            /* fused solve: X loads issued from inline asm (1) or plain loads (0); default = what scripts/check_trsm_asm.py proved for this build */
     RLHIP_OPT_SASO_MODE = 4,            /* rlhip_saso_create: 1 independent columns (RandBLAS's short-axis SASO), 0 block-affine family */
     RLHIP_OPT_HQRRP_TALL_PANEL = 5,     /* hqrrp: 1 pivots of a tall panel from the QRCP of its R factor; 0: one pivoted sweep (the reference's order) */
@@ -419,6 +419,16 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* the host layers above this ABI (include/RandLAPACK_amd/) report their own route decisions into the same counters */
 int rlhip_path_note(rlhip_ctx* ctx, int which, int64_t delta);
+/* Profiler phase markers (the reference brackets every phase of BQRRP_GPU with NVTX ranges, drivers/rl_bqrrp_gpu.hh:11,335-403; these are the
+ * ROCm equivalent, roctxRangePushA / roctxRangePop of librocprofiler-sdk-roctx, bound at run time).  Active when the roctx library is already
+ * in the process (rocprofv3 --marker-trace) or RLHIP_ROCTX=1; otherwise both calls return 0 and do nothing.  Host-side ranges: they bracket
+ * the ENQUEUE of a phase; with the drivers' timing switch on (every lap drains the stream) they bracket its execution too. */
+int rlhip_range_push(const char* name);
+int rlhip_range_pop(void);
+/* Scope switch for the products this context launches: on != 0 -> no kernel of this context may hold every CU until it is done (the
+ * persistent stream-K GEMMs give way to the tiled ones, whose workgroups retire continuously), so that work enqueued on a side queue
+ * (rlhip_side_of) finds CUs beside it.  Returns the previous setting (0 / 1), -1 on a bad context. */
+int rlhip_avoid_persistent(rlhip_ctx* ctx, int on);
 /* pure-MFMA issue-rate microbenchmark; returns achieved TFLOP/s of v_mfma_{f64,f32}_16x16x4 in *tflops_host */
 int rlhip_mfma_peak(rlhip_ctx* ctx, int is_f64, int iters, double* tflops_host);
 /* diagnostic: keep `blocks` workgroups busy for `usec` microseconds (mode 0 sleeping, 1 fp64 FMA chain, 2 fp64 MFMA stream), on the context's

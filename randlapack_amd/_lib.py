@@ -118,6 +118,9 @@ SIGNATURES = {
     "rlhip_luqrcp_piv": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rlhip_path_count": (c_i64, [c_vp, c_int]),
     "rlhip_path_note": (c_int, [c_vp, c_int, c_i64]),
+    "rlhip_range_push": (c_int, [C.c_char_p]),
+    "rlhip_range_pop": (c_int, []),
+    "rlhip_avoid_persistent": (c_int, [c_vp, c_int]),
     "rlhip_set_option": (c_int, [c_vp, c_int, c_i64]),
     "rlhip_get_option": (c_i64, [c_vp, c_int]),
     "rlhip_mfma_peak": (c_int, [c_vp, c_int, c_int, C.POINTER(c_dbl)]),

@@ -3,6 +3,7 @@
 #include "../../include/rlhip.h"
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
 
 namespace rlhip {
 struct SasoOp;
@@ -780,6 +781,42 @@ extern "C" int rlhip_path_note(rlhip_ctx* c, int which, int64_t delta) {
     if (!c || which < 0 || which >= 16) return -1;
     c->path_count[which] += delta;
     return 0;
+}
+
+// ---- profiler phase markers: roctx bound at run time (no link-time dependency on the profiler SDK)
+namespace {
+typedef int (*fn_roctx_push)(const char*);
+typedef int (*fn_roctx_pop)(void);
+struct Roctx { int state = 0; fn_roctx_push push = nullptr; fn_roctx_pop pop = nullptr; };   // state: 0 untried, 1 bound, -1 absent
+Roctx g_roctx;
+void roctx_bind() {
+    g_roctx.state = -1;
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }          // a profiler brought it along
+    const char* want = getenv("RLHIP_ROCTX");
+    if (!h && want && want[0] == '1')
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW); if (h) break; }
+    if (!h) return;
+    g_roctx.push = (fn_roctx_push)dlsym(h, "roctxRangePushA");
+    g_roctx.pop = (fn_roctx_pop)dlsym(h, "roctxRangePop");
+    if (g_roctx.push && g_roctx.pop) g_roctx.state = 1;
+}
+}  // namespace
+extern "C" int rlhip_range_push(const char* name) {
+    if (g_roctx.state == 0) roctx_bind();
+    if (g_roctx.state == 1 && name) g_roctx.push(name);
+    return 0;
+}
+extern "C" int rlhip_range_pop(void) {
+    if (g_roctx.state == 1) g_roctx.pop();
+    return 0;
+}
+extern "C" int rlhip_avoid_persistent(rlhip_ctx* c, int on) {
+    if (!c) return -1;
+    const int prev = c->avoid_persistent;
+    c->avoid_persistent = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int rlhip_mfma_peak(rlhip_ctx* c, int is_f64, int iters, double* tflops) {

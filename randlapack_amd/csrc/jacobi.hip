@@ -866,6 +866,14 @@ int jp_launch_qw(rlhip_ctx* c, JpArgs<T>& g, unsigned long long* buf, int m, int
     constexpr int smem = 2 * JB * JMT * (int)sizeof(T);
     RLHIP_FUNC_LDS(c, (jacobi_persist_kernel<T, JB, JMT, QW>), smem);
     void* kargs[] = {(void*)&g};
+    if (c->opt[RLHIP_OPT_JACOBI_PERSIST] == 3) {
+        // profiling route: the workers alone through an ORDINARY launch (rocprofv3 --pmc aborts on cooperative launches).  NW <= 16 workgroups of
+        // an otherwise idle device are resident together without the runtime's guarantee; same kernel, same protocol (uncached hand-over).
+        g.local_try = 0; g.hold_mode = 0;
+        hipLaunchKernelGGL((jacobi_persist_kernel<T, JB, JMT, QW>), dim3((unsigned)NW), dim3(1024), smem, c->stream, g);
+        const hipError_t pe = hipGetLastError();
+        return pe == hipSuccess ? 0 : 1;
+    }
     hipError_t le = hipLaunchCooperativeKernel((const void*)jacobi_persist_kernel<T, JB, JMT, QW>, dim3(grid_hold), dim3(1024), kargs, (unsigned)smem, c->stream);
     if (le != hipSuccess && grid_hold != (unsigned)NW) {
         (void)hipGetLastError();

@@ -199,6 +199,23 @@ def jacobi():
     ctx.sync()
 
 
+def jacobi_persist():
+    """the kernel that IS on the C2 path (jacobi_persist_kernel, ~2 ms of the shard step), launched the ordinary way (option 3: rocprofv3 --pmc
+    aborts on cooperative launches): the workers alone, no clock holders, uncached hand-over"""
+    d, ctx = _ctx()
+    ctx.set_option("jacobi_persist", 3)
+    import torch
+
+    n, k = 20000, 256
+    BT = d.cm_empty(n, k); ctx.fill_dense(BT, n, k, key=(4, 0))
+    S = torch.zeros(k, dtype=torch.float64, device="cuda")
+    U = d.cm_empty(n, k); VT = d.cm_empty(k, k)
+    for _ in range(REPS):
+        W = BT.clone()
+        assert ctx.lib.rlhip_gesdd_f64(ctx.h, n, k, W.data_ptr(), n, S.data_ptr(), U.data_ptr(), n, VT.data_ptr(), k, None) == 0
+    ctx.sync()
+
+
 def qrcp_tag():
     d, ctx = _ctx()
     import torch
@@ -238,7 +255,8 @@ WORKLOADS = {
                 (2000000 * 32 + 200000 * 32) * 8.0 + 16.0 * 2000000, 2.0 * 2000000 * 32, "hbm"),
     "getrf_panel_f32": (getrf_panel_f32, "getrf_panel_f32_kernel", "row-pivoted LU panel steps of the 65536 x 2048 fp32 transposed sketch (C4 qrcp_wide)",
                         None, None, "latency"),
-    "jacobi": (jacobi, "jacobi_block_kernel", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2)", None, None, "latency"),
+    "jacobi": (jacobi, "jacobi_block_kernel", "one-sided Jacobi on the 256 x 256 factor of the RSVD tail (C2), PER-ROUND kernel (not the one on the C2 path: see jacobi_persist)", None, None, "latency"),
+    "jacobi_persist": (jacobi_persist, "jacobi_persist_kernel", "one-sided Jacobi on the 256 x 256 Gram factor of the RSVD tail (C2): the persistent kernel itself, workers alone, ordinary launch", None, None, "latency"),
     "qrcp_tag": (qrcp_tag, "qrcp_tag_kernel", "geqp3 of the 1280 x 1024 fp64 sketch (C3)", None, None, "latency"),
 }
 

@@ -1,0 +1,167 @@
+"""-m gpu: the LITERAL BASELINE configs[3] path at oracle sizes -- BQRRP in fp32, row-block sharded (world 2, 3 and 8; contiguous row blocks
+and the block-cyclic layout of SURVEY 8e; Cholesky-QR panels with a Gram all-reduce and the reference's default TSQR / geqrf panels) -- on
+columns separated far beyond float rounding, so that "pivot orders bit-exact" is a statement about every block of the factorization:
+J of the sharded run == J of the single-device run == J of the oracle's float leg and of its double leg, all blocks
+(reference precedent for cross-backend J / tau / R agreement: test/drivers/test_bqrrp_gpu.cu:231-249; loop drivers/rl_bqrrp.hh:306-661).
+
+The ranks are threads of this process, one rlhip context each (tests/_world.py): the real sharded code path -- every Queue::allreduce_sum,
+shard_extent, the block-cyclic segments -- with a rank-ordered in-place sum as the transport.  The fp64 counterparts with a gloo transport and
+one process per rank live in test_gpu_sharded.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS32 = float(np.finfo(np.float32).eps)
+NEVER = 1 << 62
+M, N, B = 3072, 1024, 128
+
+_cache = {}
+
+
+def _graded32(m, n, seed, decades=4.5):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((m, n)) * np.logspace(0, -decades, n)[rng.permutation(n)]).astype(np.float32)
+
+
+def _to_dev32(A):
+    import torch
+    from randlapack_amd import device as d
+
+    return d.cm_from_numpy(A.astype(np.float64)).to(torch.float32)
+
+
+def _single_and_oracle(ctx, orc, qr_tall, apply_q):
+    """single-device fp32 factorization + the oracle's float and double legs on the same float matrix and the device's sketch"""
+    from randlapack_amd import device as d
+
+    key = (qr_tall, apply_q)
+    if key not in _cache:
+        A = _graded32(M, N, 5)
+        Ad = _to_dev32(A)
+        r = d.drv_bqrrp(ctx, Ad, M, N, B, 1.0, want_sketch=True, key=(3, 0), qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=apply_q)
+        sk = d.cm_to_numpy(r["sketch"])
+        o32 = orc.bqrrp(A, B, 1.0, qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=apply_q, sketch=sk)
+        o64 = orc.bqrrp(A.astype(np.float64), B, 1.0, qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=apply_q, sketch=sk.astype(np.float64), tol=EPS32)
+        J1 = r["J"].cpu().numpy()
+        assert r["rank"] == o32["rank"] == o64["rank"] == N
+        np.testing.assert_array_equal(o32["J"], o64["J"])           # the input is what it claims: separated beyond float rounding
+        np.testing.assert_array_equal(J1, o32["J"])
+        _cache[key] = dict(A=A, J=J1, F=d.cm_to_numpy(Ad).astype(np.float64), tau=r["tau"].cpu().numpy().astype(np.float64), sk=sk, o64=o64)
+    return _cache[key]
+
+
+@pytest.fixture(scope="module")
+def worlds():
+    from _world import World
+
+    made = {}
+
+    def get(n):
+        if n not in made:
+            made[n] = World(n)
+        return made[n]
+    yield get
+    for w in made.values():
+        w.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("cyclic", [False, True])
+@pytest.mark.parametrize("qr_tall,apply_q", [(1, 1), (2, 0)])        # the fast triple {luqr, cholqr, gemqrt} and the reference's default {luqr, geqrf, ormqr}
+@pytest.mark.parametrize("lookahead", [NEVER, 0])                    # the serial order / the replicated chain on the side queue beside the tail of the apply
+def test_bqrrp_f32_row_sharded_pivots_exact_all_blocks(ctx, orc, worlds, world, cyclic, qr_tall, apply_q, lookahead):
+    from _world import block_cyclic_rows, contiguous_rows
+    from randlapack_amd import device as d
+
+    ref = _single_and_oracle(ctx, orc, qr_tall, apply_q)
+    A = ref["A"]
+    W = worlds(world)
+    rows = [block_cyclic_rows(r, world, M, B) if cyclic else contiguous_rows(r, world, M) for r in range(world)]
+    shards = [_to_dev32(np.ascontiguousarray(A[rows[r]])) for r in range(world)]
+    W.collectives = 0
+
+    before = [c.path_count(12) for c in W.ctx]
+
+    def step(r, c):
+        with c.options(bqrrp_lookahead_min_elems=lookahead):
+            return d.drv_bqrrp(c, shards[r], len(rows[r]), N, B, 1.0, want_sketch=True, key=(3, 0), qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=apply_q,
+                               m_global=M, block_cyclic=cyclic)
+    res = W.run(step)
+    assert W.collectives > 4 * (N // B - 1), "the sharded path did not exchange"
+    took = [c.path_count(12) - b0 for c, b0 in zip(W.ctx, before)]
+    assert took == [N // B - 1 if lookahead == 0 else 0] * world, f"side-queue iterations per rank: {took}"
+    J = res[0]["J"].cpu().numpy()
+    for r in range(1, world):                                        # replicated quantities: the same bits on every rank
+        np.testing.assert_array_equal(res[r]["J"].cpu().numpy(), J)
+        np.testing.assert_array_equal(res[r]["tau"].cpu().numpy(), res[0]["tau"].cpu().numpy())
+        assert res[r]["rank"] == res[0]["rank"]
+    assert res[0]["rank"] == N
+    # the sharded sketch is the single-device sketch up to the order of the cross-rank sum ...
+    sk = d.cm_to_numpy(res[0]["sketch"])
+    assert np.abs(sk - ref["sk"]).max() <= 64 * EPS32 * np.sqrt(M) * np.abs(ref["sk"]).max()
+    # ... and EVERY block's pivots are the single-device run's = the oracle's float leg = its double leg
+    np.testing.assert_array_equal(J, ref["J"])
+    # the oracle's float leg fed THIS run's sketch: still the same pivots
+    o32 = orc.bqrrp(A, B, 1.0, qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=apply_q, sketch=sk)
+    np.testing.assert_array_equal(J, o32["J"])
+    # factors: GEQP3 format assembled from the shards == single device and the double oracle at float tolerance
+    F = np.zeros((M, N))
+    for r in range(world):
+        F[rows[r]] = d.cm_to_numpy(shards[r]).astype(np.float64)
+    Ro = np.triu(ref["o64"]["A"])[:N]
+    assert np.linalg.norm(np.triu(F)[:N] - Ro) <= EPS32**0.6 * np.linalg.norm(Ro)
+    assert np.linalg.norm(F - ref["F"]) <= EPS32**0.6 * np.linalg.norm(ref["F"])
+    np.testing.assert_allclose(res[0]["tau"].cpu().numpy(), ref["o64"]["tau"], atol=2e-4, rtol=0)
+    Q = orc.ungqr(F, res[0]["tau"].cpu().numpy().astype(np.float64))
+    A64 = A.astype(np.float64)
+    assert np.linalg.norm(A64[:, J - 1] - Q @ np.triu(F)[:N]) <= EPS32**0.75 * np.linalg.norm(A64)
+    assert np.linalg.norm(Q.T @ Q - np.eye(N)) <= EPS32**0.75 * np.sqrt(N)
+
+
+@pytest.mark.parametrize("world,cyclic", [(2, False), (3, True)])
+@pytest.mark.parametrize("qr_tall", [1, 2])
+def test_bqrrp_row_sharded_rank_deficient_blocks(ctx, orc, worlds, world, cyclic, qr_tall):
+    """A numerically rank-deficient matrix (rank r < n, the deficiency met INSIDE a block: block_rank < b_sz) on a sharded queue: both panel
+    types must leave R11's columns to the right of the deficient block's leading triangle equal to Q^T A there -- the single-device path and
+    the reference run geqrf on all b_sz panel columns (drivers/rl_bqrrp.hh:506-523), the Cholesky-QR path multiplies R_chol by the b_sz
+    columns of R_sk (:497).  fp64, so that the comparison is tight: the sharded output equals the single-device output to rounding."""
+    from _world import block_cyclic_rows, contiguous_rows
+    from randlapack_amd import device as d
+
+    m, n, b, rk = 1536, 512, 128, 300                                  # the third block (columns 256..383) is deficient from its 45th column on
+    rng = np.random.default_rng(77)
+    A = (rng.standard_normal((m, rk)) * np.logspace(0, -3, rk)) @ rng.standard_normal((rk, n))
+    tol = 1e-10
+    A1 = d.cm_from_numpy(A)
+    r1 = d.drv_bqrrp(ctx, A1, m, n, b, 1.0, want_sketch=True, key=(9, 0), qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=1, tol=tol)
+    F1, J1 = d.cm_to_numpy(A1), r1["J"].cpu().numpy()
+    assert r1["rank"] == 3 * b                                          # the reference's rank: an upper bound, the end of the deficient block
+    W = worlds(world)
+    rows = [block_cyclic_rows(r, world, m, b) if cyclic else contiguous_rows(r, world, m) for r in range(world)]
+    shards = [d.cm_from_numpy(np.ascontiguousarray(A[rows[r]])) for r in range(world)]
+    sk = r1["sketch"]
+
+    def step(r, c):
+        return d.drv_bqrrp(c, shards[r], len(rows[r]), n, b, 1.0, sketch_in=sk, key=(9, 0), qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=1,
+                           tol=tol, m_global=m, block_cyclic=cyclic)
+    res = W.run(step)
+    assert res[0]["rank"] == r1["rank"]
+    J = res[0]["J"].cpu().numpy()
+    np.testing.assert_array_equal(J, J1)
+    F = np.zeros((m, n))
+    for r in range(world):
+        F[rows[r]] = d.cm_to_numpy(shards[r])
+    # what the factorization defines: the blocks before the deficient one and the block_rank leading rows of the deficient block
+    br = rk - 2 * b
+    kk = 2 * b + br
+    tau = res[0]["tau"].cpu().numpy()
+    Q = orc.ungqr(F[:, :kk].copy(), tau[:kk])
+    R = np.triu(F)[:kk, :]
+    AJ = A[:, J - 1]
+    # the deficient block's columns lie in the span of its block_rank leading ones: A[:, J] = Q R there only if R11's columns to the right of
+    # the leading triangle were filled (Q^T A), not zeroed
+    assert np.linalg.norm(AJ[:, :3 * b] - Q @ R[:, :3 * b]) <= 1e-8 * np.linalg.norm(A), "the deficient block's row of R11 is incomplete"
+    # ... and entry for entry the single-device output (R12 of the deficient block included: the reference's cut apply, :535-547)
+    R1 = np.triu(F1)[:kk, :]
+    assert np.linalg.norm(R - R1) <= 1e-9 * np.linalg.norm(R1)
+    np.testing.assert_allclose(tau[:kk], r1["tau"].cpu().numpy()[:kk], atol=1e-9, rtol=0)
