@@ -90,16 +90,47 @@ def main():
                                  collectives=Wd.collectives, bytes_all_reduced=Wd.bytes_reduced, lookaheads_taken=int(Wd.ctx[0].path_count(12)))
     del shards
     Wd.close()
-    # ---- fp64 leg on the same float matrix and the same float sketch
+    # ---- fp64 legs on the same float matrix: rounding is 9 digits further away from every decision
     if not a.no_f64:
+        eps32 = float(np.finfo(np.float32).eps)
         A64 = A.double()
         sk64 = sk32.double()
-        with ctx.options(bqrrp_lookahead_min_elems=NEVER):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            r64 = d.drv_bqrrp(ctx, A64, m, n, b, 1.0, sketch_in=sk64, key=(4, 0), qrcp_wide=0, qr_tall=1, apply_trans_q=1, tol=float(np.finfo(np.float32).eps))
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        res["f64"] = dict(J=r64["J"].clone(), diag=A64.diagonal().abs().clone(), rank=r64["rank"])
-        out["runs"]["f64"] = dict(seconds=round(dt, 3), rank=r64["rank"])
+
+        def run64(name, thresh, sketch):
+            W64 = A64.clone()
+            with ctx.options(bqrrp_lookahead_min_elems=thresh):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r = d.drv_bqrrp(ctx, W64, m, n, b, 1.0, sketch_in=sketch, key=(4, 0), qrcp_wide=0, qr_tall=1, apply_trans_q=1, tol=eps32)
+                torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            res[name] = dict(J=r["J"].clone(), diag=W64.diagonal().abs().clone(), rank=r["rank"])
+            out["runs"][name] = dict(seconds=round(dt, 3), rank=r["rank"])
+        # (1) the float sketch promoted: the decisions of exact arithmetic on the float problem
+        run64("f64", NEVER, sk64)
+        # (2) the SCHEDULES in fp64: look-ahead and 8 row-sharded ranks against the serial order, each forming its own fp64 sketch
+        run64("f64_serial_own_sketch", NEVER, None)
+        run64("f64_lookahead_own_sketch", -1, None)
+        Wd = World(N)
+        shards = [A64[:, torch.from_numpy(rows[r]).cuda()].contiguous() for r in range(N)]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rr = Wd.run(lambda r, c: d.drv_bqrrp(c, shards[r], len(rows[r]), n, b, 1.0, key=(4, 0), qrcp_wide=0, qr_tall=1, apply_trans_q=1, tol=eps32,
+                                            m_global=m, block_cyclic=True))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        dg = torch.zeros(n, dtype=torch.float64, device="cuda")
+        for r in range(N):
+            gi = torch.from_numpy(rows[r]).cuda()
+            dg[gi] = shards[r][gi, torch.arange(len(rows[r]), device="cuda")].abs()
+        res["f64_ranks8_own_sketch"] = dict(J=rr[0]["J"].clone(), diag=dg, rank=rr[0]["rank"])
+        out["runs"]["f64_ranks8_own_sketch"] = dict(seconds_all_ranks=round(dt, 3), rank=rr[0]["rank"],
+                                                    ranks_agree=bool(all(torch.equal(rr[0]["J"], rr[r]["J"]) for r in range(N))),
+                                                    lookaheads_taken=int(Wd.ctx[0].path_count(12)))
+        del shards
+        Wd.close()
+        # (3) margin probe: the SAME fp64 factorization with every sketch entry moved by a relative 1e-7 / 1e-10 (one float rounding / a
+        #     thousandth of it): where do the decisions first move?  A decision that a 1e-7 perturbation of the sketch moves is not separated
+        #     beyond float rounding, whatever kernel does the rounding
+        g2 = torch.Generator(device="cuda").manual_seed(3)
+        for tag, rel in (("f64_sketch_perturbed_1e-7", 1e-7), ("f64_sketch_perturbed_1e-10", 1e-10)):
+            run64(tag, NEVER, sk64 * (1.0 + rel * torch.randn(sk64.shape, generator=g2, device="cuda", dtype=torch.float64)))
         del A64
     names = list(res)
     for i in range(len(names)):

@@ -105,3 +105,20 @@ def test_trsm_asm_proof_ran_and_passed_for_this_build():
     # waits of the diagonal block depend on where hipcc puts the loads that refill retired tiles (round 5: it sank them, 8 of 10 pieces flew)
     assert all(int(dma) == 0 for _, _, dma in counts), txt
     assert "built with RLHIP_TF_DRAIN=" in txt
+
+
+def test_lds_dma_proofs_of_this_build_hold():
+    """The Makefile replays the assembly of the kernels that stage operands by LDS-DMA against a model of the vector-memory counter
+    (scripts/check_lds_dma_asm.py, scripts/check_trsm_asm.py) and writes what it proved next to the objects: no request of the stage being
+    published may be outstanding at an s_barrier.  The logs of THIS build must exist, cover every such kernel and report no violation."""
+    import re
+
+    csrc = ROOT / "randlapack_amd" / "csrc"
+    for log, kernel, least in (("gemm_sk.dma_check.log", "gemm_sk_kernel", 8), ("sketch.dma_check.log", "saso_apply_dma_kernel", 2)):
+        text = (csrc / log).read_text()
+        lines = [ln for ln in text.splitlines() if kernel in ln and "LDS-DMA requests" in ln]
+        assert len(lines) >= least, text
+        assert all(ln.rstrip().endswith("-> ok") for ln in lines) and "VIOLATION" not in text and "vacuous" not in text, text
+    tri = (csrc / "tri.xasm_check.log").read_text()
+    rows = re.findall(r"(\d+) LDS-DMA requests open at a barrier", tri)
+    assert rows and all(int(r) == 0 for r in rows), tri
