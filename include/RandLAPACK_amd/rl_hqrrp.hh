@@ -151,6 +151,9 @@ int64_t hqrrp_sharded(int64_t m_loc, int64_t n_A, T* buff_A, int64_t ldim_A, int
 ///   [9..17] the sketch-QRCP kernel's own breakdown, [18..26] the panel-QR kernel's -- on the device each is ONE kernel, so only
 ///   the total slots (17 and 26) are filled, the per-step slots stay 0.
 /// Timing synchronises the queue at every stamp.
+/// On a ROW-SHARDED queue (q.world() > 1) the call dispatches to hqrrp_sharded: m_A is then THIS RANK's row count (contiguous row blocks in
+/// rank order), ldim_A >= m_A, buff_tau must hold min(global rows, n_A) entries and buff_jpvt n_A (both replicated on every rank), and
+/// *timing receives 27 entries of which only `other` [7] and `total` [8] are filled.
 template <typename T, typename RNG>
 int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff_jpvt, T* buff_tau, int64_t nb_alg, int64_t pp,
               int64_t panel_pivoting, int64_t qr_type, RandBLAS::RNGState<RNG>& state, blas::Queue& q, T* G_export = nullptr,
@@ -164,8 +167,15 @@ int64_t hqrrp(int64_t m_A, int64_t n_A, T* buff_A, int64_t ldim_A, int64_t* buff
     randlapack_require(n_A >= 0) << "hqrrp: n_A is < 0";
     randlapack_require(ldim_A >= std::max<int64_t>(1, m_A)) << "hqrrp: ldim_A is < max(1, m_A)";
     randlapack_require(nb_alg > 0 && pp >= 0) << "hqrrp: nb_alg must be > 0 and pp >= 0";
-    if (q.world() > 1)                        // row-sharded queue: m_A is this rank's row count (tau then has min(global rows, n) entries)
-        return hqrrp_sharded<T, RNG>(m_A, n_A, buff_A, ldim_A, buff_jpvt, buff_tau, nb_alg, pp, panel_pivoting, qr_type, state, q, G_export);
+    if (q.world() > 1) {                      // row-sharded queue: m_A is this rank's row count (tau then has min(global rows, n) entries)
+        const int64_t rc = hqrrp_sharded<T, RNG>(m_A, n_A, buff_A, ldim_A, buff_jpvt, buff_tau, nb_alg, pp, panel_pivoting, qr_type, state, q, G_export);
+        if (timing) {                         // the sharded loop is not instrumented per stage: 27 entries, zeros except `other` and `total`
+            const long total = us(t_begin, stamp());
+            T* tt = (T*)std::realloc(*timing, 27 * sizeof(T));
+            if (tt) { for (int i = 0; i < 27; ++i) tt[i] = (T)0; tt[7] = (T)total; tt[8] = (T)total; *timing = tt; }
+        }
+        return rc;
+    }
     const int64_t mn_A = std::min(m_A, n_A);
     if (mn_A == 0) return 0;
     const int64_t m_Y = nb_alg + pp, n_Y = n_A, ldim_Y = m_Y, ldim_V = m_Y, m_G = nb_alg + pp, n_G = m_A, ldim_G = m_G;

@@ -210,7 +210,8 @@ struct SparseLinOp {
         op.rowptr_t = colptr; op.colidx_t = rowidx; op.vals_t = v;
         return op;
     }
-    /// COO input (RandBLAS::sparse_data::COOMatrix: rows[nnz], cols[nnz], vals[nnz], any order, duplicates summed by the products): sorted
+    /// COO input (RandBLAS::sparse_data::COOMatrix: rows[nnz], cols[nnz], vals[nnz], any order): duplicate (row, col) entries are KEPT as separate
+    /// entries -- every product sums them, but fro_nrm() (the norm of the value array, as in the reference) then is not ||A||_F; sorted
     /// into CSR by the stable device counting sort of csr_transpose -- once for the values, once for the column indices (the sort is
     /// deterministic and stable, so both come out in the same order)
     static SparseLinOp from_coo(int64_t rows, int64_t cols, int64_t nnz_, const int64_t* rowidx, const int64_t* colidx_in, const T* v, blas::Queue& queue) {
@@ -279,6 +280,7 @@ struct SparseLinOp {
         blas::check(rlhip_memcpy_d2h(q.ctx(), &end, rp + row_count, sizeof(int64_t)), "d2h");
         SparseLinOp v(row_count, n_cols, end, rp, colidx + base, vals + base, q);
         v.own_.push_back(rp);
+        v.row_sharded = row_sharded; v.densify_budget = densify_budget; v.force_densified_sketch = force_densified_sketch;
         return v;
     }
     SparseLinOp col_block(int64_t col_start, int64_t col_count) {
@@ -292,6 +294,7 @@ struct SparseLinOp {
         SparseLinOp v(n_rows, col_count, end, nullptr, nullptr, nullptr, q);     // given by its columns: the rows of the parent's transpose
         v.rowptr_t = cp; v.colidx_t = colidx_t + base; v.vals_t = vals_t + base;
         v.own_.push_back(cp);
+        v.row_sharded = row_sharded; v.densify_budget = densify_budget; v.force_densified_sketch = force_densified_sketch;
         return v;
     }
     SparseLinOp submatrix(int64_t row_start, int64_t col_start, int64_t row_count, int64_t col_count) {

@@ -414,7 +414,8 @@ int rlhip_allreduce_sum_host_f64(rlhip_ctx* ctx, double* x_host, int64_t n);   /
  * (svd.hip::gesdd_tall_gram: Jacobi on A^T A, one host read), 11 the one-stream Cholesky-QR (rlhip_cholqrq),
  * 12 block iterations of BQRRP whose sketch down-date and next QRCP ran on the side queue (the look-ahead of rl_bqrrp.hh; noted by the C++
  * layer through rlhip_path_note), 13 CQRRPT calls that took the split order (rl_cqrrpt.hh), 14 sparse-sign sketches applied by the LDS-DMA kernel
- * (sketch.hip::saso_apply_dma_kernel).  -1 for an unknown index.  Tests use it to
+ * (sketch.hip::saso_apply_dma_kernel), 15 persistent Jacobi launches whose workers sat on one XCD and handed their blocks over through its L2
+ * (jacobi.hip; the other launches use the uncached hand-over: same bits, slower).  -1 for an unknown index.  Tests use it to
  * assert that the kernel / route under test is the one that ran. */
 int64_t rlhip_path_count(rlhip_ctx* ctx, int which);
 /* the host layers above this ABI (include/RandLAPACK_amd/) report their own route decisions into the same counters */

@@ -923,6 +923,7 @@ int persistent_jacobi_sweeps(rlhip_ctx* c, int m, int n, T* A, int64_t lda, T to
             const unsigned long long* tk = reinterpret_cast<const unsigned long long*>((const int*)(c->h_mail + 16) + 4);
             if (want_clk && tk[1]) fprintf(stderr, "[jacobi clock] %d sweeps, %.1f us at %.0f MHz (hold %d, same-XCD hand-over %d)\n", done_sweeps - sweep, (double)tk[1] / 100.0, (double)tk[0] / ((double)tk[1] / 100.0), hold, *((const int*)(c->h_mail + 16) + 3));
         }
+        if (*((const int*)(c->h_mail + 16) + 3) == 1) c->path_count[15]++;     // the workers shared one XCD and handed their blocks over through its L2
         if ((status != 1 && status != 2 && status != 3) || any_lost) { rlhip_ws_release(c, mark); *sweeps_out = sweep; return 1; }   // -7, a lost word anywhere, or nothing written: A untouched by this launch
         int rc = rlhip::lacpy<T>(c, 2, m, n, reinterpret_cast<const T*>(buf), m, A, lda);
         if (rc) { rlhip_ws_release(c, mark); return rc < 0 ? rc : 1; }

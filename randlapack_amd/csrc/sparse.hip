@@ -479,6 +479,11 @@ int csr_transpose(rlhip_ctx* c, int64_t m, int64_t k, const int64_t* rowptr, con
         hipLaunchKernelGGL(ct_blocksum_kernel, dim3((unsigned)nblk), dim3(1024), 0, c->stream, k, (const int64_t*)total, bsum, d_maxlen);
         hipLaunchKernelGGL(ct_blockscan_kernel, dim3(1), dim3(1024), 0, c->stream, nblk, bsum);
         hipLaunchKernelGGL(ct_rowptr3_kernel, dim3((unsigned)nblk), dim3(1024), 0, c->stream, k, (const int64_t*)total, (const int64_t*)bsum, nblk, rowptrT);
+        if (nnz > 0 && m == 1) {
+            // one source row (SparseLinOp::from_coo sorts a COO list as a 1 x rows matrix): every entry's source row is 0 -- one memset instead
+            // of ONE thread writing nnz words
+            if (hipMemsetAsync(rowid, 0, (size_t)nnz * sizeof(int64_t), c->stream) != hipSuccess) { rc = -1; break; }
+        } else
         if (nnz > 0 && m > 0) hipLaunchKernelGGL(ct_rowid_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, m, rowptr, rowid);
         if (hipMemcpyAsync(c->h_mail + 51, c->d_mail + 51, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess || rlhip_stream_sync(c) != hipSuccess) { rc = -1; break; }
         if (*(int*)(c->h_mail + 51)) { rc = -2; break; }                                   // a column index outside [0, k)

@@ -225,6 +225,7 @@ int gesdd_tall_gram(rlhip_ctx* c, int64_t m, int64_t n, const T* A, int64_t lda,
         const double dv = *(const double*)(c->h_mail + 36);
         const bool ok = (jo[0] == 1 || jo[0] == 2) && jo[2] == 0 && dv <= 1e-13;
         if (getenv("RLHIP_GESDD_TRACE")) fprintf(stderr, "[gesdd gram] jacobi status %d sweeps %d lost %d defect %.3e -> %s\n", jo[0], jo[1], jo[2], dv, ok ? "taken" : "classic route");
+        if (jo[3] == 1) c->path_count[15]++;       // same-XCD hand-over taken by the Jacobi launch (jacobi.hip)
         if (!ok) return 1;
         if (sweeps_host) *sweeps_host = jo[1];
         c->path_count[10]++;

@@ -88,15 +88,18 @@ def cqrrpt(steps):
                                        "sample": f"oracle CQRRPT (geqp3 onward, sketch supplied) on {ms}x{n}, {tc:.2f} s"}}))
 
 
-def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
+def bqrrp(steps, dtype=torch.float32, m=32768, b=2048, triple="fast"):
     ctx = _ctx()
+    # fast = {luqr, cholqr, gemqrt}; default = the reference's default-constructed object {luqr, geqrf, ormqr} (drivers/rl_bqrrp.hh:107-140)
+    QT, AQ = (1, 1) if triple == "fast" else (2, 0)
+    tname = "{luqr, cholqr, gemqrt}" if triple == "fast" else "{luqr, geqrf, ormqr} (the reference's default triple)"
     n = m
     A = d.cm_empty(m, n, dtype=dtype)
     flops = 2.0 * b * m * n + 2.0 * m * n * n - 2.0 / 3 * n**3
     best = None
     for it in range(steps + 1):
         ctx.fill_dense(A, m, n, key=(4, 0)); ctx.sync()
-        t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps), qrcp_wide=0, qr_tall=1, apply_trans_q=1); ctx.sync(); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); r = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=(it == steps), qrcp_wide=0, qr_tall=QT, apply_trans_q=AQ); ctx.sync(); dt = time.perf_counter() - t0
         if it > 0: best = dt if best is None else min(best, dt)
     apply_us = r["times_us"][5]
     ach_phase = (2.0 * m * n * n - 2.0 / 3 * n**3) / (apply_us * 1e-6) / 1e12
@@ -117,7 +120,7 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
     best_timed = best
     for it in range(2):
         ctx.fill_dense(A, m, n, key=(4, 0)); ctx.sync()
-        t0 = time.perf_counter(); r2 = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=False, qrcp_wide=0, qr_tall=1, apply_trans_q=1); ctx.sync(); dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); r2 = d.drv_bqrrp(ctx, A, m, n, b, 1.0, timing=False, qrcp_wide=0, qr_tall=QT, apply_trans_q=AQ); ctx.sync(); dt = time.perf_counter() - t0
         best = min(best, dt)
     # CPU baseline: the oracle's BQRRP restatement (same precision, same subroutine triple) on a bounded square sample with the SAME block size
     cpu = None
@@ -127,16 +130,16 @@ def bqrrp(steps, dtype=torch.float32, m=32768, b=2048):
         ms_ = 4 * b if m >= 4 * b else m
         rng = np.random.default_rng(0)
         As = rng.standard_normal((ms_, ms_)).astype(np.float32 if dtype == torch.float32 else np.float64)
-        t0 = time.perf_counter(); o = oracle.bqrrp(As, b, 1.0, qrcp_wide=0, qr_tall=1, apply_trans_q=1); tc = time.perf_counter() - t0
+        t0 = time.perf_counter(); o = oracle.bqrrp(As, b, 1.0, qrcp_wide=0, qr_tall=QT, apply_trans_q=AQ); tc = time.perf_counter() - t0
         fl_s = 2.0 * b * ms_ * ms_ + 2.0 * ms_**3 - 2.0 / 3 * ms_**3
         cpu = {"value": round(fl_s / tc / 1e9, 1), "unit": "GFLOP/s", "cores": oracle.get_threads(), "kind": "port",
-               "sample": f"oracle BQRRP {{luqr, cholqr, gemqrt}} on {ms_} x {ms_} {'fp32' if dtype == torch.float32 else 'fp64'} Gaussian, b = {b}, rank {o['rank']}, {tc:.2f} s"}
+               "sample": f"oracle BQRRP {tname} on {ms_} x {ms_} {'fp32' if dtype == torch.float32 else 'fp64'} Gaussian, b = {b}, rank {o['rank']}, {tc:.2f} s"}
     except Exception as e:  # noqa: BLE001
         cpu = {"error": repr(e)}
     print(json.dumps({"metric": f"GFLOP/s BQRRP {m} x {n} {'fp32' if dtype == torch.float32 else 'fp64'}, b={b} ({'BASELINE configs[3] on one GPU' if m == 65536 else 'single-GPU cut of BASELINE configs[3]'})",
                       "value": round(flops / best / 1e9, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": steps, "ms_per_step": round(best * 1e3, 1), "best_of": steps,
                       "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic iid N(0,1), generated on-device",
-                      "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {{luqr, cholqr, gemqrt}}", "rank": r["rank"], "times_us": r["times_us"],
+                      "config": {"workload": f"BQRRP m=n={m} b={b} d_factor=1 {tname}", "rank": r["rank"], "times_us": r["times_us"],
                                  "ms_with_subroutine_timers": round(best_timed * 1e3, 1), "frac_of_peak_whole_job": round(flops / best / 1e12 / pk, 4)},
                       "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": traffic,
                                    "traffic_source": traffic_source, "launch_ms": round(kms, 3), "flops_per_launch": 2.0 * kr * kc * b,
@@ -260,12 +263,13 @@ def abrik(steps):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("what", choices=["cqrrpt", "bqrrp", "bqrrp64", "bqrrp_full", "abrik", "rsvd_p2"]); ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--triple", choices=["fast", "default"], default="fast", help="BQRRP subroutines: fast = {luqr, cholqr, gemqrt}, default = the reference's {luqr, geqrf, ormqr}")
     ap.add_argument("--opt", action="append", default=[], help="context option name=value (e.g. saso_mode=0, cqrrpt_split_qrcp=0)")
     a = ap.parse_args()
     OPTS.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt})
     if a.what == "cqrrpt": cqrrpt(a.steps)
     elif a.what == "abrik": abrik(a.steps)
     elif a.what == "rsvd_p2": rsvd_p2(a.steps)
-    elif a.what == "bqrrp": bqrrp(a.steps)
-    elif a.what == "bqrrp_full": bqrrp(a.steps, torch.float32, 65536, 2048)      # BASELINE configs[3] itself (17 GB) on ONE device
-    else: bqrrp(a.steps, torch.float64, 16384, 512)
+    elif a.what == "bqrrp": bqrrp(a.steps, triple=a.triple)
+    elif a.what == "bqrrp_full": bqrrp(a.steps, torch.float32, 65536, 2048, a.triple)      # BASELINE configs[3] itself (17 GB) on ONE device
+    else: bqrrp(a.steps, torch.float64, 16384, 512, a.triple)

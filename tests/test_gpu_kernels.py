@@ -1163,3 +1163,39 @@ def test_saso_apply_lds_dma_route_whole_and_row_shards(ctx, orc, dd, m, n, nnz):
         acc += part
     assert np.abs(acc - ref).max() <= 2 * tol
     ctx.lib.rlhip_saso_destroy(ctx.h, S)
+
+
+def test_gesdd_jacobi_same_xcd_route_is_taken_and_changes_no_bit():
+    """The persistent Jacobi's same-XCD hand-over (jacobi.hip: workers on one XCD exchange blocks through that XCD's L2 instead of uncached
+    memory) rests on an OBSERVATION -- workgroup b lands on XCD b % 8 -- guarded by a census of HW_REG_XCC_ID: if it stops holding the launch
+    silently takes the uncached protocol and the gain is gone.  On a context that owns its stream (the shared fixture adopts torch's stream and
+    therefore launches the workers alone, where the route is not offered) path counter 15 must show that the local route WAS taken with option 1,
+    was not with option 2 (uncached always) or 3 (ordinary launch, the profiling route), and all three return the same bits."""
+    import ctypes as C
+    import torch
+
+    d = _dev()
+    c = d.Context(0, use_torch_stream=False)
+    try:
+        m, n = 20000, 256
+        A = d.cm_empty(m, n); c.fill_dense(A, m, n, key=(4, 0)); c.sync()
+        res = {}
+        for mode in (1, 2, 3):
+            c.set_option("jacobi_persist", mode)
+            W = A.clone()
+            torch.cuda.synchronize()
+            S = torch.zeros(n, dtype=torch.float64, device="cuda")
+            U, VT = d.cm_empty(m, n), d.cm_empty(n, n)
+            sw = C.c_int(0)
+            b6, b15 = c.path_count(6), c.path_count(15)
+            assert c.lib.rlhip_gesdd_f64(c.h, m, n, W.data_ptr(), m, S.data_ptr(), U.data_ptr(), m, VT.data_ptr(), n, C.byref(sw)) == 0
+            c.sync()
+            res[mode] = (S.clone(), U.clone(), VT.clone(), sw.value, c.path_count(6) - b6, c.path_count(15) - b15)
+        assert all(r[4] >= 1 for r in res.values()), "the persistent kernel did not run"
+        assert res[1][5] >= 1, "option 1: the workers were not found on one XCD (the same-XCD hand-over was never exercised on this device)"
+        assert res[2][5] == 0 and res[3][5] == 0
+        for mode in (2, 3):
+            assert res[mode][3] == res[1][3]
+            assert torch.equal(res[mode][0], res[1][0]) and torch.equal(res[mode][1], res[1][1]) and torch.equal(res[mode][2], res[1][2]), mode
+    finally:
+        c.close()

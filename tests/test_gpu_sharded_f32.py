@@ -121,17 +121,21 @@ def test_bqrrp_f32_row_sharded_pivots_exact_all_blocks(ctx, orc, worlds, world, 
 @pytest.mark.parametrize("world,cyclic", [(2, False), (3, True)])
 @pytest.mark.parametrize("qr_tall", [1, 2])
 def test_bqrrp_row_sharded_rank_deficient_blocks(ctx, orc, worlds, world, cyclic, qr_tall):
-    """A numerically rank-deficient matrix (rank r < n, the deficiency met INSIDE a block: block_rank < b_sz) on a sharded queue: both panel
+    """A numerically rank-deficient matrix (numerical rank r < n at the driver's tol, the deficiency met INSIDE a block: block_rank < b_sz) on a sharded queue: both panel
     types must leave R11's columns to the right of the deficient block's leading triangle equal to Q^T A there -- the single-device path and
     the reference run geqrf on all b_sz panel columns (drivers/rl_bqrrp.hh:506-523), the Cholesky-QR path multiplies R_chol by the b_sz
     columns of R_sk (:497).  fp64, so that the comparison is tight: the sharded output equals the single-device output to rounding."""
     from _world import block_cyclic_rows, contiguous_rows
     from randlapack_amd import device as d
 
-    m, n, b, rk = 1536, 512, 128, 300                                  # the third block (columns 256..383) is deficient from its 45th column on
+    # 300 columns at scales 1 .. 1e-2 and 212 at 1e-9 .. 1e-11, in a random order: the third block (pivots 257..384) meets the drop after 44
+    # columns (block_rank = 44 at tol = 1e-5) -- and the columns behind the drop are tiny, not zero: their pivots are still decided far above
+    # double rounding, so the whole of J is determined and the two runs can be compared entry for entry
+    m, n, b, rk = 1536, 512, 128, 300
     rng = np.random.default_rng(77)
-    A = (rng.standard_normal((m, rk)) * np.logspace(0, -3, rk)) @ rng.standard_normal((rk, n))
-    tol = 1e-10
+    s = np.concatenate([np.logspace(0, -2, rk), 1e-9 * np.logspace(0, -2, n - rk)])[rng.permutation(n)]
+    A = rng.standard_normal((m, n)) * s
+    tol = 1e-5
     A1 = d.cm_from_numpy(A)
     r1 = d.drv_bqrrp(ctx, A1, m, n, b, 1.0, want_sketch=True, key=(9, 0), qrcp_wide=0, qr_tall=qr_tall, apply_trans_q=1, tol=tol)
     F1, J1 = d.cm_to_numpy(A1), r1["J"].cpu().numpy()
@@ -147,11 +151,9 @@ def test_bqrrp_row_sharded_rank_deficient_blocks(ctx, orc, worlds, world, cyclic
     res = W.run(step)
     assert res[0]["rank"] == r1["rank"]
     J = res[0]["J"].cpu().numpy()
-    # what the factorization defines: the blocks before the deficient one and the block_rank leading columns of the deficient block (the
-    # pivots behind them are picked among numerically zero residual columns: noise)
     br = rk - 2 * b
     kk = 2 * b + br
-    np.testing.assert_array_equal(J[:kk], J1[:kk])
+    np.testing.assert_array_equal(J, J1)
     F = np.zeros((m, n))
     for r in range(world):
         F[rows[r]] = d.cm_to_numpy(shards[r])
@@ -159,14 +161,11 @@ def test_bqrrp_row_sharded_rank_deficient_blocks(ctx, orc, worlds, world, cyclic
     Q = orc.ungqr(F[:, :kk].copy(), tau[:kk])
     R = np.triu(F)[:kk, :]
     AJ = A[:, J - 1]
-    # the deficient block's columns lie in the span of its block_rank leading ones: A[:, J] = Q R there only if R11's columns to the right of
-    # the leading triangle were filled (Q^T A), not zeroed
-    assert np.linalg.norm(AJ[:, :3 * b] - Q @ R[:, :3 * b]) <= 1e-8 * np.linalg.norm(A), "the deficient block's row of R11 is incomplete"
-    # ... and entry for entry the single-device output, column by ORIGINAL column (R12 of the deficient block included: the reference's cut
-    # apply, :535-547)
+    # the columns of the deficient block behind its block_rank leading ones lie in the span of the factored columns up to 1e-9: A[:, J] = Q R
+    # there only if R11's columns to the right of the leading triangle were filled (Q^T A), not zeroed
+    assert np.linalg.norm(AJ[:, :3 * b] - Q @ R[:, :3 * b]) <= 1e-7 * np.linalg.norm(A), "the deficient block's row of R11 is incomplete"
+    # ... and entry for entry the single-device output: R11 of the deficient block and its R12 (the reference's cut apply, :535-547) included
     R1 = np.triu(F1)[:kk, :]
-    Ro, R1o = np.zeros_like(R), np.zeros_like(R1)
-    Ro[:, J - 1] = R
-    R1o[:, J1 - 1] = R1
-    assert np.linalg.norm(Ro - R1o) <= 1e-9 * np.linalg.norm(R1o)
+    assert np.linalg.norm(R - R1) <= 1e-9 * np.linalg.norm(R1)
+    assert np.abs(R[2 * b:, 3 * b:] - R1[2 * b:, 3 * b:]).max() <= 1e-9 * np.abs(R1[2 * b:, 3 * b:]).max()      # (the cut apply's own block, tiny next to the rest)
     np.testing.assert_allclose(tau[:kk], r1["tau"].cpu().numpy()[:kk], atol=1e-9, rtol=0)
