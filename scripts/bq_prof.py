@@ -10,3 +10,4 @@ for it in range(2):
     ctx.fill_dense(A, m, m, key=(4, 0)); ctx.sync()
     r = d.drv_bqrrp(ctx, A, m, m, b, 1.0, timing=True, qr_tall=1, apply_trans_q=1)
     print(r["times_us"])
+ctx.close()
