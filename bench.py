@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--n", type=int, default=N)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="context option name=value (include/rlhip.h, enum rlhip_option), e.g. jacobi_clock_holders=0; A/B runs only")
+    ap.add_argument("--busy-side", type=int, default=0, help="A/B runs only: keep this many workgroups of a SECOND stream busy with fp64 FMAs during every step (a device that is not ours alone)")
     args = ap.parse_args()
     if os.environ.get("RLHIP_BENCH_SHAPE"):      # tests: torch.distributed.run's own parser chokes on unknown short-looking options
         args.m, args.n, args.k = (int(x) for x in os.environ["RLHIP_BENCH_SHAPE"].split(","))
@@ -103,6 +105,8 @@ def main():
     from randlapack_amd import sharded
 
     ctx = dev.Context(local_rank)
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     m, n, k = args.m, args.n, args.k
     # row-block sharding: rank r owns rows [r*mloc, (r+1)*mloc) (last rank takes the remainder)
     mloc = m // world + (m % world if rank == world - 1 else 0)
@@ -113,6 +117,8 @@ def main():
     ctx.sync()
 
     def step():
+        if args.busy_side:                       # (A/B only) a second stream of this device is busy while the step runs
+            ctx.lib.rlhip_dvfs_burn(ctx.h, args.busy_side, 1, int(1.3e3 * max(1.0, 62.0 * m / 200000.0)), 1)
         if world == 1:
             return dev.drv_rsvd(ctx, A, mloc, n, k, k, 1e-12, 0, 1, key=(0, 0))
         return sharded.rsvd_rowsharded(ctx, dist, A, mloc, n, k, key=(0, 0))
@@ -229,7 +235,8 @@ def main():
                        "comm_kind": {0: "none", 1: "rccl communicator of librlhip (ncclAllReduce on the context's stream)", 2: "hook"}[int(ctx.lib.rlhip_comm_kind(ctx.h))],
                        "rccl_version": int(ctx.lib.rlhip_comm_rccl_version()) if world > 1 else None,
                        "collectives_per_step": 0 if world == 1 else 2,   # Gram matrix of Y (+ ||A||_F^2 riding on it), B^T
-                       "algorithmic_flops": flops, "qb_return": r["qb_rc"], "k_out": r["k"]},
+                       "algorithmic_flops": flops, "qb_return": r["qb_rc"], "k_out": r["k"],
+                       **({"ab_options": args.opt, "ab_busy_side_workgroups": args.busy_side} if (args.opt or args.busy_side) else {})},
             "roofline": roofline,
             "frac_of_peak_whole_job": round(value / 1e3 / (PEAK_F64_MFMA_TFLOPS * world), 4),
         }

@@ -60,7 +60,8 @@ enum rlhip_option {
     RLHIP_OPT_DRV_CQRRPT_FOLD_PIVOTING = 8,        /* CQRRPT::fold_pivoting (default 1) */
     RLHIP_OPT_DRV_CQRRPT_SPLIT_QRCP = 9,           /* CQRRPT::split_qrcp (default 1) */
     RLHIP_OPT_DRV_SPARSE_SKETCH_DENSIFY = 10,      /* linops::SparseLinOp::force_densified_sketch (default 0) */
-    RLHIP_OPT_COUNT = 11
+    RLHIP_OPT_JACOBI_CLOCK_HOLDERS = 11,           /* persistent Jacobi: 1 (default) the CUs its workers leave idle run FMA-burning holder workgroups so that DVFS keeps the clock up for the next GEMM (never on a context that shares the device with another stream); 0: the workers alone */
+    RLHIP_OPT_COUNT = 12
 };
 int rlhip_set_option(rlhip_ctx* ctx, int option, int64_t value);     /* -1 (bad context / option) or 0 */
 int64_t rlhip_get_option(rlhip_ctx* ctx, int option);                /* the stored value (-1 = default), INT64_MIN for a bad option */

@@ -69,8 +69,8 @@ int rlhip_drv_hqrrp_timed_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, i
  * well-conditioned panels are unaffected.
  * Row-sharded context (rlhip_comm_*): m and A are this rank's rows, tau needs min(global rows, n) entries; every qr_tall runs sharded
  * (cholqr: one b x b Gram all-reduce per panel; geqrf / geqrt: TSQR, the ranks' b x b triangles stacked by one all-reduce);
- * qr_tall = 1 + 16 selects the BLOCK-CYCLIC layout (global row blocks of b_sz rows dealt round-robin, block g on rank g % P, stacked in
- * increasing order in A) instead of one contiguous row block per rank.  A (m x n, lda) -> GEQP3
+ * qr_tall + 16 (16 + 3 for the object's default qr_tall) selects the BLOCK-CYCLIC layout (global row blocks of b_sz rows dealt round-robin,
+ * block g on rank g % P, stacked in increasing order in A) instead of one contiguous row block per rank.  A (m x n, lda) -> GEQP3
  * format, tau (min(m,n)), J (n) all on the device.  A_sk_in / A_sk_out: shared-sketch hooks as for CQRRPT (d x n,
  * ld d, d = (int64)(d_factor * b_sz)).  times_us[9] may be NULL.              drivers/rl_bqrrp.hh:155-665 */
 int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double d_factor, int64_t b_sz,

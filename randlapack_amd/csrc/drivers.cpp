@@ -341,7 +341,7 @@ int rlhip_drv_bqrrp_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t
         RandLAPACK::BQRRP<double, RNG> alg(q, times_us != nullptr, b_sz);
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
-        if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
+        if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; if (qr_tall == 3) qr_tall = -1; }     // + 16: block-cyclic row layout of a sharded call (16 + 3: the object's default qr_tall)
         apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }
@@ -543,7 +543,7 @@ int rlhip_drv_bqrrp_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t 
         RandLAPACK::BQRRP<float, RNG> alg(q, times_us != nullptr, b_sz);
         using Sub = RandLAPACK::BQRRPSubroutines;
         if (qrcp_wide >= 0) { if (qrcp_wide > 1) throw RandLAPACK::Error("qrcp_wide must be 0 (luqr) or 1 (geqp3)"); alg.qrcp_wide = (Sub::QRCPWide)qrcp_wide; }
-        if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; }     // + 16: block-cyclic row layout of a sharded call
+        if (qr_tall >= 16) { alg.rows_block_cyclic = true; qr_tall -= 16; if (qr_tall == 3) qr_tall = -1; }     // + 16: block-cyclic row layout of a sharded call (16 + 3: the object's default qr_tall)
         apply_bqrrp_options(ctx, alg);
         if (qr_tall >= 0) { if (qr_tall > 2) throw RandLAPACK::Error("qr_tall must be 0 (geqrt), 1 (cholqr) or 2 (geqrf)"); alg.qr_tall = (Sub::QRTall)qr_tall; }
         if (apply_trans_q >= 0) { if (apply_trans_q > 1) throw RandLAPACK::Error("apply_trans_q must be 0 (ormqr) or 1 (gemqrt)"); alg.apply_trans_q = (Sub::ApplyTransQ)apply_trans_q; }

@@ -840,7 +840,7 @@ int jacobi_verify_converged(rlhip_ctx* c, int m, int n, const T* A, int64_t lda,
 // take CUs from the other stream's kernels and make this launch wait for the whole device.
 struct JpHold { int mode, nap, delay, wgs; };
 static JpHold jp_hold(const rlhip_ctx* c) {
-    return c->avoid_persistent ? JpHold{0, 4, 0, 0} : JpHold{1, 4, 0, 1 << 20};
+    return (c->avoid_persistent || c->opt[RLHIP_OPT_JACOBI_CLOCK_HOLDERS] == 0) ? JpHold{0, 4, 0, 0} : JpHold{1, 4, 0, 1 << 20};
 }
 
 // clears the flag words and enqueues ONE persistent launch; g.A / lda / trans_upper / skip / sweep0 / max_sweeps / tol / out are the caller's

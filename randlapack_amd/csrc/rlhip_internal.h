@@ -94,7 +94,7 @@ struct rlhip_ctx {
     // > 0: columns per workgroup of the tag-exchange pivoted QR (default 4; a caller that overlaps the factorization with another kernel packs
     // the columns into fewer workgroups so that it occupies fewer CUs)
     int qrcp_cols_per_wg = 0;
-    int64_t opt[RLHIP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // rlhip_set_option; -1 = default
+    int64_t opt[RLHIP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // rlhip_set_option; -1 = default
     rlhip_ctx* side_ctx = nullptr;   // cached side context (rlhip_side_of): created on first use, destroyed with this one
     hipStream_t side = nullptr;  // second stream, created on first use (rlhip_dvfs_burn: load beside the main stream's latency-bound kernels)
     // row-sharding communicator (comm.hip), nullptr = single GPU

@@ -192,7 +192,7 @@ class Context:
 
     # ---- options (include/rlhip.h: enum rlhip_option; -1 restores the default)
     OPT = dict(cholqrq_one_stream=0, gesdd_gram=1, jacobi_persist=2, trsm_xasm=3, saso_mode=4, hqrrp_tall_panel=5,
-               bqrrp_lookahead_min_elems=6, bqrrp_cholqr_fallback=7, cqrrpt_fold_pivoting=8, cqrrpt_split_qrcp=9, sparse_sketch_densify=10)
+               bqrrp_lookahead_min_elems=6, bqrrp_cholqr_fallback=7, cqrrpt_fold_pivoting=8, cqrrpt_split_qrcp=9, sparse_sketch_densify=10, jacobi_clock_holders=11)
 
     def set_option(self, name: str, value: int) -> None:
         _lib.check(self.lib.rlhip_set_option(self.h, self.OPT[name], int(value)), "set_option")
@@ -661,7 +661,7 @@ def drv_bqrrp(ctx: Context, A, m, n, b_sz, d_factor=1.0, internal_nb=0, tol=0.0,
     rc = getattr(ctx.lib, f"rlhip_drv_bqrrp_{_suffix(A)[0]}")(ctx.h, m, n, A.data_ptr(), m, d_factor, b_sz, internal_nb, tol, tau.data_ptr(), J.data_ptr(),
                                      st, sketch_in.data_ptr() if sketch_in is not None else None,
                                      sk_out.data_ptr() if sk_out is not None else None, C.byref(rank), times,
-                                     qrcp_wide, (1 + 16) if block_cyclic else qr_tall, apply_trans_q)
+                                     qrcp_wide, (16 + (qr_tall if qr_tall >= 0 else 3)) if block_cyclic else qr_tall, apply_trans_q)
     _drv_check(ctx, rc, "bqrrp")
     out = dict(rc=rc, rank=int(rank.value), tau=tau, J=J, next_ctr=tuple(int(x) for x in st[:4]))
     if want_sketch:

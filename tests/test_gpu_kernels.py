@@ -1168,9 +1168,9 @@ def test_saso_apply_lds_dma_route_whole_and_row_shards(ctx, orc, dd, m, n, nnz):
 def test_gesdd_jacobi_same_xcd_route_is_taken_and_changes_no_bit():
     """The persistent Jacobi's same-XCD hand-over (jacobi.hip: workers on one XCD exchange blocks through that XCD's L2 instead of uncached
     memory) rests on an OBSERVATION -- workgroup b lands on XCD b % 8 -- guarded by a census of HW_REG_XCC_ID: if it stops holding the launch
-    silently takes the uncached protocol and the gain is gone.  On a context that owns its stream (the shared fixture adopts torch's stream and
-    therefore launches the workers alone, where the route is not offered) path counter 15 must show that the local route WAS taken with option 1,
-    was not with option 2 (uncached always) or 3 (ordinary launch, the profiling route), and all three return the same bits."""
+    silently takes the uncached protocol and the gain is gone.  On a context of its own (nothing else enqueued beside it) path counter 15 must
+    show that the local route WAS taken with option 1, was not with option 2 (uncached always) or 3 (ordinary launch, the profiling route),
+    and all three return the same bits."""
     import ctypes as C
     import torch
 
