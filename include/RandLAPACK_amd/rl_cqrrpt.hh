@@ -69,6 +69,7 @@ public:
         using clk = std::chrono::steady_clock;
         auto stamp = [&]() { if (timing) q.sync(); return clk::now(); };
         auto t_total0 = stamp();
+        blas::Phases ph;                 // profiler phases named like the reference's timers (rl_cqrrpt_gpu.hh:162-181): saso, qrcp, rank_reveal, a_mod_piv, a_mod_trsm, cholqr
 
         int64_t k = n;
         T* W_early = nullptr;            // split QRCP: the scratch copy of A_pre, allocated before the factorization of the sketch ...
@@ -87,6 +88,7 @@ public:
 
         // ---- sketch: S = SparseSkOp(SparseDist(d, m, nnz), state); state = S.next_state; A_hat = S * A  (:214-222)
         auto t0 = stamp();
+        ph("saso");
         {
             // Row-block sharding (one process per GPU): S is the operator for the GLOBAL row count; every rank applies its
             // column window of S to its rows and the d x n partial sketches are summed over the ranks.  Everything that
@@ -108,6 +110,7 @@ public:
             if (sketch_export) lapack::lacpy(MatrixType::General, d, n, A_hat, d, sketch_export, d, q);
         }
         auto t1 = stamp();
+        ph("qrcp");
         // ---- QRCP of the sketch (:247)
         if (qrcp == Subroutines::QRCP::hqrrp) {                                                             // :230-231
             blas::LocalOnly replicated(q);    // the sketch is replicated: every rank runs the single-device QRCP and gets the same pivots
@@ -178,6 +181,7 @@ public:
             }
         }
         auto t2 = stamp();
+        ph("rank_reveal");
 
         std::vector<T> diag(n);
         if (!diag_early.empty()) diag = diag_early;
@@ -189,6 +193,7 @@ public:
         rank = k;
         new_rank = k;
         auto t3 = stamp();
+        ph("a_mod_piv");
 
         lapack::lacpy(MatrixType::Upper, k, k, A_hat, d, R, ldr, q);                                        // :281
         // Full-rank sketches (the common case) take ONE pass over A for "permute, then precondition": the first solve reads the
@@ -203,6 +208,7 @@ public:
         if (fold_pivoting && k == n && m >= 16384) W = W_early ? W_early : ws.try_alloc<T>(ldw * n);   // no room for a second m x n matrix: the in-place order below
         if (W) {
             auto t4 = stamp();
+            ph("a_mod_trsm");
             for (int64_t i = 0; i < k; ++i)                                                                 // :296-301 diag_is_nonzero
                 if (diag[i] == (T)0) { util::col_swap(m, n, k, A, lda, J, q); return 1; }                   // (A leaves permuted, as in the reference)
             // (split QRCP: the left half of W is solved already; the right half is the same launch with other bounds.  A right half outside
@@ -210,6 +216,7 @@ public:
             if (!(half_solved && blas::trsm_gather_range(Diag::NonUnit, m, n, (T)1.0, R, ldr, A, lda, J, W, ldw, n / 2, n, q)))
                 blas::trsm_gather(Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, J, W, ldw, q);               // :288 + :302
             auto t5 = stamp();
+            ph("cholqr");
             blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, W, ldw, (T)0.0, R, ldr, q);   // :310
             if (q.world() > 1) {
                 T* G = ws.alloc<T>(k * k);
@@ -244,11 +251,13 @@ public:
         // kernel leaves its index vector untouched, so J itself is passed)
         util::col_swap(m, n, k, A, lda, J, q);
         auto t4 = stamp();
+        ph("a_mod_trsm");
 
         for (int64_t i = 0; i < k; ++i)                                                                     // :296-301 diag_is_nonzero
             if (diag[i] == (T)0) return 1;
         blas::trsm(Layout::ColMajor, Side::Right, Uplo::Upper, Op::NoTrans, Diag::NonUnit, m, k, (T)1.0, R, ldr, A, lda, q);   // :302
         auto t5 = stamp();
+        ph("cholqr");
 
         blas::syrk(Layout::ColMajor, Uplo::Upper, Op::Trans, k, m, (T)1.0, A, lda, (T)0.0, R, ldr, q);     // :310
         if (q.world() > 1) {                    // Gram matrix of the sharded rows: sum the upper triangles over the ranks
