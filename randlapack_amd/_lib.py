@@ -233,3 +233,15 @@ def check(rc: int, what: str) -> int:
     if rc < 0:
         raise RlhipError(f"{what} failed with code {rc}")
     return rc
+
+
+def lib_sha256() -> str:
+    """fingerprint of the librlhip.so this module loads: counter files (scripts/pmc_all.py) record it, the bench lines compare it -- a counter
+    file taken on THIS build is quoted even when the profiler's own overhead moved the launch time by more than 5 %"""
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()

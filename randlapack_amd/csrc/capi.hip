@@ -793,8 +793,9 @@ void roctx_bind() {
     g_roctx.state = -1;
     const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }          // a profiler brought it along
     const char* want = getenv("RLHIP_ROCTX");
+    if (want && want[0] == '0') return;                                                             // RLHIP_ROCTX=0: never
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }          // a profiler brought it along
     if (!h && want && want[0] == '1')
         for (const char* n : names) { h = dlopen(n, RTLD_NOW); if (h) break; }
     if (!h) return;

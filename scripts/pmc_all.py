@@ -67,7 +67,9 @@ def main():
     os.makedirs(out_root, exist_ok=True)
     for name in names:
         fn, filt, what, alg_bytes, flops, bound = WORKLOADS[name]
+        from randlapack_amd import _lib as _rl
         rec = {"workload": name, "kernel_filter": filt, "what": what, "bound": bound, "algorithmic_bytes": alg_bytes, "flops_per_launch": flops,
+               "librlhip_sha256": _rl.lib_sha256(),
                "command": "rocprofv3 --kernel-trace --pmc <group> --output-format csv -- python scripts/pmc_workloads.py " + name +
                           "   (three separate passes: FETCH_SIZE | WRITE_SIZE | " + " ".join(SQ) + "; scripts/pmc_all.py)",
                "correction": "FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports 1/2 of the bytes of 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM) -> "
