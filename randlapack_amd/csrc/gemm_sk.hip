@@ -603,6 +603,14 @@ int gemm_streamk(rlhip_ctx* c, int transA, int transB, int64_t m, int64_t n, int
         tune[0] = 0;
         if (const char* e = getenv("RLHIP_SK_TUNE")) sscanf(e, "%d,%d,%d,%d", &tune[0], &tune[1], &tune[2], &tune[3]);    // gs_nn, gs_tn, workgroups, stagger
     }
+    // Triangular map with few tiles (18 at n = 1024): with P = ntiles * s workgroups every tile is cut into s EQUAL K-shares, so the ntiles
+    // workgroups of one K-share walk the same rows of A at the same time (they meet in the Infinity Cache instead of streaming ntiles unrelated
+    // K ranges).  Taken when it idles < 3 % of the CUs.  C3's Gram matrix, 1048576 x 1024: 256 workgroups 17.95 ms at 2329 MHz, 252: 17.81 ms at
+    // 2391 MHz (profiles/round6_tri_gram_workgroups_ab.txt; 234 and fewer lose to the idle CUs).
+    if (tri) {
+        const int64_t per = num_cu / ntiles;
+        if (per >= 1 && ntiles * per * 100 >= 97 * (int64_t)num_cu) P = ntiles * per;
+    }
     if (tune[2] > 0 && tune[2] <= num_cu) P = tune[2];
     // Lockstep group size (sk_group).  Measured at C2 (200000 x 20000 x 256 fp64, kernel ms / FETCH_SIZE GB against 32.5 GB algorithmic):
     //   Y = A Omega (NN):   1: 29.8 / 72.8   2: 29.9 / 68.8   4: 29.9 / 52.1   8: 30.0 / 34.4   (16, 32: as 8)
