@@ -122,3 +122,17 @@ def test_lds_dma_proofs_of_this_build_hold():
     tri = (csrc / "tri.xasm_check.log").read_text()
     rows = re.findall(r"(\d+) LDS-DMA requests open at a barrier", tri)
     assert rows and all(int(r) == 0 for r in rows), tri
+
+
+def test_profiler_ranges_are_free_without_a_profiler():
+    """rlhip_range_push / _pop (the reference's NVTX ranges as roctx ranges, INTEGRATION D4) need no device and no profiler: with nothing
+    listening both return 0 and do nothing; a bad context is refused by the scope switch."""
+    import ctypes as C
+
+    from randlapack_amd import _lib
+
+    lib = _lib.load()
+    assert lib.rlhip_range_push(b"qrcp_wide") == 0
+    assert lib.rlhip_range_pop() == 0
+    assert lib.rlhip_range_pop() == 0                       # unbalanced pop: still harmless
+    assert lib.rlhip_avoid_persistent(C.c_void_p(None), 1) == -1
