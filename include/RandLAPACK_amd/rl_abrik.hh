@@ -132,6 +132,7 @@ public:
         T* Y_orth_buf = nullptr;          // k x (iter_ev k), ld k      -- sized on demand (reference: k x n up front, :247)
         T* X_orth_buf = nullptr;          // (iter_od k) x k, ld n + k  -- idem (:248)
         T* tau = ws.alloc<T>(k);
+        T* R_qr = ws.alloc<T>(k * k);            // the triangle of a fused geqrf + ungqr (lapack::geqrf_q)
         if (use_cqrrt) R_11_trans = ws.alloc<T>(k * k);
         int64_t curr_Y_cols = k, curr_X_cols = k;
         int64_t Y_i = 0, X_i = 0, R_i = -1, R_ii = 0, S_i = 0, S_ii = k;      // element offsets (the reference's moving pointers)
@@ -155,10 +156,11 @@ public:
             toc(qr_t);
         } else {
             tic();
-            lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                                       // :333
+            const bool fused = fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q);          // :333 + :342 in one pass
+            if (!fused) lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                           // :333
             toc(qr_t);
             tic();
-            lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                                    // :342
+            if (!fused) lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                        // :342
             toc(ungqr_t);
         }
         ++iter_od;
@@ -194,13 +196,15 @@ public:
                     toc(r_cpy_t);
                 } else {
                     tic();
-                    lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                               // :420
+                    const bool fused = fuse_geqrf_ungqr && lapack::geqrf_q(n, k, Y_od.p + Y_i, n, R_qr, k, q);  // :420 + :444 in one pass
+                    if (!fused) lapack::geqrf(n, k, Y_od.p + Y_i, n, tau, q);                                   // :420
                     toc(qr_t);
                     tic();
-                    util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                            // :432 (upper triangle, transposed)
+                    if (fused) util::transposition(k, k, R_qr, k, R.p + R_ii, n, 1, q);
+                    else util::transposition(k, k, Y_od.p + Y_i, n, R.p + R_ii, n, 1, q);                       // :432 (upper triangle, transposed)
                     toc(r_cpy_t);
                     tic();
-                    lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                            // :444
+                    if (!fused) lapack::ungqr(n, k, k, Y_od.p + Y_i, n, tau, q);                                // :444
                     toc(ungqr_t);
                 }
                 if (std::abs(elem(R.p + R_ii + (n + 1) * (k - 1))) < sqrt_eps) break;                           // :455-458
@@ -238,13 +242,15 @@ public:
                     toc(qr_t);
                 } else {
                     tic();
-                    lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                               // :552
+                    const bool fused = fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q);  // :552 + :570 in one pass
+                    if (!fused) lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                   // :552
                     toc(qr_t);
                     tic();
-                    lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);              // :561
+                    if (fused) lapack::lacpy(MatrixType::Upper, k, k, R_qr, k, S.p + S_ii, n + k, q);
+                    else lapack::lacpy(MatrixType::Upper, k, k, X_ev.p + X_i, m, S.p + S_ii, n + k, q);         // :561
                     toc(s_cpy_t);
                     tic();
-                    lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                            // :570
+                    if (!fused) lapack::ungqr(m, k, k, X_ev.p + X_i, m, tau, q);                                // :570
                     toc(ungqr_t);
                 }
                 if (std::abs(elem(S.p + S_ii + ((n + k) + 1) * (k - 1))) < sqrt_eps) break;                     // :595-598
@@ -299,6 +305,10 @@ public:
 
     blas::Queue& q;
     Subroutines::QR_explicit qr_exp;
+    // (not in the reference) qr_exp = geqrf_ungqr: run each geqrf + ungqr pair (:333-342, :420-444, :552-570) as ONE pass over the panel
+    // (lapack::geqrf_q: Cholesky-QR twice + the sign vector of the Householder reconstruction; same Q and R to rounding, the two calls when
+    // the panel is not tall / well conditioned enough).  (A row-sharded operator runs CQRRT panels anyway.)
+    bool fuse_geqrf_ungqr = true;
     bool verbose;
     bool timing;
     T tol;

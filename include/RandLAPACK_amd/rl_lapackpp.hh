@@ -90,6 +90,9 @@ inline void tau_from_t(int64_t k, int64_t nb, float const* T, int64_t ldt, float
 // Householder QR / LU building blocks (device tau / ipiv)
 inline int64_t geqrf(int64_t m, int64_t n, double* A, int64_t lda, double* tau, Queue& q = blas::default_queue()) { int rc = rlhip_geqrf_f64(q.ctx(), m, n, A, lda, tau); blas::check(rc, "geqrf"); return rc; }
 inline int64_t geqrf(int64_t m, int64_t n, float* A, int64_t lda, float* tau, Queue& q = blas::default_queue()) { int rc = rlhip_geqrf_f32(q.ctx(), m, n, A, lda, tau); blas::check(rc, "geqrf"); return rc; }
+// geqrf + ungqr(m, n, n) in one call (rlhip_geqrf_q): true when done (A = Q, R = the n x n triangle, zero below), false when not taken -- the caller runs the two calls
+inline bool geqrf_q(int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr, Queue& q = blas::default_queue()) { int rc = rlhip_geqrf_q_f64(q.ctx(), m, n, A, lda, R, ldr); blas::check(rc, "geqrf_q"); return rc == 0; }
+inline bool geqrf_q(int64_t m, int64_t n, float* A, int64_t lda, float* R, int64_t ldr, Queue& q = blas::default_queue()) { int rc = rlhip_geqrf_q_f32(q.ctx(), m, n, A, lda, R, ldr); blas::check(rc, "geqrf_q"); return rc == 0; }
 inline void ungqr(int64_t m, int64_t n, int64_t k, double* A, int64_t lda, double const* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_ungqr_f64(q.ctx(), m, n, k, A, lda, tau), "ungqr"); }
 inline void ungqr(int64_t m, int64_t n, int64_t k, float* A, int64_t lda, float const* tau, Queue& q = blas::default_queue()) { blas::check(rlhip_ungqr_f32(q.ctx(), m, n, k, A, lda, tau), "ungqr"); }
 // returns info (> 0: exactly singular U, factorization still complete)

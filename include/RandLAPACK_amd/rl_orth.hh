@@ -142,6 +142,8 @@ public:
         if (q.reduce_over_rows()) return detail::tsqr_q(q, m, n, A, m);   // row-sharded: TSQR, one n x n-sized exchange
         blas::Scratch ws(q);
         T* tau = ws.alloc<T>(n);
+        // geqrf + ungqr as one pass over a tall panel when the device can (lapack::geqrf_q: same Q to rounding), else the two calls
+        if (T* Rq = ws.try_alloc<T>(n * n); Rq && lapack::geqrf_q(m, n, A, m, Rq, n, q)) return 0;
         if (lapack::geqrf(m, n, A, m, tau, q)) return 1;                                                 // :157
         lapack::ungqr(m, n, n, A, m, tau, q);                                                            // :162
         return 0;

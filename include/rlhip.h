@@ -279,6 +279,13 @@ int rlhip_getrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda,
 /* lapack::geqrf (rl_orth.hh:157, rl_bqrrp.hh:356,515): Householder QR, reflectors below the diagonal, tau: DEVICE.
  * lapack::ungqr(m, n, k = n) (rl_orth.hh:162): overwrite the reflectors with the first n columns of Q (k must equal n).
  * lapack::laswp(n, A, lda, k1, k2, ipiv, 1) (rl_orth.hh:226): forward row interchanges, ipiv DEVICE int64 1-based. */
+/* geqrf FOLLOWED BY ungqr(m, n, n) in one call, for the call sites that want the explicit orthonormal factor (rl_abrik.hh:333-342, :420-444,
+ * :552-570; HQRQ, rl_orth.hh:157-162): A <- the first n columns of the Householder Q, R (n x n, ld ldr) <- the triangle geqrf leaves
+ * (zero below the diagonal).  Tall well-conditioned panels only (Cholesky-QR twice + the sign vector of the Householder reconstruction,
+ * csrc/house.hip::geqrf_q): returns 0 when done, 1 when NOT taken -- the caller then runs rlhip_geqrf + rlhip_ungqr on A, which is still its
+ * input to rounding -- < 0 on error.  Same Q and R as the two calls up to rounding. */
+int rlhip_geqrf_q_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* R, int64_t ldr);
+int rlhip_geqrf_q_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* R, int64_t ldr);
 int rlhip_geqrf_f64(rlhip_ctx* ctx, int64_t m, int64_t n, double* A, int64_t lda, double* tau);
 int rlhip_geqrf_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A, int64_t lda, float* tau);
 int rlhip_ungqr_f64(rlhip_ctx* ctx, int64_t m, int64_t n, int64_t k, double* A, int64_t lda, const double* tau);

@@ -49,6 +49,7 @@ def _blas3(T):
         "tau_from_t": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
         "any_abs_gt": [c_vp, c_i64, c_vp, T, C.POINTER(c_int)],
         "geqrf": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp],
+        "geqrf_q": [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "vrows_explicit": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64],
         "qrp_partial": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],
         "geqp3_steps": [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp],

@@ -22,6 +22,7 @@ template <typename T> int cholqrq(rlhip_ctx* c, int64_t m, int64_t k, T* A, int6
 int col_swap_i64(rlhip_ctx* c, int64_t n, int64_t k, int64_t* A, const int64_t* idx_dev);
 template <typename T> int geqp3(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, int64_t* jpvt_dev, T* tau_dev);
 template <typename T> int orhr_col(rlhip_ctx*, int64_t, int64_t, int64_t, T*, int64_t, T*, int64_t, T*);
+template <typename T> int geqrf_q(rlhip_ctx*, int64_t, int64_t, T*, int64_t, T*, int64_t, int*);
 template <typename T> int gemqrt_lt(rlhip_ctx*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t);
 template <typename T> int gemqrt_lt_head(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, int64_t, T*, int64_t, T*);
 template <typename T> int gemqrt_lt_tail(rlhip_ctx*, int64_t, int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t);
@@ -553,6 +554,11 @@ static inline int op_flag(char t, int* out) {
     }                                                                                                           \
     int rlhip_gemqrt_tail_##SUF(rlhip_ctx* c, int64_t m, int64_t n, int64_t k, const T* V, int64_t ldv, const T* W2, T* C, int64_t ldc) { \
         return rlhip::gemqrt_lt_tail<T>(c, m, n, k, V, ldv, W2, C, ldc);                                        \
+    }                                                                                                           \
+    int rlhip_geqrf_q_##SUF(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R, int64_t ldr) {         \
+        int done = 0;                                                                                            \
+        const int rc = rlhip::geqrf_q<T>(c, m, n, A, lda, R, ldr, &done);                                        \
+        return rc ? rc : (done ? 0 : 1);                                                                        \
     }                                                                                                           \
     int rlhip_vrows_explicit_##SUF(rlhip_ctx* c, int64_t br, int64_t toff, int64_t tcnt, const T* Vtop, int64_t ldv, T* out, int64_t ldo) { \
         return rlhip::vrows_explicit<T>(c, br, toff, tcnt, Vtop, ldv, out, ldo);                                \

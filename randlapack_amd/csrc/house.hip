@@ -164,6 +164,9 @@ template <typename T> int gemm(rlhip_ctx*, int, int, int64_t, int64_t, int64_t, 
 template <typename T>
 int lunp_blk(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D);
 
+template <typename T>
+static int lunp_top(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D);
+
 // A (m x n, orthonormal columns) -> V (unit lower trapezoidal, in place), T (nb x n), D (n)
 template <typename T>
 int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, T* Tm, int64_t ldt, T* D) {
@@ -174,25 +177,9 @@ int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, 
     if (nb > n) nb = n;
     if (ldt < (nb > 1 ? nb : 1)) return -8;
     if (n == 0) return 0;
-    // (1) sign-modified LU of the top n x n block: one launch of the block-pipelined kernel when it fits (qr_blk.hip), else 32-column panels
-    const int rb = lunp_blk<T>(c, n, A, lda, D);
-    if (rb < 0) return rb;
-    for (int64_t j0 = (rb == 1) ? n : 0; j0 < n; j0 += LB) {
-        const int jb = (int)((n - j0 < LB) ? (n - j0) : LB);
-        const int64_t rest = n - j0 - jb;
-        unsigned blocks = (unsigned)((rest + 255) / 256);
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(lunp_panel_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, j0, jb, A, lda, D);
-        RLHIP_LAUNCH_CHECK();
-        if (rest > 0) {
-            // L21 = A21 * U11^-1 (rows j0+jb .. n-1)
-            int rc = trsm_right_upper<T>(c, 0, rest, jb, T(1), A + j0 + j0 * lda, lda, A + (j0 + jb) + j0 * lda, lda);
-            if (rc) return rc;
-            // A22 -= L21 * U12
-            rc = gemm<T>(c, 0, 0, rest, rest, jb, T(-1), A + (j0 + jb) + j0 * lda, lda, A + j0 + (j0 + jb) * lda, lda, T(1),
-                         A + (j0 + jb) + (j0 + jb) * lda, lda);
-            if (rc) return rc;
-        }
+    {
+        const int rc1 = lunp_top<T>(c, n, A, lda, D);
+        if (rc1) return rc1;
     }
     // (2) V2 = Q2 * U^-1 for the rows below the top block
     if (m > n) {
@@ -215,6 +202,32 @@ int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, 
         if (rc) { rlhip_ws_release(c, mark); return rc; }
     }
     rlhip_ws_release(c, mark);
+    return 0;
+}
+
+// (1) of orhr_col: the sign-modified LU of the top n x n block (in place: unit lower L below, U on and above the diagonal), D = its sign
+// vector -- one launch of the block-pipelined kernel when it fits (qr_blk.hip), else 32-column panels
+template <typename T>
+static int lunp_top(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
+    const int rb = lunp_blk<T>(c, n, A, lda, D);
+    if (rb < 0) return rb;
+    for (int64_t j0 = (rb == 1) ? n : 0; j0 < n; j0 += LB) {
+        const int jb = (int)((n - j0 < LB) ? (n - j0) : LB);
+        const int64_t rest = n - j0 - jb;
+        unsigned blocks = (unsigned)((rest + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(lunp_panel_kernel<T>, dim3(blocks), dim3(256), 0, c->stream, n, j0, jb, A, lda, D);
+        RLHIP_LAUNCH_CHECK();
+        if (rest > 0) {
+            // L21 = A21 * U11^-1 (rows j0+jb .. n-1)
+            int rc = trsm_right_upper<T>(c, 0, rest, jb, T(1), A + j0 + j0 * lda, lda, A + (j0 + jb) + j0 * lda, lda);
+            if (rc) return rc;
+            // A22 -= L21 * U12
+            rc = gemm<T>(c, 0, 0, rest, rest, jb, T(-1), A + (j0 + jb) + j0 * lda, lda, A + j0 + (j0 + jb) * lda, lda, T(1),
+                         A + (j0 + jb) + (j0 + jb) * lda, lda);
+            if (rc) return rc;
+        }
+    }
     return 0;
 }
 
@@ -451,19 +464,18 @@ int saso_destroy(rlhip_ctx* c, SasoOp* op);
 template <typename T> int saso_apply(rlhip_ctx* c, const SasoOp* op, int64_t n, T alpha, const T* A, int64_t lda, T beta, T* B, int64_t ldb);
 template <typename T> int geqrf(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau_dev);
 
+// A (m x n, tall) <- its orthonormal factor by Cholesky-QR twice, R2 (n x n, ld n) <- the upper-triangular R with A_in = Q R2; for an
+// ill-conditioned panel once more behind a sparse-sketch preconditioner (below).  *good = false: A holds its input (up to rounding, or bit
+// for bit after the preconditioned attempt) and the caller takes the Householder route.  The caller owns the arena mark.
 template <typename T>
-int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done) {
-    *done = 0;
-    size_t mark = rlhip_ws_mark(c);
+static int cholqr_orthonormal(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R2, bool* good_out) {
+    *good_out = false;
     T* R1 = ws_alloc<T>(c, (size_t)n * n);
-    T* R2 = ws_alloc<T>(c, (size_t)n * n);
-    T* Tm = ws_alloc<T>(c, (size_t)n * n);
-    T* D = ws_alloc<T>(c, (size_t)n);
     T* dev1 = ws_alloc<T>(c, 4);
-    if (!R1 || !R2 || !Tm || !D || !dev1) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    if (!R1 || !dev1) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     bool good = false;
     int rc = cholqr2_inplace<T>(c, m, n, A, lda, R1, R2, dev1, &good);
-    if (rc) { rlhip_ws_release(c, mark); return rc; }
+    if (rc) return rc;
     // An ill-conditioned tall panel (ABRIK's Krylov blocks on a quickly decaying operator, rl_abrik.hh:333: cond 1e10 and beyond) is
     // where Cholesky-QR gives up and the column-by-column Householder kernel took over -- 10 ms for a 200000 x 32 panel.  Before that,
     // one more BLAS-3 attempt in the manner of CQRRT (rl_cqrrt.hh:124-200): a sparse sketch S A (2n rows), its small QR, and
@@ -505,8 +517,23 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
                 else c->path_count[5]++;
             }
         }
-        if (rc) { rlhip_ws_release(c, mark); return rc; }
+        if (rc) return rc;
     }
+    *good_out = good;
+    return 0;
+}
+
+template <typename T>
+int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, int* done) {
+    *done = 0;
+    size_t mark = rlhip_ws_mark(c);
+    T* R2 = ws_alloc<T>(c, (size_t)n * n);
+    T* Tm = ws_alloc<T>(c, (size_t)n * n);
+    T* D = ws_alloc<T>(c, (size_t)n);
+    if (!R2 || !Tm || !D) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    bool good = false;
+    int rc = cholqr_orthonormal<T>(c, m, n, A, lda, R2, &good);
+    if (rc) { rlhip_ws_release(c, mark); return rc; }
     if (!good) { rlhip_ws_release(c, mark); return 0; }                              // let Householder do it
     rc = orhr_col<T>(c, m, n, n, A, lda, Tm, n, D);                                  // V below the diagonal, T, sign vector D
     if (!rc) rc = row_sign<T>(c, n, R2, n, D);                                      // R <- D R
@@ -518,6 +545,54 @@ int geqrf_cholqr(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* tau, 
 }
 template int geqrf_cholqr<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*, int*);
 template int geqrf_cholqr<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*, int*);
+
+// geqrf followed by ungqr(m, n, n) in ONE pass for a tall panel (ABRIK's Krylov blocks, rl_abrik.hh:333-342 / :420-444 / :552-570; HQRQ,
+// rl_orth.hh:157-162): A <- the first n columns of the Householder Q, R (n x n, ld ldr) <- the triangle geqrf would have left (zero below).
+// The BLAS-3 geqrf above goes orthonormal factor -> reflectors (orhr_col over all m rows, T factor) and ungqr then goes reflectors ->
+// orthonormal factor again: two passes over the panel and ~25 launches that cancel.  LAPACK's reconstruction contract is
+// Q_cholesky = Q_householder diag(D), R_householder = diag(D) R_cholesky with D = +-1 decided by the sign-modified LU of the TOP n x n block alone
+// (orhr_col's D depends on no other row), so: Cholesky-QR twice, D from a copy of the top block, one column scaling.  Same Q and R as the two
+// calls to rounding.  *done = 0: not taken (A as geqrf_cholqr leaves it), the caller runs geqrf + ungqr.
+template <typename T>
+__global__ void scale_cols_sign_kernel(int64_t m, int64_t n, T* __restrict__ A, int64_t lda, const T* __restrict__ D) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * n) return;
+    const int64_t i = idx % m, j = idx / m;
+    if (D[j] < T(0)) A[i + j * lda] = -A[i + j * lda];
+}
+template <typename T>
+int geqrf_q(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R, int64_t ldr, int* done) {
+    *done = 0;
+    if (m < 0) return -2;
+    if (n < 0) return -3;
+    if (lda < (m > 1 ? m : 1)) return -5;
+    if (ldr < (n > 1 ? n : 1)) return -7;
+    if (n == 0 || m == 0) { *done = 1; return 0; }
+    if (!(m >= 2 * n && n >= 8 && (size_t)m * n >= 16384)) return 0;                 // (the shapes the BLAS-3 geqrf serves)
+    size_t mark = rlhip_ws_mark(c);
+    T* R2 = ws_alloc<T>(c, (size_t)n * n);
+    T* Qt = ws_alloc<T>(c, (size_t)n * n);
+    T* D = ws_alloc<T>(c, (size_t)n);
+    if (!R2 || !Qt || !D) { rlhip_ws_release(c, mark); return RLHIP_ERR_HIP(hipErrorOutOfMemory); }
+    bool good = false;
+    int rc = cholqr_orthonormal<T>(c, m, n, A, lda, R2, &good);
+    if (rc || !good) { rlhip_ws_release(c, mark); return rc; }
+    rc = lacpy<T>(c, 2, n, n, A, lda, Qt, n);
+    if (!rc) rc = lunp_top<T>(c, n, Qt, n, D);                                      // only D is wanted: the sign pattern of the top block's LU
+    if (!rc) rc = row_sign<T>(c, n, R2, n, D);                                      // R <- D R
+    if (!rc) {
+        hipLaunchKernelGGL(scale_cols_sign_kernel<T>, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, m, n, A, lda, (const T*)D);   // Q <- Q D
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) rc = RLHIP_ERR_HIP(le);
+    }
+    if (!rc) rc = laset<T>(c, 2, n, n, T(0), T(0), R, ldr);
+    if (!rc) rc = lacpy<T>(c, 0, n, n, R2, n, R, ldr);
+    rlhip_ws_release(c, mark);
+    if (!rc) *done = 1;
+    return rc;
+}
+template int geqrf_q<double>(rlhip_ctx*, int64_t, int64_t, double*, int64_t, double*, int64_t, int*);
+template int geqrf_q<float>(rlhip_ctx*, int64_t, int64_t, float*, int64_t, float*, int64_t, int*);
 
 
 // Rows [toff, toff + tcnt) of the unit-lower-triangular factor stored implicitly in Vtop (br x br: strictly lower part significant)

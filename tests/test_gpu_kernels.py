@@ -1199,3 +1199,47 @@ def test_gesdd_jacobi_same_xcd_route_is_taken_and_changes_no_bit():
             assert torch.equal(res[mode][0], res[1][0]) and torch.equal(res[mode][1], res[1][1]) and torch.equal(res[mode][2], res[1][2]), mode
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("m,n,cond,dtype", [(200000, 32, 10.0, "f64"), (20000, 256, 1e3, "f64"), (4096, 64, 1e6, "f64"), (50000, 64, 10.0, "f32"),
+                                            (3000, 40, 1e12, "f64"), (100, 64, 10.0, "f64")])
+def test_geqrf_q_equals_geqrf_then_ungqr(ctx, m, n, cond, dtype):
+    """rlhip_geqrf_q (geqrf + ungqr(m, n, n) in one pass over a tall panel: ABRIK's Krylov blocks rl_abrik.hh:333-342, HQRQ rl_orth.hh:157-162)
+    against the two calls it replaces, on the device: the same Q (Householder sign convention included) and the same triangle to rounding; a
+    panel it does not take (not tall: m < 2 n) comes back untouched with return code 1; an ill-conditioned one is either served through the
+    sketch-preconditioned route or handed back -- never wrong."""
+    import torch
+
+    d = _dev()
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    eps = float(np.finfo(np.float64 if dtype == "f64" else np.float32).eps)
+    rng = np.random.default_rng(m + n)
+    A = (np.linalg.qr(rng.standard_normal((m, n)))[0] * np.logspace(0, -np.log10(cond), n)) @ np.linalg.qr(rng.standard_normal((n, n)))[0].T
+    A0 = d.cm_from_numpy(A).to(tdt)
+    # the two calls
+    A2 = A0.clone()
+    tau = torch.zeros(n, dtype=tdt, device="cuda")
+    assert getattr(ctx.lib, f"rlhip_geqrf_{dtype}")(ctx.h, m, n, A2.data_ptr(), m, tau.data_ptr()) == 0
+    R2 = torch.triu(A2[:, :n].T.clone())                       # column-major tensor: A2[j][i] = entry (i, j)
+    assert getattr(ctx.lib, f"rlhip_ungqr_{dtype}")(ctx.h, m, n, n, A2.data_ptr(), m, tau.data_ptr()) == 0
+    # the one call
+    A1 = A0.clone()
+    R1 = torch.full((n, n), float("nan"), dtype=tdt, device="cuda")
+    rc = getattr(ctx.lib, f"rlhip_geqrf_q_{dtype}")(ctx.h, m, n, A1.data_ptr(), m, R1.data_ptr(), n)
+    ctx.sync()
+    if m < 2 * n:
+        assert rc == 1 and torch.equal(A1, A0)
+        return
+    assert rc in (0, 1)
+    if rc == 1:                                                 # handed back: the input must still be there (to rounding)
+        assert float((A1 - A0).abs().max()) <= 64 * eps * float(A0.abs().max())
+        assert cond >= 1e8, "a well-conditioned tall panel was not taken"
+        return
+    Q1, Q2 = A1.double(), A2.double()
+    R1m, R2m = R1.T.double(), R2.double()
+    tol = 200 * eps * max(cond, 1.0) if cond < 1e8 else 1e-3     # (the columns of Q that belong to the tiny singular values move by eps * cond between any two routes)
+    assert float((Q1 @ Q1.T - torch.eye(n, device="cuda", dtype=torch.float64)).abs().max()) <= 100 * eps * np.sqrt(n)          # (n x m)(m x n): Q^T Q
+    assert float((R1m - torch.triu(R1m)).abs().max()) == 0.0                                                                     # zero below the diagonal
+    assert float((Q1 - Q2).abs().max()) <= tol, "Q differs from geqrf + ungqr (sign convention or values)"
+    assert float((R1m - R2m).abs().max()) <= tol * float(R2m.abs().max())
+    assert float(((R1m.T @ Q1).T - A0.double().T).abs().max()) <= 100 * eps * float(A0.abs().max()) * np.sqrt(n)                # A = Q R
