@@ -209,7 +209,8 @@ int orhr_col(rlhip_ctx* c, int64_t m, int64_t n, int64_t nb, T* A, int64_t lda, 
 // vector -- one launch of the block-pipelined kernel when it fits (qr_blk.hip), else 32-column panels
 template <typename T>
 static int lunp_top(rlhip_ctx* c, int64_t n, T* A, int64_t lda, T* D) {
-    const int rb = lunp_blk<T>(c, n, A, lda, D);
+    // n <= one panel (ABRIK's 32-column Krylov blocks): ONE launch of the LDS panel kernel (~10 us) instead of the cooperative launch (42 us)
+    const int rb = (n <= LB) ? 0 : lunp_blk<T>(c, n, A, lda, D);
     if (rb < 0) return rb;
     for (int64_t j0 = (rb == 1) ? n : 0; j0 < n; j0 += LB) {
         const int jb = (int)((n - j0 < LB) ? (n - j0) : LB);
@@ -428,9 +429,79 @@ __global__ void r2_identity_dev_kernel(int n, const T* __restrict__ R, int64_t l
 // Cholesky-QR twice, in place: on success A = Q (orthonormal columns) and R2 = the upper-triangular R with A_in = Q R2; *good = false
 // (A restored to A_in up to rounding, or untouched) when a Cholesky factorization breaks down or the second R factor is not close to the
 // identity -- the first Q was then too far from orthonormal for the second pass to repair it (cond(A) beyond ~1e7 in fp64).
+// ---- skinny panels (n <= 64: ABRIK's Krylov blocks): X <- X R^-1 with a thread per row and R in LDS, and the whole Cholesky-QR-twice
+// sequence behind ONE host read.  The generic route reads LAPACK's info after each Cholesky factorization and the identity defect after the
+// second (three stream drains of ~25 us around ~250 us of kernels); here the factorizations are enqueued (potrf_upper_enqueue: info on the
+// device), the first solve tests that word itself and leaves X alone after a breakdown, and the three verdicts come back together.
+constexpr int SKN = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_trsm_kernel(int64_t m, int n, const T* __restrict__ R, int64_t ldr, T* __restrict__ X, int64_t ldx,
+                                                          const int* __restrict__ skip) {
+    __shared__ T sR[SKN * SKN];                     // sR[i + j * n] = R(i, j), i < j; the diagonal holds 1 / R(j, j)
+    if (skip && *skip != 0) return;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e % n, j = e / n;
+        const T v = R[i + (int64_t)j * ldr];
+        sR[e] = (i == j) ? T(1) / v : v;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    T x[SKN];
+#pragma unroll
+    for (int j = 0; j < SKN; ++j) x[j] = (j < n) ? X[r + (int64_t)j * ldx] : T(0);
+#pragma unroll
+    for (int j = 0; j < SKN; ++j) {
+        if (j < n) {
+            T sacc = x[j];
+#pragma unroll
+            for (int i = 0; i < SKN; ++i)
+                if (i < j) sacc -= x[i] * sR[i + j * n];
+            x[j] = sacc * sR[j + j * n];
+            X[r + (int64_t)j * ldx] = x[j];
+        }
+    }
+}
+template <typename T> int potrf_upper_enqueue(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_dev);
+
+template <typename T>
+static int cholqr2_skinny(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R1, T* R2, T* dev1, bool* good) {
+    *good = false;
+    int* flags = (int*)ws_alloc<int64_t>(c, 2);      // [0] info of the first factorization, [1] of the second
+    if (!flags) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
+    RLHIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int64_t), c->stream));
+    RLHIP_CHECK(hipMemsetAsync(dev1, 0, sizeof(T), c->stream));
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
+    if (!rc) rc = potrf_upper_enqueue<T>(c, n, R1, n, flags);
+    if (rc) return rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown);
+    hipLaunchKernelGGL(skinny_trsm_kernel<T>, dim3(grid), dim3(256), 0, c->stream, m, (int)n, (const T*)R1, (int64_t)n, A, lda, (const int*)flags);
+    RLHIP_LAUNCH_CHECK();
+    rc = laset<T>(c, 2, n, n, T(0), T(0), R2, n);
+    if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R2, n);
+    if (!rc) rc = potrf_upper_enqueue<T>(c, n, R2, n, flags + 2);
+    if (rc) return rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown);
+    hipLaunchKernelGGL(r2_identity_dev_kernel<T>, dim3(1), dim3(256), 0, c->stream, (int)n, R2, (int64_t)n, dev1);
+    RLHIP_LAUNCH_CHECK();
+    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 44, flags, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(hipMemcpyAsync(c->h_mail + 46, dev1, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    RLHIP_CHECK(rlhip_stream_sync(c));
+    const int info1 = *(const int*)(c->h_mail + 44), info2 = *(const int*)(c->h_mail + 45);
+    const T dev_h = *(const T*)(c->h_mail + 46);
+    if (info1) return 0;                                                             // A untouched (the solve saw the flag)
+    if (info2 || !(dev_h <= T(1e-2))) return trmm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);   // restore A = Q1 R1
+    hipLaunchKernelGGL(skinny_trsm_kernel<T>, dim3(grid), dim3(256), 0, c->stream, m, (int)n, (const T*)R2, (int64_t)n, A, lda, (const int*)nullptr);   // A = Q
+    RLHIP_LAUNCH_CHECK();
+    rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R1, n, R2, n);                   // R2 <- R2 R1
+    if (!rc) *good = true;
+    return rc;
+}
+
 template <typename T>
 static int cholqr2_inplace(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R1, T* R2, T* dev1, bool* good) {
     *good = false;
+    if (n <= SKN && m >= 4096) return cholqr2_skinny<T>(c, m, n, A, lda, R1, R2, dev1, good);
     int info = 0;
     int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
     if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
