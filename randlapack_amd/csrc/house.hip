@@ -434,33 +434,45 @@ __global__ void r2_identity_dev_kernel(int n, const T* __restrict__ R, int64_t l
 // second (three stream drains of ~25 us around ~250 us of kernels); here the factorizations are enqueued (potrf_upper_enqueue: info on the
 // device), the first solve tests that word itself and leaves X alone after a breakdown, and the three verdicts come back together.
 constexpr int SKN = 64;
-template <typename T>
-__global__ __launch_bounds__(256) void skinny_trsm_kernel(int64_t m, int n, const T* __restrict__ R, int64_t ldr, T* __restrict__ X, int64_t ldx,
+// n = N exactly (16 / 32 / 64: the block sizes ABRIK is run with): every register index is a compile-time constant and nothing is predicated.
+// (A run-time bound n <= N inside the unrolled loops -- predicated loads and stores -- sent the row to scratch: 149 us instead of ~25 at
+// 200000 x 32; other widths take the generic route.)
+template <typename T, int N>
+__global__ __launch_bounds__(256) void skinny_trsm_kernel(int64_t m, const T* __restrict__ R, int64_t ldr, T* __restrict__ X, int64_t ldx,
                                                           const int* __restrict__ skip) {
-    __shared__ T sR[SKN * SKN];                     // sR[i + j * n] = R(i, j), i < j; the diagonal holds 1 / R(j, j)
+    __shared__ T sR[N * N];                         // sR[j * N + i] = R(j, i) for j < i (row j of R, contiguous); the diagonal holds 1 / R(j, j)
     if (skip && *skip != 0) return;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        const int i = e % n, j = e / n;
-        const T v = R[i + (int64_t)j * ldr];
-        sR[e] = (i == j) ? T(1) / v : v;
+    for (int e = threadIdx.x; e < N * N; e += 256) {
+        const int j = e / N, i = e % N;             // entry (j, i); below the diagonal: never read
+        T v = R[j + (int64_t)i * ldr];
+        if (j == i) v = T(1) / v;
+        sR[e] = v;
     }
     __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
-    T x[SKN];
+    T x[N];
+    T* p = X + r;
 #pragma unroll
-    for (int j = 0; j < SKN; ++j) x[j] = (j < n) ? X[r + (int64_t)j * ldx] : T(0);
+    for (int j = 0; j < N; ++j) x[j] = p[(int64_t)j * ldx];
 #pragma unroll
-    for (int j = 0; j < SKN; ++j) {
-        if (j < n) {
-            T sacc = x[j];
+    for (int j = 0; j < N; ++j) {
+        x[j] *= sR[j * N + j];
 #pragma unroll
-            for (int i = 0; i < SKN; ++i)
-                if (i < j) sacc -= x[i] * sR[i + j * n];
-            x[j] = sacc * sR[j + j * n];
-            X[r + (int64_t)j * ldx] = x[j];
-        }
+        for (int i = j + 1; i < N; ++i) x[i] -= x[j] * sR[j * N + i];
     }
+#pragma unroll
+    for (int j = 0; j < N; ++j) p[(int64_t)j * ldx] = x[j];
+}
+template <typename T>
+static int skinny_trsm(rlhip_ctx* c, int64_t m, int64_t n, const T* R, int64_t ldr, T* X, int64_t ldx, const int* skip) {
+    const unsigned grid = (unsigned)((m + 255) / 256);
+    if (n == 16) hipLaunchKernelGGL((skinny_trsm_kernel<T, 16>), dim3(grid), dim3(256), 0, c->stream, m, R, ldr, X, ldx, skip);
+    else if (n == 32) hipLaunchKernelGGL((skinny_trsm_kernel<T, 32>), dim3(grid), dim3(256), 0, c->stream, m, R, ldr, X, ldx, skip);
+    else if (n == 64) hipLaunchKernelGGL((skinny_trsm_kernel<T, 64>), dim3(grid), dim3(256), 0, c->stream, m, R, ldr, X, ldx, skip);
+    else return -3;
+    RLHIP_LAUNCH_CHECK();
+    return 0;
 }
 template <typename T> int potrf_upper_enqueue(rlhip_ctx* c, int64_t n, T* A, int64_t lda, int* info_dev);
 
@@ -471,13 +483,12 @@ static int cholqr2_skinny(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda,
     if (!flags) return RLHIP_ERR_HIP(hipErrorOutOfMemory);
     RLHIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int64_t), c->stream));
     RLHIP_CHECK(hipMemsetAsync(dev1, 0, sizeof(T), c->stream));
-    const unsigned grid = (unsigned)((m + 255) / 256);
     int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
     if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);
     if (!rc) rc = potrf_upper_enqueue<T>(c, n, R1, n, flags);
     if (rc) return rc < 0 ? rc : RLHIP_ERR_HIP(hipErrorUnknown);
-    hipLaunchKernelGGL(skinny_trsm_kernel<T>, dim3(grid), dim3(256), 0, c->stream, m, (int)n, (const T*)R1, (int64_t)n, A, lda, (const int*)flags);
-    RLHIP_LAUNCH_CHECK();
+    rc = skinny_trsm<T>(c, m, n, R1, n, A, lda, flags);
+    if (rc) return rc;
     rc = laset<T>(c, 2, n, n, T(0), T(0), R2, n);
     if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R2, n);
     if (!rc) rc = potrf_upper_enqueue<T>(c, n, R2, n, flags + 2);
@@ -491,8 +502,8 @@ static int cholqr2_skinny(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda,
     const T dev_h = *(const T*)(c->h_mail + 46);
     if (info1) return 0;                                                             // A untouched (the solve saw the flag)
     if (info2 || !(dev_h <= T(1e-2))) return trmm_right_upper<T>(c, NonUnit, m, n, T(1), R1, n, A, lda);   // restore A = Q1 R1
-    hipLaunchKernelGGL(skinny_trsm_kernel<T>, dim3(grid), dim3(256), 0, c->stream, m, (int)n, (const T*)R2, (int64_t)n, A, lda, (const int*)nullptr);   // A = Q
-    RLHIP_LAUNCH_CHECK();
+    rc = skinny_trsm<T>(c, m, n, R2, n, A, lda, nullptr);                            // A = Q
+    if (rc) return rc;
     rc = trmm_right_upper<T>(c, NonUnit, n, n, T(1), R1, n, R2, n);                   // R2 <- R2 R1
     if (!rc) *good = true;
     return rc;
@@ -501,7 +512,7 @@ static int cholqr2_skinny(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda,
 template <typename T>
 static int cholqr2_inplace(rlhip_ctx* c, int64_t m, int64_t n, T* A, int64_t lda, T* R1, T* R2, T* dev1, bool* good) {
     *good = false;
-    if (n <= SKN && m >= 4096) return cholqr2_skinny<T>(c, m, n, A, lda, R1, R2, dev1, good);
+    if ((n == 16 || n == 32 || n == SKN) && m >= 4096) return cholqr2_skinny<T>(c, m, n, A, lda, R1, R2, dev1, good);
     int info = 0;
     int rc = laset<T>(c, 2, n, n, T(0), T(0), R1, n);
     if (!rc) rc = syrk<T>(c, Upper, 1, n, m, T(1), A, lda, T(0), R1, n);

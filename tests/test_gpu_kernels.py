@@ -763,7 +763,7 @@ def test_orhr_col_gemqrt_larft_match_lapack(ctx, orc, m, n, nb):
     lu0 = ctx.path_count(9)
     assert ctx.lib.rlhip_orhr_col_f64(ctx.h, m, n, nb, Qd.data_ptr(), m, Td.data_ptr(), nb, Dd.data_ptr()) == 0
     ctx.sync()
-    assert ctx.path_count(9) == lu0 + 1                       # the sign-modified LU ran as one block-pipelined launch (qr_blk.hip)
+    assert ctx.path_count(9) == lu0 + (1 if n > 32 else 0)    # the sign-modified LU ran as one block-pipelined launch (qr_blk.hip); a single 32-column panel takes the LDS panel kernel
     info, Ao, To, Do = orc.lapack_orhr_col(Q, nb)
     assert info == 0
     np.testing.assert_array_equal(Dd.cpu().numpy(), Do)                               # sign vector: exact
