@@ -51,6 +51,14 @@ def main():
     Af = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
     rf = d.drv_bqrrp(ctx, Af, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m, qrcp_wide=0, qr_tall=1, apply_trans_q=1)
     Af_loc, tau_f, J_f = d.cm_to_numpy(Af), rf["tau"].cpu().numpy(), rf["J"].cpu().numpy()
+    # ... and the same call with the look-ahead of call_sharded FORCED (side queue beside the tail of the apply; collectives through this
+    #     process group's hook): one process per rank, as in production
+    Al = d.cm_from_numpy(np.ascontiguousarray(Abq[rows]))
+    la0 = ctx.path_count(12)
+    with ctx.options(bqrrp_lookahead_min_elems=0):
+        rl = d.drv_bqrrp(ctx, Al, len(rows), nbq, bb, 1.0, key=(8, 0), m_global=m, qrcp_wide=0, qr_tall=1, apply_trans_q=1)
+    la_taken = ctx.path_count(12) - la0
+    Al_loc, tau_l, J_l = d.cm_to_numpy(Al), rl["tau"].cpu().numpy(), rl["J"].cpu().numpy()
     # the same factorization with the rows dealt block-cyclically (blocks of bb rows, block g on rank g % world)
     crows = np.concatenate([np.arange(g * bb, min((g + 1) * bb, m)) for g in range(rank, (m + bb - 1) // bb, world)] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
     Ac = d.cm_from_numpy(np.ascontiguousarray(Abq[crows]))
@@ -77,7 +85,7 @@ def main():
     lin = {alg: d.cm_to_numpy(d.drv_qr_linops(ctx, alg, op_loc, d_factor=2.0, nnz=2, key=(9, 0))["R"]) for alg in ("cqrrt", "cholqr", "scholqr3")}
     rsa = d.drv_abrik_linop(ctx, op_loc, 6, 1e-12, max_krylov_iters=6, key=(6, 0), qr_exp=1)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc, Af_loc, {t: v[0] for t, v in hq.items()}))
+    dist.all_gather_object(gathered, (rows, Uloc, U2loc, Qloc, Ua_loc, Ab_loc, crows, Ac_loc, Af_loc, {t: v[0] for t, v in hq.items()}, Al_loc, la_taken))
     ctx.lib.rlhip_comm_destroy(ctx.h)
     if rank == 0:
         import oracle
@@ -89,8 +97,11 @@ def main():
         Acq_out = np.zeros((m, nbq))
         Afq_out = np.zeros((m, nbq))
         Hq_out = {t: np.zeros((m, nhq)) for t in hq}
-        for rr, u, u2, qq, ua, ab, cr, ac, af, hh in gathered:
-            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac; Afq_out[rr] = af
+        Alq_out = np.zeros((m, nbq))
+        la_counts = []
+        for rr, u, u2, qq, ua, ab, cr, ac, af, hh, al, lat in gathered:
+            U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac; Afq_out[rr] = af; Alq_out[rr] = al
+            la_counts.append(int(lat))
             for t in hh:
                 Hq_out[t][rr] = hh[t]
         S, V = r["S"].cpu().numpy(), d.cm_to_numpy(r["V"])
@@ -134,6 +145,8 @@ def main():
             bq_A=float(np.linalg.norm(Abq_out - Ab1n) / np.linalg.norm(Ab1n)), bq_tau=float(np.max(np.abs(tau_b - rb1["tau"].cpu().numpy()))),
             bqf_rank=rf["rank"], bqf_J_equal=bool(np.array_equal(J_f, rb1["J"].cpu().numpy())),
             bqf_A=float(np.linalg.norm(Afq_out - Ab1n) / np.linalg.norm(Ab1n)), bqf_tau=float(np.max(np.abs(tau_f - rb1["tau"].cpu().numpy()))),
+            bql_rank=rl["rank"], bql_J_equal=bool(np.array_equal(J_l, rb1["J"].cpu().numpy())), bql_lookaheads=la_counts,
+            bql_A=float(np.linalg.norm(Alq_out - Ab1n) / np.linalg.norm(Ab1n)), bql_tau=float(np.max(np.abs(tau_l - rb1["tau"].cpu().numpy()))),
             bqc_rank=rc_["rank"], bqc_J_equal=bool(np.array_equal(J_c, rb1["J"].cpu().numpy())),
             bqc_A=float(np.linalg.norm(Acq_out - Ab1n) / np.linalg.norm(Ab1n)), bqc_tau=float(np.max(np.abs(tau_c - rb1["tau"].cpu().numpy()))),
             bq_resid=float(np.linalg.norm(Abq[:, J_b - 1] - Qb @ Rb) / np.linalg.norm(Abq)), bq_orth=float(np.linalg.norm(Qb.T @ Qb - np.eye(nbq))),

@@ -47,6 +47,10 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     assert out["bq_A"] <= 1e-10 and out["bq_tau"] <= 1e-10
     assert out["bqf_rank"] == out["bq_rank1"] and out["bqf_J_equal"]
     assert out["bqf_A"] <= 1e-10 and out["bqf_tau"] <= 1e-10
+    # ... and with the sharded look-ahead forced (side queue + this process group's collectives): every rank took it in every iteration but the last
+    assert out["bql_rank"] == out["bq_rank1"] and out["bql_J_equal"]
+    assert out["bql_A"] <= 1e-10 and out["bql_tau"] <= 1e-10
+    assert all(c >= 1 for c in out["bql_lookaheads"]), out["bql_lookaheads"]
     # row-sharded standalone hqrrp (pivoted / Householder / Cholesky-QR panels) == the single-device factorization
     for tag, h in out["hqrrp"].items():
         assert h["rc"] == [0, 0] and h["J_equal"], (tag, h)
