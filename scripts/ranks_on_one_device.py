@@ -12,7 +12,7 @@ the exchange volumes are printed so that the xGMI terms can be added.
 This is the REAL sharded code path at FULL size with world = 8 (Queue::allreduce_sum at every reduction point, shard_extent, block-cyclic rows
 for BQRRP); the result is checked against the single-device run on the assembled matrix (pivots identical, factors to rounding).
 
-usage: ranks_on_one_device.py {rsvd|cqrrpt|bqrrp} [--world 8] [--steps 2] [--check] [--m M --n N ...]
+usage: ranks_on_one_device.py {rsvd|cqrrpt|bqrrp|abrik} [--world 8] [--steps 2] [--check] [--m M --n N ...]
 """
 import argparse, ctypes as C, json, os, sys, threading, time
 
@@ -27,9 +27,61 @@ from _world import World, block_cyclic_rows          # the N-contexts-one-stream
 PEAK = {"f64": 78.6, "f32": 157.3}
 
 
+def abrik_ranks(a):
+    """BASELINE configs[4]: ABRIK on the 200000 x 200000 CSR operator (block 32, rank 128), row-sharded over N ranks (CQRRT panels: the sharded
+    ABRIK's panel QR, rl_abrik.hh), against the single-device call with the same subroutines"""
+    import scipy.sparse as sp
+    N = a.world
+    m = n = a.m or 200000
+    k, target = 32, 128
+    rng = np.random.default_rng(77)
+    rows_i = np.repeat(np.arange(m), 10)
+    colsi = (rows_i + np.tile(np.arange(-4, 6), m)) % n
+    vals = rng.standard_normal(m * 10)
+    d1 = np.exp(-np.arange(m) / 4.0) + 1e-13
+    d2 = np.exp(-np.arange(n) / 4.0) + 1e-13
+    G = sp.csr_matrix((vals * d1[rows_i] * d2[colsi], (rows_i, colsi)), shape=(m, n)); G.sum_duplicates()
+    iters = 2 * target // k
+    eps = float(np.finfo(float).eps ** 0.85)
+    W = World(N)
+    ctx1 = d.Context(0)
+    cut = [r * (m // N) for r in range(N)] + [m]
+    ops = [d.CsrOperator.from_scipy(G[cut[r]:cut[r + 1]].tocsr(), device="cuda:0") for r in range(N)]
+    best, res = None, None
+    for it in range(a.steps + 1):
+        torch.cuda.synchronize()
+        W.bytes_reduced = 0; W.collectives = 0
+        t0 = time.perf_counter()
+        res = W.run(lambda r, ctx: d.drv_abrik_linop(ctx, ops[r], k, eps, iters, key=(2, 0), qr_exp=1))
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        if it > 0:
+            best = dtm if best is None else min(best, dtm)
+    op1 = d.CsrOperator.from_scipy(G, device="cuda:0")
+    single = {}
+    for name, qe in (("cqrrt_panels", 1), ("geqrf_ungqr_panels", 0)):
+        for it in range(3):
+            ctx1.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            r1 = d.drv_abrik_linop(ctx1, op1, k, eps, iters, key=(2, 0), qr_exp=qe)
+            ctx1.sync(); torch.cuda.synchronize()
+            single[name] = min(single.get(name, 1e9), (time.perf_counter() - t0) * 1e3)
+        if qe == 1:
+            S8, S1 = res[0]["S"], r1["S"]
+            kk = min(len(S8), len(S1), 16)
+            chk = dict(iters=[res[0]["iters"], r1["iters"]], triplets=[res[0]["triplets"], r1["triplets"]],
+                       leading_sigma_rel_diff=float(((S8[:kk] - S1[:kk]).abs() / S1[:kk]).max()),
+                       ranks_agree=bool(all(torch.equal(res[0]["S"], res[r]["S"]) for r in range(N))))
+    out = {"workload": f"ABRIK {m}x{n} CSR operator (10 nonzeros per row), block {k}, {iters} Krylov iterations, {N} row-sharded ranks on ONE device (threads, one shared stream)",
+           "world": N, "wall_ms_all_ranks": round(best * 1e3, 2), "ms_per_rank": round(best * 1e3 / N, 3),
+           "what_ms_per_rank_is": "1/N of the operator's rows + every replicated stage, the real sharded code path (CQRRT panels); exchanges served in place (no transport time)",
+           "collectives_per_call": W.collectives, "bytes_all_reduced_per_call": W.bytes_reduced,
+           "single_device_ms": {kx: round(v, 3) for kx, v in single.items()}, "check_vs_single_device_cqrrt": chk}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["rsvd", "cqrrpt", "bqrrp"])
+    ap.add_argument("what", choices=["rsvd", "cqrrpt", "bqrrp", "abrik"])
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--check", action="store_true", help="also run the single-device factorization of the assembled matrix and compare")
@@ -44,6 +96,8 @@ def main():
         m, n, dt = a.m or 1048576, a.n or 1024, torch.float64
     else:
         m, n, dt = a.m or 65536, a.n or 65536, torch.float32
+    if a.what == "abrik":
+        return abrik_ranks(a)
     W = World(N)
     ctx1 = d.Context(0)                                               # world of one, for the single-device references
     # ---- the global matrix as N row shards (rank r draws its own block: key 7 + r, as bench.py does)

@@ -44,5 +44,5 @@ timeout 600 python $R/scripts/bqrrp_lookahead_ab.py 65536 2048 f32 2 > $O/${TAG}
 ( cd $R && bash scripts/c3_split_evidence.sh $TAG > $O/c3split.log 2>&1; cp gpurun_out/c3split/${TAG}_c3_* $O/ 2>/dev/null )
 # the real sharded drivers as 8 ranks on this one device: per-rank time = 1/8 of the rows + every replicated stage
 cd $R
-for w in rsvd cqrrpt bqrrp; do timeout 600 python scripts/ranks_on_one_device.py $w --check --steps 2 > $O/${TAG}_ranks8_on_one_device_$w.json 2> $O/ranks8_$w.err; done
+for w in rsvd cqrrpt bqrrp abrik; do timeout 600 python scripts/ranks_on_one_device.py $w --check --steps 2 > $O/${TAG}_ranks8_on_one_device_$w.json 2> $O/ranks8_$w.err; done
 for j in $O/${TAG}_*line.json; do echo "$(basename $j): $(cut -c1-240 $j)"; done
