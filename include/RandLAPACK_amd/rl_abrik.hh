@@ -6,12 +6,14 @@
 //   qr_exp = geqrf_ungqr  -> device geqrf + ungqr;   qr_exp = cqrrt -> CQRRT panels (rl_cqrrt.hh).
 // Row-sharded operator (one process per GPU, linop.row_sharded): X_ev / U are sharded by rows, everything n-long or k-sized is
 // replicated; exchanges: A^T X (n x k, inside the linop), the two re-orthogonalisation inner products of the X side, and
-// CQRRT's sketch + Gram all-reduces.  Needs qr_exp = cqrrt.
+// CQRRT's sketch + Gram all-reduces.  Both qr_exp run sharded: cqrrt as it is, geqrf_ungqr (the reference's default) as the sharded
+// Cholesky-QR panel + the Householder sign vector of its gathered top block (sharded_householder_qr below).
 #pragma once
 #include <chrono>
 #include <climits>
 #include <cmath>
 #include <limits>
+#include <type_traits>
 #include <vector>
 #include "rl_exceptions.hh"
 #include "rl_blaspp.hh"
@@ -92,11 +94,42 @@ public:
         randlapack_require(k > 0) << "target rank k=" << k << " must be > 0";                                   // :176
         const bool use_cqrrt = (qr_exp == Subroutines::QR_explicit::cqrrt);
         const bool sharded = q.world() > 1;       // the operator's rows (and every m-long object: X_ev, U) are sharded; n-long ones are replicated
-        randlapack_require(!sharded || use_cqrrt) << "ABRIK on a row-sharded operator needs qr_exp = cqrrt (Householder panels do not shard)";
         RandLAPACK::CQRRT<T, RNG> cqrrt(q, false, tol);                                                        // :281-285
         cqrrt.nnz = 2;
         const T d_factor = (T)1.25;
         T* R_11_trans = nullptr;
+        // Row-sharded operator with the reference's DEFAULT panels (qr_exp = geqrf_ungqr, :333-342 / :552-570): the m-long panels X are
+        // sharded by rows.  What geqrf + ungqr leave -- the orthonormal factor in LAPACK's Householder sign convention and its triangle -- is,
+        // by the reconstruction contract (lapack::orhr_col), any orthonormal factor times diag(D), D = the sign vector of the sign-modified LU
+        // of its TOP k x k block.  So: the sharded sketch-preconditioned Cholesky-QR panel (CQRRT, which row-shards: one sketch and one Gram
+        // exchange) on a PRIVATE random state (the reference's geqrf path draws nothing), the top block gathered from its owners by one k x k
+        // exchange, D on every rank, Q <- Q D, R <- D R.  Same Q and R as the single-device call to rounding; the n-long panels Y are
+        // replicated and take the ordinary single-rank route.
+        RandBLAS::RNGState<RNG> panel_state(0x5eedu);
+        int64_t m_glob_x = 0, row0_x = 0;
+        if (sharded && !use_cqrrt) q.shard_extent(A.n_rows, m_glob_x, row0_x);
+        auto sharded_householder_qr = [&](int64_t rows, T* P, T* Rout, int64_t ldr) {
+            cqrrt.rows_replicated = false;
+            const int rc = cqrrt.call(rows, k, P, rows, Rout, ldr, d_factor, panel_state);
+            randlapack_require(rc == 0) << "ABRIK: sharded panel factorization failed (code " << rc << ")";
+            blas::Scratch w5(q);
+            T* Qt = w5.alloc<T>(k * k);
+            T* Tm = w5.alloc<T>(k * k);
+            T* Dv = w5.alloc<T>(k);
+            lapack::laset(MatrixType::General, k, k, (T)0, (T)0, Qt, k, q);
+            const int64_t cnt = (row0_x < k) ? std::min<int64_t>(rows, k - row0_x) : 0;      // my rows among the global rows [0, k)
+            if (cnt > 0) lapack::lacpy(MatrixType::General, cnt, k, P, rows, Qt + row0_x, k, q);
+            q.allreduce_sum(Qt, k * k);
+            {
+                blas::LocalOnly one_rank(q);
+                lapack::orhr_col(k, k, k, Qt, k, Tm, k, Dv, q);
+            }
+            lapack::row_sign(k, Rout, ldr, Dv, q);
+            if (rows > 0) {
+                if constexpr (std::is_same<T, double>::value) blas::check(rlhip_scal_cols_f64(q.ctx(), rows, k, P, rows, Dv), "scal_cols");
+                else blas::check(rlhip_scal_cols_f32(q.ctx(), rows, k, P, rows, Dv), "scal_cols");
+            }
+        };
         // explicit QR of a panel P (rows x k, ld rows): Q in place, R (k x k upper) to Rout (ld ldr)
         auto panel_qr = [&](int64_t rows, T* P, T* Rout, int64_t ldr, bool m_long, RandBLAS::RNGState<RNG>& st) {
             if (use_cqrrt) {
@@ -156,7 +189,8 @@ public:
             toc(qr_t);
         } else {
             tic();
-            const bool fused = fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q);          // :333 + :342 in one pass
+            if (sharded) sharded_householder_qr(m, X_ev.p + X_i, R_qr, k);
+            const bool fused = sharded || (fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q));   // :333 + :342 in one pass
             if (!fused) lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                           // :333
             toc(qr_t);
             tic();
@@ -242,7 +276,8 @@ public:
                     toc(qr_t);
                 } else {
                     tic();
-                    const bool fused = fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q);  // :552 + :570 in one pass
+                    if (sharded) sharded_householder_qr(m, X_ev.p + X_i, R_qr, k);
+                    const bool fused = sharded || (fuse_geqrf_ungqr && lapack::geqrf_q(m, k, X_ev.p + X_i, m, R_qr, k, q));  // :552 + :570 in one pass
                     if (!fused) lapack::geqrf(m, k, X_ev.p + X_i, m, tau, q);                                   // :552
                     toc(qr_t);
                     tic();

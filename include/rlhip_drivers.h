@@ -105,7 +105,7 @@ int rlhip_drv_cqrrpt_gpu_f32(rlhip_ctx* ctx, int64_t m, int64_t n, float* A_host
  * max_krylov_iters <= 0 keeps the object's default (INT_MAX). */
 int rlhip_drv_abrik_f64(rlhip_ctx* ctx, int64_t m, int64_t n, const double* A, int64_t lda, int64_t k, double tol, int64_t max_krylov_iters,
                         double** U, double** Sigma, double** V, uint32_t state[6], int64_t* triplets, int64_t* iters, double* norm_R_end,
-                        int qr_exp /* 0 geqrf_ungqr, 1 cqrrt (required when the context is row-sharded), -1 default */);
+                        int qr_exp /* 0 geqrf_ungqr, 1 cqrrt, -1 default (geqrf_ungqr); both run on a row-sharded context */);
 
 /* CQRRT<double>::call (drivers/rl_cqrrt.hh:124): unpivoted CQRRPT.  A (m x n, lda) -> Q; upper triangle of R (n x n, ldr).
  * A_hat_in / A_hat_out: shared-sketch hooks as for CQRRPT (d x n, ld d, d = (int64)(d_factor * n)).  Returns 0 or 1. */

@@ -62,6 +62,9 @@ def test_rowsharded_drivers_match_single_device_and_oracle(world, m, n, k, p):
     assert out["bqc_rank"] == out["bq_rank1"] and out["bqc_J_equal"]
     assert out["bqc_A"] <= 1e-10 and out["bqc_tau"] <= 1e-10
     assert out["bq_resid"] <= 1e-12 and out["bq_orth"] <= 1e-11
+    # row-sharded ABRIK with the reference's DEFAULT panels (geqrf_ungqr): same trajectory, Ritz values and RNG state as on one device
+    assert out["abh_iters"][0] == out["abh_iters"][1] and out["abh_trip"][0] == out["abh_trip"][1] and out["abh_next_ctr"][0] == out["abh_next_ctr"][1]
+    assert out["abh_S_vs_single"] <= 1e-9 and out["abh_orthU"] <= 1e-9 and out["abh_res"] <= 1e-9
     # row-sharded ABRIK (CQRRT panels): same iteration count, same leading Ritz values as on one device
     assert (out["ab_iters"], out["ab_trip"]) == (out["ab_iters1"], out["ab_trip1"])
     assert out["ab_S_vs_single"] <= 1e-9 and out["ab_orthU"] <= 1e-9 and out["ab_res"] <= 1e-9
