@@ -110,6 +110,7 @@ public:
         if (sharded && !use_cqrrt) q.shard_extent(A.n_rows, m_glob_x, row0_x);
         auto sharded_householder_qr = [&](int64_t rows, T* P, T* Rout, int64_t ldr) {
             cqrrt.rows_replicated = false;
+            lapack::laset(MatrixType::General, k, k, (T)0, (T)0, Rout, ldr, q);      // CQRRT fills the triangle and multiplies the full k x k array (:190: the cqrrt route zeroes its buffer too)
             const int rc = cqrrt.call(rows, k, P, rows, Rout, ldr, d_factor, panel_state);
             randlapack_require(rc == 0) << "ABRIK: sharded panel factorization failed (code " << rc << ")";
             blas::Scratch w5(q);

@@ -77,8 +77,8 @@ def main():
     ra = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
     Ua_loc = d.cm_to_numpy(ra["U"])
     # ... and with the reference's DEFAULT panels (qr_exp = geqrf_ungqr): sharded Cholesky-QR panel + the Householder sign vector of its top block
-    rh = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=0)
-    Uh_loc = d.cm_to_numpy(rh["U"])
+    rha = d.drv_abrik(ctx, Aloc, len(rows), n, ka, 1e-12, ita, key=(6, 0), qr_exp=0)
+    Uh_loc = d.cm_to_numpy(rha["U"])
     # linop QR drivers and ABRIK on a ROW-SHARDED sparse operator (each rank holds a row block of the CSR matrix)
     import scipy.sparse as sp
     nsp = min(n, 60)
@@ -102,7 +102,7 @@ def main():
         Hq_out = {t: np.zeros((m, nhq)) for t in hq}
         Alq_out = np.zeros((m, nbq))
         la_counts = []
-        Uh = np.zeros((m, rh["triplets"]))
+        Uh = np.zeros((m, rha["triplets"]))
         for rr, u, u2, qq, ua, ab, cr, ac, af, hh, al, lat, uh in gathered:
             U[rr] = u; U2[rr] = u2; Qc[rr] = qq; Ua[rr] = ua; Abq_out[rr] = ab; Acq_out[cr] = ac; Afq_out[rr] = af; Alq_out[rr] = al; Uh[rr] = uh
             la_counts.append(int(lat))
@@ -121,8 +121,8 @@ def main():
         Rb = np.triu(Abq_out)[:nbq]
         ra1 = d.drv_abrik(ctx1, d.cm_from_numpy(A), m, n, ka, 1e-12, ita, key=(6, 0), qr_exp=1)
         Sa, Sa1, Va = ra["S"].cpu().numpy(), ra1["S"].cpu().numpy(), d.cm_to_numpy(ra["V"])
-        rh1 = d.drv_abrik(ctx1, d.cm_from_numpy(A), m, n, ka, 1e-12, ita, key=(6, 0), qr_exp=0)
-        Sh, Sh1, Vh = rh["S"].cpu().numpy(), rh1["S"].cpu().numpy(), d.cm_to_numpy(rh["V"])
+        rha1 = d.drv_abrik(ctx1, d.cm_from_numpy(A), m, n, ka, 1e-12, ita, key=(6, 0), qr_exp=0)
+        Sh, Sh1, Vh = rha["S"].cpu().numpy(), rha1["S"].cpu().numpy(), d.cm_to_numpy(rha["V"])
         sv = np.linalg.svd(A, compute_uv=False)
         Aq1 = d.cm_from_numpy(Acq)
         rq1 = d.drv_cqrrpt(ctx1, Aq1, m, ncq, 1.25, 4, key=(5, 0))
@@ -156,8 +156,8 @@ def main():
             bqc_rank=rc_["rank"], bqc_J_equal=bool(np.array_equal(J_c, rb1["J"].cpu().numpy())),
             bqc_A=float(np.linalg.norm(Acq_out - Ab1n) / np.linalg.norm(Ab1n)), bqc_tau=float(np.max(np.abs(tau_c - rb1["tau"].cpu().numpy()))),
             bq_resid=float(np.linalg.norm(Abq[:, J_b - 1] - Qb @ Rb) / np.linalg.norm(Abq)), bq_orth=float(np.linalg.norm(Qb.T @ Qb - np.eye(nbq))),
-            abh_iters=[rh["iters"], rh1["iters"]], abh_trip=[rh["triplets"], rh1["triplets"]], abh_next_ctr=[list(rh["next_ctr"]), list(rh1["next_ctr"])],
-            abh_S_vs_single=float(np.max(np.abs(Sh[:ka] - Sh1[:ka]) / Sh1[:ka])), abh_orthU=float(np.linalg.norm(Uh.T @ Uh - np.eye(rh["triplets"]))),
+            abh_iters=[rha["iters"], rha1["iters"]], abh_trip=[rha["triplets"], rha1["triplets"]], abh_next_ctr=[list(rha["next_ctr"]), list(rha1["next_ctr"])],
+            abh_S_vs_single=float(np.max(np.abs(Sh[:ka] - Sh1[:ka]) / Sh1[:ka])), abh_orthU=float(np.linalg.norm(Uh.T @ Uh - np.eye(rha["triplets"]))),
             abh_res=float(min(np.linalg.norm(A.T @ Uh - Vh * Sh), np.linalg.norm(A @ Vh - Uh * Sh))),
             ab_iters=ra["iters"], ab_iters1=ra1["iters"], ab_trip=ra["triplets"], ab_trip1=ra1["triplets"],
             ab_S_vs_single=float(np.max(np.abs(Sa[:ka] - Sa1[:ka]) / Sa1[:ka])),
@@ -179,6 +179,7 @@ def main():
             orthU2=float(np.linalg.norm(U2.T @ U2 - np.eye(r2["k"]))),
         )
         if os.environ.get("RLHIP_TEST_DEBUG"):
+            print("abrik default panels: sharded S", Sh[:5], "single S", Sh1[:5], "cqrrt sharded S", Sa[:5], file=sys.stderr)
             print("S", S[:5], "S1", S1[:5], "ref", ref["S"][:5], ref["k"], ref["qb_rc"], file=sys.stderr)
         print("SHARDED_RESULT " + json.dumps(out), flush=True)
     dist.destroy_process_group()
